@@ -1,0 +1,25 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_small():
+    import numpy as np
+    return np.load(os.path.join(ROOT, "tests", "golden", "own_code_small.npz"))
+
+
+@pytest.fixture(scope="session")
+def golden_encoder():
+    import numpy as np
+    return np.load(os.path.join(ROOT, "tests", "golden", "encoder.npz"))
