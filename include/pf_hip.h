@@ -1,0 +1,114 @@
+/* pf_hip.h -- C ABI of libpfhip.so: the MI355X (gfx950) hot path of PosteriFlow's
+ * conditional neural-spline flow and strain embedding.
+ *
+ * The reference (bibinthomas123/PosteriFlow) has no FFI: its seam is the Python
+ * nn.Module API.  Each entry point below names the reference method whose
+ * arithmetic it replaces (paths relative to the reference repo):
+ *
+ *   pf_flow_forward   NSFPosteriorFlow.forward               src/ahsd/models/flows.py:610-618
+ *                     + compute_psd_aware_nll (N(0,I) base)  src/ahsd/models/flows.py:727-779
+ *                     (executes nflows CompositeTransform / MADE / RQS, flows.py:459-529)
+ *   pf_flow_inverse   NSFPosteriorFlow.inverse (transform part) src/ahsd/models/flows.py:620-655
+ *   pf_flow_pack      the per-call `weight * mask` of nflows MaskedLinear, done once
+ *
+ * Conventions
+ *   - every pointer is a caller-owned DEVICE pointer unless named *_host;
+ *     the library never allocates or frees device memory;
+ *   - tensors are contiguous row-major fp32: x[B,D], ctx[B,C], z[B,D], logdet[B];
+ *   - kernels are enqueued on `stream` (a hipStream_t passed as void*), no
+ *     internal synchronisation, no global mutable state;
+ *   - return value: 0 ok, PF_ERR_* (<0) otherwise; no C++ exception crosses
+ *     the ABI; pf_last_error() returns a thread-local message.
+ */
+#ifndef PF_HIP_H
+#define PF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PF_OK 0
+#define PF_ERR_BAD_ARG (-1)      /* null pointer, negative size, misaligned pointer */
+#define PF_ERR_UNSUPPORTED (-2)  /* shape outside what the kernels are built for */
+#define PF_ERR_HIP (-3)          /* HIP runtime error at launch */
+
+#define PF_PREC_F32 0   /* f32-input MFMA (v_mfma_f32_16x16x4_f32): exact fp32, parity mode */
+#define PF_PREC_BF16 1  /* bf16 MFMA operands, fp32 accumulate: throughput mode */
+
+/* Plain-old-data description of one NSFPosteriorFlow (flows.py:379-548).
+ * conditioner: nflows MADE, num_blocks residual blocks with GLU context gate,
+ * ReversePermutation in front of every layer, tails='linear'. */
+typedef struct PfFlowDesc {
+    int32_t features;          /* D  (1..16)                                   */
+    int32_t context_features;  /* C  (0 = unconditional)                       */
+    int32_t hidden_features;   /* H  (64 or 256 in this build)                 */
+    int32_t num_bins;          /* K  (2..16)                                   */
+    int32_t num_layers;        /* L                                            */
+    int32_t num_blocks;        /* residual blocks per MADE (2)                 */
+    float tail_bound;          /* spline domain [-tail_bound, tail_bound]      */
+    float min_bin_width;       /* nflows DEFAULT_MIN_BIN_WIDTH  = 1e-3         */
+    float min_bin_height;      /* nflows DEFAULT_MIN_BIN_HEIGHT = 1e-3         */
+    float min_derivative;      /* nflows DEFAULT_MIN_DERIVATIVE = 1e-3         */
+    int32_t precision;         /* PF_PREC_*                                    */
+    int32_t reserved;
+} PfFlowDesc;
+
+/* ---- raw parameter layout -------------------------------------------------
+ * One flat fp32 buffer, layer after layer, each layer in nflows state_dict
+ * order (SURVEY.md 8a "state_dict layout"):
+ *   initial_layer.weight[H,D] .bias[H]   context_layer.weight[H,C] .bias[H]
+ *   for b in blocks: context_layer.weight[H,C] .bias[H]
+ *                    linear_layers.0.weight[H,H] .bias[H]  linear_layers.1.weight[H,H] .bias[H]
+ *   final_layer.weight[D*(3K-1),H] .bias[D*(3K-1)]
+ * (context tensors absent when C == 0).  Masks are NOT applied by the caller. */
+int64_t pf_flow_raw_param_count(const PfFlowDesc* desc);
+
+/* ---- packed weights ---------------------------------------------------------
+ * The kernels read weights pre-masked, cast to the MFMA operand type and laid
+ * out as per-wave streams of MFMA A-fragments.  Packing is a device gather
+ *     packed[i] = map[i] < 0 ? 0 : cast(raw[map[i]])
+ * driven by an index map the library builds on the HOST once per desc. */
+int64_t pf_flow_packed_bytes(const PfFlowDesc* desc);      /* size of the packed buffer        */
+int64_t pf_flow_pack_map_len(const PfFlowDesc* desc);      /* number of int32 entries in map   */
+int pf_flow_build_pack_map(const PfFlowDesc* desc, int32_t* map_host);
+int pf_flow_pack(const PfFlowDesc* desc, const float* raw, const int32_t* map,
+                 void* packed, void* stream);
+
+/* ---- forward / density ------------------------------------------------------
+ * z, logdet = transform(x[:, ar_perm], ctx)
+ * nll = -(log N(z; 0, diag(exp(log_sigma))^2) + logdet)   (PSDScaledNormal, flows.py:56-85)
+ * ar_perm: int32[D] device pointer or NULL (identity)  (flows.py:612).
+ * log_sigma: [B,D] or NULL (= zeros, what LeanNPE passes, lean_npe.py:315).
+ * Any of z / logdet / nll may be NULL.  batch may be 0 (no-op). */
+int pf_flow_forward(const PfFlowDesc* desc, const void* packed,
+                    const float* x, const float* ctx, const int32_t* ar_perm,
+                    const float* log_sigma, int64_t batch,
+                    float* z, float* logdet, float* nll, void* stream);
+
+/* ---- inverse / sampling -----------------------------------------------------
+ * x = transform^-1(z, ctx)[:, ar_inv_perm], logdet of the inverse map
+ * (nflows returns the log-det of the last autoregressive pass of each layer,
+ * which is the exact inverse log-det; flows.py:637).
+ * ctx_rows == batch: one context row per sample; ctx_rows divides batch:
+ * sample i uses context row i / (batch / ctx_rows)  (the expand().reshape()
+ * pattern of lean_npe.py:328, pipeline.py:171).
+ * fail_flags (uint32[batch] or NULL): bit 0 set where the quadratic
+ * discriminant was negative (the reference's AssertionError, flows.py:638). */
+int pf_flow_inverse(const PfFlowDesc* desc, const void* packed,
+                    const float* z, const float* ctx, int64_t ctx_rows,
+                    const int32_t* ar_inv_perm, int64_t batch,
+                    float* x, float* logdet, uint32_t* fail_flags, void* stream);
+
+/* ---- introspection ------------------------------------------------------------ */
+const char* pf_last_error(void);
+const char* pf_version(void);
+/* rows of the batch one workgroup processes for a given batch size (bench / tests) */
+int32_t pf_flow_rows_per_workgroup(const PfFlowDesc* desc, int64_t batch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PF_HIP_H */

@@ -1,0 +1,5 @@
+"""posteriflow_amd -- MI355X-native hot path of PosteriFlow (flow density / sampling
+and strain embedding) behind the reference's Python API.  See DESIGN.md."""
+from .flows import FLOW_NORM_BOUND, NSFPosteriorFlow, PSDScaledNormal, create_flow_model  # noqa: F401
+
+__all__ = ["NSFPosteriorFlow", "PSDScaledNormal", "create_flow_model", "FLOW_NORM_BOUND"]

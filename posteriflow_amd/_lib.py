@@ -1,0 +1,78 @@
+"""ctypes binding of libpfhip.so (the C ABI in include/pf_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing this
+module raises on first use, and the wrappers raise if tensors are not on the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpfhip.so")
+
+PF_OK, PF_ERR_BAD_ARG, PF_ERR_UNSUPPORTED, PF_ERR_HIP = 0, -1, -2, -3
+PF_PREC_F32, PF_PREC_BF16 = 0, 1
+PRECISIONS = {"fp32": PF_PREC_F32, "f32": PF_PREC_F32, "bf16": PF_PREC_BF16}
+
+
+class PfFlowDesc(C.Structure):
+    _fields_ = [
+        ("features", C.c_int32), ("context_features", C.c_int32),
+        ("hidden_features", C.c_int32), ("num_bins", C.c_int32),
+        ("num_layers", C.c_int32), ("num_blocks", C.c_int32),
+        ("tail_bound", C.c_float), ("min_bin_width", C.c_float),
+        ("min_bin_height", C.c_float), ("min_derivative", C.c_float),
+        ("precision", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+# every symbol include/pf_hip.h declares: (restype, argtypes)
+_P = C.POINTER(PfFlowDesc)
+SYMBOLS = {
+    "pf_flow_raw_param_count": (C.c_int64, [_P]),
+    "pf_flow_packed_bytes": (C.c_int64, [_P]),
+    "pf_flow_pack_map_len": (C.c_int64, [_P]),
+    "pf_flow_build_pack_map": (C.c_int, [_P, C.c_void_p]),
+    "pf_flow_pack": (C.c_int, [_P, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pf_flow_forward": (C.c_int, [_P, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pf_flow_inverse": (C.c_int, [_P, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                  C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pf_last_error": (C.c_char_p, []),
+    "pf_version": (C.c_char_p, []),
+    "pf_flow_rows_per_workgroup": (C.c_int32, [_P, C.c_int64]),
+}
+
+_lib = None
+
+
+class PfError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libpfhip.so (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PfError(
+                f"{LIB_PATH} not found: the HIP extension is not built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C "
+                "posteriflow_amd/csrc`). posteriflow_amd has no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(handle, name)   # AttributeError if the symbol is missing
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != PF_OK:
+        msg = lib().pf_last_error().decode()
+        if rc == PF_ERR_BAD_ARG:
+            raise ValueError(f"{what}: {msg}")
+        if rc == PF_ERR_UNSUPPORTED:
+            raise NotImplementedError(f"{what}: {msg}")
+        raise PfError(f"{what}: HIP error: {msg}")

@@ -1,0 +1,102 @@
+// pf_api.hip -- the extern "C" boundary declared in include/pf_hip.h.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "pf_flow_params.h"
+
+namespace {
+thread_local char g_err[256] = "";
+int fail(int code, const char* msg) {
+    std::snprintf(g_err, sizeof(g_err), "%s", msg);
+    return code;
+}
+int layout_of(const PfFlowDesc* d, pf::FlowLayout& L) {
+    if (!d) return fail(PF_ERR_BAD_ARG, "desc is null");
+    const int rc = pf::make_layout(*d, L);
+    if (rc != PF_OK)
+        return fail(rc, "unsupported flow shape (need D<=H/16<=16, H in {64,128,256}, K<=16, num_blocks=2)");
+    if (!(d->tail_bound > 0.f)) return fail(PF_ERR_BAD_ARG, "tail_bound must be positive");
+    if (d->min_bin_width * d->num_bins > 1.f || d->min_bin_height * d->num_bins > 1.f)
+        return fail(PF_ERR_BAD_ARG, "minimal bin size too large for the number of bins");
+    return PF_OK;
+}
+bool misaligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) != 0; }
+}  // namespace
+
+extern "C" {
+
+const char* pf_last_error(void) { return g_err; }
+const char* pf_version(void) { return "posteriflow_amd 0.1 (gfx950)"; }
+
+int64_t pf_flow_raw_param_count(const PfFlowDesc* desc) {
+    pf::FlowLayout L;
+    if (layout_of(desc, L) != PF_OK) return -1;
+    return pf::raw_param_count(L);
+}
+int64_t pf_flow_packed_bytes(const PfFlowDesc* desc) {
+    pf::FlowLayout L;
+    if (layout_of(desc, L) != PF_OK) return -1;
+    return L.weightBytes + L.biasFloats * (int64_t)sizeof(float);
+}
+int64_t pf_flow_pack_map_len(const PfFlowDesc* desc) {
+    pf::FlowLayout L;
+    if (layout_of(desc, L) != PF_OK) return -1;
+    return pf::pack_map_len(L);
+}
+int pf_flow_build_pack_map(const PfFlowDesc* desc, int32_t* map_host) {
+    pf::FlowLayout L;
+    int rc = layout_of(desc, L);
+    if (rc != PF_OK) return rc;
+    if (!map_host) return fail(PF_ERR_BAD_ARG, "map_host is null");
+    return pf::build_pack_map(L, map_host);
+}
+int pf_flow_pack(const PfFlowDesc* desc, const float* raw, const int32_t* map, void* packed, void* stream) {
+    pf::FlowLayout L;
+    int rc = layout_of(desc, L);
+    if (rc != PF_OK) return rc;
+    if (!raw || !map || !packed) return fail(PF_ERR_BAD_ARG, "null pointer");
+    if (misaligned(map, 16) || misaligned(packed, 16)) return fail(PF_ERR_BAD_ARG, "map/packed must be 16-byte aligned");
+    rc = pf::launch_pack(L, raw, map, packed, static_cast<hipStream_t>(stream));
+    return rc == PF_OK ? rc : fail(rc, hipGetErrorString(hipGetLastError()));
+}
+
+int pf_flow_forward(const PfFlowDesc* desc, const void* packed, const float* x, const float* ctx,
+                    const int32_t* ar_perm, const float* log_sigma, int64_t batch, float* z,
+                    float* logdet, float* nll, void* stream) {
+    pf::FlowLayout L;
+    int rc = layout_of(desc, L);
+    if (rc != PF_OK) return rc;
+    if (batch < 0) return fail(PF_ERR_BAD_ARG, "negative batch");
+    if (batch == 0) return PF_OK;
+    if (!packed || !x) return fail(PF_ERR_BAD_ARG, "null pointer");
+    if (L.C > 0 && !ctx) return fail(PF_ERR_BAD_ARG, "ctx is null but context_features > 0");
+    if (misaligned(packed, 16)) return fail(PF_ERR_BAD_ARG, "packed must be 16-byte aligned");
+    pf::FwdParams p{};
+    p.packed = static_cast<const char*>(packed);
+    p.x = x; p.ctx = ctx; p.ar_perm = ar_perm; p.log_sigma = log_sigma; p.z = z; p.logdet = logdet; p.nll = nll;
+    p.batch = batch; p.lay = L;
+    p.tail_bound = desc->tail_bound; p.min_w = desc->min_bin_width; p.min_h = desc->min_bin_height;
+    p.min_d = desc->min_derivative;
+    p.deriv_const = (float)std::log(std::exp(1.0 - (double)desc->min_derivative) - 1.0);
+    rc = pf::launch_flow_forward(p, static_cast<hipStream_t>(stream));
+    return rc == PF_OK ? rc : fail(rc, rc == PF_ERR_HIP ? hipGetErrorString(hipGetLastError()) : "unsupported launch shape");
+}
+
+int pf_flow_inverse(const PfFlowDesc* desc, const void* packed, const float* z, const float* ctx,
+                    int64_t ctx_rows, const int32_t* ar_inv_perm, int64_t batch, float* x,
+                    float* logdet, uint32_t* fail_flags, void* stream) {
+    (void)desc; (void)packed; (void)z; (void)ctx; (void)ctx_rows; (void)ar_inv_perm; (void)batch;
+    (void)x; (void)logdet; (void)fail_flags; (void)stream;
+    return fail(PF_ERR_UNSUPPORTED, "pf_flow_inverse: not built yet");
+}
+
+int32_t pf_flow_rows_per_workgroup(const PfFlowDesc* desc, int64_t batch) {
+    pf::FlowLayout L;
+    if (layout_of(desc, L) != PF_OK) return -1;
+    return pf::rows_per_workgroup(L, batch);
+}
+
+}  // extern "C"

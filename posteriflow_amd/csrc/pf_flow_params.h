@@ -1,0 +1,32 @@
+// pf_flow_params.h -- launch parameter blocks and internal entry points shared by
+// pf_api.hip and the kernel translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "pf_layout.h"
+
+namespace pf {
+
+struct FwdParams {
+    const char* packed;      // weights then biases
+    const float* x;          // [B, D]
+    const float* ctx;        // [B, C]
+    const int32_t* ar_perm;  // [D] or null
+    const float* log_sigma;  // [B, D] or null (PSDScaledNormal log-scale, flows.py:56-85)
+    float* z;                // [B, D] or null
+    float* logdet;           // [B] or null
+    float* nll;              // [B] or null
+    int64_t batch;
+    FlowLayout lay;
+    float tail_bound, min_w, min_h, min_d;
+    float deriv_const;       // log(exp(1 - min_d) - 1), computed in double on the host
+};
+
+int build_pack_map(const FlowLayout& L, int32_t* map);
+int64_t pack_map_len(const FlowLayout& L);
+int64_t raw_param_count(const FlowLayout& L);
+int launch_pack(const FlowLayout& L, const float* raw, const int32_t* map, void* packed, hipStream_t s);
+int rows_per_workgroup(const FlowLayout& L, int64_t batch);
+int launch_flow_forward(const FwdParams& p, hipStream_t s);
+
+}  // namespace pf

@@ -1,0 +1,191 @@
+// pf_pack.hip -- host pack-map builder + device gather that produces the packed
+// (pre-masked, fragment-ordered) weights the flow kernels stream.
+//
+// Replaces the per-call `self.weight * self.mask` of nflows MaskedLinear
+// (executed by the reference at src/ahsd/models/flows.py:615-617, 637): the
+// autoregressive masks are folded into the index map (masked entry -> -1 -> 0),
+// computed from the same degree rule:
+//   in_deg[d] = d+1;  hid_deg[u] = u % max(1,D-1) + min(1,D-1);  out_deg[f] = f+1
+//   hidden mask: deg_out >= deg_in;  output mask: deg_out > deg_in.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "pf_flow_params.h"
+
+namespace pf {
+
+struct RawOffsets {
+    int64_t in_w, in_b, c_w, c_b;
+    int64_t g_w[2], g_b[2], w0_w[2], w0_b[2], w1_w[2], w1_b[2];
+    int64_t out_w, out_b, total;
+};
+
+static RawOffsets raw_offsets(const FlowLayout& L) {
+    RawOffsets r{};
+    int64_t o = 0;
+    const int64_t H = L.H, D = L.D, C = L.C;
+    r.in_w = o; o += H * D; r.in_b = o; o += H;
+    if (C > 0) { r.c_w = o; o += H * C; r.c_b = o; o += H; } else { r.c_w = r.c_b = -1; }
+    for (int b = 0; b < L.NB; ++b) {
+        if (C > 0) { r.g_w[b] = o; o += H * C; r.g_b[b] = o; o += H; } else { r.g_w[b] = r.g_b[b] = -1; }
+        r.w0_w[b] = o; o += H * H; r.w0_b[b] = o; o += H;
+        r.w1_w[b] = o; o += H * H; r.w1_b[b] = o; o += H;
+    }
+    r.out_w = o; o += D * (int64_t)L.M * H; r.out_b = o; o += D * (int64_t)L.M;
+    r.total = o;
+    return r;
+}
+
+static inline int hid_deg(const FlowLayout& L, int u) {
+    const int hi = std::max(1, L.D - 1), lo = std::min(1, L.D - 1);
+    return u % hi + lo;
+}
+
+// spline parameter row for (tile q of the feature, row r16): widths / heights / derivs
+static inline int out_param(const FlowLayout& L, int q, int r16) {
+    if (q == 0) return r16 < L.K ? r16 : -1;
+    if (q == 1) return r16 < L.K ? L.K + r16 : -1;
+    return r16 < L.K - 1 ? 2 * L.K + r16 : -1;
+}
+
+int build_pack_map(const FlowLayout& L, int32_t* map) {
+    const RawOffsets ro = raw_offsets(L);
+    const int fragElems = L.bf16 ? 512 : 256;
+    const int per = L.bf16 ? 8 : 4;   // elements per lane
+    int64_t idx = 0;
+    for (int l = 0; l < L.L; ++l) {
+        const int64_t base = (int64_t)l * ro.total;
+        for (int w = 0; w < L.NW; ++w) {
+            for (int f = 0; f < L.NF; ++f) {
+                // decode the phase of frag f
+                int phase, t = 0, ks = 0, blk = 0;   // phase: 0 in, 1 ctx, 2 W0, 3 W1, 4 gate, 5 out
+                if (f < L.oCtx) { phase = 0; }
+                else if (f < L.oBlk0) { phase = 1; ks = f - L.oCtx; }
+                else if (f < L.oOut) {
+                    int r = f - L.oBlk0; blk = r / L.blkStride; r %= L.blkStride;
+                    if (r < L.oW1) { phase = 2; ks = r; }
+                    else if (r < L.oGate) { phase = 3; ks = r - L.oW1; }
+                    else { phase = 4; ks = r - L.oGate; }
+                } else { phase = 5; int r = f - L.oOut; t = r / L.HK; ks = r % L.HK; }
+                for (int within = 0; within < fragElems; ++within, ++idx) {
+                    const int lane = within / per, e = within % per;
+                    const int g = lane >> 4, r16 = lane & 15;
+                    // k -> source column
+                    int col;
+                    if (phase == 0) col = L.bf16 ? ((8 * g + e) & 15) : (4 * g + e);
+                    else if (phase == 1 || phase == 4) col = L.bf16 ? (32 * ks + 8 * g + e) : (16 * ks + 4 * g + e);
+                    else col = L.bf16 ? (16 * (2 * ks + (e >> 2)) + 4 * g + (e & 3)) : (16 * ks + 4 * g + e);
+                    int32_t src = -1;
+                    const int u = 16 * w + r16;   // hidden output unit of this wave
+                    switch (phase) {
+                    case 0:
+                        if (col < L.D && hid_deg(L, u) >= col + 1) src = (int32_t)(base + ro.in_w + (int64_t)u * L.D + col);
+                        break;
+                    case 1:
+                        if (col < L.C) src = (int32_t)(base + ro.c_w + (int64_t)u * L.C + col);
+                        break;
+                    case 4:
+                        if (col < L.C) src = (int32_t)(base + ro.g_w[blk] + (int64_t)u * L.C + col);
+                        break;
+                    case 2:
+                    case 3:
+                        if (hid_deg(L, u) >= hid_deg(L, col))
+                            src = (int32_t)(base + (phase == 2 ? ro.w0_w[blk] : ro.w1_w[blk]) + (int64_t)u * L.H + col);
+                        break;
+                    case 5: {
+                        const int m = out_param(L, t, r16);
+                        if (w < L.D && m >= 0 && (w + 1) > hid_deg(L, col))
+                            src = (int32_t)(base + ro.out_w + ((int64_t)w * L.M + m) * L.H + col);
+                        break;
+                    }
+                    }
+                    map[idx] = src;
+                }
+            }
+        }
+    }
+    // bias region
+    for (int l = 0; l < L.L; ++l) {
+        const int64_t base = (int64_t)l * ro.total;
+        for (int w = 0; w < L.NW; ++w) {
+            for (int s = 0; s < kBiasFloatsPerWave; ++s, ++idx) {
+                const int slot = s >> 4, r16 = s & 15;
+                const int u = 16 * w + r16;
+                int64_t src = -1;
+                if (slot == kSlotIn) src = ro.in_b + u;
+                else if (slot == kSlotCtx) { if (L.C > 0) src = ro.c_b + u; }
+                else if (slot >= kSlotBlk && slot < kSlotBlk + 3 * L.NB) {
+                    const int b = (slot - kSlotBlk) / 3, which = (slot - kSlotBlk) % 3;
+                    if (which == 0) src = ro.w0_b[b] + u;
+                    else if (which == 1) src = ro.w1_b[b] + u;
+                    else if (L.C > 0) src = ro.g_b[b] + u;
+                } else if (slot >= kSlotOut && slot < kSlotOut + 3) {
+                    const int m = out_param(L, slot - kSlotOut, r16);
+                    if (w < L.D && m >= 0) src = ro.out_b + (int64_t)w * L.M + m;
+                }
+                map[idx] = src < 0 ? -1 : (int32_t)(base + src);
+            }
+        }
+    }
+    return PF_OK;
+}
+
+int64_t pack_map_len(const FlowLayout& L) {
+    return L.fragsTotal * (L.bf16 ? 512 : 256) + L.biasFloats;
+}
+
+int64_t raw_param_count(const FlowLayout& L) { return raw_offsets(L).total * L.L; }
+
+// ---- device gather ------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict__ raw,
+                                                        const int32_t* __restrict__ map,
+                                                        __bf16* __restrict__ out, int64_t n) {
+    // 8 elements per thread -> one 16-B store
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i >= n) return;
+    const int4 m0 = *reinterpret_cast<const int4*>(map + i);
+    const int4 m1 = *reinterpret_cast<const int4*>(map + i + 4);
+    const int m[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+    typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+    bf16x8 v;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = (__bf16)(m[k] < 0 ? 0.0f : raw[m[k]]);
+    *reinterpret_cast<bf16x8*>(out + i) = v;
+}
+
+__global__ __launch_bounds__(256) void pack_f32_kernel(const float* __restrict__ raw,
+                                                       const int32_t* __restrict__ map,
+                                                       float* __restrict__ out, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    const int4 m = *reinterpret_cast<const int4*>(map + i);
+    float4 v;
+    v.x = m.x < 0 ? 0.0f : raw[m.x];
+    v.y = m.y < 0 ? 0.0f : raw[m.y];
+    v.z = m.z < 0 ? 0.0f : raw[m.z];
+    v.w = m.w < 0 ? 0.0f : raw[m.w];
+    *reinterpret_cast<float4*>(out + i) = v;
+}
+
+int launch_pack(const FlowLayout& L, const float* raw, const int32_t* map, void* packed,
+                hipStream_t stream) {
+    const int64_t nW = L.fragsTotal * (L.bf16 ? 512 : 256);
+    const int64_t nB = L.biasFloats;
+    if (L.bf16) {
+        const int64_t blocks = (nW / 8 + 255) / 256;
+        hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, raw, map,
+                           reinterpret_cast<__bf16*>(packed), nW);
+    } else {
+        const int64_t blocks = (nW / 4 + 255) / 256;
+        hipLaunchKernelGGL(pack_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, raw, map,
+                           reinterpret_cast<float*>(packed), nW);
+    }
+    float* bias_out = reinterpret_cast<float*>(reinterpret_cast<char*>(packed) + L.weightBytes);
+    const int64_t bblocks = (nB / 4 + 255) / 256;
+    hipLaunchKernelGGL(pack_f32_kernel, dim3((unsigned)bblocks), dim3(256), 0, stream, raw, map + nW,
+                       bias_out, nB);
+    return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
+}
+
+}  // namespace pf

@@ -1,0 +1,397 @@
+"""NSFPosteriorFlow on MI355X: the reference's flow API over the HIP C-ABI.
+
+Drop-in for ``ahsd.models.flows`` (reference ``src/ahsd/models/flows.py``):
+same constructor, methods, attributes and ``state_dict`` key names, but no
+tensor arithmetic happens in Python -- parameters live in ``nn.Parameter``s
+(for optimisers / checkpoints) and every evaluation is one call into
+``libpfhip.so`` (``include/pf_hip.h``).  There is no CPU path: calling the flow
+with the module or its inputs off the GPU raises.
+
+Reference line numbers below are for ``src/ahsd/models/flows.py``.
+"""
+from __future__ import annotations
+
+import logging
+import math
+import os
+from typing import Any, Dict, List, Optional, Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+FLOW_NORM_BOUND = 3.0       # src/ahsd/models/parameter_scalers.py:27
+_MIN_BIN = 1e-3             # nflows DEFAULT_MIN_{BIN_WIDTH,BIN_HEIGHT,DERIVATIVE}
+
+_log = logging.getLogger(__name__)
+
+
+# ----------------------------------------------------------------------------- #
+# parameter containers with nflows' module / buffer names (never called)
+# ----------------------------------------------------------------------------- #
+def _hidden_degrees(n: int, features: int) -> torch.Tensor:
+    return torch.arange(n) % max(1, features - 1) + min(1, features - 1)
+
+
+class _MaskedLinear(nn.Linear):
+    """Holds weight/bias + the ``mask`` / ``degrees`` buffers of nflows MaskedLinear.
+    The kernels rebuild the same masks from the degree rule (csrc/pf_pack.hip)."""
+
+    def __init__(self, in_degrees: torch.Tensor, out_features: int, features: int, is_output: bool):
+        super().__init__(len(in_degrees), out_features)
+        if is_output:
+            deg = torch.arange(1, features + 1).repeat_interleave(out_features // features)
+            mask = (deg[:, None] > in_degrees[None, :]).float()
+        else:
+            deg = _hidden_degrees(out_features, features)
+            mask = (deg[:, None] >= in_degrees[None, :]).float()
+        self.register_buffer("mask", mask)
+        self.register_buffer("degrees", deg)
+
+
+class _ResidualBlock(nn.Module):
+    def __init__(self, in_degrees, features, context_features):
+        super().__init__()
+        h = len(in_degrees)
+        if context_features:
+            self.context_layer = nn.Linear(context_features, h)
+        l0 = _MaskedLinear(in_degrees, h, features, False)
+        l1 = _MaskedLinear(l0.degrees, h, features, False)
+        self.linear_layers = nn.ModuleList([l0, l1])
+        nn.init.uniform_(l1.weight, -1e-3, 1e-3)      # nflows zero_initialization
+        nn.init.uniform_(l1.bias, -1e-3, 1e-3)
+
+
+class _MADE(nn.Module):
+    def __init__(self, features, hidden, context_features, multiplier, num_blocks=2):
+        super().__init__()
+        self.initial_layer = _MaskedLinear(torch.arange(1, features + 1), hidden, features, False)
+        if context_features:
+            self.context_layer = nn.Linear(context_features, hidden)
+        self.blocks = nn.ModuleList(
+            [_ResidualBlock(self.initial_layer.degrees, features, context_features)
+             for _ in range(num_blocks)])
+        self.final_layer = _MaskedLinear(self.initial_layer.degrees, features * multiplier,
+                                         features, True)
+
+    def ordered_parameters(self) -> List[torch.Tensor]:
+        """Raw layout of include/pf_hip.h ("raw parameter layout")."""
+        out = [self.initial_layer.weight, self.initial_layer.bias]
+        if hasattr(self, "context_layer"):
+            out += [self.context_layer.weight, self.context_layer.bias]
+        for b in self.blocks:
+            if hasattr(b, "context_layer"):
+                out += [b.context_layer.weight, b.context_layer.bias]
+            for lin in b.linear_layers:
+                out += [lin.weight, lin.bias]
+        return out + [self.final_layer.weight, self.final_layer.bias]
+
+
+class _SplineLayer(nn.Module):
+    def __init__(self, features, hidden, context_features, num_bins):
+        super().__init__()
+        self.autoregressive_net = _MADE(features, hidden, context_features, 3 * num_bins - 1)
+
+
+class _Reverse(nn.Module):
+    def __init__(self, features):
+        super().__init__()
+        self.register_buffer("_permutation", torch.arange(features - 1, -1, -1))
+
+
+class _Composite(nn.Module):
+    def __init__(self, transforms):
+        super().__init__()
+        self._transforms = nn.ModuleList(transforms)
+
+
+class _FlowAlias(nn.Module):
+    """nflows ``Flow(transform, base)`` registers the same modules a second time
+    (flows.py:532), so checkpoints carry ``flow._transform.*`` too."""
+
+    def __init__(self, transform):
+        super().__init__()
+        self._transform = transform
+
+
+# ----------------------------------------------------------------------------- #
+class PSDScaledNormal(nn.Module):
+    """Base density N(0, diag(exp(log_sigma))^2) (flows.py:28-109).  ``log_prob``
+    is two fused elementwise device ops; inside the flow's NLL it is fused into
+    the kernel epilogue instead (``pf_flow_forward(log_sigma=...)``)."""
+
+    def __init__(self, shape: Union[list, int]):
+        super().__init__()
+        self.shape = list(shape) if isinstance(shape, (list, tuple)) else [shape]
+        self.dim = self.shape[0]
+
+    def log_prob(self, z: torch.Tensor, log_sigma_psd: torch.Tensor) -> torch.Tensor:
+        if z.shape != log_sigma_psd.shape:
+            raise ValueError(f"Shape mismatch: z {z.shape} vs log_sigma_psd {log_sigma_psd.shape}")
+        quad = (z * torch.exp(-log_sigma_psd)).square().sum(dim=1)
+        return -0.5 * (quad + 2 * log_sigma_psd.sum(dim=1) + self.dim * math.log(2 * math.pi))
+
+    def sample(self, num_samples: int, log_sigma_psd: Optional[torch.Tensor] = None) -> torch.Tensor:
+        b = log_sigma_psd.shape[0] if log_sigma_psd is not None else 1
+        dev = log_sigma_psd.device if log_sigma_psd is not None else torch.device("cpu")
+        dt = log_sigma_psd.dtype if log_sigma_psd is not None else torch.float32
+        return torch.randn(b, num_samples, self.dim, device=dev, dtype=dt)
+
+
+# ----------------------------------------------------------------------------- #
+class _Packed:
+    """Device-side packed weights for one precision + the key they were built from."""
+
+    def __init__(self):
+        self.buf = None
+        self.map = None
+        self.key = None
+
+
+def _dev_ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+class NSFPosteriorFlow(nn.Module):
+    """Masked-autoregressive rational-quadratic-spline flow (flows.py:363-939).
+
+    ``precision``: ``"fp32"`` (exact f32 MFMA, matches the CPU path to ~1e-6) or
+    ``"bf16"`` (bf16 MFMA operands, fp32 accumulate: throughput mode).  Default
+    from ``$PF_FLOW_PRECISION`` or ``"fp32"``.
+    """
+
+    def __init__(self, features: int, context_features: int = 0, hidden_features: int = 256,
+                 num_layers: int = 12, num_bins: int = 16,
+                 tail_bound: Union[float, Dict[int, float]] = FLOW_NORM_BOUND,
+                 max_overlaps: int = 6, dropout: float = 0.0, temperature_scale: float = 1.5,
+                 use_masked_context: Optional[bool] = None, **kwargs):
+        super().__init__()
+        self.features = features
+        self.context_features = context_features
+        self.hidden_features = hidden_features
+        self.num_layers = num_layers
+        self.num_bins = num_bins
+        self.max_overlaps = max_overlaps
+        self.dropout = dropout
+        self.logger = _log
+        if use_masked_context is None:                                   # flows.py:409-411
+            use_masked_context = context_features > 0 and features > 0 and context_features % features == 0
+        self.use_masked_context = use_masked_context
+        if use_masked_context:
+            raise NotImplementedError(
+                "masked-context conditioner (flows.py:237-360) is not built; pass "
+                "use_masked_context=False (what LeanNPE does, lean_npe.py:294)")
+        if dropout and dropout > 0.0:
+            _log.warning("dropout=%s is applied by nflows in training mode only; the HIP path "
+                         "evaluates the conditioner without dropout", dropout)
+        # flows.py:425-435 -- per-parameter dict is kept for the API, its patching is a
+        # no-op in the reference (flows.py:502), so only the global bound takes effect.
+        if isinstance(tail_bound, dict):
+            self.per_param_tail_bounds = tail_bound
+            self.tail_bounds_list = [tail_bound.get(i, FLOW_NORM_BOUND) for i in range(features)]
+        else:
+            self.per_param_tail_bounds = None
+            self.tail_bounds_list = [tail_bound] * features
+        # flows.py:471/517: a non-float bound silently becomes FLOW_NORM_BOUND
+        self._tail_bound = tail_bound if isinstance(tail_bound, float) else FLOW_NORM_BOUND
+
+        self.temperature = nn.Parameter(torch.tensor(temperature_scale, dtype=torch.float32))
+        self.temperature_scale_init = temperature_scale
+        self.base_dist = PSDScaledNormal(shape=[features])
+
+        ctx = context_features if context_features > 0 else None
+        transforms, self._ar_transforms = [], []
+        for _ in range(num_layers):
+            transforms.append(_Reverse(features))
+            layer = _SplineLayer(features, hidden_features, ctx, num_bins)
+            transforms.append(layer)
+            self._ar_transforms.append(layer)
+        self.transform = _Composite(transforms)
+        self.flow = _FlowAlias(self.transform)
+        self.register_buffer("_ar_perm", torch.arange(features, dtype=torch.long))
+        self.register_buffer("_ar_inv_perm", torch.arange(features, dtype=torch.long))
+
+        self.precision = os.environ.get("PF_FLOW_PRECISION", "fp32")
+        self._packed: Dict[int, _Packed] = {}
+        self._perm_i32 = None
+
+    # ---- plumbing -------------------------------------------------------------
+    def _desc(self, precision: Optional[str] = None) -> _lib.PfFlowDesc:
+        prec = _lib.PRECISIONS[precision or self.precision]
+        return _lib.PfFlowDesc(self.features, self.context_features, self.hidden_features,
+                               self.num_bins, self.num_layers, 2, float(self._tail_bound),
+                               _MIN_BIN, _MIN_BIN, _MIN_BIN, prec, 0)
+
+    def _ordered_parameters(self) -> List[torch.Tensor]:
+        out = []
+        for layer in self._ar_transforms:
+            out += layer.autoregressive_net.ordered_parameters()
+        return out
+
+    def _device(self) -> torch.device:
+        dev = self.temperature.device
+        if dev.type != "cuda":
+            raise _lib.PfError(
+                "NSFPosteriorFlow is on %s: posteriflow_amd evaluates flows on the MI355X only "
+                "(no CPU fallback); move the module with .to('cuda')" % dev)
+        return dev
+
+    def packed_weights(self, precision: Optional[str] = None) -> torch.Tensor:
+        """Packed (masked, fragment-ordered) weights, rebuilt when a parameter changed."""
+        dev = self._device()
+        desc = self._desc(precision)
+        L = _lib.lib()
+        params = self._ordered_parameters()
+        key = (dev, tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
+        pk = self._packed.setdefault(desc.precision, _Packed())
+        if pk.key == key:
+            return pk.buf
+        if pk.map is None or pk.map.device != dev:
+            n = L.pf_flow_pack_map_len(desc)
+            if n < 0:
+                _lib.check(_lib.PF_ERR_UNSUPPORTED, "pf_flow_pack_map_len")
+            host = torch.empty(n, dtype=torch.int32)
+            _lib.check(L.pf_flow_build_pack_map(desc, host.data_ptr()), "pf_flow_build_pack_map")
+            pk.map = host.to(dev)
+            pk.buf = torch.empty(L.pf_flow_packed_bytes(desc), dtype=torch.uint8, device=dev)
+        raw = torch.cat([p.detach().reshape(-1).float() for p in params])
+        assert raw.numel() == L.pf_flow_raw_param_count(desc)
+        _lib.check(L.pf_flow_pack(desc, raw.data_ptr(), pk.map.data_ptr(), pk.buf.data_ptr(),
+                                  torch.cuda.current_stream(dev).cuda_stream), "pf_flow_pack")
+        pk.key = key
+        return pk.buf
+
+    def _perms(self, dev) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
+        if torch.equal(self._ar_perm.cpu(), torch.arange(self.features)):
+            return None, None
+        if self._perm_i32 is None or self._perm_i32[0].device != dev:
+            self._perm_i32 = (self._ar_perm.to(dev, torch.int32).contiguous(),
+                              self._ar_inv_perm.to(dev, torch.int32).contiguous())
+        return self._perm_i32
+
+    def _check_inputs(self, x, context, what):
+        dev = self._device()
+        if x.dim() != 2 or x.shape[1] != self.features:
+            raise ValueError(f"{what}: expected [batch, {self.features}], got {tuple(x.shape)}")
+        if x.device != dev:
+            raise _lib.PfError(f"{what}: input on {x.device}, flow on {dev}")
+        x = x.contiguous().float()
+        if self.context_features > 0 and context is not None:
+            if context.dim() != 2 or context.shape[1] != self.context_features:
+                raise ValueError(f"{what}: context must be [batch, {self.context_features}], "
+                                 f"got {tuple(context.shape)}")
+            if context.device != dev:
+                raise _lib.PfError(f"{what}: context on {context.device}, flow on {dev}")
+            context = context.contiguous().float()
+        elif self.context_features > 0:
+            raise ValueError(f"{what}: this flow was built with context_features="
+                             f"{self.context_features}; a context is required")
+        else:
+            context = None
+        return dev, x, context
+
+    def _grad_guard(self, *tensors):
+        if torch.is_grad_enabled() and (
+                any(t is not None and t.requires_grad for t in tensors)
+                or any(p.requires_grad for p in self._ordered_parameters())):
+            raise NotImplementedError(
+                "backward kernels for the flow are not built yet: call under torch.no_grad() "
+                "(DESIGN.md 'What comes next')")
+
+    def _forward_call(self, x, context, log_sigma, want_z=True):
+        dev, x, context = self._check_inputs(x, context, "NSFPosteriorFlow.forward")
+        B = x.shape[0]
+        if context is not None and context.shape[0] != B:
+            raise ValueError(f"batch mismatch: x {B} vs context {context.shape[0]}")
+        z = torch.empty_like(x) if want_z else None
+        logdet = torch.empty(B, dtype=torch.float32, device=dev)
+        nll = torch.empty(B, dtype=torch.float32, device=dev)
+        perm, _ = self._perms(dev)
+        packed = self.packed_weights()
+        _lib.check(_lib.lib().pf_flow_forward(
+            self._desc(), packed.data_ptr(), x.data_ptr(), _dev_ptr(context), _dev_ptr(perm),
+            _dev_ptr(log_sigma), B, _dev_ptr(z), logdet.data_ptr(), nll.data_ptr(),
+            torch.cuda.current_stream(dev).cuda_stream), "pf_flow_forward")
+        return z, logdet, nll
+
+    # ---- reference API ------------------------------------------------------------
+    def set_autoregressive_order(self, order: List[int]) -> None:            # flows.py:550-588
+        if sorted(order) != list(range(self.features)):
+            raise ValueError(f"order must be a permutation of range({self.features}), got {order}")
+        perm = torch.tensor(order, dtype=torch.long, device=self._ar_perm.device)
+        self._ar_perm = perm
+        self._ar_inv_perm = torch.argsort(perm)
+        self._perm_i32 = None
+
+    def _permute_context_blocks(self, context: torch.Tensor) -> torch.Tensor:  # flows.py:590-608
+        return context                                # plain-context conditioner: identity
+
+    def forward(self, x: torch.Tensor, context: Optional[torch.Tensor] = None):
+        """x -> (z, log|det dz/dx|)   (flows.py:610-618)."""
+        self._grad_guard(x, context)
+        z, logdet, _ = self._forward_call(x, context, None)
+        return z, logdet
+
+    def compute_psd_aware_nll(self, x, context, log_sigma_psd):
+        """-(log N(z; 0, Sigma_psd) + log|det|)   (flows.py:727-779); one kernel."""
+        self._grad_guard(x, context, log_sigma_psd)
+        ls = None
+        if log_sigma_psd is not None:
+            if log_sigma_psd.shape != x.shape:
+                raise ValueError(f"Shape mismatch: z {x.shape} vs log_sigma_psd {log_sigma_psd.shape}")
+            ls = log_sigma_psd.contiguous().float()
+        _, _, nll = self._forward_call(x, context, ls, want_z=False)
+        return nll
+
+    def log_prob(self, x, context=None, temperature: Optional[float] = None):
+        """Negative log-density with the temperature change of variables
+        (flows.py:657-695, to its documented math with the N(0, I) base)."""
+        self._grad_guard(x, context)
+        if context is not None and not torch.isfinite(context).all():
+            _log.warning("NSF.log_prob() detected NaN/Inf in context; replacing (shape %s)", tuple(context.shape))
+            context = torch.nan_to_num(context, nan=0.0, posinf=1e-3, neginf=-1e-3)
+        t = torch.clamp(self.temperature.detach(), 0.5, 3.0) if temperature is None \
+            else torch.as_tensor(float(temperature), device=x.device)
+        _, _, nll = self._forward_call(x / t, context, None, want_z=False)
+        out = -nll - self.features * torch.log(t)
+        return -torch.nan_to_num(out, nan=1000.0)
+
+    def compute_nll_loss(self, params_norm, context):                        # flows.py:900-908
+        return self.log_prob(params_norm, context).mean()
+
+    def compute_bounds_penalty(self, params_norm, bounds=(-FLOW_NORM_BOUND, FLOW_NORM_BOUND)):
+        lo, hi = bounds                                                      # flows.py:910-920
+        return torch.relu(lo - params_norm).mean() + torch.relu(params_norm - hi).mean()
+
+    # inverse / sampling entry points are added by flows_inverse once pf_flow_inverse is built
+    def inverse(self, z, context=None, n_overlaps=None):
+        raise NotImplementedError("pf_flow_inverse is not built yet")
+
+
+def create_flow_model(flow_type: str, features: int, context_features: int = 0,
+                      max_overlaps: int = 6, config: Optional[Any] = None, **kwargs) -> nn.Module:
+    """Factory with the reference's signature (flows.py:942-1022).  ``config`` may be a
+    mapping (or an object with attributes) holding a ``flow_config`` block with
+    num_layers / hidden_features / num_bins / dropout / tail_bound / per_param_tail_bounds."""
+    if config is not None:
+        if isinstance(config, (str, os.PathLike)):
+            import yaml
+            with open(config) as fh:
+                config = yaml.safe_load(fh)
+        fc = config.get("flow_config", {}) if isinstance(config, dict) else getattr(config, "flow_config", {})
+        fc = fc or {}
+        for name, default, cast in (("num_layers", 12, int), ("hidden_features", 256, int),
+                                    ("num_bins", 16, int), ("dropout", 0.15, float)):
+            kwargs.setdefault(name, cast(fc.get(name, default)))
+        per = fc.get("per_param_tail_bounds", None)
+        kwargs.setdefault("tail_bound", per if per else float(fc.get("tail_bound", FLOW_NORM_BOUND)))
+    kwargs.setdefault("num_layers", 12)
+    kwargs.setdefault("hidden_features", 256)
+    kwargs.setdefault("num_bins", 16)
+    kwargs.setdefault("tail_bound", FLOW_NORM_BOUND)
+    kwargs.setdefault("dropout", 0.15)
+    if flow_type.lower() != "nsf":
+        raise ValueError(f"Unknown flow_type: {flow_type}. Only 'nsf' is supported.")
+    return NSFPosteriorFlow(features=features, context_features=context_features,
+                            max_overlaps=max_overlaps, **kwargs)

@@ -1,0 +1,139 @@
+"""GPU parity: pf_flow_forward (through the NSFPosteriorFlow API and the C ABI) vs the
+CPU oracle on identical seeded inputs.
+
+Tolerances (written here on purpose):
+  fp32 mode   north_star's bar: 1e-5 relative on the NLL; z and log|det| are held to
+              the accuracy the fp32 CPU reference itself has against an fp64 evaluation
+              of the same weights (a few 1e-6 at default init), times a small factor.
+  bf16 mode   bf16 MFMA operands (8-bit mantissa): 2e-2 absolute on z, 5e-2 absolute on
+              log|det| / NLL per 10 layers -- a statistical tolerance, not a parity claim.
+"""
+import pytest
+import torch
+
+from helpers import flow_inputs, make_pair
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = {
+    # name: (D, C, H, L, K, tail_bound, batch)
+    "toy_cfg1": (4, 0, 64, 2, 8, 3.0, 256),            # BASELINE config 1
+    "leannpe_R": (11, 288, 256, 10, 16, 5.0, 300),     # reference default, ragged batch
+    "baseline_B2": (15, 288, 256, 8, 16, 5.0, 1024),   # BASELINE config 2 flow
+    "odd_shapes": (7, 40, 128, 3, 10, 2.5, 77),        # K=10, C not a multiple of 32
+}
+
+
+def run_case(name, precision, scale=1.0):
+    D, C, H, L, K, tb, B = CONFIGS[name]
+    ref, ref64, flow = make_pair(D, C, H, L, K, tb, scale=scale)
+    flow.precision = precision
+    x, ctx = flow_inputs(B, D, C, tb)
+    with torch.no_grad():
+        z32, ld32 = ref(x, ctx)
+        z64, ld64 = ref64(x.double(), None if ctx is None else ctx.double())
+        nll64 = ref64.compute_psd_aware_nll(x.double(), None if ctx is None else ctx.double(),
+                                            torch.zeros_like(x).double())
+        z, ld = flow(x.cuda(), None if ctx is None else ctx.cuda())
+        nll = flow.compute_psd_aware_nll(x.cuda(), None if ctx is None else ctx.cuda(),
+                                         torch.zeros_like(x).cuda())
+    z, ld, nll = z.cpu().double(), ld.cpu().double(), nll.cpu().double()
+    return dict(
+        ez=(z - z64).abs().max().item(), eld=(ld - ld64).abs().max().item(),
+        rnll=((nll - nll64).abs() / nll64.abs().clamp_min(1.0)).max().item(),
+        ez_ref=(z32.double() - z64).abs().max().item(),
+        eld_ref=(ld32.double() - ld64).abs().max().item(),
+        z=z, z64=z64)
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_forward_fp32_parity(name):
+    r = run_case(name, "fp32")
+    print(f"\n[{name} fp32] |z-z64| {r['ez']:.2e} (cpu fp32: {r['ez_ref']:.2e})  "
+          f"|ld-ld64| {r['eld']:.2e} (cpu fp32: {r['eld_ref']:.2e})  rel nll {r['rnll']:.2e}")
+    assert r["rnll"] < 1e-5
+    assert r["ez"] < max(4 * r["ez_ref"], 2e-5)
+    assert r["eld"] < max(4 * r["eld_ref"], 5e-5)
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_forward_bf16_tolerance(name):
+    r = run_case(name, "bf16")
+    print(f"\n[{name} bf16] |z-z64| {r['ez']:.2e}  |ld-ld64| {r['eld']:.2e}  rel nll {r['rnll']:.2e}")
+    assert r["ez"] < 2e-2 and r["eld"] < 5e-2 and r["rnll"] < 5e-3
+
+
+def test_tail_entries_are_identity_through_the_first_layer():
+    # a 1-layer flow: entries outside [-tb, tb] must come out bit-identical, with zero log-det
+    ref, _, flow = make_pair(6, 0, 64, 1, 8, 2.0)
+    x = torch.tensor([[2.5, -7.0, 0.3, 2.0, -2.0, 0.0]])
+    with torch.no_grad():
+        z, ld = flow(x.cuda())
+        zr, ldr = ref(x)
+    z = z.cpu()
+    # after ReversePermutation feature d sits at D-1-d; the wrapper's output is in layer order
+    assert z[0, 5] == 2.5 and z[0, 4] == -7.0
+    assert abs(z[0, 2].item() - 2.0) < 1e-6 and abs(z[0, 1].item() + 2.0) < 1e-6
+    assert torch.allclose(z, zr, atol=1e-5) and torch.allclose(ld.cpu(), ldr, atol=1e-5)
+
+
+def test_autoregressive_order_and_log_sigma():
+    D, C = 11, 288
+    ref, _, flow = make_pair(D, C, 256, 3, 16, 5.0)
+    order = [2, 0, 1, 10, 9, 3, 4, 8, 5, 7, 6]
+    ref.set_autoregressive_order(order)
+    flow.set_autoregressive_order(order)
+    x, ctx = flow_inputs(50, D, C, 5.0)
+    ls = torch.randn(50, D) * 0.3
+    with torch.no_grad():
+        want = ref.compute_psd_aware_nll(x, ctx, ls)
+        got = flow.compute_psd_aware_nll(x.cuda(), ctx.cuda(), ls.cuda()).cpu()
+        zr, _ = ref(x, ctx)
+        z, _ = flow(x.cuda(), ctx.cuda())
+    assert torch.allclose(z.cpu(), zr, atol=2e-5)
+    assert ((got - want).abs() / want.abs().clamp_min(1)).max() < 1e-5
+    with pytest.raises(ValueError):
+        flow.compute_psd_aware_nll(x.cuda(), ctx.cuda(), ls[:, :5].cuda())     # flows.py:68-71
+
+
+@pytest.mark.parametrize("B", [0, 1, 15, 17, 4097])
+def test_ragged_batches(B):
+    D, C = 11, 288
+    ref, _, flow = make_pair(D, C, 256, 2, 16, 5.0)
+    x, ctx = flow_inputs(B, D, C, 5.0, tails=B > 3)
+    with torch.no_grad():
+        z, ld = flow(x.cuda(), ctx.cuda())
+        assert z.shape == (B, D) and ld.shape == (B,)
+        if B:
+            zr, ldr = ref(x, ctx)
+            assert torch.allclose(z.cpu(), zr, atol=2e-5) and torch.allclose(ld.cpu(), ldr, atol=5e-5)
+
+
+def test_packed_weights_follow_parameter_updates():
+    ref, _, flow = make_pair(4, 0, 64, 2, 8, 3.0)
+    x, _ = flow_inputs(32, 4, 0, 3.0)
+    with torch.no_grad():
+        a = flow(x.cuda())[0].clone()
+        for p in flow.parameters():
+            if p.dim() == 2:
+                p.mul_(1.5)          # in-place optimiser-style update bumps ._version
+        for p in ref.parameters():
+            if p.dim() == 2:
+                p.mul_(1.5)
+        b = flow(x.cuda())[0]
+        assert not torch.allclose(a, b)
+        assert torch.allclose(b.cpu(), ref(x)[0], atol=2e-5)
+
+
+def test_errors_are_loud():
+    from posteriflow_amd import NSFPosteriorFlow
+    flow = NSFPosteriorFlow(11, 288, 256, 1, 16, 5.0, use_masked_context=False)
+    with pytest.raises(RuntimeError):            # module still on the CPU: no fallback
+        flow(torch.zeros(2, 11), torch.zeros(2, 288))
+    flow = flow.cuda()
+    with pytest.raises(ValueError):
+        flow(torch.zeros(2, 10).cuda(), torch.zeros(2, 288).cuda())
+    with pytest.raises(ValueError):
+        flow(torch.zeros(2, 11).cuda(), None)
+    with pytest.raises(NotImplementedError):
+        NSFPosteriorFlow(20, 0, 256, 1, 16, 5.0).cuda()(torch.zeros(2, 20).cuda())   # D > 16
