@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py -- flow.log_prob samples/sec at batch 4096 on N MI355X (BASELINE.json metric).
+
+One step = one pass of the hot path (NSFPosteriorFlow.compute_psd_aware_nll ==
+pf_flow_forward with the fused N(0,I) base log-density) over one batch of
+synthetic inputs already resident in HBM, followed -- when N > 1 -- by the RCCL
+all-reduce of (sum nll, count), the only exchange the path has.
+Workload: BASELINE config 3's flow (8-layer MAF-RQS, D=15, C=288, H=256, K=16,
+tail_bound 5) at batch 4096 PER GPU (weak scaling).
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  roofline     achieved = batch * dense-GEMM FLOP/sample / avg kernel time (HIP events)
+  cpu_baseline the CPU oracle (reference algorithm, fp32, all host cores) on the same batch
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+D, C, H, K, L, TB = 15, 288, 256, 16, 8, 5.0
+FINAL_LAYER_SCALE = 2.0       # DESIGN.md "Measurement": exercises the bin search, stays well-conditioned
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # MI355X_MICROARCH.md: dense MFMA peaks
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def host_threads():
+    """Threads for the CPU leg: the box's CPU share, not the host's core count (a GPU
+    box exposes the whole host in os.cpu_count() but grants ~16 cores per GPU)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:   # cgroup v2 quota
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("PF_BENCH_CPU_THREADS", "16"))))
+
+
+def flops_per_sample():
+    return 2 * L * (D * H + C * H + 2 * (2 * H * H + C * H) + H * D * (3 * K - 1))
+
+
+def make_inputs(batch, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(batch, D, generator=g) * 2 - 1
+    m = torch.rand(batch, D, generator=g) < 0.02
+    x = torch.where(m, (torch.rand(batch, D, generator=g) * 2 - 1) * 6.0, x)
+    ctx = torch.randn(batch, C, generator=g)
+    return x.to(device), ctx.to(device)
+
+
+def build_flow(device, precision):
+    from posteriflow_amd import NSFPosteriorFlow
+    torch.manual_seed(0)
+    flow = NSFPosteriorFlow(D, C, H, L, K, TB, temperature_scale=1.0, use_masked_context=False)
+    with torch.no_grad():
+        for layer in flow._ar_transforms:
+            layer.autoregressive_net.final_layer.weight.mul_(FINAL_LAYER_SCALE)
+            layer.autoregressive_net.final_layer.bias.mul_(FINAL_LAYER_SCALE)
+    flow = flow.to(device)
+    flow.precision = precision
+    return flow
+
+
+def cpu_baseline(flow, batch, budget_s=20.0):
+    """The oracle (CPU restatement of the reference's algorithm, fp32) on the host cores."""
+    from oracle.flow_ref import NSFPosteriorFlowRef
+    ref = NSFPosteriorFlowRef(D, C, H, L, K, TB, temperature_scale=1.0)
+    sd = {k: v.cpu() for k, v in flow.state_dict().items() if not k.startswith("flow.")}
+    ref.load_state_dict(sd)
+    cores = host_threads()
+    torch.set_num_threads(cores)
+    log(f"cpu baseline: {cores} threads (os.cpu_count()={os.cpu_count()})")
+    x, ctx = make_inputs(batch, 1, "cpu")
+    ls = torch.zeros_like(x)
+    times = []
+    with torch.no_grad():
+        for _ in range(2):
+            ref.compute_psd_aware_nll(x, ctx, ls)
+        t_end = time.time() + budget_s
+        while len(times) < 20 and (time.time() < t_end or len(times) < 3):
+            t0 = time.perf_counter()
+            ref.compute_psd_aware_nll(x, ctx, ls)
+            times.append(time.perf_counter() - t0)
+            log(f"cpu baseline iter {len(times)}: {times[-1] * 1e3:.1f} ms")
+    med = statistics.median(times)
+    return {"value": batch / med, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"batch {batch}, fp32, {len(times)} iterations after 2 warm-ups (median)",
+            "ms_per_batch": med * 1e3}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=4096, help="rows per GPU")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a HIP graph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    log(f"rank {rank}/{world} on {torch.cuda.get_device_name(dev)}")
+    flow = build_flow(dev, args.precision).freeze_packed()
+    log("weights packed")
+    x, ctx = make_inputs(args.batch, 1 + rank, dev)
+    nll = torch.empty(args.batch, device=dev)
+    red = torch.zeros(2, device=dev, dtype=torch.float64)
+
+    def step():
+        flow.nll_into(x, ctx, nll)
+        if world > 1:
+            red[0] = nll.sum(dtype=torch.float64)
+            red[1] = float(args.batch)
+            dist.all_reduce(red)
+
+    # one HIP graph per step on N=1 (the step is a single ~100 us kernel: eager launch
+    # overhead would otherwise be inside the measurement); eager with collectives
+    use_graph = not args.no_graph and world == 1
+    graph = None
+    stream = torch.cuda.Stream(dev)
+    with torch.cuda.stream(stream):
+        step()
+        stream.synchronize()
+        if use_graph:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                step()
+        log("step captured" if use_graph else "eager steps")
+        run = graph.replay if graph is not None else step
+        for _ in range(args.warmup):
+            run()
+        stream.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record(stream)
+        for _ in range(args.steps):
+            run()
+        e1.record(stream)
+        stream.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    dev_ms = e0.elapsed_time(e1)
+    log(f"timed {args.steps} steps: {elapsed * 1e3 / args.steps:.4f} ms/step (device {dev_ms / args.steps:.4f})")
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    # kernel-only duration: HIP events bracketing back-to-back launches of the kernel alone
+    with torch.cuda.stream(stream):
+        k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n_k = max(20, min(args.steps, 200))
+        for _ in range(5):
+            flow.nll_into(x, ctx, nll)
+        kg = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(kg, stream=stream):
+            for _ in range(n_k):
+                flow.nll_into(x, ctx, nll)
+        kg.replay()
+        stream.synchronize()
+        k0.record(stream)
+        kg.replay()
+        k1.record(stream)
+        stream.synchronize()
+        kernel_ms = k0.elapsed_time(k1) / n_k
+    log(f"kernel-only: {kernel_ms * 1e3:.2f} us")
+
+    if rank == 0:
+        fl = flops_per_sample()
+        ach = args.batch * fl / (kernel_ms * 1e-3) / 1e12
+        peak = PEAK_TFLOPS[args.precision]
+        out = {
+            "metric": "flow.log_prob samples/sec at batch 4096",
+            "value": world * args.batch * args.steps / elapsed,
+            "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if args.precision == "bf16" else "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE config 3 flow: 8-layer MAF-RQS, D=15, C=288, H=256, K=16, "
+                                   "tail_bound 5, context resident in HBM",
+                       "batch_per_gpu": args.batch, "global_batch": args.batch * world,
+                       "rows_per_workgroup": int(__import__("posteriflow_amd")._lib.lib().pf_flow_rows_per_workgroup(
+                           flow._desc(), args.batch)),
+                       "launch": "hipGraph" if graph is not None else "eager",
+                       "parallelism": f"dp{world}"},
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                         "frac": ach / peak, "traffic": None,
+                         "kernel": "pf::flow_forward_kernel", "kernel_ms": kernel_ms,
+                         "flop_per_sample": fl, "device_ms_per_step": dev_ms / args.steps},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(flow, args.batch)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

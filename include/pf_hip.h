@@ -42,9 +42,9 @@ extern "C" {
  * conditioner: nflows MADE, num_blocks residual blocks with GLU context gate,
  * ReversePermutation in front of every layer, tails='linear'. */
 typedef struct PfFlowDesc {
-    int32_t features;          /* D  (1..16)                                   */
+    int32_t features;          /* D  (1..H/16)                                 */
     int32_t context_features;  /* C  (0 = unconditional)                       */
-    int32_t hidden_features;   /* H  (64 or 256 in this build)                 */
+    int32_t hidden_features;   /* H  (64, 128, 192 or 256 in this build)       */
     int32_t num_bins;          /* K  (2..16)                                   */
     int32_t num_layers;        /* L                                            */
     int32_t num_blocks;        /* residual blocks per MADE (2)                 */

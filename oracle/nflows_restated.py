@@ -26,9 +26,47 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+import contextlib
+
 DEFAULT_MIN_BIN_WIDTH = 1e-3
 DEFAULT_MIN_BIN_HEIGHT = 1e-3
 DEFAULT_MIN_DERIVATIVE = 1e-3
+
+
+# --------------------------------------------------------------------------- #
+# optional emulation of the HIP bf16 mode's operand rounding (NOT part of the
+# reference algorithm): operands of every conditioner GEMM are rounded to bf16
+# (round-to-nearest-even), products accumulate in fp32, biases / residual state
+# stay fp32; the initial layer's x is split hi + lo (two bf16 terms) exactly as
+# the kernel does (csrc/pf_flow_fwd.hip).  Lets the bf16 kernel be checked
+# tightly against "the same arithmetic on the CPU".
+# --------------------------------------------------------------------------- #
+_EMULATE = None
+
+
+@contextlib.contextmanager
+def gemm_emulation(mode):
+    global _EMULATE
+    prev, _EMULATE = _EMULATE, mode
+    try:
+        yield
+    finally:
+        _EMULATE = prev
+
+
+def _bf16(t):
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+def linear(x, w, b, split_input=False):
+    if _EMULATE == "bf16":
+        if split_input:
+            hi = _bf16(x)
+            x = hi + _bf16(x - hi)
+        else:
+            x = _bf16(x)
+        w = _bf16(w)
+    return F.linear(x, w, b)
 
 
 # --------------------------------------------------------------------------- #
@@ -59,6 +97,8 @@ def mask_and_degrees(in_degrees: torch.Tensor, out_features: int,
 class MaskedLinear(nn.Linear):
     """upstream made.MaskedLinear: ``F.linear(x, weight * mask, bias)``."""
 
+    split_input = False   # set on MADE.initial_layer (bf16 emulation only)
+
     def __init__(self, in_degrees, out_features, autoregressive_features, is_output):
         super().__init__(len(in_degrees), out_features, bias=True)
         mask, degrees = mask_and_degrees(in_degrees, out_features,
@@ -67,7 +107,7 @@ class MaskedLinear(nn.Linear):
         self.register_buffer("degrees", degrees)
 
     def forward(self, x):
-        return F.linear(x, self.weight * self.mask, self.bias)
+        return linear(x, self.weight * self.mask, self.bias, self.split_input)
 
 
 class MaskedResidualBlock(nn.Module):
@@ -98,7 +138,8 @@ class MaskedResidualBlock(nn.Module):
         t = self.dropout(t)
         t = self.linear_layers[1](t)
         if context is not None:
-            t = F.glu(torch.cat((t, self.context_layer(context)), dim=1), dim=1)
+            gate = linear(context, self.context_layer.weight, self.context_layer.bias)
+            t = F.glu(torch.cat((t, gate), dim=1), dim=1)
         return inputs + t
 
 
@@ -110,6 +151,7 @@ class MADE(nn.Module):
         super().__init__()
         self.initial_layer = MaskedLinear(input_degrees(features), hidden_features,
                                           features, False)
+        self.initial_layer.split_input = True
         if context_features is not None:
             self.context_layer = nn.Linear(context_features, hidden_features)
         blocks, prev = [], self.initial_layer.degrees
@@ -124,7 +166,7 @@ class MADE(nn.Module):
     def forward(self, inputs, context=None):
         h = self.initial_layer(inputs)
         if context is not None:
-            h = h + F.relu(self.context_layer(context))
+            h = h + F.relu(linear(context, self.context_layer.weight, self.context_layer.bias))
         for block in self.blocks:
             h = block(h, context)
         return self.final_layer(h)

@@ -25,6 +25,8 @@
 //   is evaluated in registers by those 4 lanes with cross-lane shuffles.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "pf_flow_params.h"
 
 namespace pf {
@@ -414,8 +416,13 @@ int rows_per_workgroup(const FlowLayout& L, int64_t batch) {
     // B <= 256 CUs * 16 rows: one 16-row group per CU (weight-ingest bound);
     // larger batches amortise each streamed fragment over R column groups.
     int R = 1;
+    if (const char* f = getenv("PF_FORCE_R")) {          // test knob: force the column-group count
+        R = atoi(f);
+        if (R != 1 && R != 2 && R != 4) R = 1;
+        return 16 * R;
+    }
     if (batch > 256 * 16) R = 2;
-    if (batch > 256 * 32 * 2 && L.NW < 16) R = 4;   // R = 4 spills at 16 waves (128-VGPR cap)
+    if (batch > 256 * 32 * 2 && L.NW < 12) R = 4;   // R = 4 spills at >= 12 waves (VGPR cap)
     while (R > 1 && fwd_lds_bytes(L, R) > 160 * 1024) R >>= 1;
     return 16 * R;
 }
@@ -449,6 +456,7 @@ int launch_flow_forward(const FwdParams& p, hipStream_t s) {
     const bool bf = p.lay.bf16;
     switch (p.lay.NW) {
     case 16: return bf ? launch_nw<true, 16>(p, R, s) : launch_nw<false, 16>(p, R, s);
+    case 12: return bf ? launch_nw<true, 12>(p, R, s) : launch_nw<false, 12>(p, R, s);
     case 8:  return bf ? launch_nw<true, 8>(p, R, s) : launch_nw<false, 8>(p, R, s);
     case 4:  return bf ? launch_nw<true, 4>(p, R, s) : launch_nw<false, 4>(p, R, s);
     default: return PF_ERR_UNSUPPORTED;

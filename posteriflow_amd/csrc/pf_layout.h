@@ -61,7 +61,8 @@ struct FlowLayout {
 // returns 0 on success, PF_ERR_* otherwise
 inline PF_HD int make_layout(const PfFlowDesc& d, FlowLayout& o) {
     if (d.features < 1 || d.features > 16) return PF_ERR_UNSUPPORTED;
-    if (d.hidden_features != 64 && d.hidden_features != 128 && d.hidden_features != 256)
+    if (d.hidden_features != 64 && d.hidden_features != 128 && d.hidden_features != 192 &&
+        d.hidden_features != 256)
         return PF_ERR_UNSUPPORTED;
     if (d.num_bins < 2 || d.num_bins > 16) return PF_ERR_UNSUPPORTED;
     if (d.num_layers < 1 || d.context_features < 0 || d.num_blocks != 2) return PF_ERR_UNSUPPORTED;

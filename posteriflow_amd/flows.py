@@ -215,6 +215,34 @@ class NSFPosteriorFlow(nn.Module):
         self.precision = os.environ.get("PF_FLOW_PRECISION", "fp32")
         self._packed: Dict[int, _Packed] = {}
         self._perm_i32 = None
+        self._frozen = False
+
+    def freeze_packed(self, frozen: bool = True) -> "NSFPosteriorFlow":
+        """Inference: keep the packed weights as they are and skip the per-call scan for
+        parameter updates (call again with False, or load new weights, to re-pack)."""
+        if frozen:
+            self.packed_weights()
+        self._frozen = frozen
+        return self
+
+    def nll_into(self, x: torch.Tensor, context: Optional[torch.Tensor], out: torch.Tensor,
+                 log_sigma: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """compute_psd_aware_nll into a preallocated fp32 ``out[B]`` with no allocation and no
+        host-side checks beyond shapes: the call a serving / benchmark loop (or a HIP-graph
+        capture) issues.  Inputs must already be contiguous fp32 on the flow's device."""
+        B = x.shape[0]
+        if x.shape[1] != self.features or out.shape[0] != B or not x.is_contiguous():
+            raise ValueError("nll_into: bad shapes / non-contiguous input")
+        if self.context_features > 0 and (context is None or context.shape != (B, self.context_features)
+                                          or not context.is_contiguous()):
+            raise ValueError("nll_into: bad context")
+        dev = x.device
+        perm, _ = self._perms(dev)
+        _lib.check(_lib.lib().pf_flow_forward(
+            self._desc(), self.packed_weights().data_ptr(), x.data_ptr(), _dev_ptr(context),
+            _dev_ptr(perm), _dev_ptr(log_sigma), B, None, None, out.data_ptr(),
+            torch.cuda.current_stream(dev).cuda_stream), "pf_flow_forward")
+        return out
 
     # ---- plumbing -------------------------------------------------------------
     def _desc(self, precision: Optional[str] = None) -> _lib.PfFlowDesc:
@@ -239,8 +267,10 @@ class NSFPosteriorFlow(nn.Module):
 
     def packed_weights(self, precision: Optional[str] = None) -> torch.Tensor:
         """Packed (masked, fragment-ordered) weights, rebuilt when a parameter changed."""
-        dev = self._device()
         desc = self._desc(precision)
+        if self._frozen and desc.precision in self._packed and self._packed[desc.precision].buf is not None:
+            return self._packed[desc.precision].buf
+        dev = self._device()
         L = _lib.lib()
         params = self._ordered_parameters()
         key = (dev, tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
@@ -263,12 +293,21 @@ class NSFPosteriorFlow(nn.Module):
         return pk.buf
 
     def _perms(self, dev) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
-        if torch.equal(self._ar_perm.cpu(), torch.arange(self.features)):
-            return None, None
-        if self._perm_i32 is None or self._perm_i32[0].device != dev:
-            self._perm_i32 = (self._ar_perm.to(dev, torch.int32).contiguous(),
-                              self._ar_inv_perm.to(dev, torch.int32).contiguous())
-        return self._perm_i32
+        """(ar_perm, ar_inv_perm) as int32 device tensors, or (None, None) for identity.
+        Resolved once (one D2H copy) and cached until the order / device / weights change."""
+        if self._perm_i32 is None or self._perm_i32[0] != dev:
+            perm = self._ar_perm.detach().cpu()
+            if torch.equal(perm, torch.arange(self.features)):
+                self._perm_i32 = (dev, None, None)
+            else:
+                self._perm_i32 = (dev, self._ar_perm.to(dev, torch.int32).contiguous(),
+                                  self._ar_inv_perm.to(dev, torch.int32).contiguous())
+        return self._perm_i32[1], self._perm_i32[2]
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        self._perm_i32 = None          # _ar_perm may have come from the checkpoint
+        self._frozen = False
 
     def _check_inputs(self, x, context, what):
         dev = self._device()
@@ -301,6 +340,7 @@ class NSFPosteriorFlow(nn.Module):
 
     def _forward_call(self, x, context, log_sigma, want_z=True):
         dev, x, context = self._check_inputs(x, context, "NSFPosteriorFlow.forward")
+        self._grad_guard(x, context, log_sigma)
         B = x.shape[0]
         if context is not None and context.shape[0] != B:
             raise ValueError(f"batch mismatch: x {B} vs context {context.shape[0]}")
@@ -329,13 +369,11 @@ class NSFPosteriorFlow(nn.Module):
 
     def forward(self, x: torch.Tensor, context: Optional[torch.Tensor] = None):
         """x -> (z, log|det dz/dx|)   (flows.py:610-618)."""
-        self._grad_guard(x, context)
         z, logdet, _ = self._forward_call(x, context, None)
         return z, logdet
 
     def compute_psd_aware_nll(self, x, context, log_sigma_psd):
         """-(log N(z; 0, Sigma_psd) + log|det|)   (flows.py:727-779); one kernel."""
-        self._grad_guard(x, context, log_sigma_psd)
         ls = None
         if log_sigma_psd is not None:
             if log_sigma_psd.shape != x.shape:
@@ -347,7 +385,6 @@ class NSFPosteriorFlow(nn.Module):
     def log_prob(self, x, context=None, temperature: Optional[float] = None):
         """Negative log-density with the temperature change of variables
         (flows.py:657-695, to its documented math with the N(0, I) base)."""
-        self._grad_guard(x, context)
         if context is not None and not torch.isfinite(context).all():
             _log.warning("NSF.log_prob() detected NaN/Inf in context; replacing (shape %s)", tuple(context.shape))
             context = torch.nan_to_num(context, nan=0.0, posinf=1e-3, neginf=-1e-3)
