@@ -13,9 +13,9 @@ int fail(int code, const char* msg) {
     std::snprintf(g_err, sizeof(g_err), "%s", msg);
     return code;
 }
-int layout_of(const PfFlowDesc* d, pf::FlowLayout& L) {
+int layout_of(const PfFlowDesc* d, pf::FlowPlan& L) {
     if (!d) return fail(PF_ERR_BAD_ARG, "desc is null");
-    const int rc = pf::make_layout(*d, L);
+    const int rc = pf::make_plan(*d, L);
     if (rc != PF_OK)
         return fail(rc, "unsupported flow shape (need D<=H/16, H in {64,128,192,256}, K<=16, num_blocks=2)");
     if (!(d->tail_bound > 0.f)) return fail(PF_ERR_BAD_ARG, "tail_bound must be positive");
@@ -32,29 +32,29 @@ const char* pf_last_error(void) { return g_err; }
 const char* pf_version(void) { return "posteriflow_amd 0.1 (gfx950)"; }
 
 int64_t pf_flow_raw_param_count(const PfFlowDesc* desc) {
-    pf::FlowLayout L;
+    pf::FlowPlan L;
     if (layout_of(desc, L) != PF_OK) return -1;
     return pf::raw_param_count(L);
 }
 int64_t pf_flow_packed_bytes(const PfFlowDesc* desc) {
-    pf::FlowLayout L;
+    pf::FlowPlan L;
     if (layout_of(desc, L) != PF_OK) return -1;
     return L.weightBytes + L.biasFloats * (int64_t)sizeof(float);
 }
 int64_t pf_flow_pack_map_len(const PfFlowDesc* desc) {
-    pf::FlowLayout L;
+    pf::FlowPlan L;
     if (layout_of(desc, L) != PF_OK) return -1;
     return pf::pack_map_len(L);
 }
 int pf_flow_build_pack_map(const PfFlowDesc* desc, int32_t* map_host) {
-    pf::FlowLayout L;
+    pf::FlowPlan L;
     int rc = layout_of(desc, L);
     if (rc != PF_OK) return rc;
     if (!map_host) return fail(PF_ERR_BAD_ARG, "map_host is null");
     return pf::build_pack_map(L, map_host);
 }
 int pf_flow_pack(const PfFlowDesc* desc, const float* raw, const int32_t* map, void* packed, void* stream) {
-    pf::FlowLayout L;
+    pf::FlowPlan L;
     int rc = layout_of(desc, L);
     if (rc != PF_OK) return rc;
     if (!raw || !map || !packed) return fail(PF_ERR_BAD_ARG, "null pointer");
@@ -66,7 +66,7 @@ int pf_flow_pack(const PfFlowDesc* desc, const float* raw, const int32_t* map, v
 int pf_flow_forward(const PfFlowDesc* desc, const void* packed, const float* x, const float* ctx,
                     const int32_t* ar_perm, const float* log_sigma, int64_t batch, float* z,
                     float* logdet, float* nll, void* stream) {
-    pf::FlowLayout L;
+    pf::FlowPlan L;
     int rc = layout_of(desc, L);
     if (rc != PF_OK) return rc;
     if (batch < 0) return fail(PF_ERR_BAD_ARG, "negative batch");
@@ -77,7 +77,7 @@ int pf_flow_forward(const PfFlowDesc* desc, const void* packed, const float* x, 
     pf::FwdParams p{};
     p.packed = static_cast<const char*>(packed);
     p.x = x; p.ctx = ctx; p.ar_perm = ar_perm; p.log_sigma = log_sigma; p.z = z; p.logdet = logdet; p.nll = nll;
-    p.batch = batch; p.lay = L;
+    p.batch = batch; p.plan = L;
     p.tail_bound = desc->tail_bound; p.min_w = desc->min_bin_width; p.min_h = desc->min_bin_height;
     p.min_d = desc->min_derivative;
     p.deriv_const = (float)std::log(std::exp(1.0 - (double)desc->min_derivative) - 1.0);
@@ -94,7 +94,7 @@ int pf_flow_inverse(const PfFlowDesc* desc, const void* packed, const float* z, 
 }
 
 int32_t pf_flow_rows_per_workgroup(const PfFlowDesc* desc, int64_t batch) {
-    pf::FlowLayout L;
+    pf::FlowPlan L;
     if (layout_of(desc, L) != PF_OK) return -1;
     return pf::rows_per_workgroup(L, batch);
 }

@@ -15,10 +15,16 @@
 //   Everything is computed TRANSPOSED: out^T[unit, row] = W[unit, k] . act^T[k, row],
 //   so the weights are the MFMA A operand (streamed from L2 exactly once per
 //   workgroup, in pre-packed fragment order, straight into VGPRs) and the batch
-//   rows are the 16 MFMA columns.  Wave w owns hidden units 16w..16w+15: its
-//   residual state h lives in 4*R fp32 accumulator registers for the whole
-//   layer; activations are exchanged between waves through LDS in B-fragment
-//   order (one barrier per GEMM).  In the final masked layer wave w owns spline
+//   rows are the 16 MFMA columns.  Wave w owns 16 hidden units (degree-sorted
+//   positions 16w..16w+15, pf_layout.h): its residual state h lives in 4*R fp32
+//   accumulator registers for the whole layer; activations are exchanged between
+//   waves through LDS in B-fragment order (one barrier per GEMM).
+//   Weight streaming: each wave walks ONE linear fragment stream with a static,
+//   fully unrolled per-layer schedule and keeps kWindow = 12 fragment loads
+//   (12 KiB) in flight in a register window across phases, barriers and layer
+//   boundaries.  Entries that the autoregressive masks make all-zero for this
+//   wave are issued as out-of-range buffer loads (no memory traffic, same
+//   instruction stream, exact vmcnt accounting) and their MFMAs are skipped.  In the final masked layer wave w owns spline
 //   feature w: its 3K-1 raw parameters come out of three 16-row MFMA tiles
 //   (widths | heights | derivatives) spread over the 4 lane groups of a column,
 //   and the spline (softmax, cumsum, bin search, rational quadratic, log-det)
@@ -26,6 +32,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "pf_flow_params.h"
 
@@ -153,18 +160,31 @@ __device__ __forceinline__ void rqs_forward(const float (&uw)[4], const float (&
 //   act0/1: HK * R KiB each      activations in B-fragment order (double buffer)
 //   xb0/1 : 16 * 16R floats each layer input x^T / output z^T (double buffer)
 //   ldb   : NW * 16R floats      per-wave log-det partials
-template <bool BF16, int NW, int R>
+template <int B, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, N - 1>(f);
+    }
+}
+
+template <bool BF16, int NW, int R, int CKM>
 __global__ __launch_bounds__(NW * 64) void flow_forward_kernel(const FwdParams p) {
+    // 1024-thread workgroups have 128 VGPRs per lane; the f32 mode is MFMA-bound anyway
+    constexpr int W = NW >= 16 ? (BF16 ? 8 : 4) : kWindow;
+    using S = Sched<BF16, NW, CKM, W>;
     constexpr bool FAST = BF16;
-    constexpr int HK = BF16 ? NW / 2 : NW;           // frags per hidden tile
+    constexpr int HK = S::HK;
     constexpr int COLS = 16 * R;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const FlowLayout& L = p.lay;
+    const FlowPlan& L = p.plan;
     const int CK = L.CK, D = L.D, K = L.K;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, c = lane & 15;
     const int64_t row0 = (int64_t)blockIdx.x * COLS;
+    const int kH = L.kmaxH[wave], kO = L.kmaxO[wave];
+    const int feat = L.feat[wave];                  // spline feature of this wave (-1: none)
 
     char* s_ctx = smem;
     char* s_act0 = s_ctx + (size_t)CK * R * kFragBytes;
@@ -172,6 +192,31 @@ __global__ __launch_bounds__(NW * 64) void flow_forward_kernel(const FwdParams p
     float* s_xb0 = reinterpret_cast<float*>(s_act1 + (size_t)HK * R * kFragBytes);
     float* s_xb1 = s_xb0 + 16 * COLS;
     float* s_ldb = s_xb1 + 16 * COLS;
+
+    // ---- weight stream: buffer resource over this wave's region, register window ---------
+    const int64_t wave_frags = (int64_t)L.L * L.fragsPerLayer[wave] + kWindow;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(p.packed) + L.waveBase[wave] * kFragBytes, 0, (int)(wave_frags * kFragBytes), 0x00020000);
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    u32x4 win[W];
+    int soff = 0;                                   // wave-uniform byte position in the stream
+    auto active = [&](int kind, int ks) -> bool {
+        return kind == kAlways || (kind == kCtx && ks < CK) || (kind == kHid && ks < kH) ||
+               (kind == kOut && ks < kO);
+    };
+    // issue the load of schedule entry EN (of the layer `ok` refers to) into its window slot
+    auto fetch = [&](auto en, bool ok) {
+        constexpr int EN = decltype(en)::value;
+        const bool a = ok && active(S::kind(EN), S::ks(EN)) && !(p.ablate & 2);
+        if (p.ablate & 16) {      // experiment: OOB load instead of a branch
+            const int voff = a ? lane * 16 : 0x40000000;
+            win[EN % W] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+            soff += a ? kFragBytes : 0;
+        } else if (a) {
+            win[EN % W] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, soff, 0);
+            soff += kFragBytes;
+        }
+    };
 
     // ---- stage context (B-fragment order) and x^T ---------------------------------
     for (int s = tid; s < CK * R * 64; s += NW * 64) {
@@ -212,32 +257,32 @@ __global__ __launch_bounds__(NW * 64) void flow_forward_kernel(const FwdParams p
         s_xb0[s] = v;
         s_xb1[s] = 0.f;
     }
+    // prologue of the weight stream: first window of layer 0
+    static_for<0, W>([&](auto e) { fetch(e, true); });
     __syncthreads();
 
     float ld_acc[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) ld_acc[r] = 0.f;
-
-    const uint4* wbase = reinterpret_cast<const uint4*>(p.packed);
     const float* bbase = reinterpret_cast<const float*>(p.packed + L.weightBytes);
 
-    // one MFMA "tile GEMM": acc[r] += A(frags) . B(lds buffer), KK frags
-    auto tile_gemm = [&](const uint4* wf, int KK, const char* bsrc, f32x4 (&acc)[R]) {
-        for (int ks = 0; ks < KK; ++ks) {
-            const uint4 a = wf[(size_t)ks * 64];
+    // acc[r] += A(window slot of entry E) . B(lds fragment ks)
+    auto mma = [&](auto e, int ks, const char* bsrc, f32x4 (&acc)[R]) {
+        constexpr int E = decltype(e)::value;
+        const u32x4 a = win[E % W];
+        if (p.ablate & 4) { asm volatile("" :: "v"(a)); return; }
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const char* bp = bsrc + ((size_t)(ks * R + r) * 64 + lane) * 16;
-                if (BF16) {
-                    const bf16x8 b = *reinterpret_cast<const bf16x8*>(bp);
-                    acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), b, acc[r], 0, 0, 0);
-                } else {
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(bp);
-                    const f32x4 af = __builtin_bit_cast(f32x4, a);
+        for (int r = 0; r < R; ++r) {
+            const char* bp = bsrc + ((size_t)(ks * R + r) * 64 + lane) * 16;
+            if (BF16) {
+                const bf16x8 b = *reinterpret_cast<const bf16x8*>(bp);
+                acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), b, acc[r], 0, 0, 0);
+            } else {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(bp);
+                const f32x4 af = __builtin_bit_cast(f32x4, a);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], b[e], acc[r], 0, 0, 0);
-                }
+                for (int q = 0; q < 4; ++q)
+                    acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q], b[q], acc[r], 0, 0, 0);
             }
         }
     };
@@ -258,17 +303,34 @@ __global__ __launch_bounds__(NW * 64) void flow_forward_kernel(const FwdParams p
     auto load_bias = [&](const float* bp, int slot) {
         return *reinterpret_cast<const f32x4*>(bp + slot * 16 + 4 * g);
     };
+    auto zero = [&](f32x4 (&v)[R]) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
 
     for (int l = 0; l < L.L; ++l) {
-        const uint4* wf = wbase + L.frag_index(l, wave, 0) * 64 + lane;
         const float* bp = bbase + L.bias_index(l, wave);
         float* xin = (l & 1) ? s_xb1 : s_xb0;
         float* xout = (l & 1) ? s_xb0 : s_xb1;
+        const bool more = l + 1 < L.L;
+        // consume entries [E0, E0+N) of one GEMM (k-step = entry index - E0), refill the window
+        auto gemm = [&](auto e0, auto n, int kcount, const char* bsrc, f32x4 (&acc)[R]) {
+            constexpr int E0 = decltype(e0)::value, N = decltype(n)::value;
+            static_for<0, N>([&](auto k) {
+                constexpr int KI = decltype(k)::value;
+                if (KI < kcount) mma(std::integral_constant<int, E0 + KI>{}, KI, bsrc, acc);
+                constexpr int NX = E0 + KI + W;
+                if constexpr (NX < S::NE) fetch(std::integral_constant<int, NX>{}, true);
+                else fetch(std::integral_constant<int, NX - S::NE>{}, more);
+            });
+        };
+        using I = std::integral_constant<int, 0>;
+        (void)sizeof(I);
 
         // ---- initial layer: h = W_in x + b_in + relu(W_c ctx + b_c) ---------------------
         f32x4 h[R];
         {
-            const uint4 a = wf[(size_t)L.oIn * 64];
+            const u32x4 a = win[S::E_IN % W];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -289,14 +351,14 @@ __global__ __launch_bounds__(NW * 64) void flow_forward_kernel(const FwdParams p
                 }
                 h[r] = acc;
             }
+            fetch(std::integral_constant<int, (S::E_IN + W) % S::NE>{}, S::E_IN + W < S::NE ? true : more);
             const f32x4 b_in = load_bias(bp, kSlotIn);
 #pragma unroll
             for (int r = 0; r < R; ++r) h[r] += b_in;
+            f32x4 cacc[R];
+            zero(cacc);
+            gemm(std::integral_constant<int, S::E_CTX>{}, std::integral_constant<int, CKM>{}, CK, s_ctx, cacc);
             if (CK > 0) {
-                f32x4 cacc[R];
-#pragma unroll
-                for (int r = 0; r < R; ++r) cacc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
-                tile_gemm(wf + (size_t)L.oCtx * 64, CK, s_ctx, cacc);
                 const f32x4 b_c = load_bias(bp, kSlotCtx);
 #pragma unroll
                 for (int r = 0; r < R; ++r)
@@ -306,19 +368,18 @@ __global__ __launch_bounds__(NW * 64) void flow_forward_kernel(const FwdParams p
         }
 
         // ---- residual blocks ---------------------------------------------------------------
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const uint4* wb = wf + (size_t)(L.oBlk0 + b * L.blkStride) * 64;
+        static_for<0, 2>([&](auto bb) {
+            constexpr int b = decltype(bb)::value;
+            constexpr int EB = S::E_BLK + b * S::BLK;
             f32x4 t[R];
 #pragma unroll
             for (int r = 0; r < R; ++r)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) t[r][e] = fmaxf(h[r][e], 0.f);
             store_act(s_act0, t);
-            __syncthreads();
-#pragma unroll
-            for (int r = 0; r < R; ++r) t[r] = f32x4{0.f, 0.f, 0.f, 0.f};
-            tile_gemm(wb + (size_t)L.oW0 * 64, HK, s_act0, t);
+            if (!(p.ablate & 8)) __syncthreads();
+            zero(t);
+            gemm(std::integral_constant<int, EB>{}, std::integral_constant<int, HK>{}, kH, s_act0, t);
             {
                 const f32x4 b0 = load_bias(bp, kSlotBlk + 3 * b);
 #pragma unroll
@@ -327,16 +388,14 @@ __global__ __launch_bounds__(NW * 64) void flow_forward_kernel(const FwdParams p
                     for (int e = 0; e < 4; ++e) t[r][e] = fmaxf(t[r][e] + b0[e], 0.f);
             }
             store_act(s_act1, t);
-            __syncthreads();
-#pragma unroll
-            for (int r = 0; r < R; ++r) t[r] = f32x4{0.f, 0.f, 0.f, 0.f};
-            tile_gemm(wb + (size_t)L.oW1 * 64, HK, s_act1, t);
+            if (!(p.ablate & 8)) __syncthreads();
+            zero(t);
+            gemm(std::integral_constant<int, EB + HK>{}, std::integral_constant<int, HK>{}, kH, s_act1, t);
             const f32x4 b1 = load_bias(bp, kSlotBlk + 3 * b + 1);
+            f32x4 gt[R];
+            zero(gt);
+            gemm(std::integral_constant<int, EB + 2 * HK>{}, std::integral_constant<int, CKM>{}, CK, s_ctx, gt);
             if (CK > 0) {
-                f32x4 gt[R];
-#pragma unroll
-                for (int r = 0; r < R; ++r) gt[r] = f32x4{0.f, 0.f, 0.f, 0.f};
-                tile_gemm(wb + (size_t)L.oGate * 64, CK, s_ctx, gt);
                 const f32x4 bg = load_bias(bp, kSlotBlk + 3 * b + 2);
 #pragma unroll
                 for (int r = 0; r < R; ++r)
@@ -347,33 +406,37 @@ __global__ __launch_bounds__(NW * 64) void flow_forward_kernel(const FwdParams p
 #pragma unroll
                 for (int r = 0; r < R; ++r) h[r] += t[r] + b1;
             }
-        }
+        });
 
         // ---- final masked layer + spline: wave w owns feature w ------------------------
         store_act(s_act0, h);          // no activation in front of the final layer
-        __syncthreads();
-        if (wave < D) {
+        if (!(p.ablate & 8)) __syncthreads();
+        {
             f32x4 pw[R], ph[R], pd[R];
+            zero(pw); zero(ph); zero(pd);
+            gemm(std::integral_constant<int, S::E_OUT>{}, std::integral_constant<int, HK>{}, kO, s_act0, pw);
+            gemm(std::integral_constant<int, S::E_OUT + HK>{}, std::integral_constant<int, HK>{}, kO, s_act0, ph);
+            gemm(std::integral_constant<int, S::E_OUT + 2 * HK>{}, std::integral_constant<int, HK>{}, kO, s_act0, pd);
+            // schedule padding (never active): keep the window rolling
+            gemm(std::integral_constant<int, S::NE_RAW>{}, std::integral_constant<int, S::NE - S::NE_RAW>{}, 0, s_act0, pw);
+            if (feat >= 0) {
+                const f32x4 bw = load_bias(bp, kSlotOut), bh = load_bias(bp, kSlotOut + 1), bd = load_bias(bp, kSlotOut + 2);
 #pragma unroll
-            for (int r = 0; r < R; ++r) { pw[r] = f32x4{0.f, 0.f, 0.f, 0.f}; ph[r] = pw[r]; pd[r] = pw[r]; }
-            tile_gemm(wf + (size_t)(L.oOut) * 64, HK, s_act0, pw);
-            tile_gemm(wf + (size_t)(L.oOut + HK) * 64, HK, s_act0, ph);
-            tile_gemm(wf + (size_t)(L.oOut + 2 * HK) * 64, HK, s_act0, pd);
-            const f32x4 bw = load_bias(bp, kSlotOut), bh = load_bias(bp, kSlotOut + 1), bd = load_bias(bp, kSlotOut + 2);
+                for (int r = 0; r < R; ++r) {
+                    float uw[4], uh[4], ud[4];
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                float uw[4], uh[4], ud[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { uw[e] = pw[r][e] + bw[e]; uh[e] = ph[r][e] + bh[e]; ud[e] = pd[r][e] + bd[e]; }
-                const float xv = xin[wave * COLS + 16 * r + c];
-                float y, ld;
-                rqs_forward<FAST>(uw, uh, ud, xv, g, K, p, y, ld);
-                ld_acc[r] += ld;
-                // the next layer starts with ReversePermutation: position D-1-w
-                if (g == 0) xout[(D - 1 - wave) * COLS + 16 * r + c] = y;
+                    for (int e = 0; e < 4; ++e) { uw[e] = pw[r][e] + bw[e]; uh[e] = ph[r][e] + bh[e]; ud[e] = pd[r][e] + bd[e]; }
+                    const float xv = xin[feat * COLS + 16 * r + c];
+                    float y, ld;
+                    if (p.ablate & 1) { y = xv + uw[0] + uh[1] + ud[2]; ld = 0.f; }
+                    else rqs_forward<FAST>(uw, uh, ud, xv, g, K, p, y, ld);
+                    ld_acc[r] += ld;
+                    // the next layer starts with ReversePermutation: position D-1-w
+                    if (g == 0) xout[(D - 1 - feat) * COLS + 16 * r + c] = y;
+                }
             }
         }
-        __syncthreads();
+        if (!(p.ablate & 8)) __syncthreads();
     }
 
     // ---- epilogue: sum log-dets over features, base log-density, stores -----------------
@@ -387,7 +450,7 @@ __global__ __launch_bounds__(NW * 64) void flow_forward_kernel(const FwdParams p
         const int64_t row = row0 + tid;
         if (row < p.batch) {
             float ld = 0.f, q = 0.f, sls = 0.f;
-            for (int w = 0; w < D; ++w) ld += s_ldb[w * COLS + tid];
+            for (int w = NW - D; w < NW; ++w) ld += s_ldb[w * COLS + tid];
             for (int d = 0; d < D; ++d) {
                 const float zv = zfin[(D - 1 - d) * COLS + tid];
                 if (p.log_sigma) {           // PSDScaledNormal.log_prob, flows.py:73-83
@@ -407,33 +470,31 @@ __global__ __launch_bounds__(NW * 64) void flow_forward_kernel(const FwdParams p
 }
 
 // ---- host launcher ----------------------------------------------------------------------
-static size_t fwd_lds_bytes(const FlowLayout& L, int R) {
+static size_t fwd_lds_bytes(const FlowPlan& L, int R) {
     return (size_t)L.CK * R * kFragBytes + 2 * (size_t)L.HK * R * kFragBytes
          + (size_t)(2 * 16 * 16 * R + L.NW * 16 * R) * sizeof(float);
 }
 
-int rows_per_workgroup(const FlowLayout& L, int64_t batch) {
+int rows_per_workgroup(const FlowPlan& L, int64_t batch) {
     // B <= 256 CUs * 16 rows: one 16-row group per CU (weight-ingest bound);
     // larger batches amortise each streamed fragment over R column groups.
     int R = 1;
     if (const char* f = getenv("PF_FORCE_R")) {          // test knob: force the column-group count
         R = atoi(f);
-        if (R != 1 && R != 2 && R != 4) R = 1;
-        return 16 * R;
+        return 16 * (R == 2 ? 2 : 1);
     }
     if (batch > 256 * 16) R = 2;
-    if (batch > 256 * 32 * 2 && L.NW < 12) R = 4;   // R = 4 spills at >= 12 waves (VGPR cap)
     while (R > 1 && fwd_lds_bytes(L, R) > 160 * 1024) R >>= 1;
     return 16 * R;
 }
 
-template <bool BF16, int NW>
+template <bool BF16, int NW, int CKM>
 static int launch_nw(const FwdParams& p, int R, hipStream_t s) {
     const unsigned grid = (unsigned)((p.batch + 16 * R - 1) / (16 * R));
-    const size_t lds = fwd_lds_bytes(p.lay, R);
+    const size_t lds = fwd_lds_bytes(p.plan, R);
 #define PF_LAUNCH(RR)                                                                               \
     do {                                                                                            \
-        auto kern = flow_forward_kernel<BF16, NW, RR>;                                              \
+        auto kern = flow_forward_kernel<BF16, NW, RR, CKM>;                                         \
         if (lds > 64 * 1024 &&                                                                      \
             hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
@@ -443,24 +504,36 @@ static int launch_nw(const FwdParams& p, int R, hipStream_t s) {
     switch (R) {
     case 1: PF_LAUNCH(1); break;
     case 2: PF_LAUNCH(2); break;
-    case 4: PF_LAUNCH(4); break;
     default: return PF_ERR_UNSUPPORTED;
     }
 #undef PF_LAUNCH
     return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
 }
 
-int launch_flow_forward(const FwdParams& p, hipStream_t s) {
-    if (p.batch == 0) return PF_OK;
-    const int R = rows_per_workgroup(p.lay, p.batch) / 16;
-    const bool bf = p.lay.bf16;
-    switch (p.lay.NW) {
-    case 16: return bf ? launch_nw<true, 16>(p, R, s) : launch_nw<false, 16>(p, R, s);
-    case 12: return bf ? launch_nw<true, 12>(p, R, s) : launch_nw<false, 12>(p, R, s);
-    case 8:  return bf ? launch_nw<true, 8>(p, R, s) : launch_nw<false, 8>(p, R, s);
-    case 4:  return bf ? launch_nw<true, 4>(p, R, s) : launch_nw<false, 4>(p, R, s);
+template <bool BF16, int CKM>
+static int launch_ck(const FwdParams& p, int R, hipStream_t s) {
+    switch (p.plan.NW) {
+    case 16: return launch_nw<BF16, 16, CKM>(p, R, s);
+    case 12: return launch_nw<BF16, 12, CKM>(p, R, s);
+    case 8:  return launch_nw<BF16, 8, CKM>(p, R, s);
+    case 4:  return launch_nw<BF16, 4, CKM>(p, R, s);
     default: return PF_ERR_UNSUPPORTED;
     }
+}
+
+int launch_flow_forward(const FwdParams& p_in, hipStream_t s) {
+    if (p_in.batch == 0) return PF_OK;
+    FwdParams p = p_in;
+    if (const char* a = getenv("PF_ABLATE")) p.ablate = atoi(a);
+    const int R = rows_per_workgroup(p.plan, p.batch) / 16;
+    if (p.plan.bf16) {
+        if (p.plan.CKM == 9) return launch_ck<true, 9>(p, R, s);
+        if (p.plan.CKM == 18) return launch_ck<true, 18>(p, R, s);
+    } else {
+        if (p.plan.CKM == 18) return launch_ck<false, 18>(p, R, s);
+        if (p.plan.CKM == 36) return launch_ck<false, 36>(p, R, s);
+    }
+    return PF_ERR_UNSUPPORTED;
 }
 
 }  // namespace pf

@@ -17,16 +17,17 @@ struct FwdParams {
     float* logdet;           // [B] or null
     float* nll;              // [B] or null
     int64_t batch;
-    FlowLayout lay;
+    FlowPlan plan;
     float tail_bound, min_w, min_h, min_d;
     float deriv_const;       // log(exp(1 - min_d) - 1), computed in double on the host
+    int ablate;              // timing experiments only ($PF_ABLATE): 1 no spline, 2 no weight traffic, 4 no MFMA, 8 no barriers
 };
 
-int build_pack_map(const FlowLayout& L, int32_t* map);
-int64_t pack_map_len(const FlowLayout& L);
-int64_t raw_param_count(const FlowLayout& L);
-int launch_pack(const FlowLayout& L, const float* raw, const int32_t* map, void* packed, hipStream_t s);
-int rows_per_workgroup(const FlowLayout& L, int64_t batch);
+int build_pack_map(const FlowPlan& L, int32_t* map);
+int64_t pack_map_len(const FlowPlan& L);
+int64_t raw_param_count(const FlowPlan& L);
+int launch_pack(const FlowPlan& L, const float* raw, const int32_t* map, void* packed, hipStream_t s);
+int rows_per_workgroup(const FlowPlan& L, int64_t batch);
 int launch_flow_forward(const FwdParams& p, hipStream_t s);
 
 }  // namespace pf

@@ -21,7 +21,7 @@ struct RawOffsets {
     int64_t out_w, out_b, total;
 };
 
-static RawOffsets raw_offsets(const FlowLayout& L) {
+static RawOffsets raw_offsets(const FlowPlan& L) {
     RawOffsets r{};
     int64_t o = 0;
     const int64_t H = L.H, D = L.D, C = L.C;
@@ -37,81 +37,99 @@ static RawOffsets raw_offsets(const FlowLayout& L) {
     return r;
 }
 
-static inline int hid_deg(const FlowLayout& L, int u) {
-    const int hi = std::max(1, L.D - 1), lo = std::min(1, L.D - 1);
-    return u % hi + lo;
-}
-
 // spline parameter row for (tile q of the feature, row r16): widths / heights / derivs
-static inline int out_param(const FlowLayout& L, int q, int r16) {
+static inline int out_param(const FlowPlan& L, int q, int r16) {
     if (q == 0) return r16 < L.K ? r16 : -1;
     if (q == 1) return r16 < L.K ? L.K + r16 : -1;
     return r16 < L.K - 1 ? 2 * L.K + r16 : -1;
 }
 
-int build_pack_map(const FlowLayout& L, int32_t* map) {
+// runtime mirror of Sched<> (pf_layout.h)
+struct Entry { int phase, ks, blk, tile; bool active; };   // phase: 0 in, 1 ctx, 2 W0, 3 W1, 4 gate, 5 out
+static int sched_len(const FlowPlan& L) {
+    return 1 + L.CKM + 2 * (2 * L.HK + L.CKM) + 3 * L.HK;   // pad entries are never active
+}
+static Entry sched_entry(const FlowPlan& L, int w, int e) {
+    const int eBlk = 1 + L.CKM, blkLen = 2 * L.HK + L.CKM, eOut = eBlk + 2 * blkLen, raw = eOut + 3 * L.HK;
+    Entry x{0, 0, 0, 0, false};
+    if (e < 1) { x.phase = 0; x.active = true; }
+    else if (e < eBlk) { x.phase = 1; x.ks = e - 1; x.active = x.ks < L.CK; }
+    else if (e < eOut) {
+        int r = e - eBlk; x.blk = r / blkLen; r %= blkLen;
+        if (r < L.HK) { x.phase = 2; x.ks = r; x.active = x.ks < L.kmaxH[w]; }
+        else if (r < 2 * L.HK) { x.phase = 3; x.ks = r - L.HK; x.active = x.ks < L.kmaxH[w]; }
+        else { x.phase = 4; x.ks = r - 2 * L.HK; x.active = x.ks < L.CK; }
+    } else if (e < raw) {
+        const int r = e - eOut; x.phase = 5; x.tile = r / L.HK; x.ks = r % L.HK; x.active = x.ks < L.kmaxO[w];
+    }
+    return x;
+}
+
+int build_pack_map(const FlowPlan& L, int32_t* map) {
     const RawOffsets ro = raw_offsets(L);
     const int fragElems = L.bf16 ? 512 : 256;
     const int per = L.bf16 ? 8 : 4;   // elements per lane
+    int perm[256];
+    sorted_units(L.D, L.H, perm);
+    const int NE = sched_len(L);
     int64_t idx = 0;
-    for (int l = 0; l < L.L; ++l) {
-        const int64_t base = (int64_t)l * ro.total;
-        for (int w = 0; w < L.NW; ++w) {
-            for (int f = 0; f < L.NF; ++f) {
-                // decode the phase of frag f
-                int phase, t = 0, ks = 0, blk = 0;   // phase: 0 in, 1 ctx, 2 W0, 3 W1, 4 gate, 5 out
-                if (f < L.oCtx) { phase = 0; }
-                else if (f < L.oBlk0) { phase = 1; ks = f - L.oCtx; }
-                else if (f < L.oOut) {
-                    int r = f - L.oBlk0; blk = r / L.blkStride; r %= L.blkStride;
-                    if (r < L.oW1) { phase = 2; ks = r; }
-                    else if (r < L.oGate) { phase = 3; ks = r - L.oW1; }
-                    else { phase = 4; ks = r - L.oGate; }
-                } else { phase = 5; int r = f - L.oOut; t = r / L.HK; ks = r % L.HK; }
+    for (int w = 0; w < L.NW; ++w) {
+        if (idx != L.waveBase[w] * fragElems) return PF_ERR_BAD_ARG;
+        for (int l = 0; l < L.L; ++l) {
+            const int64_t base = (int64_t)l * ro.total;
+            for (int e = 0; e < NE; ++e) {
+                const Entry en = sched_entry(L, w, e);
+                if (!en.active) continue;
+                const int phase = en.phase, ks = en.ks, blk = en.blk;
                 for (int within = 0; within < fragElems; ++within, ++idx) {
-                    const int lane = within / per, e = within % per;
+                    const int lane = within / per, el = within % per;
                     const int g = lane >> 4, r16 = lane & 15;
-                    // k -> source column
-                    int col;
-                    if (phase == 0) col = L.bf16 ? ((8 * g + e) & 15) : (4 * g + e);
-                    else if (phase == 1 || phase == 4) col = L.bf16 ? (32 * ks + 8 * g + e) : (16 * ks + 4 * g + e);
-                    else col = L.bf16 ? (16 * (2 * ks + (e >> 2)) + 4 * g + (e & 3)) : (16 * ks + 4 * g + e);
-                    int32_t src = -1;
-                    const int u = 16 * w + r16;   // hidden output unit of this wave
+                    int col;   // k -> source column / sorted position
+                    if (phase == 0) col = L.bf16 ? ((8 * g + el) & 15) : (4 * g + el);
+                    else if (phase == 1 || phase == 4) col = L.bf16 ? (32 * ks + 8 * g + el) : (16 * ks + 4 * g + el);
+                    else col = L.bf16 ? (16 * (2 * ks + (el >> 2)) + 4 * g + (el & 3)) : (16 * ks + 4 * g + el);
+                    int64_t src = -1;
+                    const int u = perm[16 * w + r16];          // hidden output unit of this row
                     switch (phase) {
                     case 0:
-                        if (col < L.D && hid_deg(L, u) >= col + 1) src = (int32_t)(base + ro.in_w + (int64_t)u * L.D + col);
+                        if (col < L.D && hid_degree(L.D, u) >= col + 1) src = ro.in_w + (int64_t)u * L.D + col;
                         break;
                     case 1:
-                        if (col < L.C) src = (int32_t)(base + ro.c_w + (int64_t)u * L.C + col);
+                        if (col < L.C) src = ro.c_w + (int64_t)u * L.C + col;
                         break;
                     case 4:
-                        if (col < L.C) src = (int32_t)(base + ro.g_w[blk] + (int64_t)u * L.C + col);
+                        if (col < L.C) src = ro.g_w[blk] + (int64_t)u * L.C + col;
                         break;
                     case 2:
-                    case 3:
-                        if (hid_deg(L, u) >= hid_deg(L, col))
-                            src = (int32_t)(base + (phase == 2 ? ro.w0_w[blk] : ro.w1_w[blk]) + (int64_t)u * L.H + col);
+                    case 3: {
+                        const int uin = perm[col];
+                        if (hid_degree(L.D, u) >= hid_degree(L.D, uin))
+                            src = (phase == 2 ? ro.w0_w[blk] : ro.w1_w[blk]) + (int64_t)u * L.H + uin;
                         break;
+                    }
                     case 5: {
-                        const int m = out_param(L, t, r16);
-                        if (w < L.D && m >= 0 && (w + 1) > hid_deg(L, col))
-                            src = (int32_t)(base + ro.out_w + ((int64_t)w * L.M + m) * L.H + col);
+                        const int m = out_param(L, en.tile, r16);
+                        const int uin = perm[col];
+                        const int f = L.feat[w];
+                        if (f >= 0 && m >= 0 && (f + 1) > hid_degree(L.D, uin))
+                            src = ro.out_w + ((int64_t)f * L.M + m) * L.H + uin;
                         break;
                     }
                     }
-                    map[idx] = src;
+                    map[idx] = src < 0 ? -1 : (int32_t)(base + src);
                 }
             }
         }
+        for (int64_t k = 0; k < (int64_t)kWindow * fragElems; ++k) map[idx++] = -1;   // prefetch overrun pad
     }
-    // bias region
+    if (idx != L.fragsTotal * fragElems) return PF_ERR_BAD_ARG;
+    // bias region, [layer][wave][slot][r16]
     for (int l = 0; l < L.L; ++l) {
         const int64_t base = (int64_t)l * ro.total;
         for (int w = 0; w < L.NW; ++w) {
             for (int s = 0; s < kBiasFloatsPerWave; ++s, ++idx) {
                 const int slot = s >> 4, r16 = s & 15;
-                const int u = 16 * w + r16;
+                const int u = perm[16 * w + r16];
                 int64_t src = -1;
                 if (slot == kSlotIn) src = ro.in_b + u;
                 else if (slot == kSlotCtx) { if (L.C > 0) src = ro.c_b + u; }
@@ -122,7 +140,7 @@ int build_pack_map(const FlowLayout& L, int32_t* map) {
                     else if (L.C > 0) src = ro.g_b[b] + u;
                 } else if (slot >= kSlotOut && slot < kSlotOut + 3) {
                     const int m = out_param(L, slot - kSlotOut, r16);
-                    if (w < L.D && m >= 0) src = ro.out_b + (int64_t)w * L.M + m;
+                    if (L.feat[w] >= 0 && m >= 0) src = ro.out_b + (int64_t)L.feat[w] * L.M + m;
                 }
                 map[idx] = src < 0 ? -1 : (int32_t)(base + src);
             }
@@ -131,11 +149,11 @@ int build_pack_map(const FlowLayout& L, int32_t* map) {
     return PF_OK;
 }
 
-int64_t pack_map_len(const FlowLayout& L) {
+int64_t pack_map_len(const FlowPlan& L) {
     return L.fragsTotal * (L.bf16 ? 512 : 256) + L.biasFloats;
 }
 
-int64_t raw_param_count(const FlowLayout& L) { return raw_offsets(L).total * L.L; }
+int64_t raw_param_count(const FlowPlan& L) { return raw_offsets(L).total * L.L; }
 
 // ---- device gather ------------------------------------------------------------
 __global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict__ raw,
@@ -168,7 +186,7 @@ __global__ __launch_bounds__(256) void pack_f32_kernel(const float* __restrict__
     *reinterpret_cast<float4*>(out + i) = v;
 }
 
-int launch_pack(const FlowLayout& L, const float* raw, const int32_t* map, void* packed,
+int launch_pack(const FlowPlan& L, const float* raw, const int32_t* map, void* packed,
                 hipStream_t stream) {
     const int64_t nW = L.fragsTotal * (L.bf16 ? 512 : 256);
     const int64_t nB = L.biasFloats;

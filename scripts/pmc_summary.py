@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Average the per-dispatch PMC values of the flow kernels out of rocprofv3 CSV passes."""
+import csv
+import glob
+import sys
+from collections import defaultdict
+
+root = sys.argv[1]
+acc = defaultdict(lambda: defaultdict(list))
+for f in sorted(glob.glob(root + "/p*/**/*counter_collection.csv", recursive=True)):
+    with open(f) as fh:
+        for row in csv.DictReader(fh):
+            name = row.get("Kernel_Name", "")
+            if "flow_" not in name:
+                continue
+            short = name.split("(")[0].replace("void pf::", "")
+            acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
+for k, d in acc.items():
+    print(f"== {k}")
+    for c, v in sorted(d.items()):
+        print(f"  {c:34s} mean {sum(v) / len(v):16.1f}   n={len(v)}")
