@@ -1,538 +1,49 @@
-// pf_flow_fwd.hip -- fused forward pass of the masked-autoregressive
-// rational-quadratic-spline flow for gfx950 (MI355X): ALL layers of
-//   [ReversePermutation, MADE conditioner, RQS elementwise + log|det J|]
-// plus the N(0,I) base log-density run in ONE kernel; nothing but x, ctx, z,
-// logdet, nll touches HBM besides the (L2-resident) packed weights.
-//
-// Replaces (reference file:line):
-//   NSFPosteriorFlow.forward            src/ahsd/models/flows.py:610-618
-//   NSFPosteriorFlow.compute_psd_aware_nll (log_sigma = 0)  flows.py:727-779
-//   which execute nflows CompositeTransform/ReversePermutation/MADE/
-//   MaskedPiecewiseRationalQuadraticAutoregressiveTransform (built flows.py:459-529).
-//
-// Work decomposition (DESIGN.md "Kernels"):
-//   workgroup = 16*R batch rows, NW = H/16 waves (1024 threads at H = 256).
-//   Everything is computed TRANSPOSED: out^T[unit, row] = W[unit, k] . act^T[k, row],
-//   so the weights are the MFMA A operand (streamed from L2 exactly once per
-//   workgroup, in pre-packed fragment order, straight into VGPRs) and the batch
-//   rows are the 16 MFMA columns.  Wave w owns 16 hidden units (degree-sorted
-//   positions 16w..16w+15, pf_layout.h): its residual state h lives in 4*R fp32
-//   accumulator registers for the whole layer; activations are exchanged between
-//   waves through LDS in B-fragment order (one barrier per GEMM).
-//   Weight streaming: each wave walks ONE linear fragment stream with a static,
-//   fully unrolled per-layer schedule and keeps kWindow = 12 fragment loads
-//   (12 KiB) in flight in a register window across phases, barriers and layer
-//   boundaries.  Entries that the autoregressive masks make all-zero for this
-//   wave are issued as out-of-range buffer loads (no memory traffic, same
-//   instruction stream, exact vmcnt accounting) and their MFMAs are skipped.  In the final masked layer wave w owns spline
-//   feature w: its 3K-1 raw parameters come out of three 16-row MFMA tiles
-//   (widths | heights | derivatives) spread over the 4 lane groups of a column,
-//   and the spline (softmax, cumsum, bin search, rational quadratic, log-det)
-//   is evaluated in registers by those 4 lanes with cross-lane shuffles.
+// pf_flow_fwd.hip -- host dispatch of the fused flow forward kernels
+// (pf_flow_fwd_kernel.h, instantiated per (precision, NT) by pf_flow_fwd_inst.hip).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
-#include <type_traits>
 
 #include "pf_flow_params.h"
 
 namespace pf {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
+#define PF_DECL(P, N) int launch_flow_forward_p##P##_nt##N(const FwdParams&, int, hipStream_t);
+PF_DECL(0, 4) PF_DECL(0, 8) PF_DECL(0, 12) PF_DECL(0, 16)
+PF_DECL(1, 4) PF_DECL(1, 8) PF_DECL(1, 12) PF_DECL(1, 16)
+#undef PF_DECL
 
-// ---- small device helpers ------------------------------------------------------
-template <bool FAST> __device__ __forceinline__ float pf_exp(float v) { return FAST ? __expf(v) : expf(v); }
-template <bool FAST> __device__ __forceinline__ float pf_log(float v) { return FAST ? __logf(v) : logf(v); }
-template <bool FAST> __device__ __forceinline__ float pf_softplus(float u) {
-    // torch F.softplus: beta = 1, threshold = 20
-    if (FAST) return u > 20.f ? u : __logf(1.f + __expf(u));
-    return u > 20.f ? u : log1pf(expf(u));
-}
-template <bool FAST> __device__ __forceinline__ float pf_sigmoid(float v) {
-    return 1.f / (1.f + pf_exp<FAST>(-v));
-}
-// reductions over the 4 lane groups (lanes c, c+16, c+32, c+48) of one batch column
-__device__ __forceinline__ float sum4(float v) {
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    return v;
-}
-__device__ __forceinline__ float max4(float v) {
-    v = fmaxf(v, __shfl_xor(v, 16));
-    v = fmaxf(v, __shfl_xor(v, 32));
-    return v;
-}
-// exclusive prefix over the 4 lane groups of the per-group totals
-__device__ __forceinline__ float excl4(float tot, int g) {
-    const float a = __shfl_up(tot, 16), b = __shfl_up(tot, 32), c = __shfl_up(tot, 48);
-    // summed in increasing group order, like a sequential cumsum
-    float o = 0.f;
-    if (g == 1) o = a;
-    else if (g == 2) o = b + a;
-    else if (g == 3) o = (c + b) + a;
-    return o;
-}
-__device__ __forceinline__ float sel4(const float (&v)[4], int e) {
-    return e == 0 ? v[0] : (e == 1 ? v[1] : (e == 2 ? v[2] : v[3]));
-}
-
-// Knots of one spline axis held 4-per-lane: normalised bin sizes -> left/right knot of
-// bins 4g..4g+3 (nflows rational_quadratic_spline: softmax, min + (1 - min*K)*., cumsum,
-// affine to [-tb, tb], ends pinned).
-template <bool FAST>
-__device__ __forceinline__ void spline_knots(const float (&u)[4], int g, int K, float tb, float minsz,
-                                             float (&kl)[4], float (&kr)[4]) {
-    float m = -INFINITY;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) if (4 * g + e < K) m = fmaxf(m, u[e]);
-    m = max4(m);
-    float ex[4], s = 0.f;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { ex[e] = (4 * g + e < K) ? pf_exp<FAST>(u[e] - m) : 0.f; s += ex[e]; }
-    s = sum4(s);
-    const float scale = (1.f - minsz * (float)K) / s;
-    float run = 0.f, inc[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const float sz = (4 * g + e < K) ? (minsz + scale * ex[e]) : 0.f;
-        run += sz; inc[e] = run;
-    }
-    const float off = excl4(run, g);
-    const float span = 2.f * tb;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int i = 4 * g + e;
-        float r = span * (off + inc[e]) - tb;
-        if (i == K - 1) r = tb;                       // cum[..., -1] = right
-        kr[e] = r;
-    }
-    kl[0] = (g == 0) ? -tb : (span * off - tb);       // cum[..., 0] = left
-    kl[1] = kr[0]; kl[2] = kr[1]; kl[3] = kr[2];
-}
-
-// forward RQS for one (row, feature) pair evaluated by its 4 lanes.
-template <bool FAST>
-__device__ __forceinline__ void rqs_forward(const float (&uw)[4], const float (&uh)[4], const float (&ud)[4],
-                                            float x, int g, int K, const FwdParams& p, float& y, float& ld) {
-    const float tb = p.tail_bound;
-    float wl[4], wr[4], hl[4], hr[4];
-    spline_knots<FAST>(uw, g, K, tb, p.min_w, wl, wr);
-    spline_knots<FAST>(uh, g, K, tb, p.min_h, hl, hr);
-    // bin = #(knots <= x) - 1 with the last knot nudged by eps (nflows searchsorted)
-    float cnt = 0.f;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int i = 4 * g + e;
-        const float knot = (i == K - 1) ? (tb + 1e-6f) : wr[e];
-        if (i < K && x >= knot) cnt += 1.f;
-    }
-    const int bin = (int)sum4(cnt);
-    const bool own = (bin >> 2) == g;
-    const int es = bin & 3;
-    const float ud_prev = __shfl_up(ud[3], 16);        // derivative row 4g-1 from group g-1
-    const float xl = sel4(wl, es), w = sel4(wr, es) - xl;
-    const float yl = sel4(hl, es), h = sel4(hr, es) - yl;
-    const float ud_r = sel4(ud, es);                   // knot bin+1 -> deriv row bin
-    const float ud_l = es == 0 ? ud_prev : (es == 1 ? ud[0] : (es == 2 ? ud[1] : ud[2]));
-    const float d_edge = p.min_d + pf_softplus<FAST>(p.deriv_const);
-    const float dl = bin == 0 ? d_edge : p.min_d + pf_softplus<FAST>(ud_l);
-    const float dr = bin == K - 1 ? d_edge : p.min_d + pf_softplus<FAST>(ud_r);
-    const float delta = h / w;
-    const float th = (x - xl) / w;
-    const float tt = th * (1.f - th);
-    const float numer = h * (delta * th * th + dl * tt);
-    const float den = delta + (dl + dr - 2.f * delta) * tt;
-    const float yy = yl + numer / den;
-    const float omt = 1.f - th;
-    const float dnum = delta * delta * (dr * th * th + 2.f * delta * tt + dl * omt * omt);
-    const float lld = pf_log<FAST>(dnum) - 2.f * pf_log<FAST>(den);
-    y = sum4(own ? yy : 0.f);
-    ld = sum4(own ? lld : 0.f);
-    const bool inside = (x >= -tb) && (x <= tb);
-    if (!inside) { y = x; ld = 0.f; }
-}
-
-// ---- the kernel ------------------------------------------------------------------
-// LDS carve (bytes), all 16-B aligned:
-//   ctx   : CK * R KiB           context in B-fragment order
-//   act0/1: HK * R KiB each      activations in B-fragment order (double buffer)
-//   xb0/1 : 16 * 16R floats each layer input x^T / output z^T (double buffer)
-//   ldb   : NW * 16R floats      per-wave log-det partials
-template <int B, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (N > 0) {
-        f(std::integral_constant<int, B>{});
-        static_for<B + 1, N - 1>(f);
-    }
-}
-
-template <bool BF16, int NW, int R, int CKM>
-__global__ __launch_bounds__(NW * 64) void flow_forward_kernel(const FwdParams p) {
-    // 1024-thread workgroups have 128 VGPRs per lane; the f32 mode is MFMA-bound anyway
-    constexpr int W = NW >= 16 ? (BF16 ? 8 : 4) : kWindow;
-    using S = Sched<BF16, NW, CKM, W>;
-    constexpr bool FAST = BF16;
-    constexpr int HK = S::HK;
-    constexpr int COLS = 16 * R;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const FlowPlan& L = p.plan;
-    const int CK = L.CK, D = L.D, K = L.K;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = lane >> 4, c = lane & 15;
-    const int64_t row0 = (int64_t)blockIdx.x * COLS;
-    const int kH = L.kmaxH[wave], kO = L.kmaxO[wave];
-    const int feat = L.feat[wave];                  // spline feature of this wave (-1: none)
-
-    char* s_ctx = smem;
-    char* s_act0 = s_ctx + (size_t)CK * R * kFragBytes;
-    char* s_act1 = s_act0 + (size_t)HK * R * kFragBytes;
-    float* s_xb0 = reinterpret_cast<float*>(s_act1 + (size_t)HK * R * kFragBytes);
-    float* s_xb1 = s_xb0 + 16 * COLS;
-    float* s_ldb = s_xb1 + 16 * COLS;
-
-    // ---- weight stream: buffer resource over this wave's region, register window ---------
-    const int64_t wave_frags = (int64_t)L.L * L.fragsPerLayer[wave] + kWindow;
-    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(p.packed) + L.waveBase[wave] * kFragBytes, 0, (int)(wave_frags * kFragBytes), 0x00020000);
-    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-    u32x4 win[W];
-    int soff = 0;                                   // wave-uniform byte position in the stream
-    auto active = [&](int kind, int ks) -> bool {
-        return kind == kAlways || (kind == kCtx && ks < CK) || (kind == kHid && ks < kH) ||
-               (kind == kOut && ks < kO);
-    };
-    // issue the load of schedule entry EN (of the layer `ok` refers to) into its window slot
-    auto fetch = [&](auto en, bool ok) {
-        constexpr int EN = decltype(en)::value;
-        const bool a = ok && active(S::kind(EN), S::ks(EN)) && !(p.ablate & 2);
-        if (p.ablate & 16) {      // experiment: OOB load instead of a branch
-            const int voff = a ? lane * 16 : 0x40000000;
-            win[EN % W] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
-            soff += a ? kFragBytes : 0;
-        } else if (a) {
-            win[EN % W] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, soff, 0);
-            soff += kFragBytes;
-        }
-    };
-
-    // ---- stage context (B-fragment order) and x^T ---------------------------------
-    for (int s = tid; s < CK * R * 64; s += NW * 64) {
-        const int ln = s & 63, r = (s >> 6) % R, ks = s / (64 * R);
-        const int gg = ln >> 4, cc = ln & 15;
-        int64_t row = row0 + 16 * r + cc;
-        if (row >= p.batch) row = p.batch - 1;
-        const float* src = p.ctx + row * L.C;
-        if (BF16) {
-            bf16x8 v;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int col = 32 * ks + 8 * gg + j;
-                v[j] = (__bf16)(col < L.C ? src[col] : 0.f);
-            }
-            *reinterpret_cast<bf16x8*>(s_ctx + (size_t)s * 16) = v;
-        } else {
-            f32x4 v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int col = 16 * ks + 4 * gg + e;
-                v[e] = col < L.C ? src[col] : 0.f;
-            }
-            *reinterpret_cast<f32x4*>(s_ctx + (size_t)s * 16) = v;
-        }
-    }
-    for (int s = tid; s < 16 * COLS; s += NW * 64) {
-        const int d = s / COLS, col = s % COLS;
-        float v = 0.f;
-        if (d < D) {
-            int64_t row = row0 + col;
-            if (row >= p.batch) row = p.batch - 1;
-            // layer 0 sees reverse(x[:, ar_perm]): position d <- source D-1-d
-            const int sd = D - 1 - d;
-            const int src = p.ar_perm ? p.ar_perm[sd] : sd;
-            v = p.x[row * D + src];
-        }
-        s_xb0[s] = v;
-        s_xb1[s] = 0.f;
-    }
-    // prologue of the weight stream: first window of layer 0
-    static_for<0, W>([&](auto e) { fetch(e, true); });
-    __syncthreads();
-
-    float ld_acc[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) ld_acc[r] = 0.f;
-    const float* bbase = reinterpret_cast<const float*>(p.packed + L.weightBytes);
-
-    // acc[r] += A(window slot of entry E) . B(lds fragment ks)
-    auto mma = [&](auto e, int ks, const char* bsrc, f32x4 (&acc)[R]) {
-        constexpr int E = decltype(e)::value;
-        const u32x4 a = win[E % W];
-        if (p.ablate & 4) { asm volatile("" :: "v"(a)); return; }
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const char* bp = bsrc + ((size_t)(ks * R + r) * 64 + lane) * 16;
-            if (BF16) {
-                const bf16x8 b = *reinterpret_cast<const bf16x8*>(bp);
-                acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), b, acc[r], 0, 0, 0);
-            } else {
-                const f32x4 b = *reinterpret_cast<const f32x4*>(bp);
-                const f32x4 af = __builtin_bit_cast(f32x4, a);
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q], b[q], acc[r], 0, 0, 0);
-            }
-        }
-    };
-    // write this wave's 16 units x COLS activations into a B-fragment buffer
-    auto store_act = [&](char* dst, const f32x4 (&v)[R]) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            if (BF16) {
-                bf16x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[r][e];
-                *reinterpret_cast<bf16x4*>(dst + ((size_t)((wave >> 1) * R + r) * 64 + lane) * 16 + (wave & 1) * 8) = o;
-            } else {
-                *reinterpret_cast<f32x4*>(dst + ((size_t)(wave * R + r) * 64 + lane) * 16) = v[r];
-            }
-        }
-    };
-    auto load_bias = [&](const float* bp, int slot) {
-        return *reinterpret_cast<const f32x4*>(bp + slot * 16 + 4 * g);
-    };
-    auto zero = [&](f32x4 (&v)[R]) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) v[r] = f32x4{0.f, 0.f, 0.f, 0.f};
-    };
-
-    for (int l = 0; l < L.L; ++l) {
-        const float* bp = bbase + L.bias_index(l, wave);
-        float* xin = (l & 1) ? s_xb1 : s_xb0;
-        float* xout = (l & 1) ? s_xb0 : s_xb1;
-        const bool more = l + 1 < L.L;
-        // consume entries [E0, E0+N) of one GEMM (k-step = entry index - E0), refill the window
-        auto gemm = [&](auto e0, auto n, int kcount, const char* bsrc, f32x4 (&acc)[R]) {
-            constexpr int E0 = decltype(e0)::value, N = decltype(n)::value;
-            static_for<0, N>([&](auto k) {
-                constexpr int KI = decltype(k)::value;
-                if (KI < kcount) mma(std::integral_constant<int, E0 + KI>{}, KI, bsrc, acc);
-                constexpr int NX = E0 + KI + W;
-                if constexpr (NX < S::NE) fetch(std::integral_constant<int, NX>{}, true);
-                else fetch(std::integral_constant<int, NX - S::NE>{}, more);
-            });
-        };
-        using I = std::integral_constant<int, 0>;
-        (void)sizeof(I);
-
-        // ---- initial layer: h = W_in x + b_in + relu(W_c ctx + b_c) ---------------------
-        f32x4 h[R];
-        {
-            const u32x4 a = win[S::E_IN % W];
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                if (BF16) {
-                    bf16x8 b;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float v = xin[((8 * g + j) & 15) * COLS + 16 * r + c];
-                        const __bf16 hi = (__bf16)v;
-                        b[j] = g < 2 ? hi : (__bf16)(v - (float)hi);
-                    }
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), b, acc, 0, 0, 0);
-                } else {
-                    const f32x4 af = __builtin_bit_cast(f32x4, a);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], xin[(4 * g + e) * COLS + 16 * r + c], acc, 0, 0, 0);
-                }
-                h[r] = acc;
-            }
-            fetch(std::integral_constant<int, (S::E_IN + W) % S::NE>{}, S::E_IN + W < S::NE ? true : more);
-            const f32x4 b_in = load_bias(bp, kSlotIn);
-#pragma unroll
-            for (int r = 0; r < R; ++r) h[r] += b_in;
-            f32x4 cacc[R];
-            zero(cacc);
-            gemm(std::integral_constant<int, S::E_CTX>{}, std::integral_constant<int, CKM>{}, CK, s_ctx, cacc);
-            if (CK > 0) {
-                const f32x4 b_c = load_bias(bp, kSlotCtx);
-#pragma unroll
-                for (int r = 0; r < R; ++r)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) h[r][e] += fmaxf(cacc[r][e] + b_c[e], 0.f);
-            }
-        }
-
-        // ---- residual blocks ---------------------------------------------------------------
-        static_for<0, 2>([&](auto bb) {
-            constexpr int b = decltype(bb)::value;
-            constexpr int EB = S::E_BLK + b * S::BLK;
-            f32x4 t[R];
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) t[r][e] = fmaxf(h[r][e], 0.f);
-            store_act(s_act0, t);
-            if (!(p.ablate & 8)) __syncthreads();
-            zero(t);
-            gemm(std::integral_constant<int, EB>{}, std::integral_constant<int, HK>{}, kH, s_act0, t);
-            {
-                const f32x4 b0 = load_bias(bp, kSlotBlk + 3 * b);
-#pragma unroll
-                for (int r = 0; r < R; ++r)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) t[r][e] = fmaxf(t[r][e] + b0[e], 0.f);
-            }
-            store_act(s_act1, t);
-            if (!(p.ablate & 8)) __syncthreads();
-            zero(t);
-            gemm(std::integral_constant<int, EB + HK>{}, std::integral_constant<int, HK>{}, kH, s_act1, t);
-            const f32x4 b1 = load_bias(bp, kSlotBlk + 3 * b + 1);
-            f32x4 gt[R];
-            zero(gt);
-            gemm(std::integral_constant<int, EB + 2 * HK>{}, std::integral_constant<int, CKM>{}, CK, s_ctx, gt);
-            if (CK > 0) {
-                const f32x4 bg = load_bias(bp, kSlotBlk + 3 * b + 2);
-#pragma unroll
-                for (int r = 0; r < R; ++r)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        h[r][e] += (t[r][e] + b1[e]) * pf_sigmoid<FAST>(gt[r][e] + bg[e]);
-            } else {
-#pragma unroll
-                for (int r = 0; r < R; ++r) h[r] += t[r] + b1;
-            }
-        });
-
-        // ---- final masked layer + spline: wave w owns feature w ------------------------
-        store_act(s_act0, h);          // no activation in front of the final layer
-        if (!(p.ablate & 8)) __syncthreads();
-        {
-            f32x4 pw[R], ph[R], pd[R];
-            zero(pw); zero(ph); zero(pd);
-            gemm(std::integral_constant<int, S::E_OUT>{}, std::integral_constant<int, HK>{}, kO, s_act0, pw);
-            gemm(std::integral_constant<int, S::E_OUT + HK>{}, std::integral_constant<int, HK>{}, kO, s_act0, ph);
-            gemm(std::integral_constant<int, S::E_OUT + 2 * HK>{}, std::integral_constant<int, HK>{}, kO, s_act0, pd);
-            // schedule padding (never active): keep the window rolling
-            gemm(std::integral_constant<int, S::NE_RAW>{}, std::integral_constant<int, S::NE - S::NE_RAW>{}, 0, s_act0, pw);
-            if (feat >= 0) {
-                const f32x4 bw = load_bias(bp, kSlotOut), bh = load_bias(bp, kSlotOut + 1), bd = load_bias(bp, kSlotOut + 2);
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    float uw[4], uh[4], ud[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { uw[e] = pw[r][e] + bw[e]; uh[e] = ph[r][e] + bh[e]; ud[e] = pd[r][e] + bd[e]; }
-                    const float xv = xin[feat * COLS + 16 * r + c];
-                    float y, ld;
-                    if (p.ablate & 1) { y = xv + uw[0] + uh[1] + ud[2]; ld = 0.f; }
-                    else rqs_forward<FAST>(uw, uh, ud, xv, g, K, p, y, ld);
-                    ld_acc[r] += ld;
-                    // the next layer starts with ReversePermutation: position D-1-w
-                    if (g == 0) xout[(D - 1 - feat) * COLS + 16 * r + c] = y;
-                }
-            }
-        }
-        if (!(p.ablate & 8)) __syncthreads();
-    }
-
-    // ---- epilogue: sum log-dets over features, base log-density, stores -----------------
-    if (g == 0) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) s_ldb[wave * COLS + 16 * r + c] = ld_acc[r];
-    }
-    __syncthreads();
-    const float* zfin = (L.L & 1) ? s_xb1 : s_xb0;     // stored reversed (see above)
-    if (tid < COLS) {
-        const int64_t row = row0 + tid;
-        if (row < p.batch) {
-            float ld = 0.f, q = 0.f, sls = 0.f;
-            for (int w = NW - D; w < NW; ++w) ld += s_ldb[w * COLS + tid];
-            for (int d = 0; d < D; ++d) {
-                const float zv = zfin[(D - 1 - d) * COLS + tid];
-                if (p.log_sigma) {           // PSDScaledNormal.log_prob, flows.py:73-83
-                    const float ls = p.log_sigma[row * D + d];
-                    const float zs = zv / expf(ls);
-                    q += zs * zs; sls += ls;
-                } else {
-                    q += zv * zv;
-                }
-                if (p.z) p.z[row * D + d] = zv;
-            }
-            if (p.logdet) p.logdet[row] = ld;
-            // nll = -(log N(z; 0, diag(e^ls)^2) + logdet)
-            if (p.nll) p.nll[row] = 0.5f * (q + 2.f * sls + (float)D * 1.8378770664093453f) - ld;
-        }
-    }
-}
-
-// ---- host launcher ----------------------------------------------------------------------
-static size_t fwd_lds_bytes(const FlowPlan& L, int R) {
-    return (size_t)L.CK * R * kFragBytes + 2 * (size_t)L.HK * R * kFragBytes
-         + (size_t)(2 * 16 * 16 * R + L.NW * 16 * R) * sizeof(float);
+size_t fwd_lds_bytes_host(const FlowPlan& L, int R) {
+    const size_t par = (size_t)L.D * 16 * 52 * sizeof(float);
+    const size_t pb = std::max((size_t)L.HK * R * kFragBytes, par);
+    return (size_t)L.CKM * R * kFragBytes + (size_t)L.HK * R * kFragBytes + pb
+         + (size_t)(2 * 16 * 16 * R + 2 * L.NT * kBiasFloatsPerTile + L.D * 16 * R) * sizeof(float);
 }
 
 int rows_per_workgroup(const FlowPlan& L, int64_t batch) {
-    // B <= 256 CUs * 16 rows: one 16-row group per CU (weight-ingest bound);
-    // larger batches amortise each streamed fragment over R column groups.
+    // B <= 256 CUs * 16 rows: one 16-row group per CU; larger batches amortise each streamed
+    // fragment (and every instruction around it) over R = 2 column groups.
     int R = 1;
-    if (const char* f = getenv("PF_FORCE_R")) {          // test knob: force the column-group count
-        R = atoi(f);
-        return 16 * (R == 2 ? 2 : 1);
-    }
-    if (batch > 256 * 16) R = 2;
-    while (R > 1 && fwd_lds_bytes(L, R) > 160 * 1024) R >>= 1;
+    if (const char* f = getenv("PF_FORCE_R")) R = atoi(f) == 2 ? 2 : 1;   // test knob
+    else if (batch > 256 * 16) R = 2;
+    if (L.dense) R = 1;
+    while (R > 1 && fwd_lds_bytes_host(L, R) > 160 * 1024) R >>= 1;
     return 16 * R;
-}
-
-template <bool BF16, int NW, int CKM>
-static int launch_nw(const FwdParams& p, int R, hipStream_t s) {
-    const unsigned grid = (unsigned)((p.batch + 16 * R - 1) / (16 * R));
-    const size_t lds = fwd_lds_bytes(p.plan, R);
-#define PF_LAUNCH(RR)                                                                               \
-    do {                                                                                            \
-        auto kern = flow_forward_kernel<BF16, NW, RR, CKM>;                                         \
-        if (lds > 64 * 1024 &&                                                                      \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
-            return PF_ERR_HIP;                                                                      \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, s, p);                             \
-    } while (0)
-    switch (R) {
-    case 1: PF_LAUNCH(1); break;
-    case 2: PF_LAUNCH(2); break;
-    default: return PF_ERR_UNSUPPORTED;
-    }
-#undef PF_LAUNCH
-    return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
-}
-
-template <bool BF16, int CKM>
-static int launch_ck(const FwdParams& p, int R, hipStream_t s) {
-    switch (p.plan.NW) {
-    case 16: return launch_nw<BF16, 16, CKM>(p, R, s);
-    case 12: return launch_nw<BF16, 12, CKM>(p, R, s);
-    case 8:  return launch_nw<BF16, 8, CKM>(p, R, s);
-    case 4:  return launch_nw<BF16, 4, CKM>(p, R, s);
-    default: return PF_ERR_UNSUPPORTED;
-    }
 }
 
 int launch_flow_forward(const FwdParams& p_in, hipStream_t s) {
     if (p_in.batch == 0) return PF_OK;
     FwdParams p = p_in;
-    if (const char* a = getenv("PF_ABLATE")) p.ablate = atoi(a);
+    if (const char* a = getenv("PF_ABLATE")) p.ablate = atoi(a);   // only honoured by -DPF_ABLATE_BUILD builds
     const int R = rows_per_workgroup(p.plan, p.batch) / 16;
+#define PF_CASE(P, N) case N: return launch_flow_forward_p##P##_nt##N(p, R, s);
     if (p.plan.bf16) {
-        if (p.plan.CKM == 9) return launch_ck<true, 9>(p, R, s);
-        if (p.plan.CKM == 18) return launch_ck<true, 18>(p, R, s);
+        switch (p.plan.NT) { PF_CASE(1, 4) PF_CASE(1, 8) PF_CASE(1, 12) PF_CASE(1, 16) }
     } else {
-        if (p.plan.CKM == 18) return launch_ck<false, 18>(p, R, s);
-        if (p.plan.CKM == 36) return launch_ck<false, 36>(p, R, s);
+        switch (p.plan.NT) { PF_CASE(0, 4) PF_CASE(0, 8) PF_CASE(0, 12) PF_CASE(0, 16) }
     }
+#undef PF_CASE
     return PF_ERR_UNSUPPORTED;
 }
 

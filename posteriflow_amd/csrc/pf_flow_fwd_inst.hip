@@ -1,0 +1,25 @@
+// pf_flow_fwd_inst.hip -- instantiates the forward kernels of ONE (precision, NT); built
+// once per combination with -DPF_INST_BF16=<0|1> -DPF_INST_NT=<4|8|12|16> (Makefile), so the
+// variants compile in parallel.
+#include <algorithm>
+
+#include "pf_flow_fwd_kernel.h"
+
+#define PF_CAT2(a, b, c, d) a##b##c##d
+#define PF_CAT(a, b, c, d) PF_CAT2(a, b, c, d)
+
+namespace pf {
+
+int PF_CAT(launch_flow_forward_p, PF_INST_BF16, _nt, PF_INST_NT)(const FwdParams& p, int R, hipStream_t s) {
+    constexpr bool BF = PF_INST_BF16 != 0;
+    constexpr int NT = PF_INST_NT;
+    constexpr int SMALL = BF ? 3 : 6, MID = BF ? 9 : 18, LARGE = BF ? 18 : 36;
+    const int ckm = p.plan.CKM;
+    if (ckm == 0) return launch_ckm<BF, NT, 0>(p, R, s);
+    if (ckm == MID) return launch_ckm<BF, NT, MID>(p, R, s);
+    if constexpr (NT <= 8) { if (ckm == SMALL) return launch_ckm<BF, NT, SMALL>(p, R, s); }
+    if constexpr (NT == 16) { if (ckm == LARGE) return launch_ckm<BF, NT, LARGE>(p, R, s); }
+    return PF_ERR_UNSUPPORTED;
+}
+
+}  // namespace pf

@@ -1,0 +1,560 @@
+// pf_flow_fwd_kernel.h -- fused forward pass of the masked-autoregressive
+// rational-quadratic-spline flow for gfx950 (MI355X): ALL layers of
+//   [ReversePermutation, MADE conditioner, RQS elementwise + log|det J|]
+// plus the N(0,I) base log-density run in ONE kernel; nothing but x, ctx, z,
+// logdet, nll touches HBM besides the (L2-resident) packed weights.
+//
+// Replaces (reference file:line):
+//   NSFPosteriorFlow.forward            src/ahsd/models/flows.py:610-618
+//   NSFPosteriorFlow.compute_psd_aware_nll (log_sigma = 0)  flows.py:727-779
+//   which execute nflows CompositeTransform/ReversePermutation/MADE/
+//   MaskedPiecewiseRationalQuadraticAutoregressiveTransform (built flows.py:459-529).
+//
+// Work decomposition (DESIGN.md "Kernels"):
+//   workgroup = 16*R batch rows, NW = H/32 waves (512 threads at H = 256).
+//   Everything is computed TRANSPOSED: out^T[unit, row] = W[unit, k] . act^T[k, row],
+//   so the weights are the MFMA A operand (streamed from L2 exactly once per
+//   workgroup, in pre-packed fragment order, straight into VGPRs) and the batch
+//   rows are the 16 MFMA columns.  Wave w owns the hidden-tile pair (w, T-1-w)
+//   (degree-sorted 16-unit tiles, pf_layout.h) and the spline-feature pair
+//   (w, D-1-w): the block-triangular masks make the pair's useful k-range the
+//   same for every wave, so all waves run one static schedule and all-zero
+//   fragments are simply absent from the stream.  The residual state h lives in
+//   fp32 accumulator registers for the whole layer; activations are exchanged
+//   between waves through LDS in B-fragment order (one barrier per GEMM).
+//   Weight streaming: each wave walks ONE linear fragment stream, fully
+//   unrolled per layer, keeping a window of 16 unconditional fragment loads
+//   (16 KiB) in flight in registers across phases, barriers and layers, so the
+//   compiler's counted vmcnt waits are exact.  Biases are staged a layer ahead
+//   through LDS (a late bias load would drain the window).  In the final masked layer wave w owns spline
+//   the 3K-1 raw parameters of a feature come out of three 16-row MFMA tiles
+//   (widths | heights | derivatives); they are transposed through LDS and the
+//   spline (softmax, cumsum, bin search, rational quadratic, log-det) is
+//   evaluated by ONE lane per (row, feature) pair, all pairs of the workgroup
+//   at once -- no cross-lane traffic, 2.5x fewer wave-instructions than a
+//   4-lanes-per-pair in-register evaluation (measured: the kernel is
+//   instruction-issue-bound, profiles/README.md).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <type_traits>
+
+#include "pf_flow_params.h"
+
+namespace pf {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// ---- small device helpers ------------------------------------------------------
+template <bool FAST> __device__ __forceinline__ float pf_exp(float v) { return FAST ? __expf(v) : expf(v); }
+template <bool FAST> __device__ __forceinline__ float pf_log(float v) { return FAST ? __logf(v) : logf(v); }
+template <bool FAST> __device__ __forceinline__ float pf_div(float a, float b) {
+    return FAST ? a * __builtin_amdgcn_rcpf(b) : a / b;
+}
+template <bool FAST> __device__ __forceinline__ float pf_softplus(float u) {
+    // torch F.softplus: beta = 1, threshold = 20
+    if (FAST) return u > 20.f ? u : __logf(1.f + __expf(u));
+    return u > 20.f ? u : log1pf(expf(u));
+}
+template <bool FAST> __device__ __forceinline__ float pf_sigmoid(float v) {
+    return pf_div<FAST>(1.f, 1.f + pf_exp<FAST>(-v));
+}
+
+constexpr int kParStride = 52;   // floats per (row, feature) pair in the LDS transpose (48 used)
+
+// Forward RQS of one (row, feature) pair by one lane.  par: 16 raw widths | 16 raw heights |
+// 15 raw derivatives (rows >= K unused).  Follows nflows' rational_quadratic_spline /
+// unconstrained_rational_quadratic_spline (tails = 'linear') step by step: softmax,
+// min + (1 - min K) softmax, sequential cumsum, affine to [-tb, tb] with pinned ends,
+// searchsorted with the last knot + 1e-6, derivative = min_d + softplus(raw), boundary
+// derivative from the constant log(exp(1 - min_d) - 1).
+template <bool FAST>
+__device__ __forceinline__ void rqs_pair(const float* par, float x, int K, const FwdParams& p,
+                                         float& y, float& ld) {
+    float uw[16], uh[16], ud[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(par + 4 * q);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(par + 16 + 4 * q);
+        const f32x4 c = *reinterpret_cast<const f32x4*>(par + 32 + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { uw[4 * q + e] = a[e]; uh[4 * q + e] = b[e]; ud[4 * q + e] = c[e]; }
+    }
+    const float tb = p.tail_bound;
+    float mw = -INFINITY, mh = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) if (i < K) { mw = fmaxf(mw, uw[i]); mh = fmaxf(mh, uh[i]); }
+    float sw = 0.f, sh = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        uw[i] = i < K ? pf_exp<FAST>(uw[i] - mw) : 0.f; sw += uw[i];
+        uh[i] = i < K ? pf_exp<FAST>(uh[i] - mh) : 0.f; sh += uh[i];
+    }
+    const float cw = pf_div<FAST>(1.f - p.min_w * (float)K, sw);
+    const float ch = pf_div<FAST>(1.f - p.min_h * (float)K, sh);
+    const float span = 2.f * tb;
+    float cumw = 0.f, cumh = 0.f;
+    float xl = -tb, xr = tb, yl = -tb, yr = tb;
+    float dl_raw = p.deriv_const, dr_raw = p.deriv_const;
+    bool prev_ge = true;                     // x >= left knot of bin 0 (x is inside)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        if (i < K) {
+            cumw += p.min_w + cw * uw[i];
+            cumh += p.min_h + ch * uh[i];
+            const bool last = i == K - 1;
+            const float kr = last ? tb : span * cumw - tb;       // right knot of bin i (widths)
+            const float hr = last ? tb : span * cumh - tb;       // right knot of bin i (heights)
+            const float dr = last ? p.deriv_const : ud[i];       // raw derivative at that knot
+            const bool ge = x >= (last ? tb + 1e-6f : kr);       // searchsorted: last knot + eps
+            const bool sel = prev_ge && !ge;                     // x falls into bin i
+            xr = sel ? kr : xr; yr = sel ? hr : yr; dr_raw = sel ? dr : dr_raw;
+            xl = ge ? kr : xl;  yl = ge ? hr : yl;  dl_raw = ge ? dr : dl_raw;
+            prev_ge = ge;
+        }
+    }
+    const float w = xr - xl, h = yr - yl;
+    const float dl = p.min_d + pf_softplus<FAST>(dl_raw);
+    const float dr = p.min_d + pf_softplus<FAST>(dr_raw);
+    const float delta = pf_div<FAST>(h, w);
+    const float th = pf_div<FAST>(x - xl, w);
+    const float tt = th * (1.f - th);
+    const float numer = h * (delta * th * th + dl * tt);
+    const float den = delta + (dl + dr - 2.f * delta) * tt;
+    const float omt = 1.f - th;
+    const float dnum = delta * delta * (dr * th * th + 2.f * delta * tt + dl * omt * omt);
+    const bool inside = (x >= -tb) && (x <= tb);
+    y = inside ? yl + pf_div<FAST>(numer, den) : x;
+    ld = inside ? pf_log<FAST>(dnum) - 2.f * pf_log<FAST>(den) : 0.f;
+}
+
+// ---- the kernel ------------------------------------------------------------------
+// LDS carve (bytes), all 16-B aligned:
+//   ctx    : CKM * R KiB            context in B-fragment order (zero padded to CKM k-steps)
+//   act0   : HK * R KiB             activations in B-fragment order
+//   P      : max(HK*R KiB, D*16*52*4)  second activation buffer, aliased by the spline transpose
+//   xb0/1  : 16 * 16R floats each   layer input x^T / output z^T (double buffer)
+//   bias0/1: NT * 192 floats each   this / next layer's biases
+//   ldb    : D * 16R floats         per-(feature,row) log-det partials
+template <int B, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, N - 1>(f);
+    }
+}
+template <int V> using ic = std::integral_constant<int, V>;
+
+#ifdef PF_ABLATE_BUILD
+#define PF_ABL(mask) (p.ablate & (mask))
+#else
+#define PF_ABL(mask) false
+#endif
+
+template <bool BF16, int NT, int R, int CKM, bool DENSE>
+__global__ __launch_bounds__(NT * 32) void flow_forward_kernel(const FwdParams p) {
+    using S = Sched<BF16, NT, CKM, DENSE>;
+    constexpr bool FAST = BF16;
+    constexpr int NW = NT / 2, HK = S::HK, KHS = S::KHS, KOS = S::KOS, NF = S::NF;
+    constexpr int COLS = 16 * R;
+    constexpr int W = 16;                               // frags in flight per wave
+    constexpr int NE = (NF + W - 1) / W * W;            // schedule length rounded to the window
+    constexpr bool CTX_REGS = (R == 1) && CKM > 0 && CKM <= 9;   // context B fragments live in registers
+    static_assert(W <= kWindowPad, "stream pad too small");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const FlowPlan& L = p.plan;
+    const int D = L.D, K = L.K;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, c = lane & 15;
+    const int64_t row0 = (int64_t)blockIdx.x * COLS;
+    const int tA = wave, tB = NT - 1 - wave;
+    const int kA = L.kH[tA];                            // W0/W1 entries [0,kA) belong to tile A
+    const int fA = L.featA[wave], fB = L.featB[wave];   // spline features of this wave (-1: none)
+    const int kOA = fA >= 0 ? L.kO[fA] : 0;             // out entries [0,kOA) belong to feature A
+
+    const size_t p_bytes = max((size_t)HK * R * kFragBytes, (size_t)D * 16 * kParStride * sizeof(float));
+    char* s_ctx = smem;
+    char* s_act0 = s_ctx + (size_t)CKM * R * kFragBytes;
+    char* s_act1 = s_act0 + (size_t)HK * R * kFragBytes;          // region P
+    float* s_par = reinterpret_cast<float*>(s_act1);
+    float* s_xb0 = reinterpret_cast<float*>(s_act1 + p_bytes);
+    float* s_xb1 = s_xb0 + 16 * COLS;
+    float* s_bias = s_xb1 + 16 * COLS;                  // [2][NT][192]
+    float* s_ldb = s_bias + 2 * NT * kBiasFloatsPerTile;
+
+    // ---- weight stream: buffer resource over this wave's region, register window ---------
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(p.packed) + (int64_t)wave * L.fragsPerWave * kFragBytes, 0,
+        (int)(L.fragsPerWave * kFragBytes), 0x00020000);
+    u32x4 win[W];
+    int lbase = 0;                                      // byte offset of the current layer's frags
+    // entry E of the current layer was just consumed: refill its slot with entry E + W
+    auto refill = [&](auto e) {
+        constexpr int E = decltype(e)::value;
+        constexpr int EN = (E + W) % NE;
+        constexpr bool wrap = (E + W) >= NE;
+        if constexpr (EN < NF) {
+            const int off = PF_ABL(2) ? 0 : lbase + ((wrap ? NF : 0) + EN) * kFragBytes;
+            win[EN % W] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, off, 0);
+        }
+    };
+
+    // ---- stage context (B-fragment order), x^T and layer 0's biases -------------------
+    for (int s = tid; s < CKM * R * 64; s += NW * 64) {
+        const int ln = s & 63, r = (s >> 6) % R, ks = s / (64 * R);
+        const int gg = ln >> 4, cc = ln & 15;
+        int64_t row = row0 + 16 * r + cc;
+        if (row >= p.batch) row = p.batch - 1;
+        const float* src = p.ctx + row * L.C;
+        if (BF16) {
+            bf16x8 v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int col = 32 * ks + 8 * gg + j;
+                v[j] = (__bf16)(col < L.C ? src[col] : 0.f);
+            }
+            *reinterpret_cast<bf16x8*>(s_ctx + (size_t)s * 16) = v;
+        } else {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int col = 16 * ks + 4 * gg + e;
+                v[e] = col < L.C ? src[col] : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(s_ctx + (size_t)s * 16) = v;
+        }
+    }
+    for (int s = tid; s < 16 * COLS; s += NW * 64) {
+        const int d = s / COLS, col = s % COLS;
+        float v = 0.f;
+        if (d < D) {
+            int64_t row = row0 + col;
+            if (row >= p.batch) row = p.batch - 1;
+            // layer 0 sees reverse(x[:, ar_perm]): position d <- source D-1-d
+            const int sd = D - 1 - d;
+            const int src = p.ar_perm ? p.ar_perm[sd] : sd;
+            v = p.x[row * D + src];
+        }
+        s_xb0[s] = v;
+        s_xb1[s] = 0.f;
+    }
+    const float* gbias = reinterpret_cast<const float*>(p.packed + L.weightBytes);
+    for (int s = tid; s < NT * kBiasFloatsPerTile; s += NW * 64) s_bias[s] = gbias[s];
+    for (int s = tid; s < D * COLS; s += NW * 64) s_ldb[s] = 0.f;
+    // prologue of the weight stream: first window of layer 0
+    static_for<0, W>([&](auto e) {
+        constexpr int E = decltype(e)::value;
+        if constexpr (E < NF) win[E] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, E * kFragBytes, 0);
+    });
+    __syncthreads();
+
+    // B fragments of one LDS buffer -> registers
+    auto load_b = [&](const char* src, auto n, u32x4 (&bk)[decltype(n)::value][R]) {
+        constexpr int N = decltype(n)::value;
+#pragma unroll
+        for (int ks = 0; ks < N; ++ks)
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                bk[ks][r] = *reinterpret_cast<const u32x4*>(src + ((size_t)(ks * R + r) * 64 + lane) * 16);
+    };
+    u32x4 cb[CTX_REGS ? CKM : 1][R];
+    if constexpr (CTX_REGS) load_b(s_ctx, ic<CKM>{}, cb);
+
+    float ld_pair = 0.f;                                // log-det of this thread's (feature,row) pair
+
+    // acc[r] += A(window slot of entry E) . B
+    auto mma = [&](auto e, const u32x4 (&b)[R], f32x4 (&acc)[R]) {
+        constexpr int E = decltype(e)::value;
+        const u32x4 a = win[E % W];
+        if (PF_ABL(4)) { asm volatile("" :: "v"(a)); return; }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (BF16) {
+                acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                                 __builtin_bit_cast(bf16x8, b[r]), acc[r], 0, 0, 0);
+            } else {
+                const f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b[r]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q], bf[q], acc[r], 0, 0, 0);
+            }
+        }
+    };
+    // write 16 units x COLS activations of tile `tile` into a B-fragment buffer
+    auto store_act = [&](char* dst, int tile, const f32x4 (&v)[R]) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (BF16) {
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[r][e];
+                *reinterpret_cast<bf16x4*>(dst + ((size_t)((tile >> 1) * R + r) * 64 + lane) * 16 + (tile & 1) * 8) = o;
+            } else {
+                *reinterpret_cast<f32x4*>(dst + ((size_t)(tile * R + r) * 64 + lane) * 16) = v[r];
+            }
+        }
+    };
+    auto zero = [&](f32x4 (&v)[R]) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto barrier = [&]() { if (!PF_ABL(8)) __syncthreads(); };
+
+    for (int l = 0; l < L.L; ++l) {
+        float* xin = (l & 1) ? s_xb1 : s_xb0;
+        float* xout = (l & 1) ? s_xb0 : s_xb1;
+        const float* bias = s_bias + (l & 1) * NT * kBiasFloatsPerTile;
+        auto load_bias = [&](int tile, int slot) {
+            return *reinterpret_cast<const f32x4*>(bias + tile * kBiasFloatsPerTile + slot * 16 + 4 * g);
+        };
+        // next layer's biases: issued now (oldest loads of the layer), parked in LDS at its end
+        f32x4 nbA = {0.f, 0.f, 0.f, 0.f}, nbB = nbA;
+        {
+            const int ln = l + 1 < L.L ? l + 1 : l;
+            if (lane < kBiasFloatsPerTile / 4) {
+                nbA = *reinterpret_cast<const f32x4*>(gbias + L.bias_index(ln, tA) + 4 * lane);
+                nbB = *reinterpret_cast<const f32x4*>(gbias + L.bias_index(ln, tB) + 4 * lane);
+            }
+        }
+        // masked GEMM over a tile / feature pair, entries [E0, E0+N): entry i < nA is k-step i of
+        // the first accumulator, otherwise k-step N-1-i of the second (pf_layout.h); every
+        // k-step index is a compile-time constant, only the accumulator choice is per wave
+        auto gemm_pair = [&](auto e0, auto n, int nA, const u32x4 (&bk)[HK][R], f32x4 (&a0)[R], f32x4 (&a1)[R]) {
+            constexpr int E0 = decltype(e0)::value, N = decltype(n)::value;
+            static_for<0, N>([&](auto i) {
+                constexpr int I = decltype(i)::value;
+                constexpr int KA = I < HK ? I : HK - 1, KB = (N - 1 - I) < HK ? (N - 1 - I) : HK - 1;
+                if (I < nA) mma(ic<E0 + I>{}, bk[KA], a0);
+                else mma(ic<E0 + I>{}, bk[KB], a1);
+                refill(ic<E0 + I>{});
+            });
+        };
+        auto gemm_ctx = [&](auto e0, f32x4 (&a0)[R], f32x4 (&a1)[R]) {
+            constexpr int E0 = decltype(e0)::value;
+            static_for<0, CKM>([&](auto k) {
+                constexpr int KS = decltype(k)::value;
+                if constexpr (CTX_REGS) {
+                    mma(ic<E0 + 2 * KS>{}, cb[KS], a0);
+                    mma(ic<E0 + 2 * KS + 1>{}, cb[KS], a1);
+                } else {
+                    u32x4 b[1][R];
+                    load_b(s_ctx + (size_t)KS * R * kFragBytes, ic<1>{}, b);
+                    mma(ic<E0 + 2 * KS>{}, b[0], a0);
+                    mma(ic<E0 + 2 * KS + 1>{}, b[0], a1);
+                }
+                refill(ic<E0 + 2 * KS>{});
+                refill(ic<E0 + 2 * KS + 1>{});
+            });
+        };
+
+        // ---- initial layer: h = W_in x + b_in + relu(W_c ctx + b_c) ---------------------
+        f32x4 hA[R], hB[R];
+        {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accB = accA;
+                if (BF16) {
+                    bf16x8 b;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float v = xin[((8 * g + j) & 15) * COLS + 16 * r + c];
+                        const __bf16 hi = (__bf16)v;
+                        b[j] = g < 2 ? hi : (__bf16)(v - (float)hi);
+                    }
+                    accA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, win[S::E_IN % W]), b, accA, 0, 0, 0);
+                    accB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, win[(S::E_IN + 1) % W]), b, accB, 0, 0, 0);
+                } else {
+                    const f32x4 afA = __builtin_bit_cast(f32x4, win[S::E_IN % W]);
+                    const f32x4 afB = __builtin_bit_cast(f32x4, win[(S::E_IN + 1) % W]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float xv = xin[(4 * g + e) * COLS + 16 * r + c];
+                        accA = __builtin_amdgcn_mfma_f32_16x16x4f32(afA[e], xv, accA, 0, 0, 0);
+                        accB = __builtin_amdgcn_mfma_f32_16x16x4f32(afB[e], xv, accB, 0, 0, 0);
+                    }
+                }
+                hA[r] = accA; hB[r] = accB;
+            }
+            refill(ic<S::E_IN>{});
+            refill(ic<S::E_IN + 1>{});
+            const f32x4 biA = load_bias(tA, kSlotIn), biB = load_bias(tB, kSlotIn);
+#pragma unroll
+            for (int r = 0; r < R; ++r) { hA[r] += biA; hB[r] += biB; }
+            if constexpr (CKM > 0) {
+                f32x4 cA[R], cB[R];
+                zero(cA); zero(cB);
+                gemm_ctx(ic<S::E_CTX>{}, cA, cB);
+                const f32x4 bcA = load_bias(tA, kSlotCtx), bcB = load_bias(tB, kSlotCtx);
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        hA[r][e] += fmaxf(cA[r][e] + bcA[e], 0.f);
+                        hB[r][e] += fmaxf(cB[r][e] + bcB[e], 0.f);
+                    }
+            }
+        }
+
+        // ---- residual blocks ---------------------------------------------------------------
+        static_for<0, 2>([&](auto bb) {
+            constexpr int b = decltype(bb)::value;
+            constexpr int EB = S::E_BLK + b * S::BLK;
+            f32x4 tAv[R], tBv[R];
+            u32x4 bk[HK][R];
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { tAv[r][e] = fmaxf(hA[r][e], 0.f); tBv[r][e] = fmaxf(hB[r][e], 0.f); }
+            store_act(s_act0, tA, tAv);
+            store_act(s_act0, tB, tBv);
+            barrier();
+            load_b(s_act0, ic<HK>{}, bk);
+            zero(tAv); zero(tBv);
+            gemm_pair(ic<EB>{}, ic<KHS>{}, kA, bk, tAv, tBv);
+            {
+                const f32x4 b0A = load_bias(tA, kSlotBlk + 3 * b), b0B = load_bias(tB, kSlotBlk + 3 * b);
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        tAv[r][e] = fmaxf(tAv[r][e] + b0A[e], 0.f);
+                        tBv[r][e] = fmaxf(tBv[r][e] + b0B[e], 0.f);
+                    }
+            }
+            store_act(s_act1, tA, tAv);
+            store_act(s_act1, tB, tBv);
+            barrier();
+            load_b(s_act1, ic<HK>{}, bk);
+            zero(tAv); zero(tBv);
+            gemm_pair(ic<EB + KHS>{}, ic<KHS>{}, kA, bk, tAv, tBv);
+            const f32x4 b1A = load_bias(tA, kSlotBlk + 3 * b + 1), b1B = load_bias(tB, kSlotBlk + 3 * b + 1);
+            if constexpr (CKM > 0) {
+                f32x4 gA[R], gB[R];
+                zero(gA); zero(gB);
+                gemm_ctx(ic<EB + 2 * KHS>{}, gA, gB);
+                const f32x4 bgA = load_bias(tA, kSlotBlk + 3 * b + 2), bgB = load_bias(tB, kSlotBlk + 3 * b + 2);
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        hA[r][e] += (tAv[r][e] + b1A[e]) * pf_sigmoid<FAST>(gA[r][e] + bgA[e]);
+                        hB[r][e] += (tBv[r][e] + b1B[e]) * pf_sigmoid<FAST>(gB[r][e] + bgB[e]);
+                    }
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; ++r) { hA[r] += tAv[r] + b1A; hB[r] += tBv[r] + b1B; }
+            }
+        });
+
+        // ---- final masked layer: wave w produces the raw spline parameters of features (w, D-1-w) --
+        store_act(s_act0, tA, hA);          // no activation in front of the final layer
+        store_act(s_act0, tB, hB);
+        barrier();
+        f32x4 pA[3][R], pB[3][R];
+        {
+            u32x4 bk[HK][R];
+            load_b(s_act0, ic<HK>{}, bk);
+            static_for<0, 3>([&](auto qq) {
+                constexpr int q = decltype(qq)::value;
+                zero(pA[q]); zero(pB[q]);
+                gemm_pair(ic<S::E_OUT + q * KOS>{}, ic<KOS>{}, kOA, bk, pA[q], pB[q]);
+            });
+            // schedule padding: keep the window rolling up to the next multiple of W
+            static_for<NF, NE - NF>([&](auto e) { refill(e); });
+        }
+        // park the next layer's biases (the same wave reads them back next layer)
+        if (lane < kBiasFloatsPerTile / 4) {
+            float* nb = s_bias + ((l + 1) & 1) * NT * kBiasFloatsPerTile;
+            *reinterpret_cast<f32x4*>(nb + tA * kBiasFloatsPerTile + 4 * lane) = nbA;
+            *reinterpret_cast<f32x4*>(nb + tB * kBiasFloatsPerTile + 4 * lane) = nbB;
+        }
+        // ---- spline: transpose the parameters through LDS, one lane per (row, feature) pair ----
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            auto put = [&](int feat, int tile, const f32x4 (&pp)[3][R]) {
+                if (feat < 0) return;
+                float* dst = s_par + (size_t)(feat * 16 + c) * kParStride + 4 * g;
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    *reinterpret_cast<f32x4*>(dst + 16 * q) = pp[q][r] + load_bias(tile, kSlotOut + q);
+            };
+            put(fA, tA, pA);
+            put(fB, tB, pB);
+            barrier();
+            if (tid < D * 16) {
+                const int feat = tid >> 4, col = tid & 15;
+                const float xv = xin[feat * COLS + 16 * r + col];
+                float y, ld;
+                if (PF_ABL(1)) { y = xv + s_par[(size_t)tid * kParStride]; ld = 0.f; }
+                else rqs_pair<FAST>(s_par + (size_t)tid * kParStride, xv, K, p, y, ld);
+                if (r == 0) ld_pair += ld; else s_ldb[feat * COLS + 16 * r + col] += ld;
+                // the next layer starts with ReversePermutation: position D-1-feat
+                xout[(D - 1 - feat) * COLS + 16 * r + col] = y;
+            }
+            if (r + 1 < R) barrier();      // the transpose buffer is reused by the next column group
+        }
+        lbase += NF * kFragBytes;
+        barrier();
+    }
+
+    // ---- epilogue: sum log-dets over features, base log-density, stores -----------------
+    if (tid < D * 16) s_ldb[(tid >> 4) * COLS + (tid & 15)] = ld_pair;
+    __syncthreads();
+    const float* zfin = (L.L & 1) ? s_xb1 : s_xb0;     // stored reversed (see above)
+    if (tid < COLS) {
+        const int64_t row = row0 + tid;
+        if (row < p.batch) {
+            float ld = 0.f, q = 0.f, sls = 0.f;
+            for (int f = 0; f < D; ++f) ld += s_ldb[f * COLS + tid];
+            for (int d = 0; d < D; ++d) {
+                const float zv = zfin[(D - 1 - d) * COLS + tid];
+                if (p.log_sigma) {           // PSDScaledNormal.log_prob, flows.py:73-83
+                    const float ls = p.log_sigma[row * D + d];
+                    const float zs = zv / expf(ls);
+                    q += zs * zs; sls += ls;
+                } else {
+                    q += zv * zv;
+                }
+                if (p.z) p.z[row * D + d] = zv;
+            }
+            if (p.logdet) p.logdet[row] = ld;
+            // nll = -(log N(z; 0, diag(e^ls)^2) + logdet)
+            if (p.nll) p.nll[row] = 0.5f * (q + 2.f * sls + (float)D * 1.8378770664093453f) - ld;
+        }
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------
+inline size_t fwd_lds_bytes(const FlowPlan& L, int R) {
+    const size_t pb = std::max((size_t)L.HK * R * kFragBytes, (size_t)L.D * 16 * kParStride * sizeof(float));
+    return (size_t)L.CKM * R * kFragBytes + (size_t)L.HK * R * kFragBytes + pb
+         + (size_t)(2 * 16 * 16 * R + 2 * L.NT * kBiasFloatsPerTile + L.D * 16 * R) * sizeof(float);
+}
+
+template <bool BF16, int NT, int R, int CKM, bool DENSE>
+inline int launch_variant(const FwdParams& p, hipStream_t s) {
+    const unsigned grid = (unsigned)((p.batch + 16 * R - 1) / (16 * R));
+    const size_t lds = fwd_lds_bytes(p.plan, R);
+    auto kern = flow_forward_kernel<BF16, NT, R, CKM, DENSE>;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+        return PF_ERR_HIP;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT * 32), lds, s, p);
+    return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
+}
+
+// all built variants of one (precision, NT): R in {1,2} x {masked}, R = 1 x {dense}
+template <bool BF16, int NT, int CKM>
+inline int launch_ckm(const FwdParams& p, int R, hipStream_t s) {
+    if (p.plan.dense) return launch_variant<BF16, NT, 1, CKM, true>(p, s);
+    if (R == 2) return launch_variant<BF16, NT, 2, CKM, false>(p, s);
+    return launch_variant<BF16, NT, 1, CKM, false>(p, s);
+}
+
+}  // namespace pf

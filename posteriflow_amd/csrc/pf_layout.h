@@ -1,18 +1,21 @@
 // pf_layout.h -- packed-weight layout ("plan") shared by the host pack-map builder
 // and the gfx950 flow kernels.  See DESIGN.md "Data layout in HBM".
 //
-// One workgroup = NW = H/16 waves.  Hidden units are taken in DEGREE-SORTED order
-// (stable sort by MADE degree): position p <-> unit perm[p].  Wave w owns sorted
-// positions 16w..16w+15 of every H-wide layer, and spline feature NW-1-w of the
-// final layer (light hidden tiles carry the heavy output features, so every
-// wave streams about the same number of fragments per layer).  With sorted units the autoregressive masks are block lower-triangular,
-// so a wave's tile only needs the first kmaxH[w] k-steps of a masked H x H GEMM
-// and feature w only the first kmaxO[w] k-steps of the final layer: all-zero
+// Hidden units are taken in DEGREE-SORTED order (stable sort by MADE degree):
+// position p <-> unit perm[p]; tile t = positions 16t..16t+15, T = H/16 tiles.
+// With sorted units the autoregressive masks are block lower-triangular: tile t
+// of a masked H x H layer only needs its first kH[t] k-steps, spline feature f of
+// the final layer only its first kO[f] k-steps.
+//
+// One workgroup = NW = T/2 waves.  Wave w owns the tile PAIR (w, T-1-w) and the
+// feature pair (w, D-1-w): kH[w] + kH[T-1-w] and kO[w] + kO[D-1-w] are (nearly)
+// the same for every wave, so all waves run ONE static schedule with no
+// per-wave predicates, padded to the plan-wide maxima KHS / KOS.  All-zero
 // fragments are neither stored nor fetched.
 //
-// The packed buffer holds, per wave, ONE linear stream over all layers of MFMA
-// A-fragments ("frags", 1 KiB = 64 lanes x 16 B) in the exact order the wave
-// consumes them, then a bias region (fp32, 256 floats per (layer, wave)).
+// The packed buffer holds, per wave, one linear stream [layer][NF frags] of MFMA
+// A-fragments ("frags", 1 KiB = 64 lanes x 16 B) in consumption order, then a
+// bias region [layer][tile][12 slots][16] fp32.
 //
 //   bf16 mode  (v_mfma_f32_16x16x32_bf16): a frag is one MFMA A operand,
 //              lane = 16*g + r16 holds A[row r16][k = 8*g + j], j = 0..7
@@ -26,10 +29,15 @@
 //   x input        bf16: d   = (8*g + j) & 15  (k<16: bf16 hi part of x, k>=16: lo part)
 //                  f32 : d   = 4*g + e
 //
-// Per-layer schedule of a wave (entries; an entry is one frag slot, fetched only if
-// active for this wave):
-//   in(1) | ctx(CKM) | block0: W0(HK) W1(HK) gate(CKM) | block1: ... | out: 3 x HK | pad
-// kinds:  ALWAYS      CTX (ks < CK)      HID (ks < kmaxH[w])            OUT (ks < kmaxO[w])
+// Per-layer stream of a wave (tile A = w, tile B = T-1-w; feature A = w, B = D-1-w):
+//   in:   A, B                                            2
+//   ctx:  for ks < CKM: A, B                              2*CKM
+//   block b (x2):  W0: KHS entries: entry i < kH[A] is k-step i of tile A; entry
+//                      i >= KHS - kH[B] is k-step KHS-1-i of tile B (REVERSE order, so the
+//                      k-step of every entry is a compile-time constant); zero pad between
+//                  W1: KHS entries, same
+//                  gate: for ks < CKM: A, B               2*KHS + 2*CKM
+//   out:  for q in widths|heights|derivs: KOS entries, feature A forward / feature B reversed
 #pragma once
 #include <stdint.h>
 
@@ -44,58 +52,46 @@
 namespace pf {
 
 constexpr int kFragBytes = 1024;
-constexpr int kBiasFloatsPerWave = 256;   // slots of 16 floats
+constexpr int kBiasSlots = 12;            // per tile: in, ctx, 2 x (W0, W1, gate), out w|h|d, spare
+constexpr int kBiasFloatsPerTile = kBiasSlots * 16;
 constexpr int kSlotIn = 0, kSlotCtx = 1, kSlotBlk = 2 /* +3*b: W0, W1, gate */, kSlotOut = 8;
-constexpr int kWindow = 12;               // max frags a wave keeps in flight (= stream overrun pad)
-constexpr int kMaxWaves = 16;
+constexpr int kWindowPad = 16;            // frags of zero padding behind each wave's stream
+constexpr int kMaxWaves = 8;
+constexpr int kMaxTiles = 16;
 
-enum EntryKind : int { kAlways = 0, kCtx = 1, kHid = 2, kOut = 3, kNever = 4 };
-
-// compile-time schedule shared by kernel (template) and host (runtime mirror below)
-template <bool BF16, int NW, int CKM, int WIN>
+// compile-time schedule (frag offsets inside one layer of a wave's stream)
+template <bool BF16, int NT, int CKM, bool DENSE>
 struct Sched {
-    static constexpr int HK = BF16 ? NW / 2 : NW;      // frags per full hidden tile row
+    static constexpr int HK = BF16 ? NT / 2 : NT;          // frags per full hidden tile row
+    static constexpr int KHS = DENSE ? 2 * HK : HK + 2;     // entries of a masked H x H GEMM (tile pair)
+    static constexpr int KOS = DENSE ? 2 * HK : HK + 1;     // entries per spline-parameter tile (feature pair)
     static constexpr int E_IN = 0;
-    static constexpr int E_CTX = 1;
-    static constexpr int E_BLK = E_CTX + CKM;
-    static constexpr int BLK = 2 * HK + CKM;           // W0 | W1 | gate
+    static constexpr int E_CTX = 2;
+    static constexpr int E_BLK = E_CTX + 2 * CKM;
+    static constexpr int BLK = 2 * KHS + 2 * CKM;           // W0 | W1 | gate
     static constexpr int E_OUT = E_BLK + 2 * BLK;
-    static constexpr int NE_RAW = E_OUT + 3 * HK;
-    static constexpr int NE = (NE_RAW + WIN - 1) / WIN * WIN;
-    static constexpr int kind(int e) {
-        if (e < E_CTX) return kAlways;
-        if (e < E_BLK) return kCtx;
-        if (e < E_OUT) { const int r = (e - E_BLK) % BLK; return r < 2 * HK ? kHid : kCtx; }
-        if (e < NE_RAW) return kOut;
-        return kNever;
-    }
-    static constexpr int ks(int e) {
-        if (e < E_CTX) return 0;
-        if (e < E_BLK) return e - E_CTX;
-        if (e < E_OUT) { const int r = (e - E_BLK) % BLK; return r < 2 * HK ? r % HK : r - 2 * HK; }
-        if (e < NE_RAW) return (e - E_OUT) % HK;
-        return 0;
-    }
+    static constexpr int NF = E_OUT + 3 * KOS;
 };
 
 struct FlowPlan {
     int D, C, H, K, L, M, NB;   // M = 3K-1 params per feature, NB = residual blocks
     int bf16;                   // 1: bf16 frags, 0: f32 frags
-    int NW;                     // waves per workgroup = H/16
+    int NT, NW;                 // tiles = H/16, waves = NT/2
     int kstep;                  // k extent of one frag: 32 (bf16) or 16 (f32)
-    int CK, CKM, HK;            // active / scheduled context frags per tile; hidden frags per tile
-    int kmaxH[kMaxWaves];       // active k-steps of this wave's tile in a masked H x H GEMM
-    int kmaxO[kMaxWaves];       // active k-steps of this wave's feature in the final layer (0: none)
-    int feat[kMaxWaves];        // spline feature owned by the wave (NW-1-w), -1 if >= D
-    int fragsPerLayer[kMaxWaves];
-    int64_t waveBase[kMaxWaves];   // first frag of the wave's stream
-    int64_t fragsTotal;            // incl. kWindow pad frags per wave (prefetch overrun)
+    int CK, CKM, HK;            // needed / scheduled context frags per tile; frags per full hidden row
+    int dense;                  // 1: KHS = KOS = 2*HK (masks too coarse to pair up), else HK+2 / HK+1
+    int KHS, KOS, NF;
+    int kH[kMaxTiles];          // active k-steps of tile t in a masked H x H GEMM
+    int kO[kMaxTiles];          // active k-steps of feature f in the final layer
+    int featA[kMaxWaves], featB[kMaxWaves];   // features of wave w (-1: none)
+    int64_t fragsPerWave;       // L * NF + kWindowPad
+    int64_t fragsTotal;
     int64_t weightBytes;
-    int64_t biasFloats;            // L * NW * 256
+    int64_t biasFloats;         // L * NT * kBiasFloatsPerTile
     int64_t rawPerLayer;
 
-    PF_HD int64_t bias_index(int layer, int wave) const {
-        return ((int64_t)layer * NW + wave) * kBiasFloatsPerWave;
+    PF_HD int64_t bias_index(int layer, int tile) const {
+        return ((int64_t)layer * NT + tile) * kBiasFloatsPerTile;
     }
 };
 
@@ -104,12 +100,15 @@ inline int hid_degree(int D, int u) {
     return u % hi + lo;
 }
 
-// scheduled context frags for a given C: smallest supported CKM covering it
-inline int pick_ckm(bool bf16, int C) {
+// scheduled context frags per tile for a given C: smallest supported CKM covering it
+// (the set of built kernels: NT 4/8 have {0, small, mid}, NT 12 {0, mid}, NT 16 {0, mid, large})
+inline int pick_ckm(bool bf16, int NT, int C) {
+    if (C == 0) return 0;
     const int ck = (C + (bf16 ? 31 : 15)) / (bf16 ? 32 : 16);
-    const int small = bf16 ? 9 : 18, large = bf16 ? 18 : 36;
-    if (ck <= small) return small;
-    if (ck <= large) return large;
+    const int small = bf16 ? 3 : 6, mid = bf16 ? 9 : 18, large = bf16 ? 18 : 36;
+    if (NT <= 8 && ck <= small) return small;
+    if (ck <= mid) return mid;
+    if (NT == 16 && ck <= large) return large;
     return -1;
 }
 
@@ -134,36 +133,48 @@ inline int make_plan(const PfFlowDesc& d, FlowPlan& o) {
     o.D = d.features; o.C = d.context_features; o.H = d.hidden_features;
     o.K = d.num_bins; o.L = d.num_layers; o.M = 3 * d.num_bins - 1; o.NB = d.num_blocks;
     o.bf16 = d.precision == PF_PREC_BF16;
-    o.NW = o.H / 16;
+    o.NT = o.H / 16; o.NW = o.NT / 2;
     o.kstep = o.bf16 ? 32 : 16;
     o.CK = (o.C + o.kstep - 1) / o.kstep;
-    o.CKM = pick_ckm(o.bf16, o.C);
+    o.CKM = pick_ckm(o.bf16, o.NT, o.C);
     if (o.CKM < 0) return PF_ERR_UNSUPPORTED;
     o.HK = o.H / o.kstep;
     int perm[256], deg_sorted[256];
     sorted_units(o.D, o.H, perm);
     for (int p = 0; p < o.H; ++p) deg_sorted[p] = hid_degree(o.D, perm[p]);
-    for (int w = 0; w < kMaxWaves; ++w) { o.feat[w] = -1; o.kmaxH[w] = o.kmaxO[w] = 0; o.fragsPerLayer[w] = 0; o.waveBase[w] = 0; }
-    int64_t base = 0;
-    for (int w = 0; w < o.NW; ++w) {
+    for (int t = 0; t < kMaxTiles; ++t) o.kH[t] = o.kO[t] = 0;
+    for (int t = 0; t < o.NT; ++t) {
         // hidden mask: deg_out >= deg_in -> inputs with degree <= the tile's largest degree
-        const int tile_max = deg_sorted[16 * w + 15];
+        const int tile_max = deg_sorted[16 * t + 15];
         int cnt = 0;
         while (cnt < o.H && deg_sorted[cnt] <= tile_max) ++cnt;
-        o.kmaxH[w] = (cnt + o.kstep - 1) / o.kstep;
-        // output mask: deg_out (= feature+1) > deg_in
-        const int f = o.NW - 1 - w;
-        o.feat[w] = f < o.D ? f : -1;
-        cnt = 0;
-        if (f < o.D) while (cnt < o.H && deg_sorted[cnt] < f + 1) ++cnt;
-        o.kmaxO[w] = (cnt + o.kstep - 1) / o.kstep;
-        o.fragsPerLayer[w] = 1 + o.CK + o.NB * (2 * o.kmaxH[w] + o.CK) + 3 * o.kmaxO[w];
-        o.waveBase[w] = base;
-        base += (int64_t)o.L * o.fragsPerLayer[w] + kWindow;
+        o.kH[t] = (cnt + o.kstep - 1) / o.kstep;
     }
-    o.fragsTotal = base;
+    for (int f = 0; f < o.D; ++f) {
+        // output mask: deg_out (= f+1) > deg_in
+        int cnt = 0;
+        while (cnt < o.H && deg_sorted[cnt] < f + 1) ++cnt;
+        o.kO[f] = (cnt + o.kstep - 1) / o.kstep;
+    }
+    int khs = 0, kos = 0;
+    for (int w = 0; w < kMaxWaves; ++w) o.featA[w] = o.featB[w] = -1;
+    for (int w = 0; w < o.NW; ++w) {
+        const int fa = w, fb = o.D - 1 - w;
+        o.featA[w] = (fa < o.D && fa <= fb) ? fa : -1;
+        o.featB[w] = (fb > fa && fb >= 0) ? fb : -1;
+        const int h = o.kH[w] + o.kH[o.NT - 1 - w];
+        const int q = (o.featA[w] >= 0 ? o.kO[o.featA[w]] : 0) + (o.featB[w] >= 0 ? o.kO[o.featB[w]] : 0);
+        if (h > khs) khs = h;
+        if (q > kos) kos = q;
+    }
+    o.dense = (khs > o.HK + 2 || kos > o.HK + 1) ? 1 : 0;
+    o.KHS = o.dense ? 2 * o.HK : o.HK + 2;
+    o.KOS = o.dense ? 2 * o.HK : o.HK + 1;
+    o.NF = 2 + 2 * o.CKM + o.NB * (2 * o.KHS + 2 * o.CKM) + 3 * o.KOS;
+    o.fragsPerWave = (int64_t)o.L * o.NF + kWindowPad;
+    o.fragsTotal = o.fragsPerWave * o.NW;
     o.weightBytes = o.fragsTotal * kFragBytes;
-    o.biasFloats = (int64_t)o.L * o.NW * kBiasFloatsPerWave;
+    o.biasFloats = (int64_t)o.L * o.NT * kBiasFloatsPerTile;
     const int64_t ctxp = o.C > 0 ? ((int64_t)o.H * o.C + o.H) : 0;
     o.rawPerLayer = (int64_t)o.H * o.D + o.H + ctxp
                   + (int64_t)o.NB * (ctxp + 2 * ((int64_t)o.H * o.H + o.H))

@@ -44,23 +44,32 @@ static inline int out_param(const FlowPlan& L, int q, int r16) {
     return r16 < L.K - 1 ? 2 * L.K + r16 : -1;
 }
 
-// runtime mirror of Sched<> (pf_layout.h)
-struct Entry { int phase, ks, blk, tile; bool active; };   // phase: 0 in, 1 ctx, 2 W0, 3 W1, 4 gate, 5 out
-static int sched_len(const FlowPlan& L) {
-    return 1 + L.CKM + 2 * (2 * L.HK + L.CKM) + 3 * L.HK;   // pad entries are never active
-}
-static Entry sched_entry(const FlowPlan& L, int w, int e) {
-    const int eBlk = 1 + L.CKM, blkLen = 2 * L.HK + L.CKM, eOut = eBlk + 2 * blkLen, raw = eOut + 3 * L.HK;
-    Entry x{0, 0, 0, 0, false};
-    if (e < 1) { x.phase = 0; x.active = true; }
-    else if (e < eBlk) { x.phase = 1; x.ks = e - 1; x.active = x.ks < L.CK; }
-    else if (e < eOut) {
-        int r = e - eBlk; x.blk = r / blkLen; r %= blkLen;
-        if (r < L.HK) { x.phase = 2; x.ks = r; x.active = x.ks < L.kmaxH[w]; }
-        else if (r < 2 * L.HK) { x.phase = 3; x.ks = r - L.HK; x.active = x.ks < L.kmaxH[w]; }
-        else { x.phase = 4; x.ks = r - 2 * L.HK; x.active = x.ks < L.CK; }
-    } else if (e < raw) {
-        const int r = e - eOut; x.phase = 5; x.tile = r / L.HK; x.ks = r % L.HK; x.active = x.ks < L.kmaxO[w];
+// Frag f of wave w's per-layer stream -> what it holds (runtime mirror of Sched<>).
+struct Entry { int phase, ks, blk, q, tile, feat; bool pad; };   // phase: 0 in, 1 ctx, 2 W0, 3 W1, 4 gate, 5 out
+static Entry stream_entry(const FlowPlan& L, int w, int f) {
+    const int tA = w, tB = L.NT - 1 - w;
+    const int eCtx = 2, eBlk = eCtx + 2 * L.CKM, blkLen = 2 * L.KHS + 2 * L.CKM, eOut = eBlk + L.NB * blkLen;
+    Entry x{0, 0, 0, 0, tA, -1, false};
+    // pair GEMM of n entries: i < nA -> k-step i of A; i >= n - nB -> k-step n-1-i of B; else pad
+    auto pair_entry = [&](int i, int n, int nA, int nB, bool& isA, int& ks, bool& pad) {
+        isA = i < nA; pad = !isA && i < n - nB;
+        ks = isA ? i : n - 1 - i;
+    };
+    if (f < eCtx) { x.phase = 0; x.tile = f == 0 ? tA : tB; }
+    else if (f < eBlk) { const int r = f - eCtx; x.phase = 1; x.ks = r / 2; x.tile = (r & 1) ? tB : tA; x.pad = x.ks >= L.CK; }
+    else if (f < eOut) {
+        int r = f - eBlk; x.blk = r / blkLen; r %= blkLen;
+        if (r < 2 * L.KHS) {
+            x.phase = r < L.KHS ? 2 : 3;
+            bool isA; pair_entry(r % L.KHS, L.KHS, L.kH[tA], L.kH[tB], isA, x.ks, x.pad);
+            x.tile = isA ? tA : tB;
+        } else { r -= 2 * L.KHS; x.phase = 4; x.ks = r / 2; x.tile = (r & 1) ? tB : tA; x.pad = x.ks >= L.CK; }
+    } else {
+        const int r = f - eOut; x.phase = 5; x.q = r / L.KOS;
+        const int fA = L.featA[w], fB = L.featB[w];
+        bool isA; pair_entry(r % L.KOS, L.KOS, fA >= 0 ? L.kO[fA] : 0, fB >= 0 ? L.kO[fB] : 0, isA, x.ks, x.pad);
+        x.feat = isA ? fA : fB;
+        if (x.feat < 0) x.pad = true;
     }
     return x;
 }
@@ -71,17 +80,15 @@ int build_pack_map(const FlowPlan& L, int32_t* map) {
     const int per = L.bf16 ? 8 : 4;   // elements per lane
     int perm[256];
     sorted_units(L.D, L.H, perm);
-    const int NE = sched_len(L);
     int64_t idx = 0;
     for (int w = 0; w < L.NW; ++w) {
-        if (idx != L.waveBase[w] * fragElems) return PF_ERR_BAD_ARG;
         for (int l = 0; l < L.L; ++l) {
             const int64_t base = (int64_t)l * ro.total;
-            for (int e = 0; e < NE; ++e) {
-                const Entry en = sched_entry(L, w, e);
-                if (!en.active) continue;
+            for (int f = 0; f < L.NF; ++f) {
+                const Entry en = stream_entry(L, w, f);
                 const int phase = en.phase, ks = en.ks, blk = en.blk;
                 for (int within = 0; within < fragElems; ++within, ++idx) {
+                    if (en.pad) { map[idx] = -1; continue; }
                     const int lane = within / per, el = within % per;
                     const int g = lane >> 4, r16 = lane & 15;
                     int col;   // k -> source column / sorted position
@@ -89,7 +96,7 @@ int build_pack_map(const FlowPlan& L, int32_t* map) {
                     else if (phase == 1 || phase == 4) col = L.bf16 ? (32 * ks + 8 * g + el) : (16 * ks + 4 * g + el);
                     else col = L.bf16 ? (16 * (2 * ks + (el >> 2)) + 4 * g + (el & 3)) : (16 * ks + 4 * g + el);
                     int64_t src = -1;
-                    const int u = perm[16 * w + r16];          // hidden output unit of this row
+                    const int u = perm[16 * en.tile + r16];          // hidden output unit of this row
                     switch (phase) {
                     case 0:
                         if (col < L.D && hid_degree(L.D, u) >= col + 1) src = ro.in_w + (int64_t)u * L.D + col;
@@ -108,11 +115,10 @@ int build_pack_map(const FlowPlan& L, int32_t* map) {
                         break;
                     }
                     case 5: {
-                        const int m = out_param(L, en.tile, r16);
+                        const int m = out_param(L, en.q, r16);
                         const int uin = perm[col];
-                        const int f = L.feat[w];
-                        if (f >= 0 && m >= 0 && (f + 1) > hid_degree(L.D, uin))
-                            src = ro.out_w + ((int64_t)f * L.M + m) * L.H + uin;
+                        if (m >= 0 && (en.feat + 1) > hid_degree(L.D, uin))
+                            src = ro.out_w + ((int64_t)en.feat * L.M + m) * L.H + uin;
                         break;
                     }
                     }
@@ -120,16 +126,19 @@ int build_pack_map(const FlowPlan& L, int32_t* map) {
                 }
             }
         }
-        for (int64_t k = 0; k < (int64_t)kWindow * fragElems; ++k) map[idx++] = -1;   // prefetch overrun pad
+        for (int64_t k = 0; k < (int64_t)kWindowPad * fragElems; ++k) map[idx++] = -1;   // prefetch overrun pad
     }
     if (idx != L.fragsTotal * fragElems) return PF_ERR_BAD_ARG;
-    // bias region, [layer][wave][slot][r16]
+    // bias region, [layer][tile][slot][r16]; out slots of tile t hold the biases of the
+    // feature whose spline the owning wave evaluates as "A" (tile < NW) or "B" (tile >= NW)
     for (int l = 0; l < L.L; ++l) {
         const int64_t base = (int64_t)l * ro.total;
-        for (int w = 0; w < L.NW; ++w) {
-            for (int s = 0; s < kBiasFloatsPerWave; ++s, ++idx) {
+        for (int t = 0; t < L.NT; ++t) {
+            const int w = t < L.NW ? t : L.NT - 1 - t;
+            const int feat = t < L.NW ? L.featA[w] : L.featB[w];
+            for (int s = 0; s < kBiasFloatsPerTile; ++s, ++idx) {
                 const int slot = s >> 4, r16 = s & 15;
-                const int u = perm[16 * w + r16];
+                const int u = perm[16 * t + r16];
                 int64_t src = -1;
                 if (slot == kSlotIn) src = ro.in_b + u;
                 else if (slot == kSlotCtx) { if (L.C > 0) src = ro.c_b + u; }
@@ -140,7 +149,7 @@ int build_pack_map(const FlowPlan& L, int32_t* map) {
                     else if (L.C > 0) src = ro.g_b[b] + u;
                 } else if (slot >= kSlotOut && slot < kSlotOut + 3) {
                     const int m = out_param(L, slot - kSlotOut, r16);
-                    if (L.feat[w] >= 0 && m >= 0) src = ro.out_b + (int64_t)L.feat[w] * L.M + m;
+                    if (feat >= 0 && m >= 0) src = ro.out_b + (int64_t)feat * L.M + m;
                 }
                 map[idx] = src < 0 ? -1 : (int32_t)(base + src);
             }
