@@ -77,7 +77,7 @@ int pf_flow_forward(const PfFlowDesc* desc, const void* packed, const float* x, 
     pf::FwdParams p{};
     p.packed = static_cast<const char*>(packed);
     p.x = x; p.ctx = ctx; p.ar_perm = ar_perm; p.log_sigma = log_sigma; p.z = z; p.logdet = logdet; p.nll = nll;
-    p.batch = batch; p.plan = L;
+    p.batch = batch; p.ctx_rows = batch; p.fail_flags = nullptr; p.plan = L;
     p.tail_bound = desc->tail_bound; p.min_w = desc->min_bin_width; p.min_h = desc->min_bin_height;
     p.min_d = desc->min_derivative;
     p.deriv_const = (float)std::log(std::exp(1.0 - (double)desc->min_derivative) - 1.0);
@@ -88,9 +88,29 @@ int pf_flow_forward(const PfFlowDesc* desc, const void* packed, const float* x, 
 int pf_flow_inverse(const PfFlowDesc* desc, const void* packed, const float* z, const float* ctx,
                     int64_t ctx_rows, const int32_t* ar_inv_perm, int64_t batch, float* x,
                     float* logdet, uint32_t* fail_flags, void* stream) {
-    (void)desc; (void)packed; (void)z; (void)ctx; (void)ctx_rows; (void)ar_inv_perm; (void)batch;
-    (void)x; (void)logdet; (void)fail_flags; (void)stream;
-    return fail(PF_ERR_UNSUPPORTED, "pf_flow_inverse: not built yet");
+    pf::FlowPlan L;
+    int rc = layout_of(desc, L);
+    if (rc != PF_OK) return rc;
+    if (batch < 0) return fail(PF_ERR_BAD_ARG, "negative batch");
+    if (batch == 0) return PF_OK;
+    if (!packed || !z) return fail(PF_ERR_BAD_ARG, "null pointer");
+    if (L.C > 0) {
+        if (!ctx) return fail(PF_ERR_BAD_ARG, "ctx is null but context_features > 0");
+        if (ctx_rows < 1 || batch % ctx_rows != 0)
+            return fail(PF_ERR_BAD_ARG, "ctx_rows must be >= 1 and divide batch");
+    } else {
+        ctx_rows = batch;
+    }
+    if (misaligned(packed, 16)) return fail(PF_ERR_BAD_ARG, "packed must be 16-byte aligned");
+    pf::FwdParams p{};
+    p.packed = static_cast<const char*>(packed);
+    p.x = z; p.ctx = ctx; p.ar_perm = ar_inv_perm; p.log_sigma = nullptr; p.z = x; p.logdet = logdet;
+    p.nll = nullptr; p.batch = batch; p.ctx_rows = ctx_rows; p.fail_flags = fail_flags; p.plan = L;
+    p.tail_bound = desc->tail_bound; p.min_w = desc->min_bin_width; p.min_h = desc->min_bin_height;
+    p.min_d = desc->min_derivative;
+    p.deriv_const = (float)std::log(std::exp(1.0 - (double)desc->min_derivative) - 1.0);
+    rc = pf::launch_flow_inverse(p, static_cast<hipStream_t>(stream));
+    return rc == PF_OK ? rc : fail(rc, rc == PF_ERR_HIP ? hipGetErrorString(hipGetLastError()) : "unsupported launch shape");
 }
 
 int32_t pf_flow_rows_per_workgroup(const PfFlowDesc* desc, int64_t batch) {

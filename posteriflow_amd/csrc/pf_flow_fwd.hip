@@ -9,7 +9,9 @@
 
 namespace pf {
 
-#define PF_DECL(P, N) int launch_flow_forward_p##P##_nt##N(const FwdParams&, int, hipStream_t);
+#define PF_DECL(P, N)                                                           \
+    int launch_flow_forward_p##P##_nt##N(const FwdParams&, int, hipStream_t); \
+    int launch_flow_inverse_p##P##_nt##N(const FwdParams&, int, hipStream_t);
 PF_DECL(0, 4) PF_DECL(0, 8) PF_DECL(0, 12) PF_DECL(0, 16)
 PF_DECL(1, 4) PF_DECL(1, 8) PF_DECL(1, 12) PF_DECL(1, 16)
 #undef PF_DECL
@@ -18,7 +20,7 @@ size_t fwd_lds_bytes_host(const FlowPlan& L, int R) {
     const size_t par = (size_t)L.D * 16 * 52 * sizeof(float);
     const size_t pb = std::max((size_t)L.HK * R * kFragBytes, par);
     return (size_t)L.CKM * R * kFragBytes + (size_t)L.HK * R * kFragBytes + pb
-         + (size_t)(2 * 16 * 16 * R + 2 * L.NT * kBiasFloatsPerTile + L.D * 16 * R) * sizeof(float);
+         + (size_t)(3 * 16 * 16 * R + 2 * L.NT * kBiasFloatsPerTile + L.D * 16 * R) * sizeof(float);
 }
 
 int rows_per_workgroup(const FlowPlan& L, int64_t batch) {
@@ -38,6 +40,19 @@ int launch_flow_forward(const FwdParams& p_in, hipStream_t s) {
     if (const char* a = getenv("PF_ABLATE")) p.ablate = atoi(a);   // only honoured by -DPF_ABLATE_BUILD builds
     const int R = rows_per_workgroup(p.plan, p.batch) / 16;
 #define PF_CASE(P, N) case N: return launch_flow_forward_p##P##_nt##N(p, R, s);
+    if (p.plan.bf16) {
+        switch (p.plan.NT) { PF_CASE(1, 4) PF_CASE(1, 8) PF_CASE(1, 12) PF_CASE(1, 16) }
+    } else {
+        switch (p.plan.NT) { PF_CASE(0, 4) PF_CASE(0, 8) PF_CASE(0, 12) PF_CASE(0, 16) }
+    }
+#undef PF_CASE
+    return PF_ERR_UNSUPPORTED;
+}
+
+int launch_flow_inverse(const FwdParams& p, hipStream_t s) {
+    if (p.batch == 0) return PF_OK;
+    const int R = rows_per_workgroup(p.plan, p.batch) / 16;
+#define PF_CASE(P, N) case N: return launch_flow_inverse_p##P##_nt##N(p, R, s);
     if (p.plan.bf16) {
         switch (p.plan.NT) { PF_CASE(1, 4) PF_CASE(1, 8) PF_CASE(1, 12) PF_CASE(1, 16) }
     } else {

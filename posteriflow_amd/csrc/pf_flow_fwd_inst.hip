@@ -1,5 +1,5 @@
 // pf_flow_fwd_inst.hip -- instantiates the forward kernels of ONE (precision, NT); built
-// once per combination with -DPF_INST_BF16=<0|1> -DPF_INST_NT=<4|8|12|16> (Makefile), so the
+// once per combination with -DPF_INST_BF16=<0|1> -DPF_INST_NT=<4|8|12|16> -DPF_INST_INV=<0|1> (Makefile), so the
 // variants compile in parallel.
 #include <algorithm>
 
@@ -10,15 +10,21 @@
 
 namespace pf {
 
-int PF_CAT(launch_flow_forward_p, PF_INST_BF16, _nt, PF_INST_NT)(const FwdParams& p, int R, hipStream_t s) {
+#if PF_INST_INV
+#define PF_NAME launch_flow_inverse_p
+#else
+#define PF_NAME launch_flow_forward_p
+#endif
+int PF_CAT(PF_NAME, PF_INST_BF16, _nt, PF_INST_NT)(const FwdParams& p, int R, hipStream_t s) {
     constexpr bool BF = PF_INST_BF16 != 0;
+    constexpr bool INV = PF_INST_INV != 0;
     constexpr int NT = PF_INST_NT;
     constexpr int SMALL = BF ? 3 : 6, MID = BF ? 9 : 18, LARGE = BF ? 18 : 36;
     const int ckm = p.plan.CKM;
-    if (ckm == 0) return launch_ckm<BF, NT, 0>(p, R, s);
-    if (ckm == MID) return launch_ckm<BF, NT, MID>(p, R, s);
-    if constexpr (NT <= 8) { if (ckm == SMALL) return launch_ckm<BF, NT, SMALL>(p, R, s); }
-    if constexpr (NT == 16) { if (ckm == LARGE) return launch_ckm<BF, NT, LARGE>(p, R, s); }
+    if (ckm == 0) return launch_ckm<BF, NT, 0, INV>(p, R, s);
+    if (ckm == MID) return launch_ckm<BF, NT, MID, INV>(p, R, s);
+    if constexpr (NT <= 8) { if (ckm == SMALL) return launch_ckm<BF, NT, SMALL, INV>(p, R, s); }
+    if constexpr (NT == 16) { if (ckm == LARGE) return launch_ckm<BF, NT, LARGE, INV>(p, R, s); }
     return PF_ERR_UNSUPPORTED;
 }
 

@@ -131,6 +131,78 @@ __device__ __forceinline__ void rqs_pair(const float* par, float x, int K, const
     ld = inside ? pf_log<FAST>(dnum) - 2.f * pf_log<FAST>(den) : 0.f;
 }
 
+
+// Inverse RQS of one (row, feature) pair by one lane: given y (the transform's output) find
+// x.  nflows rational_quadratic_spline(inverse=True): bin search on the cumulative HEIGHTS,
+// root of the quadratic a t^2 + b t + c via 2c / (-b - sqrt(b^2 - 4ac)); returns the
+// log-det of the inverse map (= -forward log-det at the root).  `bad` is set where the
+// discriminant is negative (the reference asserts there, flows.py:635-642).
+template <bool FAST>
+__device__ __forceinline__ void rqs_pair_inverse(const float* par, float yin, int K, const FwdParams& p,
+                                                 float& x, float& ld, bool& bad) {
+    float uw[16], uh[16], ud[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(par + 4 * q);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(par + 16 + 4 * q);
+        const f32x4 c = *reinterpret_cast<const f32x4*>(par + 32 + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { uw[4 * q + e] = a[e]; uh[4 * q + e] = b[e]; ud[4 * q + e] = c[e]; }
+    }
+    const float tb = p.tail_bound;
+    float mw = -INFINITY, mh = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) if (i < K) { mw = fmaxf(mw, uw[i]); mh = fmaxf(mh, uh[i]); }
+    float sw = 0.f, sh = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        uw[i] = i < K ? pf_exp<FAST>(uw[i] - mw) : 0.f; sw += uw[i];
+        uh[i] = i < K ? pf_exp<FAST>(uh[i] - mh) : 0.f; sh += uh[i];
+    }
+    const float cw = pf_div<FAST>(1.f - p.min_w * (float)K, sw);
+    const float ch = pf_div<FAST>(1.f - p.min_h * (float)K, sh);
+    const float span = 2.f * tb;
+    float cumw = 0.f, cumh = 0.f;
+    float xl = -tb, xr = tb, yl = -tb, yr = tb;
+    float dl_raw = p.deriv_const, dr_raw = p.deriv_const;
+    bool prev_ge = true;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        if (i < K) {
+            cumw += p.min_w + cw * uw[i];
+            cumh += p.min_h + ch * uh[i];
+            const bool last = i == K - 1;
+            const float kr = last ? tb : span * cumw - tb;
+            const float hr = last ? tb : span * cumh - tb;
+            const float dr = last ? p.deriv_const : ud[i];
+            const bool ge = yin >= (last ? tb + 1e-6f : hr);     // search on the heights
+            const bool sel = prev_ge && !ge;
+            xr = sel ? kr : xr; yr = sel ? hr : yr; dr_raw = sel ? dr : dr_raw;
+            xl = ge ? kr : xl;  yl = ge ? hr : yl;  dl_raw = ge ? dr : dl_raw;
+            prev_ge = ge;
+        }
+    }
+    const float w = xr - xl, h = yr - yl;
+    const float dl = p.min_d + pf_softplus<FAST>(dl_raw);
+    const float dr = p.min_d + pf_softplus<FAST>(dr_raw);
+    const float delta = pf_div<FAST>(h, w);
+    const float dy = yin - yl;
+    const float s2 = dl + dr - 2.f * delta;
+    const float a = dy * s2 + h * (delta - dl);
+    const float b = h * dl - dy * s2;
+    const float c = -delta * dy;
+    const float disc = b * b - 4.f * a * c;
+    const float root = pf_div<FAST>(2.f * c, -b - sqrtf(fmaxf(disc, 0.f)));
+    const float tt = root * (1.f - root);
+    const float den = delta + s2 * tt;
+    const float omt = 1.f - root;
+    const float dnum = delta * delta * (dr * root * root + 2.f * delta * tt + dl * omt * omt);
+    const bool inside = (yin >= -tb) && (yin <= tb);
+    bad = inside && !(disc >= 0.f);
+    x = inside ? root * w + xl : yin;
+    ld = inside ? -(pf_log<FAST>(dnum) - 2.f * pf_log<FAST>(den)) : 0.f;
+}
+
 // ---- the kernel ------------------------------------------------------------------
 // LDS carve (bytes), all 16-B aligned:
 //   ctx    : CKM * R KiB            context in B-fragment order (zero padded to CKM k-steps)
@@ -154,8 +226,8 @@ template <int V> using ic = std::integral_constant<int, V>;
 #define PF_ABL(mask) false
 #endif
 
-template <bool BF16, int NT, int R, int CKM, bool DENSE>
-__global__ __launch_bounds__(NT * 32) void flow_forward_kernel(const FwdParams p) {
+template <bool BF16, int NT, int R, int CKM, bool DENSE, bool INV>
+__global__ __launch_bounds__(NT * 32) void flow_kernel(const FwdParams p) {
     using S = Sched<BF16, NT, CKM, DENSE>;
     constexpr bool FAST = BF16;
     constexpr int NW = NT / 2, HK = S::HK, KHS = S::KHS, KOS = S::KOS, NF = S::NF;
@@ -172,9 +244,11 @@ __global__ __launch_bounds__(NT * 32) void flow_forward_kernel(const FwdParams p
     const int g = lane >> 4, c = lane & 15;
     const int64_t row0 = (int64_t)blockIdx.x * COLS;
     const int tA = wave, tB = NT - 1 - wave;
-    const int kA = L.kH[tA];                            // W0/W1 entries [0,kA) belong to tile A
-    const int fA = L.featA[wave], fB = L.featB[wave];   // spline features of this wave (-1: none)
-    const int kOA = fA >= 0 ? L.kO[fA] : 0;             // out entries [0,kOA) belong to feature A
+    // per-wave constants, forced into SGPRs
+    const int kA = __builtin_amdgcn_readfirstlane(L.kH[tA]);      // W0/W1 entries [0,kA): tile A
+    const int fA = __builtin_amdgcn_readfirstlane(L.featA[wave]); // spline features (-1: none)
+    const int fB = __builtin_amdgcn_readfirstlane(L.featB[wave]);
+    const int kOA = __builtin_amdgcn_readfirstlane(fA >= 0 ? L.kO[fA] : 0);   // out entries [0,kOA): feature A
 
     const size_t p_bytes = max((size_t)HK * R * kFragBytes, (size_t)D * 16 * kParStride * sizeof(float));
     char* s_ctx = smem;
@@ -183,7 +257,8 @@ __global__ __launch_bounds__(NT * 32) void flow_forward_kernel(const FwdParams p
     float* s_par = reinterpret_cast<float*>(s_act1);
     float* s_xb0 = reinterpret_cast<float*>(s_act1 + p_bytes);
     float* s_xb1 = s_xb0 + 16 * COLS;
-    float* s_bias = s_xb1 + 16 * COLS;                  // [2][NT][192]
+    float* s_xb2 = s_xb1 + 16 * COLS;                   // inverse only (forward: unused)
+    float* s_bias = s_xb2 + 16 * COLS;                  // [2][NT][192]
     float* s_ldb = s_bias + 2 * NT * kBiasFloatsPerTile;
 
     // ---- weight stream: buffer resource over this wave's region, register window ---------
@@ -192,14 +267,17 @@ __global__ __launch_bounds__(NT * 32) void flow_forward_kernel(const FwdParams p
         const_cast<char*>(p.packed) + (int64_t)wave * L.fragsPerWave * kFragBytes, 0,
         (int)(L.fragsPerWave * kFragBytes), 0x00020000);
     u32x4 win[W];
-    int lbase = 0;                                      // byte offset of the current layer's frags
-    // entry E of the current layer was just consumed: refill its slot with entry E + W
+    // forward walks the layers 0..L-1 once; the inverse walks L-1..0 with D conditioner
+    // passes per layer (nflows AutoregressiveTransform.inverse), re-reading the layer's frags
+    int lbase = INV ? (L.L - 1) * NF * kFragBytes : 0;  // byte offset of the current layer's frags
+    int nbase = 0;                                      // ... of the frags consumed after this pass
+    // entry E of the current pass was just consumed: refill its slot with entry E + W
     auto refill = [&](auto e) {
         constexpr int E = decltype(e)::value;
         constexpr int EN = (E + W) % NE;
         constexpr bool wrap = (E + W) >= NE;
         if constexpr (EN < NF) {
-            const int off = PF_ABL(2) ? 0 : lbase + ((wrap ? NF : 0) + EN) * kFragBytes;
+            const int off = PF_ABL(2) ? 0 : (wrap ? nbase : lbase) + EN * kFragBytes;
             win[EN % W] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, off, 0);
         }
     };
@@ -210,6 +288,7 @@ __global__ __launch_bounds__(NT * 32) void flow_forward_kernel(const FwdParams p
         const int gg = ln >> 4, cc = ln & 15;
         int64_t row = row0 + 16 * r + cc;
         if (row >= p.batch) row = p.batch - 1;
+        if (INV) row /= (p.batch / p.ctx_rows);          // sample i uses context row i / (B / ctx_rows)
         const float* src = p.ctx + row * L.C;
         if (BF16) {
             bf16x8 v;
@@ -235,21 +314,29 @@ __global__ __launch_bounds__(NT * 32) void flow_forward_kernel(const FwdParams p
         if (d < D) {
             int64_t row = row0 + col;
             if (row >= p.batch) row = p.batch - 1;
-            // layer 0 sees reverse(x[:, ar_perm]): position d <- source D-1-d
-            const int sd = D - 1 - d;
-            const int src = p.ar_perm ? p.ar_perm[sd] : sd;
-            v = p.x[row * D + src];
+            if (INV) {
+                v = p.x[row * D + d];                    // z, in the last layer's coordinates
+            } else {
+                // layer 0 sees reverse(x[:, ar_perm]): position d <- source D-1-d
+                const int sd = D - 1 - d;
+                const int src = p.ar_perm ? p.ar_perm[sd] : sd;
+                v = p.x[row * D + src];
+            }
         }
         s_xb0[s] = v;
         s_xb1[s] = 0.f;
+        s_xb2[s] = 0.f;
     }
     const float* gbias = reinterpret_cast<const float*>(p.packed + L.weightBytes);
-    for (int s = tid; s < NT * kBiasFloatsPerTile; s += NW * 64) s_bias[s] = gbias[s];
+    {
+        const float* b0 = gbias + (INV ? L.bias_index(L.L - 1, 0) : 0);
+        for (int s = tid; s < NT * kBiasFloatsPerTile; s += NW * 64) s_bias[s] = b0[s];
+    }
     for (int s = tid; s < D * COLS; s += NW * 64) s_ldb[s] = 0.f;
     // prologue of the weight stream: first window of layer 0
     static_for<0, W>([&](auto e) {
         constexpr int E = decltype(e)::value;
-        if constexpr (E < NF) win[E] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, E * kFragBytes, 0);
+        if constexpr (E < NF) win[E] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, lbase + E * kFragBytes, 0);
     });
     __syncthreads();
 
@@ -305,17 +392,30 @@ __global__ __launch_bounds__(NT * 32) void flow_forward_kernel(const FwdParams p
     };
     auto barrier = [&]() { if (!PF_ABL(8)) __syncthreads(); };
 
-    for (int l = 0; l < L.L; ++l) {
-        float* xin = (l & 1) ? s_xb1 : s_xb0;
+    uint32_t bad_pair = 0;
+    const int n_pass = INV ? D : 1;
+    // inverse buffers rotate: yb = this layer's known output, xc = current estimate of its
+    // input (conditioner input), yn = the previous layer's output being assembled
+    float* yb = s_xb0; float* xc = s_xb1; float* yn = s_xb2;
+    for (int it = 0; it < L.L * n_pass; ++it) {
+        const int step = it / n_pass, pass = it - step * n_pass;
+        const int l = INV ? L.L - 1 - step : step;      // layer being evaluated
+        const bool last_pass = pass == n_pass - 1;
+        float* xin = INV ? xc : ((l & 1) ? s_xb1 : s_xb0);
         float* xout = (l & 1) ? s_xb0 : s_xb1;
-        const float* bias = s_bias + (l & 1) * NT * kBiasFloatsPerTile;
+        const int bsel = INV ? (step & 1) : (l & 1);
+        const float* bias = s_bias + bsel * NT * kBiasFloatsPerTile;
+        {   // where the stream continues after this pass
+            const int lnext = INV ? (last_pass ? l - 1 : l) : l + 1;
+            nbase = (lnext < 0 ? 0 : lnext) * NF * kFragBytes;
+        }
         auto load_bias = [&](int tile, int slot) {
             return *reinterpret_cast<const f32x4*>(bias + tile * kBiasFloatsPerTile + slot * 16 + 4 * g);
         };
         // next layer's biases: issued now (oldest loads of the layer), parked in LDS at its end
         f32x4 nbA = {0.f, 0.f, 0.f, 0.f}, nbB = nbA;
         {
-            const int ln = l + 1 < L.L ? l + 1 : l;
+            const int ln = INV ? (l > 0 ? l - 1 : 0) : (l + 1 < L.L ? l + 1 : l);
             if (lane < kBiasFloatsPerTile / 4) {
                 nbA = *reinterpret_cast<const f32x4*>(gbias + L.bias_index(ln, tA) + 4 * lane);
                 nbB = *reinterpret_cast<const f32x4*>(gbias + L.bias_index(ln, tB) + 4 * lane);
@@ -468,8 +568,8 @@ __global__ __launch_bounds__(NT * 32) void flow_forward_kernel(const FwdParams p
             static_for<NF, NE - NF>([&](auto e) { refill(e); });
         }
         // park the next layer's biases (the same wave reads them back next layer)
-        if (lane < kBiasFloatsPerTile / 4) {
-            float* nb = s_bias + ((l + 1) & 1) * NT * kBiasFloatsPerTile;
+        if (last_pass && lane < kBiasFloatsPerTile / 4) {
+            float* nb = s_bias + (bsel ^ 1) * NT * kBiasFloatsPerTile;
             *reinterpret_cast<f32x4*>(nb + tA * kBiasFloatsPerTile + 4 * lane) = nbA;
             *reinterpret_cast<f32x4*>(nb + tB * kBiasFloatsPerTile + 4 * lane) = nbB;
         }
@@ -488,23 +588,65 @@ __global__ __launch_bounds__(NT * 32) void flow_forward_kernel(const FwdParams p
             barrier();
             if (tid < D * 16) {
                 const int feat = tid >> 4, col = tid & 15;
-                const float xv = xin[feat * COLS + 16 * r + col];
-                float y, ld;
-                if (PF_ABL(1)) { y = xv + s_par[(size_t)tid * kParStride]; ld = 0.f; }
-                else rqs_pair<FAST>(s_par + (size_t)tid * kParStride, xv, K, p, y, ld);
-                if (r == 0) ld_pair += ld; else s_ldb[feat * COLS + 16 * r + col] += ld;
-                // the next layer starts with ReversePermutation: position D-1-feat
-                xout[(D - 1 - feat) * COLS + 16 * r + col] = y;
+                if constexpr (INV) {
+                    const float yv = yb[feat * COLS + 16 * r + col];
+                    float xv, ld; bool bad;
+                    rqs_pair_inverse<FAST>(s_par + (size_t)tid * kParStride, yv, K, p, xv, ld, bad);
+                    xc[feat * COLS + 16 * r + col] = xv;         // conditioner input of the next pass
+                    if (last_pass) {
+                        if (r == 0) ld_pair += ld; else s_ldb[feat * COLS + 16 * r + col] += ld;
+                        bad_pair |= bad ? (1u << r) : 0u;
+                        // undo this layer's ReversePermutation: previous layer's output position D-1-feat
+                        yn[(D - 1 - feat) * COLS + 16 * r + col] = xv;
+                    }
+                } else {
+                    const float xv = xin[feat * COLS + 16 * r + col];
+                    float y, ld;
+                    if (PF_ABL(1)) { y = xv + s_par[(size_t)tid * kParStride]; ld = 0.f; }
+                    else rqs_pair<FAST>(s_par + (size_t)tid * kParStride, xv, K, p, y, ld);
+                    if (r == 0) ld_pair += ld; else s_ldb[feat * COLS + 16 * r + col] += ld;
+                    // the next layer starts with ReversePermutation: position D-1-feat
+                    xout[(D - 1 - feat) * COLS + 16 * r + col] = y;
+                }
             }
             if (r + 1 < R) barrier();      // the transpose buffer is reused by the next column group
         }
-        lbase += NF * kFragBytes;
+        lbase = nbase;
         barrier();
+        if (INV && last_pass) {
+            // next (= previous) layer: its output is what we just assembled; estimate restarts at 0
+            float* t = yb; yb = yn; yn = t;
+            for (int s = tid; s < D * COLS; s += NW * 64) xc[s] = 0.f;
+            barrier();
+        }
     }
 
     // ---- epilogue: sum log-dets over features, base log-density, stores -----------------
     if (tid < D * 16) s_ldb[(tid >> 4) * COLS + (tid & 15)] = ld_pair;
     __syncthreads();
+    if constexpr (INV) {
+        // yb holds reverse(u_0) = x[:, ar_perm]; undo the autoregressive order (flows.py:648)
+        if (tid < D * 16 && p.fail_flags && bad_pair) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if ((bad_pair >> r) & 1) {
+                    const int64_t row = row0 + 16 * r + (tid & 15);
+                    if (row < p.batch) atomicOr(p.fail_flags + row, 1u);
+                }
+        }
+        if (tid < COLS) {
+            const int64_t row = row0 + tid;
+            if (row < p.batch) {
+                float ld = 0.f;
+                for (int f = 0; f < D; ++f) ld += s_ldb[f * COLS + tid];
+                for (int d = 0; d < D; ++d) {
+                    const int src = p.ar_perm ? p.ar_perm[d] : d;      // ar_inv_perm
+                    if (p.z) p.z[row * D + d] = yb[src * COLS + tid];
+                }
+                if (p.logdet) p.logdet[row] = ld;
+            }
+        }
+    } else {
     const float* zfin = (L.L & 1) ? s_xb1 : s_xb0;     // stored reversed (see above)
     if (tid < COLS) {
         const int64_t row = row0 + tid;
@@ -527,20 +669,21 @@ __global__ __launch_bounds__(NT * 32) void flow_forward_kernel(const FwdParams p
             if (p.nll) p.nll[row] = 0.5f * (q + 2.f * sls + (float)D * 1.8378770664093453f) - ld;
         }
     }
+    }
 }
 
 // ---- host side ---------------------------------------------------------------------------
 inline size_t fwd_lds_bytes(const FlowPlan& L, int R) {
     const size_t pb = std::max((size_t)L.HK * R * kFragBytes, (size_t)L.D * 16 * kParStride * sizeof(float));
     return (size_t)L.CKM * R * kFragBytes + (size_t)L.HK * R * kFragBytes + pb
-         + (size_t)(2 * 16 * 16 * R + 2 * L.NT * kBiasFloatsPerTile + L.D * 16 * R) * sizeof(float);
+         + (size_t)(3 * 16 * 16 * R + 2 * L.NT * kBiasFloatsPerTile + L.D * 16 * R) * sizeof(float);
 }
 
-template <bool BF16, int NT, int R, int CKM, bool DENSE>
+template <bool BF16, int NT, int R, int CKM, bool DENSE, bool INV>
 inline int launch_variant(const FwdParams& p, hipStream_t s) {
     const unsigned grid = (unsigned)((p.batch + 16 * R - 1) / (16 * R));
     const size_t lds = fwd_lds_bytes(p.plan, R);
-    auto kern = flow_forward_kernel<BF16, NT, R, CKM, DENSE>;
+    auto kern = flow_kernel<BF16, NT, R, CKM, DENSE, INV>;
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
@@ -550,11 +693,11 @@ inline int launch_variant(const FwdParams& p, hipStream_t s) {
 }
 
 // all built variants of one (precision, NT): R in {1,2} x {masked}, R = 1 x {dense}
-template <bool BF16, int NT, int CKM>
+template <bool BF16, int NT, int CKM, bool INV>
 inline int launch_ckm(const FwdParams& p, int R, hipStream_t s) {
-    if (p.plan.dense) return launch_variant<BF16, NT, 1, CKM, true>(p, s);
-    if (R == 2) return launch_variant<BF16, NT, 2, CKM, false>(p, s);
-    return launch_variant<BF16, NT, 1, CKM, false>(p, s);
+    if (p.plan.dense) return launch_variant<BF16, NT, 1, CKM, true, INV>(p, s);
+    if (R == 2) return launch_variant<BF16, NT, 2, CKM, false, INV>(p, s);
+    return launch_variant<BF16, NT, 1, CKM, false, INV>(p, s);
 }
 
 }  // namespace pf

@@ -11,12 +11,14 @@ struct FwdParams {
     const char* packed;      // weights then biases
     const float* x;          // [B, D]
     const float* ctx;        // [B, C]
-    const int32_t* ar_perm;  // [D] or null
+    const int32_t* ar_perm;  // [D] or null (forward: ar_perm; inverse: ar_inv_perm)
     const float* log_sigma;  // [B, D] or null (PSDScaledNormal log-scale, flows.py:56-85)
     float* z;                // [B, D] or null
     float* logdet;           // [B] or null
     float* nll;              // [B] or null
     int64_t batch;
+    int64_t ctx_rows;        // inverse: context rows (divides batch); forward: == batch
+    uint32_t* fail_flags;    // inverse: [B] or null, bit 0 = negative discriminant
     FlowPlan plan;
     float tail_bound, min_w, min_h, min_d;
     float deriv_const;       // log(exp(1 - min_d) - 1), computed in double on the host
@@ -29,5 +31,6 @@ int64_t raw_param_count(const FlowPlan& L);
 int launch_pack(const FlowPlan& L, const float* raw, const int32_t* map, void* packed, hipStream_t s);
 int rows_per_workgroup(const FlowPlan& L, int64_t batch);
 int launch_flow_forward(const FwdParams& p, hipStream_t s);
+int launch_flow_inverse(const FwdParams& p, hipStream_t s);
 
 }  // namespace pf

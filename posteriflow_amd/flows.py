@@ -401,9 +401,128 @@ class NSFPosteriorFlow(nn.Module):
         lo, hi = bounds                                                      # flows.py:910-920
         return torch.relu(lo - params_norm).mean() + torch.relu(params_norm - hi).mean()
 
-    # inverse / sampling entry points are added by flows_inverse once pf_flow_inverse is built
-    def inverse(self, z, context=None, n_overlaps=None):
-        raise NotImplementedError("pf_flow_inverse is not built yet")
+    # ---- inverse / sampling ------------------------------------------------------------------
+    def _inverse_call(self, z, context, ctx_rows):
+        dev = self._device()
+        B = z.shape[0]
+        x = torch.empty_like(z)
+        logdet = torch.empty(B, dtype=torch.float32, device=dev)
+        flags = torch.zeros(B, dtype=torch.int32, device=dev)
+        _, inv_perm = self._perms(dev)
+        _lib.check(_lib.lib().pf_flow_inverse(
+            self._desc(), self.packed_weights().data_ptr(), z.data_ptr(), _dev_ptr(context),
+            ctx_rows, _dev_ptr(inv_perm), B, x.data_ptr(), logdet.data_ptr(), flags.data_ptr(),
+            torch.cuda.current_stream(dev).cuda_stream), "pf_flow_inverse")
+        return x, logdet, flags
+
+    def inverse(self, z: torch.Tensor, context: Optional[torch.Tensor] = None,
+                n_overlaps: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """z -> (x, log|det dx/dz|), deterministic (flows.py:620-655).
+
+        Same post-processing as the reference: non-finite context entries are replaced
+        (nan -> 0, +-inf -> +-1e-3), the result is un-permuted, nan_to_num'ed and clamped to
+        +-FLOW_NORM_BOUND.  Where the spline's quadratic has a negative discriminant the
+        reference raises inside nflows and falls back to x = z, log_det = 0 for the WHOLE
+        batch (flows.py:638-642); here the fallback is applied to the affected rows only
+        (per-row flags from the kernel, no host synchronisation).
+
+        ``context`` may have fewer rows than ``z`` if the counts divide: sample i then uses
+        context row i // (len(z) // len(context)), the expand().reshape() pattern of
+        lean_npe.py:328 / pipeline.py:171 without materialising the copies; a stride-0
+        (``expand``-ed) context is recognised and treated as a single row.
+        """
+        dev = self._device()
+        if z.dim() != 2 or z.shape[1] != self.features:
+            raise ValueError(f"NSFPosteriorFlow.inverse: expected [batch, {self.features}], got {tuple(z.shape)}")
+        if z.device != dev:
+            raise _lib.PfError(f"NSFPosteriorFlow.inverse: input on {z.device}, flow on {dev}")
+        if torch.is_grad_enabled() and (z.requires_grad or (context is not None and context.requires_grad)):
+            raise NotImplementedError("inverse() has no backward (every reference caller runs it under no_grad)")
+        z = z.contiguous().float()
+        B = z.shape[0]
+        ctx_rows = B
+        if self.context_features > 0:
+            if context is None:
+                raise ValueError("NSFPosteriorFlow.inverse: this flow requires a context")
+            if context.dim() != 2 or context.shape[1] != self.context_features:
+                raise ValueError(f"NSFPosteriorFlow.inverse: context must be [rows, {self.context_features}], "
+                                 f"got {tuple(context.shape)}")
+            if context.device != dev:
+                raise _lib.PfError(f"NSFPosteriorFlow.inverse: context on {context.device}, flow on {dev}")
+            if context.shape[0] == B and B > 1 and context.stride(0) == 0:
+                context = context[:1]                      # expand()-ed single row
+            ctx_rows = context.shape[0]
+            if ctx_rows < 1 or (B and B % ctx_rows != 0):
+                raise ValueError(f"NSFPosteriorFlow.inverse: {ctx_rows} context rows do not divide batch {B}")
+            context = torch.nan_to_num(context.float(), nan=0.0, posinf=1e-3, neginf=-1e-3).contiguous()
+        else:
+            context = None
+        x, logdet, flags = self._inverse_call(z, context, ctx_rows)
+        bad = flags.bool()
+        x = torch.where(bad[:, None], z, x)
+        logdet = torch.where(bad, torch.zeros_like(logdet), logdet)
+        x = torch.nan_to_num(x, nan=0.0, posinf=1.0, neginf=-1.0)
+        return torch.clamp(x, -FLOW_NORM_BOUND, FLOW_NORM_BOUND), logdet
+
+    def _temperature(self, temperature, dev):
+        if temperature is None:
+            return torch.clamp(self.temperature.detach(), 0.5, 3.0)
+        return torch.tensor(float(temperature), dtype=torch.float32, device=dev)
+
+    @torch.no_grad()
+    def sample(self, num_samples: int, context: Optional[torch.Tensor] = None,
+               temperature: Optional[float] = None) -> torch.Tensor:
+        """Draws from p(x | context): z ~ N(0, T^2 I) through the inverse (flows.py:697-725).
+        Returns [batch, num_samples, D] with a context, [num_samples, D] without.  (The
+        reference's version feeds a 3-D z into the 2-D transform, flows.py:714 vs :101-109;
+        this follows its documented intent.)"""
+        dev = self._device()
+        t = self._temperature(temperature, dev)
+        if context is not None:
+            b = context.shape[0]
+            z = torch.randn(b * num_samples, self.features, device=dev) * t
+            x, _ = self.inverse(z, context)              # context rows are grouped, not copied
+            x = x.reshape(b, num_samples, self.features)
+        else:
+            z = torch.randn(num_samples, self.features, device=dev) * t
+            x, _ = self.inverse(z, None)
+        return torch.clamp(x, -FLOW_NORM_BOUND, FLOW_NORM_BOUND)
+
+    @torch.no_grad()
+    def sample_psd_aware(self, num_samples: int, context: torch.Tensor,
+                         log_sigma_psd: torch.Tensor) -> torch.Tensor:
+        """[batch, num_samples, D]: unit-normal base through the inverse, clamp, then the
+        factored scale exp(log_sigma_psd) applied outside the flow (flows.py:781-842)."""
+        b = context.shape[0]
+        z = self.base_dist.sample(num_samples, log_sigma_psd).to(context.device)
+        x, _ = self.inverse(z.reshape(b * num_samples, self.features), context)
+        x = torch.clamp(x, -FLOW_NORM_BOUND, FLOW_NORM_BOUND).reshape(b, num_samples, self.features)
+        return x * torch.exp(log_sigma_psd).unsqueeze(1)
+
+    def sample_with_uncertainty(self, num_samples: int, context: torch.Tensor,
+                                n_overlaps: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        samples = self.sample(num_samples, context)                          # flows.py:844-878
+        if context.shape[0] == 1 and samples.dim() == 3:
+            samples = samples.squeeze(0)
+        dim = 1 if samples.dim() == 3 else 0
+        return {"samples": samples, "mean": samples.mean(dim=dim), "std": samples.std(dim=dim),
+                "n_overlaps": n_overlaps[0] if n_overlaps is not None else None}
+
+    def extract_signals(self, strain_batch: torch.Tensor, context: torch.Tensor,
+                        n_samples: int = 50, return_all_samples: bool = False) -> Dict:
+        samples = self.sample(n_samples, context)                            # flows.py:880-898
+        dim = 0 if samples.dim() == 2 else 1
+        out = {"mean": samples.mean(dim=dim), "std": samples.std(dim=dim), "cov": None}
+        if return_all_samples:
+            out["samples_all"] = samples
+        return out
+
+    def compute_endpoint_loss(self, params_norm: torch.Tensor, context: torch.Tensor) -> torch.Tensor:
+        with torch.no_grad():                                                # flows.py:922-939
+            zmin = torch.full_like(params_norm, -FLOW_NORM_BOUND)
+            xmin, _ = self.inverse(zmin, context)
+            xmax, _ = self.inverse(-zmin, context)
+        return (torch.relu(xmin - params_norm) + torch.relu(params_norm - xmax)).mean()
 
 
 def create_flow_model(flow_type: str, features: int, context_features: int = 0,

@@ -1,0 +1,110 @@
+"""GPU parity of pf_flow_inverse (sampling direction) against the CPU oracle's D-pass
+autoregressive inverse, plus the size-independent round-trip property.
+
+Tolerances: fp32 mode -- |x - x_oracle64| within 4x the CPU fp32 path's own error against
+fp64 (floor 5e-5: the inverse of a contracting map amplifies rounding), inverse log-det
+likewise; round trip forward(inverse(z)) == z to 2e-4 and logdet_fwd + logdet_inv == 0 to
+2e-3 on well-conditioned weights.  bf16 mode -- round trip within 0.1 (statistical)."""
+import pytest
+import torch
+
+from helpers import flow_inputs, make_pair
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = {
+    "toy_cfg1": (4, 0, 64, 2, 8, 3.0, 256),
+    "leannpe_R": (11, 288, 256, 10, 16, 5.0, 200),
+    "baseline_B5": (15, 288, 256, 12, 16, 5.0, 128),     # BASELINE config 5 flow (12 layers)
+    "odd_shapes": (7, 40, 128, 3, 10, 2.5, 77),
+}
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_inverse_fp32_parity(name):
+    D, C, H, L, K, tb, B = CONFIGS[name]
+    ref, ref64, flow = make_pair(D, C, H, L, K, tb)
+    g = torch.Generator().manual_seed(3)
+    z = torch.randn(B, D, generator=g) * 1.5
+    z[0, 0] = tb; z[1, D - 1] = -tb; z[2, 0] = 1.4 * tb        # on / beyond the spline domain
+    ctx = torch.randn(B, C, generator=g) if C else None
+    with torch.no_grad():
+        x32, ld32 = ref.inverse_raw(z, ctx)
+        x64, ld64 = ref64.inverse_raw(z.double(), None if ctx is None else ctx.double())
+        x, ld, flags = flow._inverse_call(z.cuda().contiguous(), None if ctx is None else ctx.cuda().contiguous(), B)
+    x, ld = x.cpu().double(), ld.cpu().double()
+    ex, eld = (x - x64).abs().max().item(), (ld - ld64).abs().max().item()
+    ex_ref, eld_ref = (x32.double() - x64).abs().max().item(), (ld32.double() - ld64).abs().max().item()
+    print(f"\n[{name}] |x-x64| {ex:.2e} (cpu fp32 {ex_ref:.2e})  |ld-ld64| {eld:.2e} (cpu fp32 {eld_ref:.2e})")
+    assert int(flags.sum()) == 0
+    assert ex < max(4 * ex_ref, 5e-5) and eld < max(4 * eld_ref, 2e-4)
+    # wrapper semantics: clamp to +-3 (flows.py:654), same as the oracle's wrapper
+    with torch.no_grad():
+        xw, _ = flow.inverse(z.cuda(), None if ctx is None else ctx.cuda())
+    assert xw.abs().max() <= 3.0
+    assert (xw.cpu().double() - x64.clamp(-3.0, 3.0)).abs().max() < max(4 * ex_ref, 5e-5)
+
+
+@pytest.mark.parametrize("precision,tol_x,tol_ld", [("fp32", 2e-4, 2e-3), ("bf16", 0.1, 1.0)])
+def test_round_trip_full_size(precision, tol_x, tol_ld):
+    # BASELINE-sized batch, property only (the CPU oracle would need minutes for the D-pass inverse)
+    D, C = 15, 288
+    _, _, flow = make_pair(D, C, 256, 8, 16, 5.0)
+    flow.precision = precision
+    B = 8192
+    g = torch.Generator().manual_seed(5)
+    z = (torch.randn(B, D, generator=g) * 1.2).cuda()
+    ctx = torch.randn(B, C, generator=g).cuda()
+    with torch.no_grad():
+        x, ldi, flags = flow._inverse_call(z, ctx, B)
+        z2, ldf = flow(x, ctx)
+    err = (z2 - z).abs().max(dim=1).values
+    print(f"\n[{precision}] round trip |z2-z| med {err.median():.2e} max {err.max():.2e}  "
+          f"|ld_f+ld_i| max {(ldf + ldi).abs().max():.2e}")
+    assert int(flags.sum()) == 0
+    assert err.quantile(0.99) < tol_x and (ldf + ldi).abs().quantile(0.99) < tol_ld
+
+
+def test_grouped_and_expanded_context_and_order():
+    D, C = 11, 288
+    ref, _, flow = make_pair(D, C, 256, 3, 16, 5.0)
+    order = [2, 0, 1, 10, 9, 3, 4, 8, 5, 7, 6]
+    ref.set_autoregressive_order(order)
+    flow.set_autoregressive_order(order)
+    g = torch.Generator().manual_seed(9)
+    ctx = torch.randn(4, C, generator=g)
+    z = torch.randn(4 * 32, D, generator=g)
+    rep = ctx.unsqueeze(1).expand(4, 32, C).reshape(4 * 32, C)          # lean_npe.py:328
+    with torch.no_grad():
+        want, wld = ref.inverse(z, rep)
+        a, ald = flow.inverse(z.cuda(), rep.cuda())                       # one context row per sample
+        b, bld = flow.inverse(z.cuda(), ctx.cuda())                       # 4 rows grouped over 128 samples
+        c1, _ = flow.inverse(z[:32].cuda(), ctx[:1].cuda().expand(32, -1))  # stride-0 expand, pipeline.py:171
+    assert torch.allclose(a.cpu(), want, atol=1e-4) and torch.allclose(ald.cpu(), wld, atol=1e-3)
+    assert torch.equal(a, b) and torch.equal(ald, bld)
+    assert torch.equal(c1, a[:32])
+    with pytest.raises(ValueError):
+        flow.inverse(z.cuda(), ctx[:3].cuda())                           # 3 does not divide 128
+
+
+def test_sampling_api_and_nonfinite_context():
+    D, C = 11, 288
+    ref, _, flow = make_pair(D, C, 256, 2, 16, 5.0)
+    ctx = torch.randn(3, C)
+    ctx[1, 5] = float("nan"); ctx[2, 7] = float("inf")
+    torch.manual_seed(0)
+    s = flow.sample(64, ctx.cuda())
+    assert s.shape == (3, 64, D) and torch.isfinite(s).all() and s.abs().max() <= 3.0
+    ls = torch.randn(3, D).cuda() * 0.1
+    sp = flow.sample_psd_aware(16, ctx.cuda(), ls)
+    assert sp.shape == (3, 16, D) and torch.isfinite(sp).all()
+    out = flow.sample_with_uncertainty(32, ctx[:1].cuda())
+    assert out["samples"].shape == (32, D) and out["mean"].shape == (D,)
+    # a finite-context row is unaffected by the sanitising of the others
+    with torch.no_grad():
+        z = torch.randn(8, D)
+        got, _ = flow.inverse(z.cuda(), ctx[:1].cuda())
+        want, _ = ref.inverse(z, ctx[:1].expand(8, -1))
+    assert torch.allclose(got.cpu(), want, atol=1e-4)
+    pen = flow.compute_endpoint_loss(torch.zeros(3, D).cuda(), ctx.cuda())
+    assert pen.ndim == 0 and torch.isfinite(pen)
