@@ -1,0 +1,185 @@
+"""CPU-only checks (-m "not gpu"): the C-ABI library loads and exports every symbol of
+include/pf_hip.h, host-side planning / packing logic, error conventions, and the 2-rank
+gloo path of the data-parallel helper.  No kernel is launched here."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="session")
+def lib():
+    from posteriflow_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return _lib
+
+
+def test_library_exports_every_declared_symbol(lib):
+    header = open(os.path.join(ROOT, "include", "pf_hip.h")).read()
+    declared = set(re.findall(r"\b(pf_[a-z_]+)\s*\(", header))
+    assert declared == set(lib.SYMBOLS), declared ^ set(lib.SYMBOLS)
+    handle = lib.lib()
+    for name in declared:
+        assert hasattr(handle, name)
+    assert b"gfx950" in handle.pf_version()
+
+
+def desc_of(lib, D, C, H, K, L, prec):
+    return lib.PfFlowDesc(D, C, H, K, L, 2, 5.0, 1e-3, 1e-3, 1e-3, lib.PRECISIONS[prec], 0)
+
+
+def raw_layout(D, C, H, K, nb=2):
+    """(name, rows, cols) of one layer in the raw parameter order of pf_hip.h."""
+    M = 3 * K - 1
+    out = [("in_w", H, D), ("in_b", H, 1)]
+    if C:
+        out += [("c_w", H, C), ("c_b", H, 1)]
+    for b in range(nb):
+        if C:
+            out += [(f"g{b}_w", H, C), (f"g{b}_b", H, 1)]
+        out += [(f"w0{b}_w", H, H), (f"w0{b}_b", H, 1), (f"w1{b}_w", H, H), (f"w1{b}_b", H, 1)]
+    return out + [("out_w", D * M, H), ("out_b", D * M, 1)]
+
+
+@pytest.mark.parametrize("D,C,H,K,L", [(11, 288, 256, 16, 2), (15, 288, 256, 16, 2), (4, 0, 64, 8, 2),
+                                       (7, 40, 128, 10, 3), (2, 5, 64, 4, 1)])
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+def test_pack_map_covers_exactly_the_unmasked_weights(lib, D, C, H, K, L, prec):
+    """Every weight the autoregressive masks keep appears in the map (once; the x-input layer
+    twice in bf16 mode for the hi/lo split), every masked weight never; all biases appear once."""
+    from oracle import nflows_restated as nfr
+    d = desc_of(lib, D, C, H, K, L, prec)
+    h = lib.lib()
+    n = h.pf_flow_pack_map_len(C_byref(d))
+    assert n > 0
+    m = np.empty(n, dtype=np.int32)
+    assert h.pf_flow_build_pack_map(C_byref(d), m.ctypes.data) == 0
+    per_layer = h.pf_flow_raw_param_count(C_byref(d)) // L
+    counts = np.bincount(m[m >= 0], minlength=per_layer * L)
+    t = nfr.MaskedPiecewiseRationalQuadraticAutoregressiveTransform(D, H, C or None, K, 5.0)
+    net = t.autoregressive_net
+    masks = {"in_w": net.initial_layer.mask.numpy(), "out_w": net.final_layer.mask.numpy()}
+    for b in range(2):
+        masks[f"w0{b}_w"] = net.blocks[b].linear_layers[0].mask.numpy()
+        masks[f"w1{b}_w"] = net.blocks[b].linear_layers[1].mask.numpy()
+    for layer in range(L):
+        off = layer * per_layer
+        for name, r, c in raw_layout(D, C, H, K):
+            got = counts[off:off + r * c].reshape(r, c)
+            want = masks.get(name, np.ones((r, c))).astype(np.int64)
+            if name == "in_w" and prec == "bf16":
+                want = 2 * want
+            assert np.array_equal(got, want), (layer, name)
+            off += r * c
+        assert off == (layer + 1) * per_layer
+    assert sum(p.numel() for p in t.parameters()) == per_layer
+
+
+def C_byref(x):
+    return C.byref(x)
+
+
+def test_plan_sizes_and_unsupported_shapes(lib):
+    h = lib.lib()
+    d = desc_of(lib, 15, 288, 256, 16, 8, "bf16")
+    packed = h.pf_flow_packed_bytes(C_byref(d))
+    dense_bf16 = 2 * 8 * (256 * 15 + 3 * 256 * 288 + 4 * 256 * 256 + 15 * 47 * 256)
+    assert 0.6 * dense_bf16 < packed < 0.9 * dense_bf16        # mask-aware stream is smaller than dense
+    assert h.pf_flow_rows_per_workgroup(C_byref(d), 4096) == 16
+    assert h.pf_flow_rows_per_workgroup(C_byref(d), 65536) == 32
+    for bad in (desc_of(lib, 17, 288, 256, 16, 8, "bf16"),     # D > H/16
+                desc_of(lib, 11, 288, 384, 16, 8, "bf16"),     # H not built
+                desc_of(lib, 11, 288, 256, 17, 8, "bf16"),     # K > 16
+                desc_of(lib, 11, 5000, 256, 16, 8, "bf16")):   # C too large
+        assert h.pf_flow_packed_bytes(C_byref(bad)) == -1
+        assert h.pf_flow_forward(C_byref(bad), None, None, None, None, None, 4, None, None, None, None) == lib.PF_ERR_UNSUPPORTED
+    # argument checks happen before any launch
+    assert h.pf_flow_forward(C_byref(d), None, None, None, None, None, 4, None, None, None, None) == lib.PF_ERR_BAD_ARG
+    assert h.pf_flow_forward(C_byref(d), None, None, None, None, None, 0, None, None, None, None) == lib.PF_OK
+    assert h.pf_flow_forward(C_byref(d), None, None, None, None, None, -1, None, None, None, None) == lib.PF_ERR_BAD_ARG
+    assert b"null" in h.pf_last_error() or b"negative" in h.pf_last_error()
+    with pytest.raises(ValueError):
+        lib.check(lib.PF_ERR_BAD_ARG, "x")
+    with pytest.raises(NotImplementedError):
+        lib.check(lib.PF_ERR_UNSUPPORTED, "x")
+
+
+def test_module_api_on_cpu_is_loud_not_silent(lib):
+    from posteriflow_amd import NSFPosteriorFlow, create_flow_model
+    from oracle.flow_ref import NSFPosteriorFlowRef
+    flow = create_flow_model("nsf", 11, 288, config={"flow_config": {"num_layers": 3, "tail_bound": 5.0}},
+                             use_masked_context=False)
+    assert isinstance(flow, NSFPosteriorFlow) and flow.num_layers == 3 and flow._tail_bound == 5.0
+    assert NSFPosteriorFlow(4, 0, 64, 1, 8, tail_bound=5)._tail_bound == 3.0       # flows.py:517 quirk
+    with pytest.raises(ValueError):
+        create_flow_model("realnvp", 4)
+    with pytest.raises(NotImplementedError):
+        NSFPosteriorFlow(16, 256, 256, 1, 16)          # 256 % 16 == 0 -> masked context auto-on (flows.py:409)
+    with pytest.raises(RuntimeError):                   # no CPU fallback
+        flow(torch.zeros(2, 11), torch.zeros(2, 288))
+    with pytest.raises(RuntimeError):
+        flow.inverse(torch.zeros(2, 11), torch.zeros(2, 288))
+    # state_dict is interchangeable with the oracle's (nflows names) plus the flow._transform aliases
+    ref = NSFPosteriorFlowRef(11, 288, 256, 3, 16, 5.0)
+    sd = flow.state_dict()
+    rsd = ref.state_dict()
+    assert set(rsd) <= set(sd)
+    assert {k for k in sd if k not in rsd} == {"flow._transform." + k[len("transform."):] for k in rsd if k.startswith("transform.")}
+    for k, v in rsd.items():
+        assert sd[k].shape == v.shape, k
+    assert torch.equal(sd["transform._transforms.1.autoregressive_net.final_layer.mask"],
+                       rsd["transform._transforms.1.autoregressive_net.final_layer.mask"])
+    with pytest.raises(ValueError):
+        flow.set_autoregressive_order([0] * 11)
+    base = flow.base_dist
+    with pytest.raises(ValueError):
+        base.log_prob(torch.zeros(2, 11), torch.zeros(2, 5))
+
+
+def test_psd_scaled_normal_matches_reference_golden(golden_small):
+    from posteriflow_amd import PSDScaledNormal
+    base = PSDScaledNormal([11])
+    z = torch.from_numpy(golden_small["base_z"]); ls = torch.from_numpy(golden_small["base_ls"])
+    np.testing.assert_allclose(base.log_prob(z, ls).numpy(), golden_small["base_logp_ls"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(base.log_prob(z, torch.zeros_like(z)).numpy(), golden_small["base_logp_zero"],
+                               rtol=1e-5, atol=1e-5)
+    assert base.sample(7, ls).shape == (32, 7, 11)
+
+
+DIST_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from posteriflow_amd.dist import global_mean_nll, shard_bounds
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+g = torch.Generator().manual_seed(0)
+nll = torch.randn(1001, generator=g) * 3 + 20          # same on every rank
+lo, hi = shard_bounds(1001, rank, world)
+mean = global_mean_nll(nll[lo:hi])
+want = nll.double().mean()
+assert abs(mean.item() - want.item()) < 1e-12, (mean.item(), want.item())
+covered = torch.zeros(1001); covered[lo:hi] = 1
+dist.all_reduce(covered)
+assert torch.all(covered == 1)
+dist.destroy_process_group()
+print("ok", rank)
+"""
+
+
+def test_data_parallel_mean_nll_gloo_world2(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(DIST_WORKER)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29533", str(script), ROOT]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.count("ok") == 2
