@@ -1,0 +1,308 @@
+"""LeanNPE on MI355X: strain embedding -> context -> flow, with the reference's module API.
+
+Counterpart of the reference's ``src/ahsd/models/lean_npe.py`` (LN) and
+``src/ahsd/models/coherent_encoder.py`` (CE): same class names, constructor arguments,
+attributes and ``state_dict`` keys, so checkpoints written by
+``experiments/train_lean_npe.py:421-427`` load unchanged and ``inference/pipeline.py`` can use it
+as is.  The flow is :class:`posteriflow_amd.flows.NSFPosteriorFlow` (HIP, ``libpfhip.so``).
+
+Embedding status: the submodules below hold the parameters under the
+reference's names; this round the embedding is evaluated with device tensor ops
+(``Conv1d``/``TransformerEncoder``/``MultiheadAttention`` on the GPU) -- the hand-written HIP
+stem / fusion kernels replace ``_stem`` and ``_fuse`` next.  It is pinned against golden
+vectors produced by the reference's own classes (tests/golden/encoder.npz).
+"""
+from __future__ import annotations
+
+import math
+import warnings
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .flows import NSFPosteriorFlow
+
+PARAM_NAMES = ["mass_1", "mass_2", "luminosity_distance", "ra", "dec", "theta_jn", "psi",
+               "phase", "geocent_time", "a1", "a2"]                     # LN:41-45
+
+# name -> (low, high, log-space)                                          LN:54-66
+_PRIOR_BOX = {
+    "mass_1": (1.0, 105.0, True), "mass_2": (1.0, 105.0, True),
+    "luminosity_distance": (40.0, 2200.0, True),
+    "ra": (0.0, 2.0 * math.pi, False), "dec": (-0.5 * math.pi, 0.5 * math.pi, False),
+    "theta_jn": (0.0, math.pi, False), "psi": (0.0, math.pi, False),
+    "phase": (0.0, 2.0 * math.pi, False), "geocent_time": (-1.6, 1.6, False),
+    "a1": (0.0, 1.0, False), "a2": (0.0, 1.0, False),
+}
+_PERIODIC = frozenset(("ra", "phase", "psi"))                            # LN:71
+_PREMERGER_TIME = (-1.6, 5.2)                                            # LN:82-83
+
+
+class ParamScaler:
+    """Fixed invertible map physical parameters <-> [-1, 1] (LN:48-114).  [B, 11] elementwise
+    work, evaluated with device tensor ops; ``RANGES`` / ``CIRCULAR`` kept as in the reference."""
+
+    RANGES = _PRIOR_BOX
+    CIRCULAR = tuple(sorted(_PERIODIC))
+
+    def __init__(self, param_names: List[str] = PARAM_NAMES, premerger: bool = False):
+        self.param_names = list(param_names)
+        self.premerger = premerger
+        lows, highs, logs = [], [], []
+        for name in self.param_names:
+            lo, hi, is_log = _PRIOR_BOX[name]
+            if premerger and name == "geocent_time":
+                lo, hi = _PREMERGER_TIME
+            lows.append(math.log(lo) if is_log else lo)
+            highs.append(math.log(hi) if is_log else hi)
+            logs.append(is_log)
+        self.lo = torch.tensor(lows, dtype=torch.float32)
+        self.hi = torch.tensor(highs, dtype=torch.float32)
+        self.log_mask = torch.tensor(logs, dtype=torch.bool)
+        self.circ_mask = torch.tensor([n in _PERIODIC for n in self.param_names], dtype=torch.bool)
+
+    def to(self, device):
+        for attr in ("lo", "hi", "log_mask", "circ_mask"):
+            setattr(self, attr, getattr(self, attr).to(device))
+        return self
+
+    def normalize(self, x: torch.Tensor) -> torch.Tensor:
+        u = torch.where(self.log_mask, x.clamp_min(1e-6).log(), x)
+        return (2.0 * (u - self.lo) / (self.hi - self.lo) - 1.0).clamp(-1.0, 1.0)
+
+    def denormalize(self, y: torch.Tensor) -> torch.Tensor:
+        u = (y.clamp(-1.0, 1.0) + 1.0) / 2.0 * (self.hi - self.lo) + self.lo
+        return torch.where(self.log_mask, u.exp(), u)
+
+    def wrap(self, y: torch.Tensor) -> torch.Tensor:
+        """periodic parameters wrap exactly, bounded ones clamp (LN:100-104)."""
+        return torch.where(self.circ_mask, torch.remainder(y + 1.0, 2.0) - 1.0, y.clamp(-1.0, 1.0))
+
+
+class SinusoidalPositions(nn.Module):
+    def __init__(self, d_model: int, max_len: int = 512):
+        super().__init__()
+        pos = torch.arange(max_len, dtype=torch.float32)[:, None]
+        freq = torch.exp(torch.arange(0, d_model, 2, dtype=torch.float32) * (-math.log(10000.0) / d_model))
+        table = torch.zeros(max_len, d_model)
+        table[:, 0::2] = torch.sin(pos * freq)
+        table[:, 1::2] = torch.cos(pos * freq)
+        self.register_buffer("pe", table)
+
+    def forward(self, n: int) -> torch.Tensor:
+        return self.pe[:n]
+
+
+_STEM_SPEC = ((1, 32, 64, 8), (32, 64, 16, 4), (64, 128, 8, 4))          # + (128, d_model, 4, 2)  LN:158-163
+
+
+class LeanStrainEncoder(nn.Module):
+    """Whitened strain [B, n_det, 16384] -> context [B, context_dim] (LN:131-252)."""
+
+    def __init__(self, n_detectors: int = 3, d_model: int = 192, n_layers: int = 3, n_heads: int = 6,
+                 n_pool_queries: int = 8, n_energy_windows: int = 16, context_dim: int = 256,
+                 dropout: float = 0.05, psd_bands: int = 0):
+        super().__init__()
+        self.n_detectors, self.n_energy_windows = n_detectors, n_energy_windows
+        self.context_dim, self.psd_bands = context_dim, psd_bands
+        convs = []
+        for cin, cout, k, s in _STEM_SPEC + ((128, d_model, 4, 2),):
+            convs += [nn.Conv1d(cin, cout, kernel_size=k, stride=s), nn.GELU()]
+        self.stem = nn.Sequential(*convs)
+        self.detector_embed = nn.Embedding(n_detectors, d_model)
+        self.pos = SinusoidalPositions(d_model)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            block = nn.TransformerEncoderLayer(d_model=d_model, nhead=n_heads, dim_feedforward=4 * d_model,
+                                               dropout=dropout, activation="gelu", batch_first=True,
+                                               norm_first=True)
+            self.fusion = nn.TransformerEncoder(block, num_layers=n_layers)
+        self.pool_queries = nn.Parameter(torch.randn(n_pool_queries, d_model) / math.sqrt(d_model))
+        self.pool_attn = nn.MultiheadAttention(d_model, n_heads, batch_first=True)
+        self.energy_mlp = nn.Sequential(nn.Linear(n_detectors * n_energy_windows, 64), nn.GELU(),
+                                        nn.Linear(64, 64), nn.GELU())
+        extra = 0
+        if psd_bands > 0:
+            self.noise_mlp = nn.Sequential(nn.Linear(n_detectors * psd_bands, 64), nn.GELU(),
+                                           nn.Linear(64, 32), nn.GELU())
+            extra = 32
+        self.out_proj = nn.Sequential(nn.Linear(n_pool_queries * d_model + 64 + extra, 512), nn.GELU(),
+                                      nn.Linear(512, context_dim))
+
+    # --- pieces (the HIP kernels slot in here) ---------------------------------------------
+    @staticmethod
+    def _sanitize(strain):                                                # LN:207
+        return torch.nan_to_num(strain, nan=0.0, posinf=100.0, neginf=-100.0).clamp(-100.0, 100.0)
+
+    def _window_log_energy(self, clean):                                  # LN:210-212
+        b, d, t = clean.shape
+        w = self.n_energy_windows
+        return clean[:, :, : (t // w) * w].reshape(b, d, w, -1).square().mean(dim=-1).add(1e-8).log()
+
+    def _stem(self, clean):
+        b, d, t = clean.shape
+        return self.stem(torch.asinh(clean).reshape(b * d, 1, t)).transpose(1, 2)       # [B*D, 61, E]
+
+    def _fuse(self, tokens):
+        return self.fusion(tokens)
+
+    def _compute_feats(self, strain, asd_bands=None, extra_tokens=None):
+        """[B, 8*d_model + 64 (+32)] pre-projection features and the sanitised strain (LN:199-243)."""
+        b, d, _ = strain.shape
+        clean = self._sanitize(strain)
+        energy = self.energy_mlp(self._window_log_energy(clean).reshape(b, -1))
+        tok = self._stem(clean)
+        n_tok, e = tok.shape[1], tok.shape[2]
+        tok = (tok + self.pos(n_tok)).reshape(b, d, n_tok, e) + self.detector_embed.weight[None, :d, None, :]
+        tok = tok.reshape(b, d * n_tok, e)
+        if extra_tokens is not None:
+            tok = torch.cat([extra_tokens, tok], dim=1)
+        tok = self._fuse(tok)
+        pooled, _ = self.pool_attn(self.pool_queries.unsqueeze(0).expand(b, -1, -1), tok, tok)
+        parts = [pooled.reshape(b, -1), energy]
+        if self.psd_bands > 0:
+            if asd_bands is None:
+                asd_bands = strain.new_zeros(b, self.n_detectors, self.psd_bands)
+            parts.append(self.noise_mlp(asd_bands.reshape(b, -1)))
+        return torch.cat(parts, dim=1), clean
+
+    def forward(self, strain, asd_bands=None):
+        feats, _ = self._compute_feats(strain, asd_bands)
+        return self.out_proj(feats)
+
+
+_SR, _T_LEN, _F_LO, _F_HI = 4096, 16384, 20.0, 1024.0
+
+
+class CoherentEncoder(LeanStrainEncoder):
+    """LeanStrainEncoder plus frequency-domain geometry tokens (CE:42-123): band energies,
+    power-weighted pair coherence (|g|, cos, sin), GCC delay + sharpness, log-amplitude ratio
+    -> MLP -> 4 tokens prepended to the fusion transformer."""
+
+    def __init__(self, geometry_bands: int = 16, geom_hidden: int = 128, n_geom_tokens: int = 4,
+                 tau_max_ms: float = 30.0, **kw):
+        super().__init__(**kw)
+        self.K, self.n_geom_tokens = int(geometry_bands), int(n_geom_tokens)
+        self.d_model = self.detector_embed.embedding_dim
+        self.n_rfft = _T_LEN // 2 + 1
+        freqs = np.fft.rfftfreq(_T_LEN, 1.0 / _SR)
+        keep = (freqs >= _F_LO) & (freqs < _F_HI)
+        self.band_lo, self.Nf = int(np.argmax(keep)), int(keep.sum())
+        fb = freqs[keep]
+        edges = np.geomspace(_F_LO, _F_HI, self.K + 1)
+        member = np.stack([(fb >= edges[k]) & (fb < edges[k + 1]) for k in range(self.K)]).astype(np.float32)
+        self.register_buffer("Bsum", torch.from_numpy(member))
+        self.register_buffer("bcount", torch.from_numpy(member).sum(1).clamp_min(1.0))
+        self.maxlag = int(tau_max_ms * 1e-3 * _SR)
+        self.register_buffer("lags_norm", torch.arange(-self.maxlag, self.maxlag + 1).float() / self.maxlag)
+        self.pairs = [(i, j) for i in range(self.n_detectors) for j in range(i + 1, self.n_detectors)]
+        rel_dim = self.n_detectors * self.K + len(self.pairs) * (3 * self.K + 3)
+        self.geom_mlp = nn.Sequential(nn.Linear(rel_dim, geom_hidden), nn.GELU(),
+                                      nn.Linear(geom_hidden, geom_hidden), nn.GELU())
+        self.geom_to_tokens = nn.Linear(geom_hidden, self.n_geom_tokens * self.d_model)
+
+    def _geometry_rel(self, clean):
+        b = clean.shape[0]
+        spec = torch.fft.rfft(clean.float().contiguous(), norm="ortho", dim=-1)
+        spec = spec[..., self.band_lo: self.band_lo + self.Nf]
+        re, im = spec.real, spec.imag
+        power = re * re + im * im
+        amp = torch.sqrt(power + 1e-12)
+        feats = [torch.log(power @ self.Bsum.T / self.bcount + 1e-8).reshape(b, -1)]
+        for i, j in self.pairs:
+            xr = re[:, i] * re[:, j] + im[:, i] * im[:, j]
+            xi = im[:, i] * re[:, j] - re[:, i] * im[:, j]
+            den = (amp[:, i] * amp[:, j]) @ self.Bsum.T + 1e-8
+            gr, gi = xr @ self.Bsum.T / den, xi @ self.Bsum.T / den
+            gm = torch.sqrt(gr * gr + gi * gi) + 1e-8
+            feats += [gm, gr / gm, gi / gm]
+            full = torch.zeros(b, self.n_rfft, dtype=torch.complex64, device=clean.device)
+            full[:, self.band_lo: self.band_lo + self.Nf] = torch.complex(xr, xi)
+            cc = torch.fft.irfft(full, n=_T_LEN, dim=-1)
+            a = torch.cat([cc[:, -self.maxlag:], cc[:, : self.maxlag + 1]], dim=1).abs()
+            feats += [self.lags_norm[a.argmax(-1)].unsqueeze(-1),
+                      (a.max(-1).values / (a.mean(-1) + 1e-8)).unsqueeze(-1)]
+            ei, ej = power[:, i].sum(-1), power[:, j].sum(-1)
+            feats.append((torch.log(ei + 1e-8) - torch.log(ej + 1e-8)).unsqueeze(-1))
+        return torch.cat(feats, dim=-1)
+
+    def forward(self, strain, asd_bands=None):
+        clean = self._sanitize(strain)
+        g = self.geom_mlp(self._geometry_rel(clean))
+        gtok = self.geom_to_tokens(g).reshape(-1, self.n_geom_tokens, self.d_model)
+        feats, _ = self._compute_feats(clean, asd_bands, extra_tokens=gtok)
+        return self.out_proj(feats)
+
+
+class LeanNPE(nn.Module):
+    """Encoder + signal-rank embedding + NSF flow, pure NLL (LN:255-338)."""
+
+    def __init__(self, param_names: List[str] = PARAM_NAMES, context_dim: int = 256, rank_dim: int = 32,
+                 max_signals: int = 5, flow_layers: int = 10, flow_hidden: int = 256, flow_bins: int = 16,
+                 encoder_kwargs: Optional[dict] = None, premerger: bool = False, psd_cond: bool = False,
+                 psd_bands: int = 16, encoder_type: str = "conv"):
+        super().__init__()
+        self.param_names, self.max_signals = list(param_names), max_signals
+        self.context_dim, self.encoder_type = context_dim, encoder_type
+        self.psd_cond = psd_cond or encoder_type == "coherent"           # LN:271
+        self.scaler = ParamScaler(self.param_names, premerger=premerger)
+        kw = dict(encoder_kwargs or {})
+        if encoder_type == "coherent":
+            self.encoder = CoherentEncoder(context_dim=context_dim, psd_bands=psd_bands, **kw)
+        else:
+            if psd_cond:
+                kw["psd_bands"] = psd_bands
+            self.encoder = LeanStrainEncoder(context_dim=context_dim, **kw)
+        self.rank_embed = nn.Embedding(max_signals, rank_dim)
+        self.flow = NSFPosteriorFlow(features=len(self.param_names), context_features=context_dim + rank_dim,
+                                     hidden_features=flow_hidden, num_layers=flow_layers, num_bins=flow_bins,
+                                     tail_bound=5.0, dropout=0.0, temperature_scale=1.0,
+                                     use_masked_context=False)
+        self.flow.temperature.requires_grad_(False)                     # LN:297
+
+    def _full_context(self, context: torch.Tensor, rank: torch.Tensor) -> torch.Tensor:
+        return torch.cat([context, self.rank_embed(rank)], dim=1)
+
+    def encode(self, strain, asd_bands=None):
+        return self.encoder(strain, asd_bands) if self.psd_cond else self.encoder(strain)
+
+    def nll(self, strain, params_phys, rank, context=None, asd_bands=None):
+        """[B] negative log-likelihood of physical parameters (LN:306-316)."""
+        if context is None:
+            context = self.encode(strain, asd_bands)
+        ctx = self._full_context(context, rank)
+        y = self.scaler.normalize(params_phys)
+        return self.flow.compute_psd_aware_nll(y, ctx, None)            # log_sigma = 0 fused in-kernel
+
+    @torch.no_grad()
+    def sample_posterior(self, strain, rank: int = 0, n_samples: int = 256, asd_bands=None):
+        """[B, n_samples, 11] posterior draws in physical units (LN:318-332); the per-event
+        context is passed once, not replicated n_samples times."""
+        context = self.encode(strain, asd_bands)
+        b = context.shape[0]
+        r = torch.full((b,), rank, dtype=torch.long, device=context.device)
+        ctx = self._full_context(context, r)
+        z = torch.randn(b * n_samples, len(self.param_names), device=context.device)
+        y, _ = self.flow.inverse(z, ctx)
+        return self.scaler.denormalize(self.scaler.wrap(y).reshape(b, n_samples, -1))
+
+    def to(self, *args, **kwargs):
+        out = super().to(*args, **kwargs)
+        self.scaler.to(next(self.parameters()).device)
+        return out
+
+
+def batch_nll(model: LeanNPE, strain, params, nsig, asd_bands=None):
+    """Mean per-signal NLL of a batch of events with up to ``max_signals`` signals each
+    (experiments/train_lean_npe.py:108-127), as ONE flow call: the (event, rank) pairs with
+    rank < nsig are flattened instead of looping over ranks with host syncs;
+    sum / count is identical."""
+    context = model.encode(strain, asd_bands)
+    b, r_max = params.shape[0], params.shape[1]
+    ranks = torch.arange(r_max, device=nsig.device)[None, :].expand(b, r_max)
+    keep = ranks < nsig[:, None]
+    ev = torch.arange(b, device=nsig.device)[:, None].expand(b, r_max)[keep]
+    rk = ranks[keep]
+    return model.nll(None, params[ev, rk], rk, context=context[ev]).mean()
