@@ -38,6 +38,10 @@ extern "C" {
 #define PF_PREC_F32 0   /* f32-input MFMA (v_mfma_f32_16x16x4_f32): exact fp32, parity mode */
 #define PF_PREC_BF16 1  /* bf16 MFMA operands, fp32 accumulate: throughput mode */
 
+/* PfFlowDesc.reserved flag bits */
+#define PF_FLAG_HOIST_CTX 1  /* evaluate the context projections of all layers once, up front,
+                              * into the caller's workspace (pf_flow_workspace_bytes) */
+
 /* Plain-old-data description of one NSFPosteriorFlow (flows.py:379-548).
  * conditioner: nflows MADE, num_blocks residual blocks with GLU context gate,
  * ReversePermutation in front of every layer, tails='linear'. */
@@ -53,7 +57,7 @@ typedef struct PfFlowDesc {
     float min_bin_height;      /* nflows DEFAULT_MIN_BIN_HEIGHT = 1e-3         */
     float min_derivative;      /* nflows DEFAULT_MIN_DERIVATIVE = 1e-3         */
     int32_t precision;         /* PF_PREC_*                                    */
-    int32_t reserved;
+    int32_t reserved;          /* flags: PF_FLAG_*                             */
 } PfFlowDesc;
 
 /* ---- raw parameter layout -------------------------------------------------
@@ -77,6 +81,11 @@ int pf_flow_build_pack_map(const PfFlowDesc* desc, int32_t* map_host);
 int pf_flow_pack(const PfFlowDesc* desc, const float* raw, const int32_t* map,
                  void* packed, void* stream);
 
+/* ---- workspace ----------------------------------------------------------------
+ * Bytes of caller-owned device scratch pf_flow_forward / pf_flow_inverse need for a
+ * call with `ctx_rows` context rows (0 unless PF_FLAG_HOIST_CTX is set). */
+int64_t pf_flow_workspace_bytes(const PfFlowDesc* desc, int64_t ctx_rows);
+
 /* ---- forward / density ------------------------------------------------------
  * z, logdet = transform(x[:, ar_perm], ctx)
  * nll = -(log N(z; 0, diag(exp(log_sigma))^2) + logdet)   (PSDScaledNormal, flows.py:56-85)
@@ -86,7 +95,8 @@ int pf_flow_pack(const PfFlowDesc* desc, const float* raw, const int32_t* map,
 int pf_flow_forward(const PfFlowDesc* desc, const void* packed,
                     const float* x, const float* ctx, const int32_t* ar_perm,
                     const float* log_sigma, int64_t batch,
-                    float* z, float* logdet, float* nll, void* stream);
+                    float* z, float* logdet, float* nll,
+                    void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- inverse / sampling -----------------------------------------------------
  * x = transform^-1(z, ctx)[:, ar_inv_perm], logdet of the inverse map
@@ -100,7 +110,8 @@ int pf_flow_forward(const PfFlowDesc* desc, const void* packed,
 int pf_flow_inverse(const PfFlowDesc* desc, const void* packed,
                     const float* z, const float* ctx, int64_t ctx_rows,
                     const int32_t* ar_inv_perm, int64_t batch,
-                    float* x, float* logdet, uint32_t* fail_flags, void* stream);
+                    float* x, float* logdet, uint32_t* fail_flags,
+                    void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- introspection ------------------------------------------------------------ */
 const char* pf_last_error(void);

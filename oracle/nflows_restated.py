@@ -58,8 +58,13 @@ def _bf16(t):
     return t.to(torch.bfloat16).to(t.dtype)
 
 
+def round_projection(t):
+    """hoisted-context bf16 mode stores relu / sigmoid of the context projections as bf16"""
+    return _bf16(t) if _EMULATE == "bf16_hoist" else t
+
+
 def linear(x, w, b, split_input=False):
-    if _EMULATE == "bf16":
+    if _EMULATE in ("bf16", "bf16_hoist"):
         if split_input:
             hi = _bf16(x)
             x = hi + _bf16(x - hi)
@@ -139,7 +144,10 @@ class MaskedResidualBlock(nn.Module):
         t = self.linear_layers[1](t)
         if context is not None:
             gate = linear(context, self.context_layer.weight, self.context_layer.bias)
-            t = F.glu(torch.cat((t, gate), dim=1), dim=1)
+            if _EMULATE == "bf16_hoist":
+                t = t * round_projection(torch.sigmoid(gate))
+            else:
+                t = F.glu(torch.cat((t, gate), dim=1), dim=1)
         return inputs + t
 
 
@@ -166,7 +174,7 @@ class MADE(nn.Module):
     def forward(self, inputs, context=None):
         h = self.initial_layer(inputs)
         if context is not None:
-            h = h + F.relu(linear(context, self.context_layer.weight, self.context_layer.bias))
+            h = h + round_projection(F.relu(linear(context, self.context_layer.weight, self.context_layer.bias)))
         for block in self.blocks:
             h = block(h, context)
         return self.final_layer(h)

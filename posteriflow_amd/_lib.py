@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libpfhip.so")
 
 PF_OK, PF_ERR_BAD_ARG, PF_ERR_UNSUPPORTED, PF_ERR_HIP = 0, -1, -2, -3
 PF_PREC_F32, PF_PREC_BF16 = 0, 1
+PF_FLAG_HOIST_CTX = 1
 PRECISIONS = {"fp32": PF_PREC_F32, "f32": PF_PREC_F32, "bf16": PF_PREC_BF16}
 
 
@@ -35,10 +36,13 @@ SYMBOLS = {
     "pf_flow_pack_map_len": (C.c_int64, [_P]),
     "pf_flow_build_pack_map": (C.c_int, [_P, C.c_void_p]),
     "pf_flow_pack": (C.c_int, [_P, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pf_flow_workspace_bytes": (C.c_int64, [_P, C.c_int64]),
     "pf_flow_forward": (C.c_int, [_P, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                  C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                  C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_int64, C.c_void_p]),
     "pf_flow_inverse": (C.c_int, [_P, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
-                                  C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                  C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_int64, C.c_void_p]),
     "pf_last_error": (C.c_char_p, []),
     "pf_version": (C.c_char_p, []),
     "pf_flow_rows_per_workgroup": (C.c_int32, [_P, C.c_int64]),

@@ -39,7 +39,7 @@ int64_t pf_flow_raw_param_count(const PfFlowDesc* desc) {
 int64_t pf_flow_packed_bytes(const PfFlowDesc* desc) {
     pf::FlowPlan L;
     if (layout_of(desc, L) != PF_OK) return -1;
-    return L.weightBytes + L.biasFloats * (int64_t)sizeof(float);
+    return L.packed_bytes();
 }
 int64_t pf_flow_pack_map_len(const PfFlowDesc* desc) {
     pf::FlowPlan L;
@@ -63,9 +63,29 @@ int pf_flow_pack(const PfFlowDesc* desc, const float* raw, const int32_t* map, v
     return rc == PF_OK ? rc : fail(rc, hipGetErrorString(hipGetLastError()));
 }
 
+int64_t pf_flow_workspace_bytes(const PfFlowDesc* desc, int64_t ctx_rows) {
+    pf::FlowPlan L;
+    if (layout_of(desc, L) != PF_OK || ctx_rows < 0) return -1;
+    return pf::ctx_project_bytes(L, ctx_rows);
+}
+
+// hoisted plans: run the context projection into the workspace, hand it to the chain kernel
+static int project_context(const pf::FlowPlan& L, pf::FwdParams& p, void* workspace, int64_t workspace_bytes,
+                           hipStream_t s) {
+    p.cproj = nullptr;
+    if (!L.hoist) return PF_OK;
+    const int64_t need = pf::ctx_project_bytes(L, p.ctx_rows);
+    if (!workspace || workspace_bytes < need) return fail(PF_ERR_BAD_ARG, "workspace too small (pf_flow_workspace_bytes)");
+    if (misaligned(workspace, 16)) return fail(PF_ERR_BAD_ARG, "workspace must be 16-byte aligned");
+    const int rc = pf::launch_ctx_project(L, p.packed, p.ctx, p.ctx_rows, workspace, s);
+    if (rc != PF_OK) return fail(rc, hipGetErrorString(hipGetLastError()));
+    p.cproj = workspace;
+    return PF_OK;
+}
+
 int pf_flow_forward(const PfFlowDesc* desc, const void* packed, const float* x, const float* ctx,
                     const int32_t* ar_perm, const float* log_sigma, int64_t batch, float* z,
-                    float* logdet, float* nll, void* stream) {
+                    float* logdet, float* nll, void* workspace, int64_t workspace_bytes, void* stream) {
     pf::FlowPlan L;
     int rc = layout_of(desc, L);
     if (rc != PF_OK) return rc;
@@ -81,13 +101,16 @@ int pf_flow_forward(const PfFlowDesc* desc, const void* packed, const float* x, 
     p.tail_bound = desc->tail_bound; p.min_w = desc->min_bin_width; p.min_h = desc->min_bin_height;
     p.min_d = desc->min_derivative;
     p.deriv_const = (float)std::log(std::exp(1.0 - (double)desc->min_derivative) - 1.0);
+    rc = project_context(L, p, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+    if (rc != PF_OK) return rc;
     rc = pf::launch_flow_forward(p, static_cast<hipStream_t>(stream));
     return rc == PF_OK ? rc : fail(rc, rc == PF_ERR_HIP ? hipGetErrorString(hipGetLastError()) : "unsupported launch shape");
 }
 
 int pf_flow_inverse(const PfFlowDesc* desc, const void* packed, const float* z, const float* ctx,
                     int64_t ctx_rows, const int32_t* ar_inv_perm, int64_t batch, float* x,
-                    float* logdet, uint32_t* fail_flags, void* stream) {
+                    float* logdet, uint32_t* fail_flags, void* workspace, int64_t workspace_bytes,
+                    void* stream) {
     pf::FlowPlan L;
     int rc = layout_of(desc, L);
     if (rc != PF_OK) return rc;
@@ -109,6 +132,8 @@ int pf_flow_inverse(const PfFlowDesc* desc, const void* packed, const float* z, 
     p.tail_bound = desc->tail_bound; p.min_w = desc->min_bin_width; p.min_h = desc->min_bin_height;
     p.min_d = desc->min_derivative;
     p.deriv_const = (float)std::log(std::exp(1.0 - (double)desc->min_derivative) - 1.0);
+    rc = project_context(L, p, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+    if (rc != PF_OK) return rc;
     rc = pf::launch_flow_inverse(p, static_cast<hipStream_t>(stream));
     return rc == PF_OK ? rc : fail(rc, rc == PF_ERR_HIP ? hipGetErrorString(hipGetLastError()) : "unsupported launch shape");
 }

@@ -352,6 +352,20 @@ __global__ __launch_bounds__(NT * 32) void flow_kernel(const FwdParams p) {
     u32x4 cb[CTX_REGS ? CKM : 1][R];
     if constexpr (CTX_REGS) load_b(s_ctx, ic<CKM>{}, cb);
 
+    // hoisted context projections (pf_flow_ctx.hip): 4 consecutive sorted units of one tile for
+    // this lane's batch column, already relu'd / sigmoid'ed
+    auto load_proj = [&](int l, int j, int tile, int r) -> f32x4 {
+        int64_t row = row0 + 16 * r + c;
+        if (row >= p.batch) row = p.batch - 1;
+        if (INV) row /= (p.batch / p.ctx_rows);
+        // fragment order of pf_flow_ctx.hip: [row/64][tile u][(row/16)%4][g*16 + row%16][4]
+        const size_t u = ((size_t)l * 3 + j) * NT + tile;
+        const size_t off = ((((size_t)(row >> 6) * (3 * L.L * NT) + u) * 4 + ((row >> 4) & 3)) * 64
+                            + (g * 16 + (row & 15))) * 4;
+        return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.cproj) + off);
+    };
+    const bool hoisted = CKM == 0 && p.cproj != nullptr;
+
     float ld_pair = 0.f;                                // log-det of this thread's (feature,row) pair
 
     // acc[r] += A(window slot of entry E) . B
@@ -421,6 +435,15 @@ __global__ __launch_bounds__(NT * 32) void flow_kernel(const FwdParams p) {
                 nbB = *reinterpret_cast<const f32x4*>(gbias + L.bias_index(ln, tB) + 4 * lane);
             }
         }
+        f32x4 prA[3][R], prB[3][R];
+        if constexpr (CKM == 0) {
+            if (hoisted) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int r = 0; r < R; ++r) { prA[j][r] = load_proj(l, j, tA, r); prB[j][r] = load_proj(l, j, tB, r); }
+            }
+        }
         // masked GEMM over a tile / feature pair, entries [E0, E0+N): entry i < nA is k-step i of
         // the first accumulator, otherwise k-step N-1-i of the second (pf_layout.h); every
         // k-step index is a compile-time constant, only the accumulator choice is per wave
@@ -485,6 +508,12 @@ __global__ __launch_bounds__(NT * 32) void flow_kernel(const FwdParams p) {
             const f32x4 biA = load_bias(tA, kSlotIn), biB = load_bias(tB, kSlotIn);
 #pragma unroll
             for (int r = 0; r < R; ++r) { hA[r] += biA; hB[r] += biB; }
+            if constexpr (CKM == 0) {
+                if (hoisted) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) { hA[r] += prA[0][r]; hB[r] += prB[0][r]; }
+                }
+            }
             if constexpr (CKM > 0) {
                 f32x4 cA[R], cB[R];
                 zero(cA); zero(cB);
@@ -545,6 +574,12 @@ __global__ __launch_bounds__(NT * 32) void flow_kernel(const FwdParams p) {
                         hA[r][e] += (tAv[r][e] + b1A[e]) * pf_sigmoid<FAST>(gA[r][e] + bgA[e]);
                         hB[r][e] += (tBv[r][e] + b1B[e]) * pf_sigmoid<FAST>(gB[r][e] + bgB[e]);
                     }
+            } else if (hoisted) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    hA[r] += (tAv[r] + b1A) * prA[1 + b][r];
+                    hB[r] += (tBv[r] + b1B) * prB[1 + b][r];
+                }
             } else {
 #pragma unroll
                 for (int r = 0; r < R; ++r) { hA[r] += tAv[r] + b1A; hB[r] += tBv[r] + b1B; }

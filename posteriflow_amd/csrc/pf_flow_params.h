@@ -19,6 +19,7 @@ struct FwdParams {
     int64_t batch;
     int64_t ctx_rows;        // inverse: context rows (divides batch); forward: == batch
     uint32_t* fail_flags;    // inverse: [B] or null, bit 0 = negative discriminant
+    const void* cproj;       // hoisted plans: fp32 projections in fragment order (else null)
     FlowPlan plan;
     float tail_bound, min_w, min_h, min_d;
     float deriv_const;       // log(exp(1 - min_d) - 1), computed in double on the host
@@ -32,5 +33,8 @@ int launch_pack(const FlowPlan& L, const float* raw, const int32_t* map, void* p
 int rows_per_workgroup(const FlowPlan& L, int64_t batch);
 int launch_flow_forward(const FwdParams& p, hipStream_t s);
 int launch_flow_inverse(const FwdParams& p, hipStream_t s);
+int launch_ctx_project(const FlowPlan& L, const char* packed, const float* ctx, int64_t ctx_rows,
+                       void* out, hipStream_t s);
+int64_t ctx_project_bytes(const FlowPlan& L, int64_t ctx_rows);
 
 }  // namespace pf

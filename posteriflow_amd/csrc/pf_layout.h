@@ -17,6 +17,14 @@
 // A-fragments ("frags", 1 KiB = 64 lanes x 16 B) in consumption order, then a
 // bias region [layer][tile][12 slots][16] fp32.
 //
+// Hoisted-context plans (PF_FLAG_HOIST_CTX): the context GEMMs are not part of the
+// per-wave streams (CKM = 0); their weights form a third region, [(layer*3 + j)*NT +
+// tile][CK frags] (j = 0 MADE context layer, 1/2 the gates of block 0/1) followed by
+// [(layer*3 + j)*NT + tile][16] fp32 biases, consumed by the context-projection kernel,
+// whose output (in MFMA C-fragment order, [row/64][(layer*3+j)*NT+tile][4][64][4]) = relu /
+// sigmoid of the projections is read by the layer chain instead of recomputing it per layer (and, in the
+// inverse, per autoregressive pass).
+//
 //   bf16 mode  (v_mfma_f32_16x16x32_bf16): a frag is one MFMA A operand,
 //              lane = 16*g + r16 holds A[row r16][k = 8*g + j], j = 0..7
 //   f32 mode   (v_mfma_f32_16x16x4_f32): a frag feeds 4 MFMAs (a 16-wide k-group),
@@ -79,6 +87,7 @@ struct FlowPlan {
     int NT, NW;                 // tiles = H/16, waves = NT/2
     int kstep;                  // k extent of one frag: 32 (bf16) or 16 (f32)
     int CK, CKM, HK;            // needed / scheduled context frags per tile; frags per full hidden row
+    int hoist;                  // 1: context projections hoisted (CKM = 0 in the streams)
     int dense;                  // 1: KHS = KOS = 2*HK (masks too coarse to pair up), else HK+2 / HK+1
     int KHS, KOS, NF;
     int kH[kMaxTiles];          // active k-steps of tile t in a masked H x H GEMM
@@ -88,7 +97,16 @@ struct FlowPlan {
     int64_t fragsTotal;
     int64_t weightBytes;
     int64_t biasFloats;         // L * NT * kBiasFloatsPerTile
+    int64_t ctxFrags;           // hoisted: 3 * L * NT * CK frags of context weights, else 0
+    int64_t ctxBiasFloats;      // hoisted: 3 * L * NT * 16
     int64_t rawPerLayer;
+
+    PF_HD int64_t packed_bytes() const {
+        return weightBytes + (biasFloats + ctxBiasFloats) * (int64_t)sizeof(float) + ctxFrags * kFragBytes;
+    }
+    // byte offsets of the regions inside the packed buffer
+    PF_HD int64_t ctx_frag_offset() const { return weightBytes + biasFloats * (int64_t)sizeof(float); }
+    PF_HD int64_t ctx_bias_offset() const { return ctx_frag_offset() + ctxFrags * kFragBytes; }
 
     PF_HD int64_t bias_index(int layer, int tile) const {
         return ((int64_t)layer * NT + tile) * kBiasFloatsPerTile;
@@ -136,8 +154,9 @@ inline int make_plan(const PfFlowDesc& d, FlowPlan& o) {
     o.NT = o.H / 16; o.NW = o.NT / 2;
     o.kstep = o.bf16 ? 32 : 16;
     o.CK = (o.C + o.kstep - 1) / o.kstep;
-    o.CKM = pick_ckm(o.bf16, o.NT, o.C);
-    if (o.CKM < 0) return PF_ERR_UNSUPPORTED;
+    o.hoist = (d.reserved & PF_FLAG_HOIST_CTX) && o.C > 0 ? 1 : 0;
+    o.CKM = o.hoist ? 0 : pick_ckm(o.bf16, o.NT, o.C);
+    if (o.CKM < 0 || o.CK > 64) return PF_ERR_UNSUPPORTED;
     o.HK = o.H / o.kstep;
     int perm[256], deg_sorted[256];
     sorted_units(o.D, o.H, perm);
@@ -175,6 +194,8 @@ inline int make_plan(const PfFlowDesc& d, FlowPlan& o) {
     o.fragsTotal = o.fragsPerWave * o.NW;
     o.weightBytes = o.fragsTotal * kFragBytes;
     o.biasFloats = (int64_t)o.L * o.NT * kBiasFloatsPerTile;
+    o.ctxFrags = o.hoist ? (int64_t)3 * o.L * o.NT * o.CK : 0;
+    o.ctxBiasFloats = o.hoist ? (int64_t)3 * o.L * o.NT * 16 : 0;
     const int64_t ctxp = o.C > 0 ? ((int64_t)o.H * o.C + o.H) : 0;
     o.rawPerLayer = (int64_t)o.H * o.D + o.H + ctxp
                   + (int64_t)o.NB * (ctxp + 2 * ((int64_t)o.H * o.H + o.H))

@@ -129,6 +129,7 @@ int build_pack_map(const FlowPlan& L, int32_t* map) {
         for (int64_t k = 0; k < (int64_t)kWindowPad * fragElems; ++k) map[idx++] = -1;   // prefetch overrun pad
     }
     if (idx != L.fragsTotal * fragElems) return PF_ERR_BAD_ARG;
+    // (bias region follows; the hoisted context region comes after it)
     // bias region, [layer][tile][slot][r16]; out slots of tile t hold the biases of the
     // feature whose spline the owning wave evaluates as "A" (tile < NW) or "B" (tile >= NW)
     for (int l = 0; l < L.L; ++l) {
@@ -141,12 +142,12 @@ int build_pack_map(const FlowPlan& L, int32_t* map) {
                 const int u = perm[16 * t + r16];
                 int64_t src = -1;
                 if (slot == kSlotIn) src = ro.in_b + u;
-                else if (slot == kSlotCtx) { if (L.C > 0) src = ro.c_b + u; }
+                else if (slot == kSlotCtx) { if (L.C > 0 && !L.hoist) src = ro.c_b + u; }
                 else if (slot >= kSlotBlk && slot < kSlotBlk + 3 * L.NB) {
                     const int b = (slot - kSlotBlk) / 3, which = (slot - kSlotBlk) % 3;
                     if (which == 0) src = ro.w0_b[b] + u;
                     else if (which == 1) src = ro.w1_b[b] + u;
-                    else if (L.C > 0) src = ro.g_b[b] + u;
+                    else if (L.C > 0 && !L.hoist) src = ro.g_b[b] + u;
                 } else if (slot >= kSlotOut && slot < kSlotOut + 3) {
                     const int m = out_param(L, slot - kSlotOut, r16);
                     if (feat >= 0 && m >= 0) src = ro.out_b + (int64_t)feat * L.M + m;
@@ -155,11 +156,39 @@ int build_pack_map(const FlowPlan& L, int32_t* map) {
             }
         }
     }
+    // hoisted context projections: frags [(l*3 + j)*NT + t][ks], then biases [(l*3 + j)*NT + t][16]
+    if (L.hoist) {
+        for (int l = 0; l < L.L; ++l) {
+            const int64_t base = (int64_t)l * ro.total;
+            for (int j = 0; j < 3; ++j) {
+                const int64_t wsrc = j == 0 ? ro.c_w : ro.g_w[j - 1];
+                for (int t = 0; t < L.NT; ++t)
+                    for (int ks = 0; ks < L.CK; ++ks)
+                        for (int within = 0; within < fragElems; ++within, ++idx) {
+                            const int lane = within / per, el = within % per;
+                            const int g = lane >> 4, r16 = lane & 15;
+                            const int col = L.bf16 ? (32 * ks + 8 * g + el) : (16 * ks + 4 * g + el);
+                            const int u = perm[16 * t + r16];
+                            map[idx] = col < L.C ? (int32_t)(base + wsrc + (int64_t)u * L.C + col) : -1;
+                        }
+            }
+        }
+        for (int l = 0; l < L.L; ++l) {
+            const int64_t base = (int64_t)l * ro.total;
+            for (int j = 0; j < 3; ++j) {
+                const int64_t bsrc = j == 0 ? ro.c_b : ro.g_b[j - 1];
+                for (int t = 0; t < L.NT; ++t)
+                    for (int r16 = 0; r16 < 16; ++r16, ++idx)
+                        map[idx] = (int32_t)(base + bsrc + perm[16 * t + r16]);
+            }
+        }
+    }
     return PF_OK;
 }
 
 int64_t pack_map_len(const FlowPlan& L) {
-    return L.fragsTotal * (L.bf16 ? 512 : 256) + L.biasFloats;
+    const int64_t fe = L.bf16 ? 512 : 256;
+    return L.fragsTotal * fe + L.biasFloats + L.ctxFrags * fe + L.ctxBiasFloats;
 }
 
 int64_t raw_param_count(const FlowPlan& L) { return raw_offsets(L).total * L.L; }
@@ -197,21 +226,28 @@ __global__ __launch_bounds__(256) void pack_f32_kernel(const float* __restrict__
 
 int launch_pack(const FlowPlan& L, const float* raw, const int32_t* map, void* packed,
                 hipStream_t stream) {
-    const int64_t nW = L.fragsTotal * (L.bf16 ? 512 : 256);
-    const int64_t nB = L.biasFloats;
-    if (L.bf16) {
-        const int64_t blocks = (nW / 8 + 255) / 256;
-        hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, raw, map,
-                           reinterpret_cast<__bf16*>(packed), nW);
-    } else {
-        const int64_t blocks = (nW / 4 + 255) / 256;
-        hipLaunchKernelGGL(pack_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, raw, map,
-                           reinterpret_cast<float*>(packed), nW);
-    }
-    float* bias_out = reinterpret_cast<float*>(reinterpret_cast<char*>(packed) + L.weightBytes);
-    const int64_t bblocks = (nB / 4 + 255) / 256;
-    hipLaunchKernelGGL(pack_f32_kernel, dim3((unsigned)bblocks), dim3(256), 0, stream, raw, map + nW,
-                       bias_out, nB);
+    const int64_t fe = L.bf16 ? 512 : 256;
+    auto gather_w = [&](const int32_t* m, void* dst, int64_t n) {
+        if (n == 0) return;
+        if (L.bf16) {
+            hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, stream, raw, m,
+                               reinterpret_cast<__bf16*>(dst), n);
+        } else {
+            hipLaunchKernelGGL(pack_f32_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, raw, m,
+                               reinterpret_cast<float*>(dst), n);
+        }
+    };
+    auto gather_f = [&](const int32_t* m, void* dst, int64_t n) {
+        if (n == 0) return;
+        hipLaunchKernelGGL(pack_f32_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, raw, m,
+                           reinterpret_cast<float*>(dst), n);
+    };
+    char* out = reinterpret_cast<char*>(packed);
+    const int64_t nW = L.fragsTotal * fe, nB = L.biasFloats, nCW = L.ctxFrags * fe, nCB = L.ctxBiasFloats;
+    gather_w(map, out, nW);
+    gather_f(map + nW, out + L.weightBytes, nB);
+    gather_w(map + nW + nB, out + L.ctx_frag_offset(), nCW);
+    gather_f(map + nW + nB + nCW, out + L.ctx_bias_offset(), nCB);
     return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
 }
 

@@ -159,6 +159,12 @@ class NSFPosteriorFlow(nn.Module):
     ``precision``: ``"fp32"`` (exact f32 MFMA, matches the CPU path to ~1e-6) or
     ``"bf16"`` (bf16 MFMA operands, fp32 accumulate: throughput mode).  Default
     from ``$PF_FLOW_PRECISION`` or ``"fp32"``.
+
+    ``hoist_context``: evaluate the context projections of all layers once per call in one
+    GEMM instead of inside every layer / autoregressive pass (same arithmetic, projections kept
+    in fp32).  ``None`` (default) = measured
+    choice: hoisted for the inverse / sampling (the projections would otherwise be recomputed
+    in all D passes), in-layer for the forward / density path (108 us vs 86 + 33 us at B = 4096).
     """
 
     def __init__(self, features: int, context_features: int = 0, hidden_features: int = 256,
@@ -213,7 +219,10 @@ class NSFPosteriorFlow(nn.Module):
         self.register_buffer("_ar_inv_perm", torch.arange(features, dtype=torch.long))
 
         self.precision = os.environ.get("PF_FLOW_PRECISION", "fp32")
-        self._packed: Dict[int, _Packed] = {}
+        env = os.environ.get("PF_FLOW_HOIST", "")
+        self.hoist_context = None if env == "" else env != "0"
+        self._workspace = None
+        self._packed: Dict[tuple, _Packed] = {}
         self._perm_i32 = None
         self._frozen = False
 
@@ -221,7 +230,9 @@ class NSFPosteriorFlow(nn.Module):
         """Inference: keep the packed weights as they are and skip the per-call scan for
         parameter updates (call again with False, or load new weights, to re-pack)."""
         if frozen:
+            self._frozen = False
             self.packed_weights()
+            self.packed_weights(inverse=True)
         self._frozen = frozen
         return self
 
@@ -238,18 +249,31 @@ class NSFPosteriorFlow(nn.Module):
             raise ValueError("nll_into: bad context")
         dev = x.device
         perm, _ = self._perms(dev)
+        desc = self._desc()
+        ws, ws_bytes = self._ws(desc, B, dev)
         _lib.check(_lib.lib().pf_flow_forward(
-            self._desc(), self.packed_weights().data_ptr(), x.data_ptr(), _dev_ptr(context),
+            desc, self.packed_weights().data_ptr(), x.data_ptr(), _dev_ptr(context),
             _dev_ptr(perm), _dev_ptr(log_sigma), B, None, None, out.data_ptr(),
-            torch.cuda.current_stream(dev).cuda_stream), "pf_flow_forward")
+            _dev_ptr(ws), ws_bytes, torch.cuda.current_stream(dev).cuda_stream), "pf_flow_forward")
         return out
 
     # ---- plumbing -------------------------------------------------------------
-    def _desc(self, precision: Optional[str] = None) -> _lib.PfFlowDesc:
+    def _desc(self, precision: Optional[str] = None, inverse: bool = False) -> _lib.PfFlowDesc:
         prec = _lib.PRECISIONS[precision or self.precision]
+        hoist = inverse if self.hoist_context is None else self.hoist_context
+        flags = _lib.PF_FLAG_HOIST_CTX if (hoist and self.context_features > 0) else 0
         return _lib.PfFlowDesc(self.features, self.context_features, self.hidden_features,
                                self.num_bins, self.num_layers, 2, float(self._tail_bound),
-                               _MIN_BIN, _MIN_BIN, _MIN_BIN, prec, 0)
+                               _MIN_BIN, _MIN_BIN, _MIN_BIN, prec, flags)
+
+    def _ws(self, desc, ctx_rows: int, dev):
+        """Caller-owned scratch for the hoisted context projections (grown on demand)."""
+        need = _lib.lib().pf_flow_workspace_bytes(desc, ctx_rows)
+        if need <= 0:
+            return None, 0
+        if self._workspace is None or self._workspace.device != dev or self._workspace.numel() < need:
+            self._workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+        return self._workspace, need
 
     def _ordered_parameters(self) -> List[torch.Tensor]:
         out = []
@@ -265,16 +289,17 @@ class NSFPosteriorFlow(nn.Module):
                 "(no CPU fallback); move the module with .to('cuda')" % dev)
         return dev
 
-    def packed_weights(self, precision: Optional[str] = None) -> torch.Tensor:
+    def packed_weights(self, precision: Optional[str] = None, inverse: bool = False) -> torch.Tensor:
         """Packed (masked, fragment-ordered) weights, rebuilt when a parameter changed."""
-        desc = self._desc(precision)
-        if self._frozen and desc.precision in self._packed and self._packed[desc.precision].buf is not None:
-            return self._packed[desc.precision].buf
+        desc = self._desc(precision, inverse)
+        ck = (desc.precision, desc.reserved)
+        if self._frozen and ck in self._packed and self._packed[ck].buf is not None:
+            return self._packed[ck].buf
         dev = self._device()
         L = _lib.lib()
         params = self._ordered_parameters()
         key = (dev, tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
-        pk = self._packed.setdefault(desc.precision, _Packed())
+        pk = self._packed.setdefault((desc.precision, desc.reserved), _Packed())
         if pk.key == key:
             return pk.buf
         if pk.map is None or pk.map.device != dev:
@@ -349,10 +374,12 @@ class NSFPosteriorFlow(nn.Module):
         nll = torch.empty(B, dtype=torch.float32, device=dev)
         perm, _ = self._perms(dev)
         packed = self.packed_weights()
+        desc = self._desc()
+        ws, ws_bytes = self._ws(desc, B, dev)
         _lib.check(_lib.lib().pf_flow_forward(
-            self._desc(), packed.data_ptr(), x.data_ptr(), _dev_ptr(context), _dev_ptr(perm),
+            desc, packed.data_ptr(), x.data_ptr(), _dev_ptr(context), _dev_ptr(perm),
             _dev_ptr(log_sigma), B, _dev_ptr(z), logdet.data_ptr(), nll.data_ptr(),
-            torch.cuda.current_stream(dev).cuda_stream), "pf_flow_forward")
+            _dev_ptr(ws), ws_bytes, torch.cuda.current_stream(dev).cuda_stream), "pf_flow_forward")
         return z, logdet, nll
 
     # ---- reference API ------------------------------------------------------------
@@ -409,10 +436,12 @@ class NSFPosteriorFlow(nn.Module):
         logdet = torch.empty(B, dtype=torch.float32, device=dev)
         flags = torch.zeros(B, dtype=torch.int32, device=dev)
         _, inv_perm = self._perms(dev)
+        desc = self._desc(inverse=True)
+        ws, ws_bytes = self._ws(desc, ctx_rows, dev)
         _lib.check(_lib.lib().pf_flow_inverse(
-            self._desc(), self.packed_weights().data_ptr(), z.data_ptr(), _dev_ptr(context),
+            desc, self.packed_weights(inverse=True).data_ptr(), z.data_ptr(), _dev_ptr(context),
             ctx_rows, _dev_ptr(inv_perm), B, x.data_ptr(), logdet.data_ptr(), flags.data_ptr(),
-            torch.cuda.current_stream(dev).cuda_stream), "pf_flow_inverse")
+            _dev_ptr(ws), ws_bytes, torch.cuda.current_stream(dev).cuda_stream), "pf_flow_inverse")
         return x, logdet, flags
 
     def inverse(self, z: torch.Tensor, context: Optional[torch.Tensor] = None,

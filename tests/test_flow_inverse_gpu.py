@@ -20,10 +20,12 @@ CONFIGS = {
 }
 
 
+@pytest.mark.parametrize("hoist", [None, False], ids=["hoisted", "inlayer"])
 @pytest.mark.parametrize("name", list(CONFIGS))
-def test_inverse_fp32_parity(name):
+def test_inverse_fp32_parity(name, hoist):
     D, C, H, L, K, tb, B = CONFIGS[name]
     ref, ref64, flow = make_pair(D, C, H, L, K, tb)
+    flow.hoist_context = hoist
     g = torch.Generator().manual_seed(3)
     z = torch.randn(B, D, generator=g) * 1.5
     z[0, 0] = tb; z[1, D - 1] = -tb; z[2, 0] = 1.4 * tb        # on / beyond the spline domain

@@ -33,8 +33,8 @@ def test_library_exports_every_declared_symbol(lib):
     assert b"gfx950" in handle.pf_version()
 
 
-def desc_of(lib, D, C, H, K, L, prec):
-    return lib.PfFlowDesc(D, C, H, K, L, 2, 5.0, 1e-3, 1e-3, 1e-3, lib.PRECISIONS[prec], 0)
+def desc_of(lib, D, C, H, K, L, prec, flags=0):
+    return lib.PfFlowDesc(D, C, H, K, L, 2, 5.0, 1e-3, 1e-3, 1e-3, lib.PRECISIONS[prec], flags)
 
 
 def raw_layout(D, C, H, K, nb=2):
@@ -52,12 +52,13 @@ def raw_layout(D, C, H, K, nb=2):
 
 @pytest.mark.parametrize("D,C,H,K,L", [(11, 288, 256, 16, 2), (15, 288, 256, 16, 2), (4, 0, 64, 8, 2),
                                        (7, 40, 128, 10, 3), (2, 5, 64, 4, 1)])
+@pytest.mark.parametrize("hoist", [0, 1])
 @pytest.mark.parametrize("prec", ["bf16", "fp32"])
-def test_pack_map_covers_exactly_the_unmasked_weights(lib, D, C, H, K, L, prec):
+def test_pack_map_covers_exactly_the_unmasked_weights(lib, D, C, H, K, L, prec, hoist):
     """Every weight the autoregressive masks keep appears in the map (once; the x-input layer
     twice in bf16 mode for the hi/lo split), every masked weight never; all biases appear once."""
     from oracle import nflows_restated as nfr
-    d = desc_of(lib, D, C, H, K, L, prec)
+    d = desc_of(lib, D, C, H, K, L, prec, hoist)
     h = lib.lib()
     n = h.pf_flow_pack_map_len(C_byref(d))
     assert n > 0
@@ -101,11 +102,11 @@ def test_plan_sizes_and_unsupported_shapes(lib):
                 desc_of(lib, 11, 288, 256, 17, 8, "bf16"),     # K > 16
                 desc_of(lib, 11, 5000, 256, 16, 8, "bf16")):   # C too large
         assert h.pf_flow_packed_bytes(C_byref(bad)) == -1
-        assert h.pf_flow_forward(C_byref(bad), None, None, None, None, None, 4, None, None, None, None) == lib.PF_ERR_UNSUPPORTED
+        assert h.pf_flow_forward(C_byref(bad), None, None, None, None, None, 4, None, None, None, None, 0, None) == lib.PF_ERR_UNSUPPORTED
     # argument checks happen before any launch
-    assert h.pf_flow_forward(C_byref(d), None, None, None, None, None, 4, None, None, None, None) == lib.PF_ERR_BAD_ARG
-    assert h.pf_flow_forward(C_byref(d), None, None, None, None, None, 0, None, None, None, None) == lib.PF_OK
-    assert h.pf_flow_forward(C_byref(d), None, None, None, None, None, -1, None, None, None, None) == lib.PF_ERR_BAD_ARG
+    assert h.pf_flow_forward(C_byref(d), None, None, None, None, None, 4, None, None, None, None, 0, None) == lib.PF_ERR_BAD_ARG
+    assert h.pf_flow_forward(C_byref(d), None, None, None, None, None, 0, None, None, None, None, 0, None) == lib.PF_OK
+    assert h.pf_flow_forward(C_byref(d), None, None, None, None, None, -1, None, None, None, None, 0, None) == lib.PF_ERR_BAD_ARG
     assert b"null" in h.pf_last_error() or b"negative" in h.pf_last_error()
     with pytest.raises(ValueError):
         lib.check(lib.PF_ERR_BAD_ARG, "x")
