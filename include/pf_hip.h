@@ -10,6 +10,7 @@
  *                     (executes nflows CompositeTransform / MADE / RQS, flows.py:459-529)
  *   pf_flow_inverse   NSFPosteriorFlow.inverse (transform part) src/ahsd/models/flows.py:620-655
  *   pf_flow_pack      the per-call `weight * mask` of nflows MaskedLinear, done once
+ *   pf_embed_stem_forward  LeanStrainEncoder stem + energy windows  src/ahsd/models/lean_npe.py:207-217
  *
  * Conventions
  *   - every pointer is a caller-owned DEVICE pointer unless named *_host;
@@ -112,6 +113,23 @@ int pf_flow_inverse(const PfFlowDesc* desc, const void* packed,
                     const int32_t* ar_inv_perm, int64_t batch,
                     float* x, float* logdet, uint32_t* fail_flags,
                     void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- strain-embedding stem ------------------------------------------------------
+ * tokens[N,61,192], log_energy[N,16] = stem(strain[N,16384]) for N = batch * n_detectors
+ * sequences: replaces lean_npe.py:207 (sanitise), :210-212 (window log-energy) and :216-217
+ * (asinh + 4 strided Conv1d + GELU, shared across detectors) of LeanStrainEncoder.
+ * Raw parameters: flat fp32 [stem.0.weight, stem.0.bias, stem.2.weight, stem.2.bias,
+ * stem.4.*, stem.6.*] (Conv1d layout [cout][cin][k]).  precision: PF_PREC_*.
+ * workspace: pf_embed_stem_workspace_bytes(precision, N) bytes of device scratch. */
+int64_t pf_embed_stem_raw_param_count(void);
+int64_t pf_embed_stem_packed_bytes(int32_t precision);
+int64_t pf_embed_stem_pack_map_len(int32_t precision);
+int pf_embed_stem_build_pack_map(int32_t precision, int32_t* map_host);
+int pf_embed_stem_pack(int32_t precision, const float* raw, const int32_t* map, void* packed, void* stream);
+int64_t pf_embed_stem_workspace_bytes(int32_t precision, int64_t n_sequences);
+int pf_embed_stem_forward(int32_t precision, const void* packed, const float* strain,
+                          int64_t n_sequences, float* tokens, float* log_energy,
+                          void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- introspection ------------------------------------------------------------ */
 const char* pf_last_error(void);

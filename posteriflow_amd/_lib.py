@@ -43,6 +43,14 @@ SYMBOLS = {
     "pf_flow_inverse": (C.c_int, [_P, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                   C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_int64, C.c_void_p]),
+    "pf_embed_stem_raw_param_count": (C.c_int64, []),
+    "pf_embed_stem_packed_bytes": (C.c_int64, [C.c_int32]),
+    "pf_embed_stem_pack_map_len": (C.c_int64, [C.c_int32]),
+    "pf_embed_stem_build_pack_map": (C.c_int, [C.c_int32, C.c_void_p]),
+    "pf_embed_stem_pack": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pf_embed_stem_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int64]),
+    "pf_embed_stem_forward": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_int64, C.c_void_p]),
     "pf_last_error": (C.c_char_p, []),
     "pf_version": (C.c_char_p, []),
     "pf_flow_rows_per_workgroup": (C.c_int32, [_P, C.c_int64]),

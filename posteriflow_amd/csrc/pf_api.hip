@@ -7,6 +7,17 @@
 
 #include "pf_flow_params.h"
 
+namespace pf {
+int64_t stem_pack_map_len(bool bf16);
+int64_t stem_raw_count();
+int64_t stem_packed_bytes(bool bf16);
+void stem_build_pack_map(bool bf16, int32_t* map);
+int64_t stem_workspace_bytes(bool bf16, int64_t n_seq);
+int stem_forward(bool bf16, const char* packed, const float* strain, int64_t n_seq, float* tokens,
+                 float* log_energy, char* ws, hipStream_t s);
+int launch_gather(bool bf16, const float* raw, const int32_t* map, void* out, int64_t n, hipStream_t s);
+}  // namespace pf
+
 namespace {
 thread_local char g_err[256] = "";
 int fail(int code, const char* msg) {
@@ -136,6 +147,61 @@ int pf_flow_inverse(const PfFlowDesc* desc, const void* packed, const float* z, 
     if (rc != PF_OK) return rc;
     rc = pf::launch_flow_inverse(p, static_cast<hipStream_t>(stream));
     return rc == PF_OK ? rc : fail(rc, rc == PF_ERR_HIP ? hipGetErrorString(hipGetLastError()) : "unsupported launch shape");
+}
+
+// ---- strain-embedding stem -----------------------------------------------------------------
+static int prec_ok(int32_t precision) {
+    return (precision == PF_PREC_F32 || precision == PF_PREC_BF16) ? PF_OK : fail(PF_ERR_BAD_ARG, "bad precision");
+}
+int64_t pf_embed_stem_raw_param_count(void) { return pf::stem_raw_count(); }
+int64_t pf_embed_stem_packed_bytes(int32_t precision) {
+    return prec_ok(precision) == PF_OK ? pf::stem_packed_bytes(precision == PF_PREC_BF16) : -1;
+}
+int64_t pf_embed_stem_pack_map_len(int32_t precision) {
+    return prec_ok(precision) == PF_OK ? pf::stem_pack_map_len(precision == PF_PREC_BF16) : -1;
+}
+int pf_embed_stem_build_pack_map(int32_t precision, int32_t* map_host) {
+    if (prec_ok(precision) != PF_OK) return PF_ERR_BAD_ARG;
+    if (!map_host) return fail(PF_ERR_BAD_ARG, "map_host is null");
+    pf::stem_build_pack_map(precision == PF_PREC_BF16, map_host);
+    return PF_OK;
+}
+int pf_embed_stem_pack(int32_t precision, const float* raw, const int32_t* map, void* packed, void* stream) {
+    if (prec_ok(precision) != PF_OK) return PF_ERR_BAD_ARG;
+    if (!raw || !map || !packed) return fail(PF_ERR_BAD_ARG, "null pointer");
+    if (misaligned(map, 16) || misaligned(packed, 16)) return fail(PF_ERR_BAD_ARG, "map/packed must be 16-byte aligned");
+    const bool bf = precision == PF_PREC_BF16;
+    // weights (operand type) then biases (fp32), the order of pf::stem_build_pack_map
+    int64_t nbias = 0;
+    const int couts[4] = {32, 64, 128, 192};
+    for (int c : couts) nbias += c;
+    const int64_t nw = pf::stem_pack_map_len(bf) - nbias;
+    const int64_t wbytes = pf::stem_packed_bytes(bf) - nbias * 4;
+    int rc = pf::launch_gather(bf, raw, map, packed, nw, static_cast<hipStream_t>(stream));
+    if (rc == PF_OK)
+        rc = pf::launch_gather(false, raw, map + nw, static_cast<char*>(packed) + wbytes, nbias, static_cast<hipStream_t>(stream));
+    return rc == PF_OK ? rc : fail(rc, hipGetErrorString(hipGetLastError()));
+}
+int64_t pf_embed_stem_workspace_bytes(int32_t precision, int64_t n_sequences) {
+    if (prec_ok(precision) != PF_OK || n_sequences < 0) return -1;
+    return pf::stem_workspace_bytes(precision == PF_PREC_BF16, n_sequences);
+}
+int pf_embed_stem_forward(int32_t precision, const void* packed, const float* strain, int64_t n_sequences,
+                          float* tokens, float* log_energy, void* workspace, int64_t workspace_bytes,
+                          void* stream) {
+    if (prec_ok(precision) != PF_OK) return PF_ERR_BAD_ARG;
+    if (n_sequences < 0) return fail(PF_ERR_BAD_ARG, "negative n_sequences");
+    if (n_sequences == 0) return PF_OK;
+    if (n_sequences > 65535) return fail(PF_ERR_UNSUPPORTED, "at most 65535 sequences per call");
+    if (!packed || !strain || !tokens) return fail(PF_ERR_BAD_ARG, "null pointer");
+    const bool bf = precision == PF_PREC_BF16;
+    if (!workspace || workspace_bytes < pf::stem_workspace_bytes(bf, n_sequences))
+        return fail(PF_ERR_BAD_ARG, "workspace too small (pf_embed_stem_workspace_bytes)");
+    if (misaligned(packed, 16) || misaligned(strain, 16) || misaligned(tokens, 16) || misaligned(workspace, 256))
+        return fail(PF_ERR_BAD_ARG, "packed/strain/tokens must be 16-byte, workspace 256-byte aligned");
+    const int rc = pf::stem_forward(bf, static_cast<const char*>(packed), strain, n_sequences, tokens, log_energy,
+                                    static_cast<char*>(workspace), static_cast<hipStream_t>(stream));
+    return rc == PF_OK ? rc : fail(rc, hipGetErrorString(hipGetLastError()));
 }
 
 int32_t pf_flow_rows_per_workgroup(const PfFlowDesc* desc, int64_t batch) {

@@ -1,0 +1,352 @@
+// pf_embed.hip -- the convolutional stem of PosteriFlow's strain embedding on gfx950.
+//
+// Replaces (reference src/ahsd/models/lean_npe.py):
+//   :207      nan_to_num / clamp of the raw whitened strain
+//   :210-212  per-detector, per-window log mean-square ("energy branch")
+//   :216-217  asinh -> Conv1d(1,32,k64,s8) GELU Conv1d(32,64,k16,s4) GELU
+//             Conv1d(64,128,k8,s4) GELU Conv1d(128,192,k4,s2) GELU -> tokens [N, 61, 192]
+//
+// Every convolution is an implicit GEMM.  Activations are kept POSITION-MAJOR ([pos][ch], channels
+// contiguous), so the im2col row of output position p -- taps p*s .. p*s+k-1, all channels -- is one
+// CONTIGUOUS span of k*Cin elements starting at p*s*Cin: the GEMM's A rows are overlapping windows of
+// the activation array and nothing is ever materialised.  The reduction length is 64 (conv1) or 512
+// (conv2-4).  As in the flow kernels the product is formed transposed,
+//   out^T[ch, pos] = W[ch, kk] . act^T[kk, pos],
+// so the weights are the MFMA A operand (pre-packed fragments, streamed from L2 exactly once per
+// workgroup by the wave that owns that channel tile) and 16 output positions are the MFMA columns.
+// The input span of a workgroup is staged once in LDS, de-interleaved by (position mod stride) and
+// by 64-byte channel blocks, which makes every B-fragment read of a wave one contiguous 1 KiB.
+// conv1 reads the raw fp32 strain with coalesced 16-byte loads and fuses sanitise + asinh + the
+// log-energy windows of the same samples.
+//
+//   bf16 mode: v_mfma_f32_16x16x32_bf16, activations stored bf16 between layers (fp32 tokens out)
+//   f32  mode: v_mfma_f32_16x16x4_f32,   activations fp32 throughout (parity mode)
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+
+#include "../../include/pf_hip.h"
+
+namespace pf {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+constexpr int kStemLayers = 4;
+struct StemLayer { int cin, cout, kw, stride, lin, lout; };
+// 16384 -> 2041 -> 507 -> 125 -> 61   (lean_npe.py:158-163)
+__host__ __device__ constexpr StemLayer stem_layer(int i) {
+    return i == 0 ? StemLayer{1, 32, 64, 8, 16384, 2041}
+         : i == 1 ? StemLayer{32, 64, 16, 4, 2041, 507}
+         : i == 2 ? StemLayer{64, 128, 8, 4, 507, 125}
+                  : StemLayer{128, 192, 4, 2, 125, 61};
+}
+
+struct ConvParams {
+    const void* in;         // FIRST: fp32 strain [N][16384]; else activations [N][lin][cin]
+    const u32x4* wfrags;    // [cout/16][ksteps][64 lanes]
+    const float* bias;      // [cout]
+    void* out;              // [N][lout][cout]  (LAST: fp32)
+    float* log_energy;      // FIRST: [N][16]
+    int64_t n_seq;
+};
+
+__device__ __forceinline__ float gelu_exact(float x) {         // nn.GELU() default: erf form
+    return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
+}
+
+// One workgroup: CG*16 output positions of one sequence; wave w owns channel tiles w*TPW..
+template <bool BF16, int LAYER, int CG, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void conv_gemm_kernel(const ConvParams p) {
+    constexpr StemLayer SL = stem_layer(LAYER);
+    constexpr bool FIRST = LAYER == 0, LAST = LAYER == kStemLayers - 1;
+    constexpr int CIN = SL.cin, COUT = SL.cout, KW = SL.kw, S = SL.stride, LIN = SL.lin, LOUT = SL.lout;
+    constexpr int KK = KW * CIN;                       // reduction length (64 or 512)
+    constexpr int KSTEP = BF16 ? 32 : 16;              // kk per fragment
+    constexpr int NKS = KK / KSTEP;
+    constexpr int ESZ = BF16 ? 2 : 4;                  // activation element size
+    constexpr int CHB = 64 / ESZ;                      // channels per 64-byte LDS row (32 | 16)
+    constexpr int TPW = (COUT / 16) / NWAVES;          // channel tiles per wave
+    static_assert(TPW * NWAVES * 16 == COUT, "channel tiles must divide over the waves");
+    constexpr int P = CG * 16;                         // output positions per workgroup
+    constexpr int SPAN = (P - 1) * S + KW;             // input positions needed
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, c = lane & 15;
+    const int64_t n = blockIdx.y;
+    const int p0 = blockIdx.x * P;                     // first output position
+    const int in0 = p0 * S;                            // first input position of the span
+
+    // ---- stage the input span ------------------------------------------------------------------
+    if constexpr (FIRST) {
+        // raw strain: coalesced float4 loads; sanitise (lean_npe.py:207), energy of the 2048 samples
+        // this workgroup "owns", asinh, store as a contiguous signal in LDS
+        const float* src = reinterpret_cast<const float*>(p.in) + n * LIN;
+        float sq[2] = {0.f, 0.f};
+        for (int i = tid * 4; i < SPAN; i += NWAVES * 64 * 4) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (in0 + i + 3 < LIN) v = *reinterpret_cast<const f32x4*>(src + in0 + i);
+            else
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (in0 + i + e < LIN) v[e] = src[in0 + i + e];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = v[e];
+                x = (x != x) ? 0.f : x;                                    // nan -> 0
+                x = fminf(fmaxf(x, -100.f), 100.f);                        // +-inf -> +-100, clamp
+                if (i + e < P * S) sq[(i + e) >> 10] += x * x;             // own range: 2 windows of 1024
+                v[e] = asinhf(x);
+            }
+            if (BF16) {
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+                *reinterpret_cast<bf16x4*>(smem + (size_t)i * 2) = o;
+            } else {
+                *reinterpret_cast<f32x4*>(smem + (size_t)i * 4) = v;
+            }
+        }
+        // window energies: wave shuffle reduction, then one atomic per wave into LDS
+        float* s_e = reinterpret_cast<float*>(smem + (((size_t)SPAN * ESZ + 15) & ~(size_t)15));
+        if (tid < 2) s_e[tid] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            float v = sq[w];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+            if (lane == 0) atomicAdd(&s_e[w], v);
+        }
+        __syncthreads();
+        if (tid < 2 && p.log_energy) {
+            const int w = 2 * blockIdx.x + tid;
+            if (w < 16) p.log_energy[n * 16 + w] = logf(s_e[tid] * (1.f / 1024.f) + 1e-8f);
+        }
+    } else {
+        // activations [pos][CIN] -> LDS rows (r = pos % S, channel block, q = pos / S), 64 B each
+        constexpr int CB = CIN / CHB;                  // channel blocks per position
+        constexpr int Q = (SPAN + S - 1) / S + 1;      // rows per (r, block)
+        const char* src = reinterpret_cast<const char*>(p.in) + ((size_t)n * LIN) * CIN * ESZ;
+        constexpr int CHUNKS = CIN * ESZ / 16;         // 16-byte chunks per position
+        for (int i = tid; i < SPAN * CHUNKS; i += NWAVES * 64) {
+            const int pos = i / CHUNKS, ch16 = i - pos * CHUNKS;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (in0 + pos < LIN) v = *reinterpret_cast<const u32x4*>(src + ((size_t)(in0 + pos) * CIN * ESZ) + ch16 * 16);
+            const int r = pos % S, q = pos / S;
+            const int cb = ch16 / 4, sub = ch16 & 3;   // 4 chunks per 64-byte row
+            *reinterpret_cast<u32x4*>(smem + ((size_t)((r * CB + cb) * Q + q) * 64) + sub * 16) = v;
+        }
+        __syncthreads();
+    }
+
+    // B fragment (ks, column group cg): 8 (bf16) / 4 (fp32) consecutive kk for output position
+    // p0 + 16 cg + c at k-slot g
+    auto bfrag = [&](int ks, int cg) -> u32x4 {
+        if constexpr (FIRST) {
+            // kk = tap: sample index S*p + KSTEP*ks + (KSTEP/4)*g .. ; contiguous signal
+            const int idx = S * (16 * cg + c) + KSTEP * ks + (KSTEP / 4) * g;
+            return *reinterpret_cast<const u32x4*>(smem + (size_t)idx * ESZ);
+        } else {
+            constexpr int CB = CIN / CHB;
+            constexpr int Q = (SPAN + S - 1) / S + 1;
+            const int kk0 = KSTEP * ks;                // kk = tap * CIN + ch
+            const int tap = kk0 / CIN, cb = (kk0 % CIN) / CHB;
+            const int r = tap % S, q = 16 * cg + c + tap / S;
+            return *reinterpret_cast<const u32x4*>(smem + ((size_t)((r * CB + cb) * Q + q) * 64) + g * 16);
+        }
+    };
+
+    const float* bias = p.bias;
+#pragma unroll 1
+    for (int t = 0; t < TPW; ++t) {
+        const int tile = wave * TPW + t;
+        const u32x4* wf = p.wfrags + (size_t)tile * NKS * 64 + lane;
+        f32x4 acc[CG];
+#pragma unroll
+        for (int cg = 0; cg < CG; ++cg) acc[cg] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // weight fragments of this tile: register double buffer in chunks of 8 k-steps
+        constexpr int CH = NKS < 8 ? NKS : 8;
+        u32x4 a0[CH], a1[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) a0[k] = wf[(size_t)k * 64];
+#pragma unroll 1
+        for (int k0 = 0; k0 < NKS; k0 += 2 * CH) {
+            if (k0 + CH < NKS) {
+#pragma unroll
+                for (int k = 0; k < CH; ++k) a1[k] = wf[(size_t)(k0 + CH + k) * 64];
+            }
+            auto run = [&](const u32x4 (&a)[CH], int kb) {
+#pragma unroll
+                for (int k = 0; k < CH; ++k) {
+#pragma unroll
+                    for (int cg = 0; cg < CG; ++cg) {
+                        const u32x4 b = bfrag(kb + k, cg);
+                        if (BF16) {
+                            acc[cg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                __builtin_bit_cast(bf16x8, a[k]), __builtin_bit_cast(bf16x8, b), acc[cg], 0, 0, 0);
+                        } else {
+                            const f32x4 af = __builtin_bit_cast(f32x4, a[k]), bf = __builtin_bit_cast(f32x4, b);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                acc[cg] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q], bf[q], acc[cg], 0, 0, 0);
+                        }
+                    }
+                }
+            };
+            run(a0, k0);
+            if (k0 + CH < NKS) {
+                if (k0 + 2 * CH < NKS) {
+#pragma unroll
+                    for (int k = 0; k < CH; ++k) a0[k] = wf[(size_t)(k0 + 2 * CH + k) * 64];
+                }
+                run(a1, k0 + CH);
+            }
+        }
+        // epilogue: bias + GELU, 4 consecutive channels of one position per lane
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + tile * 16 + 4 * g);
+#pragma unroll
+        for (int cg = 0; cg < CG; ++cg) {
+            const int pos = p0 + 16 * cg + c;
+            if (pos < LOUT) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_exact(acc[cg][e] + b4[e]);
+                const size_t off = ((size_t)n * LOUT + pos) * COUT + tile * 16 + 4 * g;
+                if (BF16 && !LAST) {
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+                    *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p.out) + off) = o;
+                } else {
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + off) = v;
+                }
+            }
+        }
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------------
+struct StemGeom { int cg, nwaves; };
+// positions per workgroup / waves per workgroup for each layer
+constexpr StemGeom stem_geom(int layer) {
+    return layer == 0 ? StemGeom{16, 2} : layer == 1 ? StemGeom{16, 4} : layer == 2 ? StemGeom{8, 8}
+                                                                                       : StemGeom{4, 12};
+}
+
+static size_t stem_lds(int layer, bool bf16) {
+    const StemLayer L = stem_layer(layer);
+    const StemGeom G = stem_geom(layer);
+    const int esz = bf16 ? 2 : 4, P = G.cg * 16, span = (P - 1) * L.stride + L.kw;
+    if (layer == 0) return (((size_t)span * esz + 15) & ~(size_t)15) + 64;
+    const int chb = 64 / esz, cb = L.cin / chb, q = (span + L.stride - 1) / L.stride + 1;
+    return (size_t)L.stride * cb * q * 64;
+}
+
+int64_t stem_weight_frags(int layer, bool bf16) {
+    const StemLayer L = stem_layer(layer);
+    return (int64_t)(L.cout / 16) * (L.kw * L.cin / (bf16 ? 32 : 16));
+}
+
+// element map of the packed stem weights: for each layer, frags [tile][ks][lane][elems]; source =
+// index into the flat concatenation of (conv weight [cout][cin][kw], bias [cout]) over the 4 layers
+int64_t stem_pack_map_len(bool bf16) {
+    int64_t n = 0;
+    for (int l = 0; l < kStemLayers; ++l) n += stem_weight_frags(l, bf16) * (bf16 ? 512 : 256) + stem_layer(l).cout;
+    return n;
+}
+int64_t stem_raw_count() {
+    int64_t n = 0;
+    for (int l = 0; l < kStemLayers; ++l) { const StemLayer L = stem_layer(l); n += (int64_t)L.cout * L.cin * L.kw + L.cout; }
+    return n;
+}
+int64_t stem_packed_bytes(bool bf16) {
+    int64_t n = 0;
+    for (int l = 0; l < kStemLayers; ++l) n += stem_weight_frags(l, bf16) * 1024 + stem_layer(l).cout * 4;
+    return n;
+}
+void stem_build_pack_map(bool bf16, int32_t* map) {
+    const int per = bf16 ? 8 : 4, kstep = bf16 ? 32 : 16;
+    int64_t idx = 0, raw0 = 0;
+    // weights of all layers first (each layer's frags), then all biases -- mirrored by stem_offsets()
+    for (int l = 0; l < kStemLayers; ++l) {
+        const StemLayer L = stem_layer(l);
+        const int nks = L.kw * L.cin / kstep;
+        for (int tile = 0; tile < L.cout / 16; ++tile)
+            for (int ks = 0; ks < nks; ++ks)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < per; ++e, ++idx) {
+                        const int g = lane >> 4, r16 = lane & 15;
+                        const int kk = bf16 ? (32 * ks + 8 * g + e) : (16 * ks + 4 * g + e);
+                        const int tap = kk / L.cin, ch = kk % L.cin, co = tile * 16 + r16;
+                        map[idx] = (int32_t)(raw0 + ((int64_t)co * L.cin + ch) * L.kw + tap);
+                    }
+        raw0 += (int64_t)L.cout * L.cin * L.kw + L.cout;
+    }
+    raw0 = 0;
+    for (int l = 0; l < kStemLayers; ++l) {
+        const StemLayer L = stem_layer(l);
+        for (int co = 0; co < L.cout; ++co, ++idx) map[idx] = (int32_t)(raw0 + (int64_t)L.cout * L.cin * L.kw + co);
+        raw0 += (int64_t)L.cout * L.cin * L.kw + L.cout;
+    }
+}
+// byte offsets inside the packed buffer: weights of layer l, then (after all weights) biases
+static void stem_offsets(bool bf16, int64_t (&w_off)[kStemLayers], int64_t (&b_off)[kStemLayers]) {
+    int64_t o = 0;
+    for (int l = 0; l < kStemLayers; ++l) { w_off[l] = o; o += stem_weight_frags(l, bf16) * 1024; }
+    for (int l = 0; l < kStemLayers; ++l) { b_off[l] = o; o += stem_layer(l).cout * 4; }
+}
+
+int64_t stem_workspace_bytes(bool bf16, int64_t n_seq) {
+    // two ping-pong activation buffers, sized for the largest intermediate ([2041][32] elements)
+    const int64_t esz = bf16 ? 2 : 4;
+    const int64_t a = (int64_t)stem_layer(0).lout * stem_layer(0).cout, b = (int64_t)stem_layer(1).lout * stem_layer(1).cout;
+    return n_seq * (a + b) * esz + 256;
+}
+
+template <bool BF16, int LAYER>
+static int launch_layer(const ConvParams& p, hipStream_t s) {
+    constexpr StemGeom G = stem_geom(LAYER);
+    constexpr StemLayer L = stem_layer(LAYER);
+    const size_t lds = stem_lds(LAYER, BF16);
+    auto k = conv_gemm_kernel<BF16, LAYER, G.cg, G.nwaves>;
+    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PF_ERR_HIP;
+    const unsigned gx = (L.lout + G.cg * 16 - 1) / (G.cg * 16);
+    hipLaunchKernelGGL(k, dim3(gx, (unsigned)p.n_seq), dim3(G.nwaves * 64), lds, s, p);
+    return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
+}
+
+template <bool BF16>
+static int stem_forward_t(const char* packed, const float* strain, int64_t n_seq, float* tokens,
+                          float* log_energy, char* ws, hipStream_t s) {
+    int64_t w_off[kStemLayers], b_off[kStemLayers];
+    stem_offsets(BF16, w_off, b_off);
+    const int64_t esz = BF16 ? 2 : 4;
+    char* act0 = ws;
+    char* act1 = ws + (((int64_t)n_seq * stem_layer(0).lout * stem_layer(0).cout * esz + 255) & ~(int64_t)255);
+    ConvParams p{};
+    p.n_seq = n_seq;
+    auto set = [&](int l, const void* in, void* out) {
+        p.in = in; p.out = out; p.wfrags = reinterpret_cast<const u32x4*>(packed + w_off[l]);
+        p.bias = reinterpret_cast<const float*>(packed + b_off[l]); p.log_energy = l == 0 ? log_energy : nullptr;
+    };
+    int rc;
+    set(0, strain, act0);  if ((rc = launch_layer<BF16, 0>(p, s)) != PF_OK) return rc;
+    set(1, act0, act1);    if ((rc = launch_layer<BF16, 1>(p, s)) != PF_OK) return rc;
+    set(2, act1, act0);    if ((rc = launch_layer<BF16, 2>(p, s)) != PF_OK) return rc;
+    set(3, act0, tokens);  return launch_layer<BF16, 3>(p, s);
+}
+
+int stem_forward(bool bf16, const char* packed, const float* strain, int64_t n_seq, float* tokens,
+                 float* log_energy, char* ws, hipStream_t s) {
+    return bf16 ? stem_forward_t<true>(packed, strain, n_seq, tokens, log_energy, ws, s)
+                : stem_forward_t<false>(packed, strain, n_seq, tokens, log_energy, ws, s);
+}
+
+}  // namespace pf

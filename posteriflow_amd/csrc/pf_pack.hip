@@ -224,6 +224,19 @@ __global__ __launch_bounds__(256) void pack_f32_kernel(const float* __restrict__
     *reinterpret_cast<float4*>(out + i) = v;
 }
 
+// generic gather used by other packers: n elements of operand type (bf16) or fp32
+int launch_gather(bool bf16, const float* raw, const int32_t* map, void* out, int64_t n, hipStream_t stream) {
+    if (n == 0) return PF_OK;
+    if (bf16) {
+        hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, stream, raw, map,
+                           reinterpret_cast<__bf16*>(out), n);
+    } else {
+        hipLaunchKernelGGL(pack_f32_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, raw, map,
+                           reinterpret_cast<float*>(out), n);
+    }
+    return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
+}
+
 int launch_pack(const FlowPlan& L, const float* raw, const int32_t* map, void* packed,
                 hipStream_t stream) {
     const int64_t fe = L.bf16 ? 512 : 256;

@@ -6,11 +6,12 @@ attributes and ``state_dict`` keys, so checkpoints written by
 ``experiments/train_lean_npe.py:421-427`` load unchanged and ``inference/pipeline.py`` can use it
 as is.  The flow is :class:`posteriflow_amd.flows.NSFPosteriorFlow` (HIP, ``libpfhip.so``).
 
-Embedding status: the submodules below hold the parameters under the
-reference's names; this round the embedding is evaluated with device tensor ops
-(``Conv1d``/``TransformerEncoder``/``MultiheadAttention`` on the GPU) -- the hand-written HIP
-stem / fusion kernels replace ``_stem`` and ``_fuse`` next.  It is pinned against golden
-vectors produced by the reference's own classes (tests/golden/encoder.npz).
+Embedding status: the submodules below hold the parameters under the reference's
+names.  The convolutional stem and the energy windows (the part that reads the raw strain from
+HBM: sanitise, window log-energy, asinh, 4 strided convolutions + GELU) run in hand-written HIP
+kernels (``csrc/pf_embed.hip`` via ``pf_embed_stem_forward``); the small fusion transformer,
+attention pooling and MLPs run on device tensor ops this round.  Pinned against golden vectors
+produced by the reference's own classes (tests/golden/encoder.npz).
 """
 from __future__ import annotations
 
@@ -22,6 +23,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import _lib
 from .flows import NSFPosteriorFlow
 
 PARAM_NAMES = ["mass_1", "mass_2", "luminosity_distance", "ra", "dec", "theta_jn", "psi",
@@ -131,7 +133,52 @@ class LeanStrainEncoder(nn.Module):
         self.out_proj = nn.Sequential(nn.Linear(n_pool_queries * d_model + 64 + extra, 512), nn.GELU(),
                                       nn.Linear(512, context_dim))
 
-    # --- pieces (the HIP kernels slot in here) ---------------------------------------------
+    # --- HIP stem ------------------------------------------------------------------------------
+    _allow_tensor_op_stem = False
+    precision = "fp32"        # "fp32": f32 MFMA, matches the CPU path to ~1e-6; "bf16": throughput
+
+    def _stem_params(self):
+        return [p for i in (0, 2, 4, 6) for p in (self.stem[i].weight, self.stem[i].bias)]
+
+    def _stem_hip(self, strain):
+        """(tokens [B*D, 61, E], log_energy [B, D, 16]) from the RAW strain [B, D, 16384]: one
+        pf_embed_stem_forward call (sanitise + energy windows + asinh + conv stem + GELU)."""
+        b, d, t = strain.shape
+        dev = strain.device
+        if dev.type != "cuda":
+            raise _lib.PfError(f"LeanStrainEncoder stem runs on the MI355X only (input on {dev}); no CPU fallback")
+        e = self.stem[6].out_channels
+        if t != 16384 or e != 192:
+            raise NotImplementedError("pf_embed_stem_forward is built for 4 s @ 4096 Hz segments and d_model = 192")
+        L = _lib.lib()
+        prec = _lib.PRECISIONS[self.precision]
+        params = self._stem_params()
+        key = (dev, prec, tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
+        st = self.__dict__.setdefault("_stem_state", {})
+        if st.get("key") != key:
+            if st.get("map_prec") != (dev, prec):
+                host = torch.empty(L.pf_embed_stem_pack_map_len(prec), dtype=torch.int32)
+                _lib.check(L.pf_embed_stem_build_pack_map(prec, host.data_ptr()), "pf_embed_stem_build_pack_map")
+                st["map"], st["map_prec"] = host.to(dev), (dev, prec)
+                st["packed"] = torch.empty(L.pf_embed_stem_packed_bytes(prec), dtype=torch.uint8, device=dev)
+            raw = torch.cat([p.detach().reshape(-1).float() for p in params])
+            assert raw.numel() == L.pf_embed_stem_raw_param_count()
+            _lib.check(L.pf_embed_stem_pack(prec, raw.data_ptr(), st["map"].data_ptr(), st["packed"].data_ptr(),
+                                            torch.cuda.current_stream(dev).cuda_stream), "pf_embed_stem_pack")
+            st["key"] = key
+        n = b * d
+        x = strain.reshape(n, t).contiguous().float()
+        need = L.pf_embed_stem_workspace_bytes(prec, n)
+        if st.get("ws") is None or st["ws"].numel() < need or st["ws"].device != dev:
+            st["ws"] = torch.empty(need, dtype=torch.uint8, device=dev)
+        tokens = torch.empty(n, 61, e, dtype=torch.float32, device=dev)
+        log_energy = torch.empty(n, 16, dtype=torch.float32, device=dev)
+        _lib.check(L.pf_embed_stem_forward(prec, st["packed"].data_ptr(), x.data_ptr(), n, tokens.data_ptr(),
+                                           log_energy.data_ptr(), st["ws"].data_ptr(), need,
+                                           torch.cuda.current_stream(dev).cuda_stream), "pf_embed_stem_forward")
+        return tokens, log_energy.reshape(b, d, 16)
+
+    # --- pieces evaluated with device tensor ops ---------------------------------------------------
     @staticmethod
     def _sanitize(strain):                                                # LN:207
         return torch.nan_to_num(strain, nan=0.0, posinf=100.0, neginf=-100.0).clamp(-100.0, 100.0)
@@ -152,8 +199,17 @@ class LeanStrainEncoder(nn.Module):
         """[B, 8*d_model + 64 (+32)] pre-projection features and the sanitised strain (LN:199-243)."""
         b, d, _ = strain.shape
         clean = self._sanitize(strain)
-        energy = self.energy_mlp(self._window_log_energy(clean).reshape(b, -1))
-        tok = self._stem(clean)
+        if self._allow_tensor_op_stem:
+            # explicit opt-in only (autograd through device tensor ops, CPU wiring tests)
+            tok, log_energy = self._stem(clean), self._window_log_energy(clean)
+        elif torch.is_grad_enabled() and (strain.requires_grad or any(p.requires_grad for p in self._stem_params())):
+            raise NotImplementedError("the HIP stem has no backward yet: run the encoder under torch.no_grad() "
+                                      "(or set encoder._allow_tensor_op_stem = True to train through device tensor ops)")
+        elif self.n_energy_windows != 16:
+            raise NotImplementedError("pf_embed_stem_forward computes 16 energy windows")
+        else:
+            tok, log_energy = self._stem_hip(strain)       # raises off the GPU: no CPU fallback
+        energy = self.energy_mlp(log_energy.reshape(b, -1))
         n_tok, e = tok.shape[1], tok.shape[2]
         tok = (tok + self.pos(n_tok)).reshape(b, d, n_tok, e) + self.detector_embed.weight[None, :d, None, :]
         tok = tok.reshape(b, d * n_tok, e)

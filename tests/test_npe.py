@@ -25,6 +25,8 @@ def _load(enc, seed, skip=("pos.pe",)):
     sd = recipe.fill_state_dict(shapes, seed=seed)
     missing = enc.load_state_dict(sd, strict=False)
     assert sorted(missing.missing_keys) == sorted(skip)
+    for p in enc.parameters():
+        p.requires_grad_(False)
     return enc.eval()
 
 
@@ -32,6 +34,9 @@ def _load(enc, seed, skip=("pos.pe",)):
 def test_lean_strain_encoder_golden_cpu(golden_encoder, tag, ndet, psd):
     torch.set_num_threads(4)
     enc = _load(npe.LeanStrainEncoder(n_detectors=ndet, psd_bands=psd), 100 + ndet + psd)
+    with pytest.raises(RuntimeError):
+        enc(torch.zeros(1, ndet, 16384))            # product path: no CPU fallback
+    enc._allow_tensor_op_stem = True                # wiring / state_dict check on the CPU only
     strain = recipe.strain_batch(4, ndet, seed=7)
     asd = torch.from_numpy(golden_encoder[f"{tag}_asd"]) if psd else None
     with torch.no_grad():
@@ -42,6 +47,7 @@ def test_lean_strain_encoder_golden_cpu(golden_encoder, tag, ndet, psd):
 def test_coherent_encoder_golden_cpu(golden_encoder):
     torch.set_num_threads(4)
     enc = _load(npe.CoherentEncoder(context_dim=256, psd_bands=16), 200, skip=("pos.pe", "Bsum", "bcount", "lags_norm"))
+    enc._allow_tensor_op_stem = True
     assert [enc.band_lo, enc.Nf, enc.maxlag] == list(golden_encoder["coh_band"])
     strain = recipe.strain_batch(4, 3, seed=9)
     with torch.no_grad():
@@ -63,6 +69,36 @@ def test_state_dict_layout_matches_reference_names():
     assert sum(p.numel() for p in m.encoder.parameters()) == 2642336          # SURVEY 8c probe
     assert not m.flow.temperature.requires_grad and m.flow._tail_bound == 5.0
     assert sum(p.numel() for p in npe.CoherentEncoder(context_dim=256, psd_bands=16).parameters()) == 2805376
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,ndet", [("det3", 3), ("det1", 1)])
+def test_hip_stem_against_reference_golden(golden_encoder, tag, ndet):
+    """pf_embed_stem_forward (through LeanStrainEncoder._stem_hip) vs the reference's own stem /
+    energy-window outputs.  fp32 mode: 2e-5 abs (values O(1)); bf16 mode: 3e-2 (bf16 operands, K = 512)."""
+    enc = _load(npe.LeanStrainEncoder(n_detectors=ndet), 100 + ndet).cuda()
+    strain = recipe.strain_batch(4, ndet, seed=7).cuda()
+    want_tok = torch.from_numpy(golden_encoder[f"{tag}_stem_out"]).transpose(1, 2)      # [2, 61, 192]
+    with torch.no_grad():
+        tok, le = enc._stem_hip(strain)
+        assert tok.shape == (4 * ndet, 61, 192) and le.shape == (4, ndet, 16)
+        np.testing.assert_allclose(le.cpu().numpy(), golden_encoder[f"{tag}_log_energy"], rtol=1e-5, atol=1e-5)
+        err = (tok[:2].cpu() - want_tok).abs().max().item()
+        print(f"\n[{tag}] fp32 stem max abs err {err:.2e}")
+        assert err < 2e-5
+        ctx = enc(strain)
+        np.testing.assert_allclose(ctx.cpu().numpy(), golden_encoder[f"{tag}_ctx"], rtol=2e-3, atol=1e-3)
+        enc.precision = "bf16"
+        tok16, _ = enc._stem_hip(strain)
+        err16 = (tok16[:2].cpu() - want_tok).abs().max().item()
+        print(f"[{tag}] bf16 stem max abs err {err16:.2e}")
+        assert err16 < 3e-2
+    with pytest.raises(RuntimeError):
+        enc._stem_hip(strain.cpu())
+    for p in enc.parameters():
+        p.requires_grad_(True)
+    with pytest.raises(NotImplementedError):
+        enc(strain)
 
 
 @pytest.mark.gpu
