@@ -102,6 +102,43 @@ def cpu_baseline(flow, batch, budget_s=20.0):
             "ms_per_batch": med * 1e3}
 
 
+def extras(flow, dev, batch):
+    """Side measurements on the same GPU (not part of `value`): sampling through pf_flow_inverse
+    (one context row, as inference/pipeline.py:169-173) and the strain embedding of BASELINE
+    config 3 (3 detectors, batch rows) -- HIP stem alone and the whole LeanStrainEncoder."""
+    from posteriflow_amd import npe
+    out = {}
+
+    def timed(fn, reps):
+        fn(); torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / reps
+
+    with torch.no_grad():
+        ctx1 = torch.randn(1, C, device=dev)
+        for n in (4096, 131072):
+            z = torch.randn(n, D, device=dev)
+            dt = timed(lambda: flow.inverse(z, ctx1), 5 if n <= 4096 else 2)
+            out[f"inverse_draws_per_s_{n}"] = n / dt
+        enc = npe.LeanStrainEncoder().to(dev).eval()
+        enc.precision = flow.precision
+        strain = torch.randn(batch, 3, 16384, device=dev)
+        dt = timed(lambda: enc._stem_hip(strain), 3)
+        out["stem_events_per_s"] = batch / dt
+        out["stem_tflops"] = batch * 3 * 34.98e6 * 2 / dt / 1e12          # SURVEY 2.3: 34.98 M MAC / detector
+        out["stem_strain_read_GBps"] = batch * 3 * 16384 * 4 / dt / 1e9
+        dt = timed(lambda: [enc(strain[i:i + 512]) for i in range(0, batch, 512)], 1)
+        out["encoder_events_per_s"] = batch / dt
+        nll = torch.empty(batch, device=dev)
+        x, ctx = make_inputs(batch, 1, dev)
+        out["config3_end_to_end_events_per_s"] = batch / (dt + timed(lambda: flow.nll_into(x, ctx, nll), 10))
+    log("extras: " + ", ".join(f"{k}={v:.3g}" for k, v in out.items()))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -111,6 +148,7 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the sampling / embedding side measurements")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -221,6 +259,8 @@ def main():
                          "kernel": "pf::flow_forward_kernel", "kernel_ms": kernel_ms,
                          "flop_per_sample": fl, "device_ms_per_step": dev_ms / args.steps},
         }
+        if not args.no_extras and world == 1:
+            out["extras"] = extras(flow, dev, args.batch)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(flow, args.batch)
         print(json.dumps(out))

@@ -139,3 +139,34 @@ def test_lean_npe_nll_and_sampling_gpu(golden_encoder):
             torch.zeros_like(p))
         want_b = lean_ref.batch_nll_ref(ref_nll, ctx_cpu, params, nsig).item()
         assert abs(got - want_b) / abs(want_b) < 1e-3
+
+
+@pytest.mark.gpu
+def test_inference_sampling_loop_gpu():
+    """pipeline.py:57-76, 161-186 counterpart: physical-units log q against the oracle's closed
+    form on the same draws, railing mask, mass ordering, chunking invariance of shapes."""
+    from helpers import oracle_state_for_product
+    from oracle.flow_ref import NSFPosteriorFlowRef
+    from posteriflow_amd import inference
+    torch.manual_seed(0)
+    model = npe.LeanNPE(flow_layers=2)
+    _load(model.encoder, 103)
+    ref_flow = NSFPosteriorFlowRef(11, 288, 256, 2, 16, 5.0, temperature_scale=1.0)
+    model.flow.load_state_dict(oracle_state_for_product(ref_flow))
+    model = model.to("cuda").eval()
+    strain = recipe.strain_batch(1, 3, seed=7).cuda()
+    out = inference.sample_event(model, strain, num_samples=5000, rank=1, seed=3, batch_size=2048)
+    s, logq = out["samples"], out["logq"]
+    assert s.shape == (5000, 11) and s.dtype == torch.float64 and logq.shape == (5000,)
+    assert (s[:, 0] >= s[:, 1]).all()                                           # m1 >= m2
+    lo, hi = npe.ParamScaler().denormalize(torch.tensor([[-1.0] * 11, [1.0] * 11])).double()
+    assert (s.cpu() >= lo - 1e-6).all() and (s.cpu() <= hi * (1 + 1e-6)).all()
+    assert 0.0 <= out["boundary_railing_frac"].item() <= 1.0
+    # log q check on a fresh set of normalised points (no mass swap involved)
+    g = torch.Generator().manual_seed(5)
+    y = (torch.rand(64, 11, generator=g) * 1.9 - 0.95)
+    full = torch.cat([out["context"].cpu(), model.rank_embed.weight.cpu()[torch.tensor([1])]], dim=1)
+    got = inference.log_prob_physical(model, y.cuda(), full.cuda()).cpu()
+    neg = ref_flow.compute_psd_aware_nll(y, full.expand(64, -1), torch.zeros_like(y))
+    want = lean_ref.log_prob_physical(neg, y, lean_ref.ParamScalerRef())
+    assert ((got - want).abs() / want.abs().clamp_min(1)).max() < 1e-4
