@@ -355,17 +355,13 @@ class NSFPosteriorFlow(nn.Module):
             context = None
         return dev, x, context
 
-    def _grad_guard(self, *tensors):
-        if torch.is_grad_enabled() and (
-                any(t is not None and t.requires_grad for t in tensors)
-                or any(p.requires_grad for p in self._ordered_parameters())):
-            raise NotImplementedError(
-                "backward kernels for the flow are not built yet: call under torch.no_grad() "
-                "(DESIGN.md 'What comes next')")
+    def _needs_grad(self, *tensors) -> bool:
+        return torch.is_grad_enabled() and (
+            any(t is not None and t.requires_grad for t in tensors)
+            or any(p.requires_grad for p in self._ordered_parameters()))
 
-    def _forward_call(self, x, context, log_sigma, want_z=True):
+    def _forward_call(self, x, context, log_sigma, want_z=True, guard=True):
         dev, x, context = self._check_inputs(x, context, "NSFPosteriorFlow.forward")
-        self._grad_guard(x, context, log_sigma)
         B = x.shape[0]
         if context is not None and context.shape[0] != B:
             raise ValueError(f"batch mismatch: x {B} vs context {context.shape[0]}")
@@ -382,6 +378,14 @@ class NSFPosteriorFlow(nn.Module):
             _dev_ptr(ws), ws_bytes, torch.cuda.current_stream(dev).cuda_stream), "pf_flow_forward")
         return z, logdet, nll
 
+    def _nll(self, x, context, log_sigma):
+        """nll[B]; differentiable (interim tensor-op backward, _flow_autograd.py) when grad is needed."""
+        if self._needs_grad(x, context, log_sigma):
+            from ._flow_autograd import FlowNLL
+            dev, x, context = self._check_inputs(x, context, "NSFPosteriorFlow.compute_psd_aware_nll")
+            return FlowNLL.apply(self, x, context, log_sigma, *self._ordered_parameters())[0]
+        return self._forward_call(x, context, log_sigma, want_z=False)[2]
+
     # ---- reference API ------------------------------------------------------------
     def set_autoregressive_order(self, order: List[int]) -> None:            # flows.py:550-588
         if sorted(order) != list(range(self.features)):
@@ -396,6 +400,10 @@ class NSFPosteriorFlow(nn.Module):
 
     def forward(self, x: torch.Tensor, context: Optional[torch.Tensor] = None):
         """x -> (z, log|det dz/dx|)   (flows.py:610-618)."""
+        if self._needs_grad(x, context):
+            from ._flow_autograd import FlowForward
+            dev, x, context = self._check_inputs(x, context, "NSFPosteriorFlow.forward")
+            return FlowForward.apply(self, x, context, *self._ordered_parameters())
         z, logdet, _ = self._forward_call(x, context, None)
         return z, logdet
 
@@ -406,8 +414,7 @@ class NSFPosteriorFlow(nn.Module):
             if log_sigma_psd.shape != x.shape:
                 raise ValueError(f"Shape mismatch: z {x.shape} vs log_sigma_psd {log_sigma_psd.shape}")
             ls = log_sigma_psd.contiguous().float()
-        _, _, nll = self._forward_call(x, context, ls, want_z=False)
-        return nll
+        return self._nll(x, context, ls)
 
     def log_prob(self, x, context=None, temperature: Optional[float] = None):
         """Negative log-density with the temperature change of variables
@@ -415,9 +422,9 @@ class NSFPosteriorFlow(nn.Module):
         if context is not None and not torch.isfinite(context).all():
             _log.warning("NSF.log_prob() detected NaN/Inf in context; replacing (shape %s)", tuple(context.shape))
             context = torch.nan_to_num(context, nan=0.0, posinf=1e-3, neginf=-1e-3)
-        t = torch.clamp(self.temperature.detach(), 0.5, 3.0) if temperature is None \
+        t = torch.clamp(self.temperature, 0.5, 3.0) if temperature is None \
             else torch.as_tensor(float(temperature), device=x.device)
-        _, _, nll = self._forward_call(x / t, context, None, want_z=False)
+        nll = self._nll(x / t, context, None)
         out = -nll - self.features * torch.log(t)
         return -torch.nan_to_num(out, nan=1000.0)
 

@@ -199,12 +199,13 @@ class LeanStrainEncoder(nn.Module):
         """[B, 8*d_model + 64 (+32)] pre-projection features and the sanitised strain (LN:199-243)."""
         b, d, _ = strain.shape
         clean = self._sanitize(strain)
-        if self._allow_tensor_op_stem:
-            # explicit opt-in only (autograd through device tensor ops, CPU wiring tests)
+        needs_grad = torch.is_grad_enabled() and (
+            strain.requires_grad or any(p.requires_grad for p in self._stem_params()))
+        if self._allow_tensor_op_stem or (needs_grad and strain.device.type == "cuda"):
+            # interim backward path: the HIP stem has no backward kernels yet, so a differentiable
+            # call evaluates the stem with device tensor ops under autograd (DESIGN.md "Backward");
+            # _allow_tensor_op_stem additionally opens this path off the GPU for CPU wiring tests only
             tok, log_energy = self._stem(clean), self._window_log_energy(clean)
-        elif torch.is_grad_enabled() and (strain.requires_grad or any(p.requires_grad for p in self._stem_params())):
-            raise NotImplementedError("the HIP stem has no backward yet: run the encoder under torch.no_grad() "
-                                      "(or set encoder._allow_tensor_op_stem = True to train through device tensor ops)")
         elif self.n_energy_windows != 16:
             raise NotImplementedError("pf_embed_stem_forward computes 16 energy windows")
         else:
@@ -344,8 +345,9 @@ class LeanNPE(nn.Module):
         y, _ = self.flow.inverse(z, ctx)
         return self.scaler.denormalize(self.scaler.wrap(y).reshape(b, n_samples, -1))
 
-    def to(self, *args, **kwargs):
-        out = super().to(*args, **kwargs)
+    def _apply(self, fn, *args, **kwargs):
+        # .to() / .cuda() / .cpu(): keep the (non-module) scaler on the parameters' device (LN:334-338)
+        out = super()._apply(fn, *args, **kwargs)
         self.scaler.to(next(self.parameters()).device)
         return out
 

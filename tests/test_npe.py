@@ -95,10 +95,14 @@ def test_hip_stem_against_reference_golden(golden_encoder, tag, ndet):
         assert err16 < 3e-2
     with pytest.raises(RuntimeError):
         enc._stem_hip(strain.cpu())
+    # differentiable call: interim tensor-op stem under autograd, same value as the HIP stem
+    enc.precision = "fp32"
     for p in enc.parameters():
         p.requires_grad_(True)
-    with pytest.raises(NotImplementedError):
-        enc(strain)
+    ctx_g = enc(strain)
+    assert ctx_g.requires_grad and torch.allclose(ctx_g.detach(), ctx, rtol=1e-3, atol=1e-3)
+    ctx_g.square().sum().backward()
+    assert enc.stem[0].weight.grad is not None and torch.isfinite(enc.stem[0].weight.grad).all()
 
 
 @pytest.mark.gpu
