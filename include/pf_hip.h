@@ -42,6 +42,11 @@ extern "C" {
 /* PfFlowDesc.reserved flag bits */
 #define PF_FLAG_HOIST_CTX 1  /* evaluate the context projections of all layers once, up front,
                               * into the caller's workspace (pf_flow_workspace_bytes) */
+#define PF_FLAG_MASKED_CONTEXT 2 /* the reference's masked-context conditioner (flows.py:112-360,
+                              * full_context=True): context added between the two masked linears of
+                              * a block instead of the GLU gate, no ReversePermutation between
+                              * layers; implies PF_FLAG_HOIST_CTX.  Raw layout unchanged (the block's
+                              * context_layer weight/bias take the place of the gate's). */
 
 /* Plain-old-data description of one NSFPosteriorFlow (flows.py:379-548).
  * conditioner: nflows MADE, num_blocks residual blocks with GLU context gate,

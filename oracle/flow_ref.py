@@ -3,8 +3,8 @@
 TEST INFRASTRUCTURE (see ``oracle/__init__.py``).  ``NSFPosteriorFlowRef``
 follows ``NSFPosteriorFlow`` method by method; line numbers refer to
 ``/root/reference/src/ahsd/models/flows.py``.  Only the plain-context
-conditioner is restated here (``use_masked_context=False`` is what LeanNPE
-uses, ``lean_npe.py:294``).
+conditioner is what LeanNPE uses (``use_masked_context=False``, ``lean_npe.py:294``); the
+masked-context variant (flows.py:112-360) is restated too.
 """
 from __future__ import annotations
 
@@ -42,7 +42,7 @@ class PSDScaledNormalRef(nn.Module):
 class NSFPosteriorFlowRef(nn.Module):
     def __init__(self, features, context_features=0, hidden_features=256,
                  num_layers=12, num_bins=16, tail_bound=FLOW_NORM_BOUND,
-                 dropout=0.0, temperature_scale=1.5, scale_by_sqrt_hidden=False):
+                 dropout=0.0, temperature_scale=1.5, scale_by_sqrt_hidden=False, use_masked_context=False):
         super().__init__()
         self.features = features
         self.context_features = context_features
@@ -52,15 +52,20 @@ class NSFPosteriorFlowRef(nn.Module):
         self.tail_bound = tb
         self.temperature = nn.Parameter(torch.tensor(temperature_scale, dtype=torch.float32))
         self.base_dist = PSDScaledNormalRef([features])
+        self.use_masked_context = use_masked_context
+        self.n_context_blocks = features if use_masked_context else None
+        self.context_block_dim = context_features // features if use_masked_context else None
         ts = []
         for _ in range(num_layers):  # flows.py:449-526
-            ts.append(nfr.ReversePermutation(features))
+            if not use_masked_context:       # flows.py:459-460: no permutation in masked-context mode
+                ts.append(nfr.ReversePermutation(features))
             ts.append(nfr.MaskedPiecewiseRationalQuadraticAutoregressiveTransform(
                 features, hidden_features,
                 context_features if context_features > 0 else None,
                 num_bins=num_bins, tail_bound=tb, num_blocks=2,
                 dropout_probability=dropout,
-                scale_by_sqrt_hidden=scale_by_sqrt_hidden))
+                scale_by_sqrt_hidden=scale_by_sqrt_hidden,
+                masked_context_blocks=(features, context_features // features) if use_masked_context else None))
         self.transform = nfr.CompositeTransform(ts)
         self.register_buffer("_ar_perm", torch.arange(features))
         self.register_buffer("_ar_inv_perm", torch.arange(features))
@@ -72,11 +77,19 @@ class NSFPosteriorFlowRef(nn.Module):
         self._ar_perm = torch.tensor(order, dtype=torch.long)
         self._ar_inv_perm = torch.argsort(self._ar_perm)
 
+    # flows.py:590-608
+    def _permute_context_blocks(self, context):
+        if not self.use_masked_context:
+            return context
+        b = context.shape[0]
+        blocks = context.view(b, self.n_context_blocks, self.context_block_dim)[:, self._ar_perm, :]
+        return blocks.reshape(b, -1)
+
     # flows.py:610-618
     def forward(self, x, context=None):
         x = x[:, self._ar_perm]
         if self.context_features > 0 and context is not None:
-            return self.transform(x, context)
+            return self.transform(x, self._permute_context_blocks(context))
         return self.transform(x)
 
     # flows.py:620-655
@@ -85,7 +98,7 @@ class NSFPosteriorFlowRef(nn.Module):
             context = torch.nan_to_num(context, nan=0.0, posinf=1e-3, neginf=-1e-3)
         if self.context_features > 0 and context is not None:
             try:
-                x, ld = self.transform.inverse(z, context)
+                x, ld = self.transform.inverse(z, self._permute_context_blocks(context))
             except AssertionError:
                 x, ld = z, z.new_zeros(z.shape[0])
         else:
@@ -97,7 +110,7 @@ class NSFPosteriorFlowRef(nn.Module):
 
     def inverse_raw(self, z, context=None):
         """transform.inverse without the wrapper's clamp (for round-trip KATs)."""
-        x, ld = self.transform.inverse(z, context)
+        x, ld = self.transform.inverse(z, None if context is None else self._permute_context_blocks(context))
         return x[:, self._ar_inv_perm], ld
 
     # flows.py:727-779

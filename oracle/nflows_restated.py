@@ -181,6 +181,74 @@ class MADE(nn.Module):
 
 
 # --------------------------------------------------------------------------- #
+# masked-context conditioner -- the reference's OWN variant (src/ahsd/models/flows.py:112-303):
+# context enters ADDITIVELY between the two masked linears of a block through a masked linear
+# over n_blocks x block_dim context columns (mask all-ones unless full_context=False).
+# --------------------------------------------------------------------------- #
+class MaskedContextLinear(nn.Module):
+    """flows.py:112-183"""
+
+    def __init__(self, n_blocks, block_dim, hidden_degrees, full_context=True):
+        super().__init__()
+        h = hidden_degrees.shape[0]
+        self.weight = nn.Parameter(torch.empty(h, n_blocks * block_dim))
+        self.bias = nn.Parameter(torch.zeros(h))
+        nn.init.kaiming_uniform_(self.weight, a=5 ** 0.5)
+        if full_context:
+            in_deg = torch.full((n_blocks * block_dim,), -1, dtype=torch.long)
+        else:
+            in_deg = torch.arange(n_blocks).repeat_interleave(block_dim)
+        self.register_buffer("mask", (hidden_degrees[:, None] >= in_deg[None, :]).float())
+
+    def forward(self, ctx):
+        return linear(ctx, self.weight * self.mask, self.bias)
+
+
+class MaskedContextResidualBlock(nn.Module):
+    """flows.py:186-234: relu, W0, + ctx, relu, W1, residual add (no gate)."""
+
+    def __init__(self, in_degrees, autoregressive_features, n_blocks, block_dim):
+        super().__init__()
+        features = len(in_degrees)
+        self.context_layer = MaskedContextLinear(n_blocks, block_dim, in_degrees)
+        l0 = MaskedLinear(in_degrees, features, autoregressive_features, False)
+        l1 = MaskedLinear(l0.degrees, features, autoregressive_features, False)
+        self.linear_layers = nn.ModuleList([l0, l1])
+        self.degrees = l1.degrees
+        nn.init.uniform_(l1.weight, -1e-3, 1e-3)
+        nn.init.uniform_(l1.bias, -1e-3, 1e-3)
+
+    def forward(self, inputs, context=None):
+        t = self.linear_layers[0](F.relu(inputs))
+        if context is not None:
+            t = t + self.context_layer(context)
+        t = self.linear_layers[1](F.relu(t))
+        return inputs + t
+
+
+class MADEWithMaskedContext(nn.Module):
+    """flows.py:237-303"""
+
+    def __init__(self, features, hidden_features, n_blocks, block_dim, num_blocks=2, output_multiplier=1):
+        super().__init__()
+        self.initial_layer = MaskedLinear(input_degrees(features), hidden_features, features, False)
+        self.initial_layer.split_input = True
+        deg = self.initial_layer.degrees
+        self.context_layer = MaskedContextLinear(n_blocks, block_dim, deg)
+        self.blocks = nn.ModuleList([MaskedContextResidualBlock(deg, features, n_blocks, block_dim)
+                                     for _ in range(num_blocks)])
+        self.final_layer = MaskedLinear(deg, features * output_multiplier, features, True)
+
+    def forward(self, inputs, context=None):
+        h = self.initial_layer(inputs)
+        if context is not None:
+            h = h + F.relu(self.context_layer(context))
+        for block in self.blocks:
+            h = block(h, context)
+        return self.final_layer(h)
+
+
+# --------------------------------------------------------------------------- #
 # rational-quadratic spline (upstream nflows.transforms.splines.rational_quadratic,
 # nflows.utils.torchutils.searchsorted)
 # --------------------------------------------------------------------------- #
@@ -321,7 +389,7 @@ class MaskedPiecewiseRationalQuadraticAutoregressiveTransform(nn.Module):
 
     def __init__(self, features, hidden_features, context_features=None,
                  num_bins=10, tail_bound=1.0, num_blocks=2,
-                 dropout_probability=0.0, scale_by_sqrt_hidden=False,
+                 dropout_probability=0.0, scale_by_sqrt_hidden=False, masked_context_blocks=None,
                  min_bin_width=DEFAULT_MIN_BIN_WIDTH,
                  min_bin_height=DEFAULT_MIN_BIN_HEIGHT,
                  min_derivative=DEFAULT_MIN_DERIVATIVE):
@@ -337,9 +405,13 @@ class MaskedPiecewiseRationalQuadraticAutoregressiveTransform(nn.Module):
         # exposes a `hidden_features` attribute; upstream MADE does not
         #  -> inactive by default, switchable for audit.
         self.scale_by_sqrt_hidden = scale_by_sqrt_hidden
-        self.autoregressive_net = MADE(features, hidden_features, context_features,
-                                       num_blocks, self.output_multiplier(),
-                                       dropout_probability)
+        if masked_context_blocks:     # (n_blocks, block_dim): flows.py:306-360
+            self.autoregressive_net = MADEWithMaskedContext(features, hidden_features, *masked_context_blocks,
+                                                            num_blocks, self.output_multiplier())
+        else:
+            self.autoregressive_net = MADE(features, hidden_features, context_features,
+                                           num_blocks, self.output_multiplier(),
+                                           dropout_probability)
 
     def output_multiplier(self):
         return 3 * self.num_bins - 1

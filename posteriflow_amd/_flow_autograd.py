@@ -55,16 +55,21 @@ def rqs_forward(x, uw, uh, ud, tail_bound):
     return torch.where(inside, y, x), torch.where(inside, lad, torch.zeros_like(lad))
 
 
-def made_forward(net, x, ctx):
-    """nflows MADE over the parameter container ``flows._MADE`` (weights * masks, GLU context gates)."""
+def made_forward(net, x, ctx, additive=False):
+    """nflows MADE over the parameter container ``flows._MADE`` (weights * masks); context enters
+    through GLU gates (nflows) or, for the reference's masked-context variant, additively between the
+    two masked linears of a block (flows.py:225-234)."""
     lin = lambda m, v: F.linear(v, m.weight * m.mask, m.bias)
+    cl = lambda m, v: F.linear(v, m.weight * m.mask, m.bias) if hasattr(m, "mask") else m(v)
     h = lin(net.initial_layer, x)
     if ctx is not None:
-        h = h + F.relu(net.context_layer(ctx))
+        h = h + F.relu(cl(net.context_layer, ctx))
     for blk in net.blocks:
         t = lin(blk.linear_layers[0], F.relu(h))
+        if additive and ctx is not None:
+            t = t + cl(blk.context_layer, ctx)
         t = lin(blk.linear_layers[1], F.relu(t))
-        if ctx is not None:
+        if ctx is not None and not additive:
             t = t * torch.sigmoid(blk.context_layer(ctx))
         h = h + t
     return lin(net.final_layer, h)
@@ -75,9 +80,11 @@ def flow_forward(flow, x, ctx):
     x = x[:, flow._ar_perm]
     k, d = flow.num_bins, flow.features
     logdet = x.new_zeros(x.shape[0])
+    additive = bool(getattr(flow, "use_masked_context", False))
     for layer in flow._ar_transforms:
-        x = x.flip(1)                                                   # ReversePermutation
-        p = made_forward(layer.autoregressive_net, x, ctx).view(-1, d, 3 * k - 1)
+        if not additive:
+            x = x.flip(1)                                               # ReversePermutation
+        p = made_forward(layer.autoregressive_net, x, ctx, additive).view(-1, d, 3 * k - 1)
         x, lad = rqs_forward(x, p[..., :k], p[..., k:2 * k], p[..., 2 * k:], float(flow._tail_bound))
         logdet = logdet + lad.sum(dim=1)
     return x, logdet

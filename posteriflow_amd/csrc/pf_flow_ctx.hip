@@ -29,6 +29,7 @@ struct CtxParams {
     void* out;              // [rows/64][tiles][4][64][4] fp32 (MFMA C-fragment order)
     int64_t rows;
     int C, CK, NT, tiles, tiles_per_wave;
+    int additive;           // 1: block projections are plain affine terms (masked-context conditioner)
 };
 
 constexpr int kCtxRowGroups = 4;   // 64 context rows per workgroup
@@ -133,7 +134,8 @@ __global__ __launch_bounds__(256) void ctx_project_kernel(const CtxParams p) {
         }
         if (kc != n_chunks - 1) return;
         const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + (size_t)u * 16 + 4 * g);
-        const bool is_gate = ((u / p.NT) % 3) != 0;
+        const bool is_first = ((u / p.NT) % 3) == 0;
+        const bool is_gate = !is_first && !p.additive;
 #pragma unroll
         for (int rg = 0; rg < kCtxRowGroups; ++rg) {
             f32x4 v;
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(256) void ctx_project_kernel(const CtxParams p) {
             for (int e = 0; e < 4; ++e) {
                 const float t = acc[rg][e] + b[e];
                 if (is_gate) v[e] = BF16 ? __builtin_amdgcn_rcpf(1.f + __expf(-t)) : 1.f / (1.f + expf(-t));
-                else v[e] = fmaxf(t, 0.f);
+                else v[e] = is_first ? fmaxf(t, 0.f) : t;
             }
             // fragment order [row block of 64][tile][row group][lane][4]: one 1-KiB contiguous
             // store per wave-instruction; rows past the end are padding
@@ -174,7 +176,7 @@ int launch_ctx_project(const FlowPlan& L, const char* packed, const float* ctx, 
     p.frags = reinterpret_cast<const u32x4*>(packed + L.ctx_frag_offset());
     p.bias = reinterpret_cast<const float*>(packed + L.ctx_bias_offset());
     p.ctx = ctx; p.out = out; p.rows = ctx_rows;
-    p.C = L.C; p.CK = L.CK; p.NT = L.NT; p.tiles = 3 * L.L * L.NT;
+    p.C = L.C; p.CK = L.CK; p.NT = L.NT; p.tiles = 3 * L.L * L.NT; p.additive = L.additive;
     const unsigned row_blocks = (unsigned)((ctx_rows + 63) / 64);
     // enough workgroups to fill the chip when there are few row blocks
     int tpw = 12;

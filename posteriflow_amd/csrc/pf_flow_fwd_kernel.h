@@ -318,7 +318,7 @@ __global__ __launch_bounds__(NT * 32) void flow_kernel(const FwdParams p) {
                 v = p.x[row * D + d];                    // z, in the last layer's coordinates
             } else {
                 // layer 0 sees reverse(x[:, ar_perm]): position d <- source D-1-d
-                const int sd = D - 1 - d;
+                const int sd = L.additive ? d : D - 1 - d;
                 const int src = p.ar_perm ? p.ar_perm[sd] : sd;
                 v = p.x[row * D + src];
             }
@@ -365,6 +365,9 @@ __global__ __launch_bounds__(NT * 32) void flow_kernel(const FwdParams p) {
         return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.cproj) + off);
     };
     const bool hoisted = CKM == 0 && p.cproj != nullptr;
+    const bool additive = hoisted && L.additive;        // masked-context conditioner (flows.py:186-234)
+    // position of feature d in the next layer's input (ReversePermutation unless masked-context)
+    auto rv = [&](int d) { return L.additive ? d : D - 1 - d; };
 
     float ld_pair = 0.f;                                // log-det of this thread's (feature,row) pair
 
@@ -547,6 +550,12 @@ __global__ __launch_bounds__(NT * 32) void flow_kernel(const FwdParams p) {
             gemm_pair(ic<EB>{}, ic<KHS>{}, kA, bk, tAv, tBv);
             {
                 const f32x4 b0A = load_bias(tA, kSlotBlk + 3 * b), b0B = load_bias(tB, kSlotBlk + 3 * b);
+                if constexpr (CKM == 0) {
+                    if (additive) {          // t = W0 relu(h) + b0 + ctx_layer(ctx)
+#pragma unroll
+                        for (int r = 0; r < R; ++r) { tAv[r] += prA[1 + b][r]; tBv[r] += prB[1 + b][r]; }
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -574,7 +583,7 @@ __global__ __launch_bounds__(NT * 32) void flow_kernel(const FwdParams p) {
                         hA[r][e] += (tAv[r][e] + b1A[e]) * pf_sigmoid<FAST>(gA[r][e] + bgA[e]);
                         hB[r][e] += (tBv[r][e] + b1B[e]) * pf_sigmoid<FAST>(gB[r][e] + bgB[e]);
                     }
-            } else if (hoisted) {
+            } else if (hoisted && !additive) {
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     hA[r] += (tAv[r] + b1A) * prA[1 + b][r];
@@ -632,7 +641,7 @@ __global__ __launch_bounds__(NT * 32) void flow_kernel(const FwdParams p) {
                         if (r == 0) ld_pair += ld; else s_ldb[feat * COLS + 16 * r + col] += ld;
                         bad_pair |= bad ? (1u << r) : 0u;
                         // undo this layer's ReversePermutation: previous layer's output position D-1-feat
-                        yn[(D - 1 - feat) * COLS + 16 * r + col] = xv;
+                        yn[rv(feat) * COLS + 16 * r + col] = xv;
                     }
                 } else {
                     const float xv = xin[feat * COLS + 16 * r + col];
@@ -641,7 +650,7 @@ __global__ __launch_bounds__(NT * 32) void flow_kernel(const FwdParams p) {
                     else rqs_pair<FAST>(s_par + (size_t)tid * kParStride, xv, K, p, y, ld);
                     if (r == 0) ld_pair += ld; else s_ldb[feat * COLS + 16 * r + col] += ld;
                     // the next layer starts with ReversePermutation: position D-1-feat
-                    xout[(D - 1 - feat) * COLS + 16 * r + col] = y;
+                    xout[rv(feat) * COLS + 16 * r + col] = y;
                 }
             }
             if (r + 1 < R) barrier();      // the transpose buffer is reused by the next column group
@@ -689,7 +698,7 @@ __global__ __launch_bounds__(NT * 32) void flow_kernel(const FwdParams p) {
             float ld = 0.f, q = 0.f, sls = 0.f;
             for (int f = 0; f < D; ++f) ld += s_ldb[f * COLS + tid];
             for (int d = 0; d < D; ++d) {
-                const float zv = zfin[(D - 1 - d) * COLS + tid];
+                const float zv = zfin[rv(d) * COLS + tid];
                 if (p.log_sigma) {           // PSDScaledNormal.log_prob, flows.py:73-83
                     const float ls = p.log_sigma[row * D + d];
                     const float zs = zv / expf(ls);

@@ -88,6 +88,7 @@ struct FlowPlan {
     int kstep;                  // k extent of one frag: 32 (bf16) or 16 (f32)
     int CK, CKM, HK;            // needed / scheduled context frags per tile; frags per full hidden row
     int hoist;                  // 1: context projections hoisted (CKM = 0 in the streams)
+    int additive;               // 1: masked-context conditioner: additive context, no reverse permutation
     int dense;                  // 1: KHS = KOS = 2*HK (masks too coarse to pair up), else HK+2 / HK+1
     int KHS, KOS, NF;
     int kH[kMaxTiles];          // active k-steps of tile t in a masked H x H GEMM
@@ -154,7 +155,8 @@ inline int make_plan(const PfFlowDesc& d, FlowPlan& o) {
     o.NT = o.H / 16; o.NW = o.NT / 2;
     o.kstep = o.bf16 ? 32 : 16;
     o.CK = (o.C + o.kstep - 1) / o.kstep;
-    o.hoist = (d.reserved & PF_FLAG_HOIST_CTX) && o.C > 0 ? 1 : 0;
+    o.additive = (d.reserved & PF_FLAG_MASKED_CONTEXT) ? 1 : 0;
+    o.hoist = (d.reserved & (PF_FLAG_HOIST_CTX | PF_FLAG_MASKED_CONTEXT)) && o.C > 0 ? 1 : 0;
     o.CKM = o.hoist ? 0 : pick_ckm(o.bf16, o.NT, o.C);
     if (o.CKM < 0 || o.CK > 64) return PF_ERR_UNSUPPORTED;
     o.HK = o.H / o.kstep;

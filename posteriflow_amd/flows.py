@@ -50,11 +50,25 @@ class _MaskedLinear(nn.Linear):
         self.register_buffer("degrees", deg)
 
 
+class _MaskedContextLinear(nn.Module):
+    """Parameters of the reference's MaskedContextLinear (flows.py:112-183, full_context=True:
+    the mask buffer is all ones)."""
+
+    def __init__(self, n_blocks: int, block_dim: int, hidden: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(hidden, n_blocks * block_dim))
+        self.bias = nn.Parameter(torch.zeros(hidden))
+        nn.init.kaiming_uniform_(self.weight, a=5 ** 0.5)
+        self.register_buffer("mask", torch.ones(hidden, n_blocks * block_dim))
+
+
 class _ResidualBlock(nn.Module):
-    def __init__(self, in_degrees, features, context_features):
+    def __init__(self, in_degrees, features, context_features, masked_blocks=None):
         super().__init__()
         h = len(in_degrees)
-        if context_features:
+        if masked_blocks:
+            self.context_layer = _MaskedContextLinear(masked_blocks[0], masked_blocks[1], h)
+        elif context_features:
             self.context_layer = nn.Linear(context_features, h)
         l0 = _MaskedLinear(in_degrees, h, features, False)
         l1 = _MaskedLinear(l0.degrees, h, features, False)
@@ -64,13 +78,15 @@ class _ResidualBlock(nn.Module):
 
 
 class _MADE(nn.Module):
-    def __init__(self, features, hidden, context_features, multiplier, num_blocks=2):
+    def __init__(self, features, hidden, context_features, multiplier, num_blocks=2, masked_blocks=None):
         super().__init__()
         self.initial_layer = _MaskedLinear(torch.arange(1, features + 1), hidden, features, False)
-        if context_features:
+        if masked_blocks:
+            self.context_layer = _MaskedContextLinear(masked_blocks[0], masked_blocks[1], hidden)
+        elif context_features:
             self.context_layer = nn.Linear(context_features, hidden)
         self.blocks = nn.ModuleList(
-            [_ResidualBlock(self.initial_layer.degrees, features, context_features)
+            [_ResidualBlock(self.initial_layer.degrees, features, context_features, masked_blocks)
              for _ in range(num_blocks)])
         self.final_layer = _MaskedLinear(self.initial_layer.degrees, features * multiplier,
                                          features, True)
@@ -89,9 +105,10 @@ class _MADE(nn.Module):
 
 
 class _SplineLayer(nn.Module):
-    def __init__(self, features, hidden, context_features, num_bins):
+    def __init__(self, features, hidden, context_features, num_bins, masked_blocks=None):
         super().__init__()
-        self.autoregressive_net = _MADE(features, hidden, context_features, 3 * num_bins - 1)
+        self.autoregressive_net = _MADE(features, hidden, context_features, 3 * num_bins - 1,
+                                        masked_blocks=masked_blocks)
 
 
 class _Reverse(nn.Module):
@@ -183,11 +200,14 @@ class NSFPosteriorFlow(nn.Module):
         self.logger = _log
         if use_masked_context is None:                                   # flows.py:409-411
             use_masked_context = context_features > 0 and features > 0 and context_features % features == 0
-        self.use_masked_context = use_masked_context
-        if use_masked_context:
-            raise NotImplementedError(
-                "masked-context conditioner (flows.py:237-360) is not built; pass "
-                "use_masked_context=False (what LeanNPE does, lean_npe.py:294)")
+        self.use_masked_context = bool(use_masked_context)
+        if self.use_masked_context:                                      # flows.py:412-421
+            if context_features <= 0 or context_features % features != 0:
+                raise ValueError("use_masked_context needs context_features to be a positive multiple of features")
+            self.n_context_blocks = features
+            self.context_block_dim = context_features // features
+        else:
+            self.n_context_blocks = self.context_block_dim = None
         if dropout and dropout > 0.0:
             _log.warning("dropout=%s is applied by nflows in training mode only; the HIP path "
                          "evaluates the conditioner without dropout", dropout)
@@ -208,9 +228,11 @@ class NSFPosteriorFlow(nn.Module):
 
         ctx = context_features if context_features > 0 else None
         transforms, self._ar_transforms = [], []
+        mblocks = (self.n_context_blocks, self.context_block_dim) if self.use_masked_context else None
         for _ in range(num_layers):
-            transforms.append(_Reverse(features))
-            layer = _SplineLayer(features, hidden_features, ctx, num_bins)
+            if not self.use_masked_context:                              # flows.py:459-460
+                transforms.append(_Reverse(features))
+            layer = _SplineLayer(features, hidden_features, ctx, num_bins, mblocks)
             transforms.append(layer)
             self._ar_transforms.append(layer)
         self.transform = _Composite(transforms)
@@ -262,6 +284,8 @@ class NSFPosteriorFlow(nn.Module):
         prec = _lib.PRECISIONS[precision or self.precision]
         hoist = inverse if self.hoist_context is None else self.hoist_context
         flags = _lib.PF_FLAG_HOIST_CTX if (hoist and self.context_features > 0) else 0
+        if self.use_masked_context:
+            flags = _lib.PF_FLAG_HOIST_CTX | _lib.PF_FLAG_MASKED_CONTEXT
         return _lib.PfFlowDesc(self.features, self.context_features, self.hidden_features,
                                self.num_bins, self.num_layers, 2, float(self._tail_bound),
                                _MIN_BIN, _MIN_BIN, _MIN_BIN, prec, flags)
@@ -347,7 +371,7 @@ class NSFPosteriorFlow(nn.Module):
                                  f"got {tuple(context.shape)}")
             if context.device != dev:
                 raise _lib.PfError(f"{what}: context on {context.device}, flow on {dev}")
-            context = context.contiguous().float()
+            context = self._permute_context_blocks(context).contiguous().float()
         elif self.context_features > 0:
             raise ValueError(f"{what}: this flow was built with context_features="
                              f"{self.context_features}; a context is required")
@@ -361,7 +385,10 @@ class NSFPosteriorFlow(nn.Module):
             or any(p.requires_grad for p in self._ordered_parameters()))
 
     def _forward_call(self, x, context, log_sigma, want_z=True, guard=True):
-        dev, x, context = self._check_inputs(x, context, "NSFPosteriorFlow.forward")
+        if guard:
+            dev, x, context = self._check_inputs(x, context, "NSFPosteriorFlow.forward")
+        else:                       # already validated (and context blocks permuted) by the caller
+            dev = x.device
         B = x.shape[0]
         if context is not None and context.shape[0] != B:
             raise ValueError(f"batch mismatch: x {B} vs context {context.shape[0]}")
@@ -396,7 +423,13 @@ class NSFPosteriorFlow(nn.Module):
         self._perm_i32 = None
 
     def _permute_context_blocks(self, context: torch.Tensor) -> torch.Tensor:  # flows.py:590-608
-        return context                                # plain-context conditioner: identity
+        """masked-context mode: context block i follows whatever parameter sits at autoregressive
+        position i (identity for the default order and for the plain conditioner)."""
+        if not self.use_masked_context:
+            return context
+        b = context.shape[0]
+        blocks = context.view(b, self.n_context_blocks, self.context_block_dim)[:, self._ar_perm, :]
+        return blocks.reshape(b, self.n_context_blocks * self.context_block_dim)
 
     def forward(self, x: torch.Tensor, context: Optional[torch.Tensor] = None):
         """x -> (z, log|det dz/dx|)   (flows.py:610-618)."""
@@ -490,7 +523,8 @@ class NSFPosteriorFlow(nn.Module):
             ctx_rows = context.shape[0]
             if ctx_rows < 1 or (B and B % ctx_rows != 0):
                 raise ValueError(f"NSFPosteriorFlow.inverse: {ctx_rows} context rows do not divide batch {B}")
-            context = torch.nan_to_num(context.float(), nan=0.0, posinf=1e-3, neginf=-1e-3).contiguous()
+            context = torch.nan_to_num(context.float(), nan=0.0, posinf=1e-3, neginf=-1e-3)
+            context = self._permute_context_blocks(context).contiguous()
         else:
             context = None
         x, logdet, flags = self._inverse_call(z, context, ctx_rows)

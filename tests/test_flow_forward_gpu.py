@@ -171,3 +171,51 @@ def test_errors_are_loud():
         flow(torch.zeros(2, 11).cuda(), None)
     with pytest.raises(NotImplementedError):
         NSFPosteriorFlow(20, 0, 256, 1, 16, 5.0).cuda()(torch.zeros(2, 20).cuda())   # D > 16
+
+
+def test_masked_context_conditioner_a14():
+    """The reference's masked-context variant (flows.py:112-360; auto-on when C % D == 0): additive
+    context, no ReversePermutation, context blocks follow the autoregressive order."""
+    from helpers import oracle_state_for_product
+    from oracle.flow_ref import NSFPosteriorFlowRef, scale_final_layers
+    from posteriflow_amd import NSFPosteriorFlow
+    D, C, H, L, K, tb = 11, 264, 256, 4, 16, 5.0                      # 264 = 11 blocks x 24
+    torch.manual_seed(0)
+    ref = NSFPosteriorFlowRef(D, C, H, L, K, tb, temperature_scale=1.0, use_masked_context=True)
+    ref64 = NSFPosteriorFlowRef(D, C, H, L, K, tb, temperature_scale=1.0, use_masked_context=True).double()
+    ref64.load_state_dict(ref.state_dict())
+    flow = NSFPosteriorFlow(D, C, H, L, K, tb, temperature_scale=1.0)              # auto-enabled
+    assert flow.use_masked_context and flow.n_context_blocks == 11 and flow.context_block_dim == 24
+    assert "transform._transforms.0.autoregressive_net.blocks.0.context_layer.mask" in flow.state_dict()
+    assert len(flow.transform._transforms) == L                                     # no permutation modules
+    flow.load_state_dict(oracle_state_for_product(ref))
+    flow = flow.cuda()
+    order = [2, 0, 1, 10, 9, 3, 4, 8, 5, 7, 6]
+    for f in (ref, ref64, flow):
+        f.set_autoregressive_order(order)
+    x, ctx = flow_inputs(200, D, C, tb)
+    with torch.no_grad():
+        z64, ld64 = ref64(x.double(), ctx.double())
+        z32, ld32 = ref(x, ctx)
+        for prec in ("fp32", "bf16"):
+            flow.precision = prec
+            z, ld = flow(x.cuda(), ctx.cuda())
+            ez, eld = (z.cpu().double() - z64).abs().max().item(), (ld.cpu().double() - ld64).abs().max().item()
+            print(f"\n[masked-context {prec}] |z-z64| {ez:.2e} |ld-ld64| {eld:.2e} "
+                  f"(cpu fp32: {(z32.double() - z64).abs().max():.2e} / {(ld32.double() - ld64).abs().max():.2e})")
+            if prec == "fp32":
+                assert ez < max(4 * (z32.double() - z64).abs().max().item(), 2e-5)
+                assert eld < max(4 * (ld32.double() - ld64).abs().max().item(), 5e-5)
+            else:
+                assert ez < 0.5 and eld < 4.0
+        flow.precision = "fp32"
+        zz = torch.randn(64, D)
+        xi, _, flags = flow._inverse_call(zz.cuda(), flow._permute_context_blocks(ctx[:64].cuda()).contiguous(), 64)
+        xr, _ = ref64.inverse_raw(zz.double(), ctx[:64].double())
+        assert int(flags.sum()) == 0 and (xi.cpu().double() - xr).abs().max() < 2e-4
+    # gradients through the interim backward follow the additive form too
+    xg = x[:32].cuda().requires_grad_(True)
+    flow.compute_psd_aware_nll(xg, ctx[:32].cuda(), None).sum().backward()
+    xr_ = x[:32].clone().requires_grad_(True)
+    ref.compute_psd_aware_nll(xr_, ctx[:32], torch.zeros(32, D)).sum().backward()
+    assert ((xg.grad.cpu() - xr_.grad).abs().max() / xr_.grad.abs().max()) < 1e-3

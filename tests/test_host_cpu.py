@@ -123,8 +123,8 @@ def test_module_api_on_cpu_is_loud_not_silent(lib):
     assert NSFPosteriorFlow(4, 0, 64, 1, 8, tail_bound=5)._tail_bound == 3.0       # flows.py:517 quirk
     with pytest.raises(ValueError):
         create_flow_model("realnvp", 4)
-    with pytest.raises(NotImplementedError):
-        NSFPosteriorFlow(16, 256, 256, 1, 16)          # 256 % 16 == 0 -> masked context auto-on (flows.py:409)
+    mc = NSFPosteriorFlow(16, 256, 256, 1, 16)            # 256 % 16 == 0 -> masked context auto-on (flows.py:409)
+    assert mc.use_masked_context and mc.context_block_dim == 16 and len(mc.transform._transforms) == 1
     with pytest.raises(RuntimeError):                   # no CPU fallback
         flow(torch.zeros(2, 11), torch.zeros(2, 288))
     with pytest.raises(RuntimeError):
