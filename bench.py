@@ -149,33 +149,59 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the sampling / embedding side measurements")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: rehearsal of the N > 1 path on fewer GPUs than ranks (collective through the host)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    if args.backend == "gloo":
+        local = local % torch.cuda.device_count()         # rehearsal: ranks may share a GPU
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     log(f"rank {rank}/{world} on {torch.cuda.get_device_name(dev)}")
     flow = build_flow(dev, args.precision).freeze_packed()
     log("weights packed")
     x, ctx = make_inputs(args.batch, 1 + rank, dev)
     nll = torch.empty(args.batch, device=dev)
-    red = torch.zeros(2, device=dev, dtype=torch.float64)
+    # N > 1: (sum nll, count) all-reduced every step over RCCL -- the path's only exchange.  One
+    # reduction kernel per step; the 8-byte collective is launched asynchronously and double-buffered
+    # so that it overlaps the next step's flow kernel (it is latency-, not bandwidth-bound).
+    red = torch.zeros(2, 2, device=dev, dtype=torch.float32)
+    red[:, 1] = float(args.batch)
+    works = [None, None]
+    state = {"k": 0}
 
     def step():
         flow.nll_into(x, ctx, nll)
         if world > 1:
-            red[0] = nll.sum(dtype=torch.float64)
-            red[1] = float(args.batch)
-            dist.all_reduce(red)
+            k = state["k"] & 1
+            if works[k] is not None:
+                works[k].wait()                           # stream-side wait: the buffer is free again
+            torch.sum(nll, dim=0, out=red[k, 0])
+            if args.backend == "nccl":
+                works[k] = dist.all_reduce(red[k], async_op=True)
+            else:
+                host = red[k].cpu()
+                dist.all_reduce(host)
+                red[k].copy_(host); red[k, 1] = float(args.batch)
+            state["k"] += 1
+
+    def drain():
+        for w in works:
+            if w is not None:
+                w.wait()
 
     # one HIP graph per step on N=1 (the step is a single ~100 us kernel: eager launch
     # overhead would otherwise be inside the measurement); eager with collectives
@@ -193,6 +219,7 @@ def main():
         run = graph.replay if graph is not None else step
         for _ in range(args.warmup):
             run()
+        drain()
         stream.synchronize()
         if world > 1:
             dist.barrier()
@@ -202,6 +229,7 @@ def main():
         e0.record(stream)
         for _ in range(args.steps):
             run()
+        drain()
         e1.record(stream)
         stream.synchronize()
         if world > 1:
@@ -211,7 +239,7 @@ def main():
     dev_ms = e0.elapsed_time(e1)
     log(f"timed {args.steps} steps: {elapsed * 1e3 / args.steps:.4f} ms/step (device {dev_ms / args.steps:.4f})")
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
@@ -234,6 +262,10 @@ def main():
         kernel_ms = k0.elapsed_time(k1) / n_k
     log(f"kernel-only: {kernel_ms * 1e3:.2f} us")
 
+    mean_nll = None
+    if world > 1:
+        last = red[(state["k"] - 1) & 1].cpu()
+        mean_nll = (last[0] / (last[1] if args.backend == "nccl" else args.batch * world)).item()
     if rank == 0:
         fl = flops_per_sample()
         ach = args.batch * fl / (kernel_ms * 1e-3) / 1e12
@@ -252,7 +284,8 @@ def main():
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "rows_per_workgroup": int(__import__("posteriflow_amd")._lib.lib().pf_flow_rows_per_workgroup(
                            flow._desc(), args.batch)),
-                       "launch": "hipGraph" if graph is not None else "eager",
+                       "launch": "hipGraph" if graph is not None else "eager + async all-reduce",
+                       "global_mean_nll": mean_nll,
                        "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                          "frac": ach / peak, "traffic": None,
