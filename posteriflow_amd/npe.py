@@ -225,9 +225,16 @@ class LeanStrainEncoder(nn.Module):
             parts.append(self.noise_mlp(asd_bands.reshape(b, -1)))
         return torch.cat(parts, dim=1), clean
 
+    def _autocast(self, dev):
+        """bf16 mode: the tensor-op part (fusion transformer, pooling, MLPs) runs its GEMMs in bf16
+        too (fp32 accumulate), like the HIP stem; fp32 mode: nothing changes."""
+        on = self.precision == "bf16" and dev.type == "cuda"
+        return torch.autocast("cuda", dtype=torch.bfloat16, enabled=on)
+
     def forward(self, strain, asd_bands=None):
-        feats, _ = self._compute_feats(strain, asd_bands)
-        return self.out_proj(feats)
+        with self._autocast(strain.device):
+            feats, _ = self._compute_feats(strain, asd_bands)
+            return self.out_proj(feats).float()
 
 
 _SR, _T_LEN, _F_LO, _F_HI = 4096, 16384, 20.0, 1024.0
@@ -287,10 +294,12 @@ class CoherentEncoder(LeanStrainEncoder):
 
     def forward(self, strain, asd_bands=None):
         clean = self._sanitize(strain)
-        g = self.geom_mlp(self._geometry_rel(clean))
-        gtok = self.geom_to_tokens(g).reshape(-1, self.n_geom_tokens, self.d_model)
-        feats, _ = self._compute_feats(clean, asd_bands, extra_tokens=gtok)
-        return self.out_proj(feats)
+        rel = self._geometry_rel(clean)                      # FFT features stay fp32
+        with self._autocast(strain.device):
+            g = self.geom_mlp(rel)
+            gtok = self.geom_to_tokens(g).reshape(-1, self.n_geom_tokens, self.d_model)
+            feats, _ = self._compute_feats(clean, asd_bands, extra_tokens=gtok)
+            return self.out_proj(feats).float()
 
 
 class LeanNPE(nn.Module):

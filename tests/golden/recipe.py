@@ -66,3 +66,68 @@ def physical_params(batch: int, seed: int) -> torch.Tensor:
     p[5, 9] = 1.5
     p[6, 2] = 10.0         # below range
     return p
+
+
+# ---- remix cache (noise.npy / signals.npy / params.npy / events.json) ---------------------------
+REMIX_T = 16384
+
+
+def remix_cache(out_dir: str, seed: int = 5, n_noise: int = 7, with_real_bank: bool = True) -> dict:
+    """A tiny synthetic cache in the on-disk layout ``RemixDataset`` reads (remix_data.py:49-111):
+    6 events with 1, 2, 3, 5, 1, 2 signals; parameters chosen so that every relabel guard is hit
+    (distance near both guard limits, |t_c| beyond 1.45).  With ``with_real_bank`` also a
+    real-noise bank: per detector two whitened segments (5 s) with their ASDs and a design ASD."""
+    import json
+    import os
+
+    import numpy as np
+
+    rng = np.random.default_rng(seed)
+    os.makedirs(out_dir, exist_ok=True)
+    counts = [1, 2, 3, 5, 1, 2]
+    m = sum(counts)
+    t = np.arange(REMIX_T, dtype=np.float64) / 4096.0
+    noise = rng.standard_normal((n_noise, 3, REMIX_T)).astype(np.float16)
+    signals = np.zeros((m, 3, REMIX_T), dtype=np.float16)
+    params = np.zeros((m, 11), dtype=np.float32)
+    for k in range(m):
+        f0, t0 = 25.0 + 9.0 * k, 1.0 + 0.17 * k
+        env = np.exp(-((t - t0) / 0.25) ** 2)
+        for d in range(3):
+            amp = (0.6 + 0.3 * d) * (1.0 + 0.2 * k)
+            signals[k, d] = (amp * env * np.sin(2 * np.pi * (f0 * t + 30.0 * t * t) + 0.7 * d)).astype(np.float16)
+        params[k] = [5.0 + 60.0 * rng.uniform(), 5.0 + 40.0 * rng.uniform(), 100.0 + 1500.0 * rng.uniform(),
+                     6.28 * rng.uniform(), rng.uniform(-1.5, 1.5), 3.14 * rng.uniform(), 3.14 * rng.uniform(),
+                     6.28 * rng.uniform(), rng.uniform(-1.2, 1.2), rng.uniform(), rng.uniform()]
+    params[0, 2] = 46.0         # d/s < 45 for s > 1.03: rescale rejected
+    params[1, 2] = 2090.0       # d/s > 2100 for s < 0.995: rescale rejected
+    params[2, 8] = 1.5          # |t_c| >= 1.45: no time shift
+    params[4, 8] = -1.47
+    params[3, 2] = 0.5          # loudness uses max(d, 1)
+    events, start = [], 0
+    for c in counts:
+        events.append([start, c])
+        start += c
+    np.save(os.path.join(out_dir, "noise.npy"), noise)
+    np.save(os.path.join(out_dir, "signals.npy"), signals)
+    np.save(os.path.join(out_dir, "params.npy"), params)
+    with open(os.path.join(out_dir, "events.json"), "w") as fh:
+        json.dump({"n_noise": n_noise, "n_signals": m, "events": events}, fh)
+    if with_real_bank:
+        bank = os.path.join(out_dir, "real_bank")
+        os.makedirs(bank, exist_ok=True)
+        nf = REMIX_T // 2 + 1
+        f = np.fft.rfftfreq(REMIX_T, 1.0 / 4096.0)
+        for di, d in enumerate(("H1", "L1", "V1")):
+            design = (1e-23 * (1.0 + (60.0 / np.maximum(f, 5.0)) ** 4 + (f / 900.0) ** 2)).astype(np.float64)
+            np.save(os.path.join(bank, f"design_asd_{d}.npy"), design)
+            for j in range(2):
+                seg = rng.standard_normal(REMIX_T + 4096 + 512 * j).astype(np.float16)
+                wobble = 1.0 + 0.5 * np.sin(f / (70.0 + 25.0 * di + 11.0 * j)) ** 2
+                asd = design * wobble
+                if j == 1:
+                    asd[:40] = 0.0              # exercises the max(asd, 1e-30) + clip(…, 1/50, 50) guards
+                    asd[nf - 30:] *= 1e3
+                np.save(os.path.join(bank, f"{d}_{j:02d}_strain.npy"), seg)
+                np.save(os.path.join(bank, f"{d}_{j:02d}_asd.npy"), asd)
+    return {"n_noise": n_noise, "n_signals": m, "events": events}
