@@ -10,6 +10,7 @@
  *                     (executes nflows CompositeTransform / MADE / RQS, flows.py:459-529)
  *   pf_flow_inverse   NSFPosteriorFlow.inverse (transform part) src/ahsd/models/flows.py:620-655
  *   pf_flow_pack      the per-call `weight * mask` of nflows MaskedLinear, done once
+ *   pf_remix_forward  RemixDataset.__getitem__ (algebra)      experiments/remix_data.py:218-299
  *   pf_embed_stem_forward  LeanStrainEncoder stem + energy windows  src/ahsd/models/lean_npe.py:207-217
  *
  * Conventions
@@ -135,6 +136,25 @@ int64_t pf_embed_stem_workspace_bytes(int32_t precision, int64_t n_sequences);
 int pf_embed_stem_forward(int32_t precision, const void* packed, const float* strain,
                           int64_t n_sequences, float* tokens, float* log_energy,
                           void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- training-example remix ------------------------------------------
+ * The deterministic half of RemixDataset.__getitem__ (experiments/remix_data.py:218-299) for a
+ * batch of examples whose random decisions have already been drawn:
+ *   strain[b,d,:] = f32(noise_pool[noise_row[b], d, :])
+ *                   + sum_{k < nsig[b]} scale[b,k] * roll(f32(signal_pool[sig_start[b]+k, d, :]), shift[b,k])
+ * (fp32, summed in k order, bit-identical to the numpy arithmetic of remix_data.py:232-260),
+ * detector d of example b replaced by fill[fill_row[b,d], :] where fill_row[b,d] >= 0
+ * (detector dropout, :262-279), net_snr[b] = ||sig_sum over kept detectors||_2 (:286).
+ * Pools are fp16 [rows][3][16384] (the memmap cache layout, remix_data.py:49-111); noise_row[b] < 0
+ * = no pool noise (the caller adds its own, e.g. real-noise crops).  Rows outside a pool contribute 0.
+ * sig_sum (fp32 [batch][3][16384]) and net_snr may be NULL; fill_row may be NULL (no dropout).
+ * workspace: pf_remix_workspace_bytes(batch) bytes, 8-byte aligned. */
+int64_t pf_remix_workspace_bytes(int64_t batch);
+int pf_remix_forward(const void* noise_pool, int64_t n_noise, const void* signal_pool, int64_t n_signals,
+                     const int64_t* noise_row, const int64_t* sig_start, const int32_t* nsig,
+                     const float* scale, const int32_t* shift, const int32_t* fill_row, const float* fill,
+                     int64_t n_fill, int64_t batch, float* strain, float* sig_sum, float* net_snr,
+                     void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- introspection ------------------------------------------------------------ */
 const char* pf_last_error(void);

@@ -52,6 +52,11 @@ SYMBOLS = {
     "pf_embed_stem_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int64]),
     "pf_embed_stem_forward": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_int64, C.c_void_p]),
+    "pf_remix_workspace_bytes": (C.c_int64, [C.c_int64]),
+    "pf_remix_forward": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                   C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                   C.c_void_p]),
     "pf_last_error": (C.c_char_p, []),
     "pf_version": (C.c_char_p, []),
     "pf_flow_rows_per_workgroup": (C.c_int32, [_P, C.c_int64]),

@@ -15,6 +15,11 @@ void stem_build_pack_map(bool bf16, int32_t* map);
 int64_t stem_workspace_bytes(bool bf16, int64_t n_seq);
 int stem_forward(bool bf16, const char* packed, const float* strain, int64_t n_seq, float* tokens,
                  float* log_energy, char* ws, hipStream_t s);
+int64_t remix_workspace_bytes(int64_t batch);
+int remix_forward(const void* noise, int64_t n_noise, const void* signals, int64_t n_signals,
+                  const int64_t* noise_row, const int64_t* sig_start, const int32_t* nsig, const float* scale,
+                  const int32_t* shift, const int32_t* fill_row, const float* fill, int64_t n_fill, int64_t batch,
+                  float* strain, float* sig_sum, float* net_snr, void* ws, hipStream_t s);
 int launch_gather(bool bf16, const float* raw, const int32_t* map, void* out, int64_t n, hipStream_t s);
 }  // namespace pf
 
@@ -201,6 +206,30 @@ int pf_embed_stem_forward(int32_t precision, const void* packed, const float* st
         return fail(PF_ERR_BAD_ARG, "packed/strain/tokens must be 16-byte, workspace 256-byte aligned");
     const int rc = pf::stem_forward(bf, static_cast<const char*>(packed), strain, n_sequences, tokens, log_energy,
                                     static_cast<char*>(workspace), static_cast<hipStream_t>(stream));
+    return rc == PF_OK ? rc : fail(rc, hipGetErrorString(hipGetLastError()));
+}
+
+// ---- training-example remix --------------------------------------------------------------------
+int64_t pf_remix_workspace_bytes(int64_t batch) { return batch < 0 ? -1 : pf::remix_workspace_bytes(batch); }
+int pf_remix_forward(const void* noise_pool, int64_t n_noise, const void* signal_pool, int64_t n_signals,
+                     const int64_t* noise_row, const int64_t* sig_start, const int32_t* nsig,
+                     const float* scale, const int32_t* shift, const int32_t* fill_row, const float* fill,
+                     int64_t n_fill, int64_t batch, float* strain, float* sig_sum, float* net_snr,
+                     void* workspace, int64_t workspace_bytes, void* stream) {
+    if (batch < 0 || n_noise < 0 || n_signals < 0 || n_fill < 0) return fail(PF_ERR_BAD_ARG, "negative count");
+    if (batch == 0) return PF_OK;
+    if (batch > (int64_t(1) << 26)) return fail(PF_ERR_UNSUPPORTED, "at most 2^26 examples per call");
+    if (!noise_row || !sig_start || !nsig || !scale || !shift || !strain)
+        return fail(PF_ERR_BAD_ARG, "null pointer");
+    if ((n_noise > 0 && !noise_pool) || (n_signals > 0 && !signal_pool) || (n_fill > 0 && !fill))
+        return fail(PF_ERR_BAD_ARG, "pool pointer is null but its row count is not 0");
+    if (!workspace || workspace_bytes < pf::remix_workspace_bytes(batch))
+        return fail(PF_ERR_BAD_ARG, "workspace too small (pf_remix_workspace_bytes)");
+    if (misaligned(workspace, 8) || misaligned(strain, 4) || misaligned(noise_pool, 2) || misaligned(signal_pool, 2))
+        return fail(PF_ERR_BAD_ARG, "misaligned pointer");
+    const int rc = pf::remix_forward(noise_pool, n_noise, signal_pool, n_signals, noise_row, sig_start, nsig, scale,
+                                     shift, fill_row, fill, n_fill, batch, strain, sig_sum, net_snr, workspace,
+                                     static_cast<hipStream_t>(stream));
     return rc == PF_OK ? rc : fail(rc, hipGetErrorString(hipGetLastError()));
 }
 
