@@ -225,8 +225,9 @@ int pf_remix_forward(const void* noise_pool, int64_t n_noise, const void* signal
         return fail(PF_ERR_BAD_ARG, "pool pointer is null but its row count is not 0");
     if (!workspace || workspace_bytes < pf::remix_workspace_bytes(batch))
         return fail(PF_ERR_BAD_ARG, "workspace too small (pf_remix_workspace_bytes)");
-    if (misaligned(workspace, 8) || misaligned(strain, 4) || misaligned(noise_pool, 2) || misaligned(signal_pool, 2))
-        return fail(PF_ERR_BAD_ARG, "misaligned pointer");
+    if (misaligned(workspace, 8) || misaligned(strain, 16) || misaligned(noise_pool, 16) || misaligned(signal_pool, 16) ||
+        misaligned(sig_sum, 16) || misaligned(fill, 16))
+        return fail(PF_ERR_BAD_ARG, "pools, fill, strain and sig_sum must be 16-byte aligned (workspace 8)");
     const int rc = pf::remix_forward(noise_pool, n_noise, signal_pool, n_signals, noise_row, sig_start, nsig, scale,
                                      shift, fill_row, fill, n_fill, batch, strain, sig_sum, net_snr, workspace,
                                      static_cast<hipStream_t>(stream));
