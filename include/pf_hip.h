@@ -105,6 +105,23 @@ int pf_flow_forward(const PfFlowDesc* desc, const void* packed,
                     float* z, float* logdet, float* nll,
                     void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- training: forward that keeps what the backward needs, and the spline backward ----------
+ * pf_flow_forward_train = pf_flow_forward that additionally writes layer_inputs[L][batch][D]: the
+ * input of every layer's conditioner (after the layer's ReversePermutation), i.e. what nflows'
+ * autograd graph would have kept alive under flows.py:615-617.  layer_inputs may be NULL.
+ * pf_flow_rqs_backward: hand-derived backward of the rational-quadratic spline with linear tails
+ * for rows x D (input, raw parameters [rows][D][3K-1] in nflows order) pairs: given dL/dy [rows][D]
+ * and dL/dlogabsdet [rows] returns dL/d(raw parameters) and the direct part of dL/du.  Uses only
+ * features, num_bins, tail_bound and the min_* fields of desc. */
+int pf_flow_forward_train(const PfFlowDesc* desc, const void* packed,
+                          const float* x, const float* ctx, const int32_t* ar_perm,
+                          const float* log_sigma, int64_t batch,
+                          float* z, float* logdet, float* nll, float* layer_inputs,
+                          void* workspace, int64_t workspace_bytes, void* stream);
+int pf_flow_rqs_backward(const PfFlowDesc* desc, const float* u, const float* params,
+                         const float* grad_y, const float* grad_logabsdet, int64_t rows,
+                         float* grad_params, float* grad_u, void* stream);
+
 /* ---- inverse / sampling -----------------------------------------------------
  * x = transform^-1(z, ctx)[:, ar_inv_perm], logdet of the inverse map
  * (nflows returns the log-det of the last autoregressive pass of each layer,

@@ -1,11 +1,22 @@
-"""Interim backward of the flow (DESIGN.md "Backward"): the FORWARD value of every differentiable
-call comes from the HIP kernel (``pf_flow_forward``); ``backward`` re-evaluates the layer chain with
-device tensor ops under autograd and differentiates that (SURVEY.md 7.1 step 6 allows exactly this
-until the hand-written RQS / masked-MLP backward kernels exist).  Nothing here runs on the CPU and
-nothing imports the oracle.
+"""Backward of the flow.  The FORWARD value of every differentiable call comes from the HIP kernel
+(``pf_flow_forward_train``), which also keeps the input of every layer's conditioner.
+
+Plain conditioner (what LeanNPE uses): ``flow_backward`` --
+  1. re-evaluates the ten conditioners from the kept inputs, *batched over layers* (they are independent
+     given their inputs): one GEMM for all context projections, ``baddbmm`` over the layer dimension for
+     the masked linears;
+  2. walks the layer chain backwards: the spline backward is the hand-written HIP kernel
+     ``pf_flow_rqs_backward`` (pf_flow_bwd.hip), the masked-MLP data gradients are plain GEMMs;
+  3. forms every weight gradient with batched GEMMs over the layer dimension and the context gradient
+     with one GEMM.
+GEMMs go to the vendor library through torch (plain library GEMMs); nothing runs on the CPU and nothing
+imports the oracle.
+
+Masked-context conditioner (flows.py:112-360, not used by LeanNPE): ``backward`` re-evaluates the
+chain with device tensor ops under autograd (``flow_forward`` below) and differentiates that.
 
 The tensor-op evaluation follows nflows (MADE with GLU-gated residual blocks, rational-quadratic
-spline with linear tails, ReversePermutation before every layer) but is written sync-free: no boolean
+spline with linear tails, ReversePermutation before every layer) and is written sync-free: no boolean
 indexing, the tail branch is a ``torch.where`` over a computation done on clamped inputs so that the
 unselected branch is always finite (no NaN gradients)."""
 from __future__ import annotations
@@ -14,6 +25,8 @@ import math
 
 import torch
 import torch.nn.functional as F
+
+from . import _lib
 
 _MIN = 1e-3            # nflows DEFAULT_MIN_BIN_WIDTH / HEIGHT / DERIVATIVE
 
@@ -90,23 +103,153 @@ def flow_forward(flow, x, ctx):
     return x, logdet
 
 
+# ---- fast path: HIP spline backward + layer-batched GEMMs ---------------------------------------------
+def _rqs_backward(flow, u, params, gy, glad, gparams):
+    """pf_flow_rqs_backward on [B, D] pairs; writes dL/d(raw parameters) into ``gparams`` and returns the
+    direct part of dL/du."""
+    gu = torch.empty_like(u)
+    _lib.check(_lib.lib().pf_flow_rqs_backward(
+        flow._desc(), u.data_ptr(), params.data_ptr(), gy.data_ptr(), glad.data_ptr(), u.shape[0],
+        gparams.data_ptr(), gu.data_ptr(), torch.cuda.current_stream(u.device).cuda_stream), "pf_flow_rqs_backward")
+    return gu
+
+
+@torch.no_grad()
+def flow_backward(flow, U, ctx, g_z, g_lad):
+    """U [L, B, D] conditioner inputs kept by the forward kernel; g_z [B, D] = dL/dz, g_lad [B] =
+    dL/dlogdet.  Returns (dL/dx [B, D], dL/dctx or None, parameter gradients in
+    ``flow._ordered_parameters()`` order)."""
+    nets = [t.autoregressive_net for t in flow._ar_transforms]
+    Ln, B, D = U.shape
+    nb = len(nets[0].blocks)
+    has_ctx = ctx is not None
+    st = lambda f: torch.stack([f(n) for n in nets])
+    net0 = nets[0]                                   # every layer has the same degrees, hence masks
+    m0, mf = net0.initial_layer.mask, net0.final_layer.mask
+    m1 = [net0.blocks[j].linear_layers[0].mask for j in range(nb)]
+    m2 = [net0.blocks[j].linear_layers[1].mask for j in range(nb)]
+    W0, b0 = st(lambda n: n.initial_layer.weight) * m0, st(lambda n: n.initial_layer.bias)
+    Wf, bf = st(lambda n: n.final_layer.weight) * mf, st(lambda n: n.final_layer.bias)
+    W1 = [st(lambda n: n.blocks[j].linear_layers[0].weight) * m1[j] for j in range(nb)]
+    W2 = [st(lambda n: n.blocks[j].linear_layers[1].weight) * m2[j] for j in range(nb)]
+    b1 = [st(lambda n: n.blocks[j].linear_layers[0].bias) for j in range(nb)]
+    b2 = [st(lambda n: n.blocks[j].linear_layers[1].bias) for j in range(nb)]
+    H = W0.shape[1]
+
+    # 1. conditioners, batched over layers
+    if has_ctx:
+        C = ctx.shape[1]
+        Wcat = torch.cat([st(lambda n: n.context_layer.weight)]
+                         + [st(lambda n: n.blocks[j].context_layer.weight) for j in range(nb)], dim=1)
+        bcat = torch.cat([st(lambda n: n.context_layer.bias)]
+                         + [st(lambda n: n.blocks[j].context_layer.bias) for j in range(nb)], dim=1)
+        proj = torch.addmm(bcat.reshape(-1), ctx, Wcat.reshape(-1, C).t())
+        proj = proj.view(B, Ln, 1 + nb, H).permute(1, 2, 0, 3)                   # [L, 1+nb, B, H]
+        pc = proj[:, 0]
+        gates = [torch.sigmoid(proj[:, 1 + j]) for j in range(nb)]
+    h = torch.baddbmm(b0[:, None, :], U, W0.transpose(1, 2))
+    if has_ctx:
+        h = h + F.relu(pc)
+    hs, t1s, t2s = [h], [], []
+    for j in range(nb):
+        t1 = torch.baddbmm(b1[j][:, None, :], F.relu(h), W1[j].transpose(1, 2))
+        t2 = torch.baddbmm(b2[j][:, None, :], F.relu(t1), W2[j].transpose(1, 2))
+        h = h + (t2 * gates[j] if has_ctx else t2)
+        hs.append(h), t1s.append(t1), t2s.append(t2)
+    params = torch.baddbmm(bf[:, None, :], h, Wf.transpose(1, 2))                 # [L, B, D(3K-1)]
+
+    # 2. the chain, last layer first
+    Gp, Gh0 = torch.empty_like(params), torch.empty_like(hs[0])
+    Gt1 = [torch.empty_like(hs[0]) for _ in range(nb)]
+    Gt2 = [torch.empty_like(hs[0]) for _ in range(nb)]
+    if has_ctx:
+        Gc = torch.empty(Ln, 1 + nb, B, H, dtype=U.dtype, device=U.device)
+    gy = g_z.contiguous()
+    g_lad = g_lad.contiguous()
+    for l in range(Ln - 1, -1, -1):
+        gu = _rqs_backward(flow, U[l], params[l], gy, g_lad, Gp[l])
+        gh = Gp[l] @ Wf[l]
+        for j in range(nb - 1, -1, -1):
+            if has_ctx:
+                gate = gates[j][l]
+                gt2 = gh * gate
+                Gc[l, 1 + j] = gh * t2s[j][l] * gate * (1.0 - gate)
+            else:
+                gt2 = gh
+            Gt2[j][l] = gt2
+            gt1 = (gt2 @ W2[j][l]) * (t1s[j][l] > 0)
+            Gt1[j][l] = gt1
+            gh = gh + (gt1 @ W1[j][l]) * (hs[j][l] > 0)
+        Gh0[l] = gh
+        if has_ctx:
+            Gc[l, 0] = gh * (pc[l] > 0)
+        gu = gu + gh @ W0[l]
+        gy = gu.flip(1).contiguous()                 # through this layer's ReversePermutation
+    g_x = gy[:, flow._ar_inv_perm]                   # gy = dL/d x[:, ar_perm]
+
+    # 3. weight gradients, batched over layers
+    gWf, gbf = torch.bmm(Gp.transpose(1, 2), hs[nb]) * mf, Gp.sum(1)
+    gW0, gb0 = torch.bmm(Gh0.transpose(1, 2), U) * m0, Gh0.sum(1)
+    gW1 = [torch.bmm(Gt1[j].transpose(1, 2), F.relu(hs[j])) * m1[j] for j in range(nb)]
+    gW2 = [torch.bmm(Gt2[j].transpose(1, 2), F.relu(t1s[j])) * m2[j] for j in range(nb)]
+    gb1, gb2 = [g.sum(1) for g in Gt1], [g.sum(1) for g in Gt2]
+    g_ctx = None
+    if has_ctx:
+        flat = Gc.permute(2, 0, 1, 3).reshape(B, -1)                            # [B, L (1+nb) H]
+        gWcat = (flat.t() @ ctx).view(Ln, 1 + nb, H, C)
+        gbcat = flat.sum(0).view(Ln, 1 + nb, H)
+        g_ctx = flat @ Wcat.reshape(-1, C)
+    grads = []
+    for l in range(Ln):
+        grads += [gW0[l], gb0[l]]
+        if has_ctx:
+            grads += [gWcat[l, 0], gbcat[l, 0]]
+        for j in range(nb):
+            if has_ctx:
+                grads += [gWcat[l, 1 + j], gbcat[l, 1 + j]]
+            grads += [gW1[j][l], gb1[j][l], gW2[j][l], gb2[j][l]]
+        grads += [gWf[l], gbf[l]]
+    return g_x, g_ctx, grads
+
+
+def _fast(flow) -> bool:
+    return not bool(getattr(flow, "use_masked_context", False))
+
+
+def _layer_inputs(flow, x):
+    return torch.empty(flow.num_layers, x.shape[0], flow.features, dtype=torch.float32, device=x.device)
+
+
 class FlowNLL(torch.autograd.Function):
     """nll[B] = -(log N(z; 0, diag(e^ls)^2) + logdet); forward on the HIP kernel."""
 
     @staticmethod
     def forward(ctx_, flow, x, context, log_sigma, *params):
+        U = _layer_inputs(flow, x) if _fast(flow) else None
         with torch.no_grad():
-            z, logdet, nll = flow._forward_call(x, context, log_sigma, want_z=True, guard=False)
+            z, logdet, nll = flow._forward_call(x, context, log_sigma, want_z=True, guard=False, layer_inputs=U)
         ctx_.flow = flow
-        ctx_.save_for_backward(x, context, log_sigma)
+        ctx_.save_for_backward(x, context, log_sigma, U, z)
         ctx_.mark_non_differentiable(z, logdet)
         return nll, z, logdet
 
     @staticmethod
     def backward(ctx_, g_nll, _gz, _gld):
         flow = ctx_.flow
-        x, context, log_sigma = ctx_.saved_tensors
+        x, context, log_sigma, U, z = ctx_.saved_tensors
         params = [p for p in flow._ordered_parameters()]
+        if U is not None:
+            # nll = 0.5 sum (z e^-ls)^2 + sum ls + const - logdet
+            if log_sigma is None:
+                g_z, gl = g_nll[:, None] * z, None
+            else:
+                zs2 = (z * torch.exp(-log_sigma)).square()
+                g_z = g_nll[:, None] * z * torch.exp(-2.0 * log_sigma)
+                gl = g_nll[:, None] * (1.0 - zs2) if ctx_.needs_input_grad[3] else None
+            gx, gc, gp = flow_backward(flow, U, context, g_z, -g_nll)
+            return (None, gx if ctx_.needs_input_grad[1] else None,
+                    gc if (context is not None and ctx_.needs_input_grad[2]) else None, gl,
+                    *[g if p.requires_grad else None for g, p in zip(gp, params)])
         with torch.enable_grad():
             xs = x.detach().requires_grad_(x.requires_grad)
             cs = None if context is None else context.detach().requires_grad_(context.requires_grad)
@@ -134,17 +277,25 @@ class FlowForward(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx_, flow, x, context, *params):
+        U = _layer_inputs(flow, x) if _fast(flow) else None
         with torch.no_grad():
-            z, logdet, _ = flow._forward_call(x, context, None, want_z=True, guard=False)
+            z, logdet, _ = flow._forward_call(x, context, None, want_z=True, guard=False, layer_inputs=U)
         ctx_.flow = flow
-        ctx_.save_for_backward(x, context)
+        ctx_.save_for_backward(x, context, U)
         return z, logdet
 
     @staticmethod
     def backward(ctx_, gz, gld):
         flow = ctx_.flow
-        x, context = ctx_.saved_tensors
+        x, context, U = ctx_.saved_tensors
         params = [p for p in flow._ordered_parameters()]
+        if U is not None:
+            gz = torch.zeros_like(x) if gz is None else gz
+            gld = torch.zeros(x.shape[0], device=x.device) if gld is None else gld
+            gx, gc, gp = flow_backward(flow, U, context, gz, gld)
+            return (None, gx if ctx_.needs_input_grad[1] else None,
+                    gc if (context is not None and ctx_.needs_input_grad[2]) else None,
+                    *[g if p.requires_grad else None for g, p in zip(gp, params)])
         with torch.enable_grad():
             xs = x.detach().requires_grad_(x.requires_grad)
             cs = None if context is None else context.detach().requires_grad_(context.requires_grad)

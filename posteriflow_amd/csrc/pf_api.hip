@@ -20,6 +20,8 @@ int remix_forward(const void* noise, int64_t n_noise, const void* signals, int64
                   const int64_t* noise_row, const int64_t* sig_start, const int32_t* nsig, const float* scale,
                   const int32_t* shift, const int32_t* fill_row, const float* fill, int64_t n_fill, int64_t batch,
                   float* strain, float* sig_sum, float* net_snr, void* ws, hipStream_t s);
+int rqs_backward(const PfFlowDesc& d, float deriv_const, const float* u, const float* params, const float* gy,
+                 const float* glad, int64_t n, float* gparams, float* gu, hipStream_t s);
 int launch_gather(bool bf16, const float* raw, const int32_t* map, void* out, int64_t n, hipStream_t s);
 }  // namespace pf
 
@@ -99,9 +101,10 @@ static int project_context(const pf::FlowPlan& L, pf::FwdParams& p, void* worksp
     return PF_OK;
 }
 
-int pf_flow_forward(const PfFlowDesc* desc, const void* packed, const float* x, const float* ctx,
-                    const int32_t* ar_perm, const float* log_sigma, int64_t batch, float* z,
-                    float* logdet, float* nll, void* workspace, int64_t workspace_bytes, void* stream) {
+int pf_flow_forward_train(const PfFlowDesc* desc, const void* packed, const float* x, const float* ctx,
+                          const int32_t* ar_perm, const float* log_sigma, int64_t batch, float* z,
+                          float* logdet, float* nll, float* layer_inputs, void* workspace,
+                          int64_t workspace_bytes, void* stream) {
     pf::FlowPlan L;
     int rc = layout_of(desc, L);
     if (rc != PF_OK) return rc;
@@ -113,7 +116,7 @@ int pf_flow_forward(const PfFlowDesc* desc, const void* packed, const float* x, 
     pf::FwdParams p{};
     p.packed = static_cast<const char*>(packed);
     p.x = x; p.ctx = ctx; p.ar_perm = ar_perm; p.log_sigma = log_sigma; p.z = z; p.logdet = logdet; p.nll = nll;
-    p.batch = batch; p.ctx_rows = batch; p.fail_flags = nullptr; p.plan = L;
+    p.batch = batch; p.ctx_rows = batch; p.fail_flags = nullptr; p.plan = L; p.u_save = layer_inputs;
     p.tail_bound = desc->tail_bound; p.min_w = desc->min_bin_width; p.min_h = desc->min_bin_height;
     p.min_d = desc->min_derivative;
     p.deriv_const = (float)std::log(std::exp(1.0 - (double)desc->min_derivative) - 1.0);
@@ -121,6 +124,30 @@ int pf_flow_forward(const PfFlowDesc* desc, const void* packed, const float* x, 
     if (rc != PF_OK) return rc;
     rc = pf::launch_flow_forward(p, static_cast<hipStream_t>(stream));
     return rc == PF_OK ? rc : fail(rc, rc == PF_ERR_HIP ? hipGetErrorString(hipGetLastError()) : "unsupported launch shape");
+}
+
+int pf_flow_forward(const PfFlowDesc* desc, const void* packed, const float* x, const float* ctx,
+                    const int32_t* ar_perm, const float* log_sigma, int64_t batch, float* z,
+                    float* logdet, float* nll, void* workspace, int64_t workspace_bytes, void* stream) {
+    return pf_flow_forward_train(desc, packed, x, ctx, ar_perm, log_sigma, batch, z, logdet, nll, nullptr,
+                                 workspace, workspace_bytes, stream);
+}
+
+int pf_flow_rqs_backward(const PfFlowDesc* desc, const float* u, const float* params, const float* grad_y,
+                         const float* grad_logabsdet, int64_t rows, float* grad_params, float* grad_u,
+                         void* stream) {
+    if (!desc) return fail(PF_ERR_BAD_ARG, "desc is null");
+    if (desc->features < 1 || desc->num_bins < 2 || desc->num_bins > 16)
+        return fail(PF_ERR_UNSUPPORTED, "need features >= 1 and 2 <= num_bins <= 16");
+    if (!(desc->tail_bound > 0.f)) return fail(PF_ERR_BAD_ARG, "tail_bound must be positive");
+    if (rows < 0) return fail(PF_ERR_BAD_ARG, "negative rows");
+    if (rows == 0) return PF_OK;
+    if (!u || !params || !grad_y || !grad_logabsdet || !grad_params || !grad_u)
+        return fail(PF_ERR_BAD_ARG, "null pointer");
+    const float dc = (float)std::log(std::exp(1.0 - (double)desc->min_derivative) - 1.0);
+    const int rc = pf::rqs_backward(*desc, dc, u, params, grad_y, grad_logabsdet, rows, grad_params, grad_u,
+                                    static_cast<hipStream_t>(stream));
+    return rc == PF_OK ? rc : fail(rc, hipGetErrorString(hipGetLastError()));
 }
 
 int pf_flow_inverse(const PfFlowDesc* desc, const void* packed, const float* z, const float* ctx,

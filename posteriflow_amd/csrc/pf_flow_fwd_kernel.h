@@ -645,6 +645,10 @@ __global__ __launch_bounds__(NT * 32) void flow_kernel(const FwdParams p) {
                     }
                 } else {
                     const float xv = xin[feat * COLS + 16 * r + col];
+                    if (p.u_save) {          // training: the backward re-evaluates each conditioner from this
+                        const int64_t row = row0 + 16 * r + col;
+                        if (row < p.batch) p.u_save[((int64_t)l * p.batch + row) * D + feat] = xv;
+                    }
                     float y, ld;
                     if (PF_ABL(1)) { y = xv + s_par[(size_t)tid * kParStride]; ld = 0.f; }
                     else rqs_pair<FAST>(s_par + (size_t)tid * kParStride, xv, K, p, y, ld);

@@ -19,6 +19,7 @@ struct FwdParams {
     int64_t batch;
     int64_t ctx_rows;        // inverse: context rows (divides batch); forward: == batch
     uint32_t* fail_flags;    // inverse: [B] or null, bit 0 = negative discriminant
+    float* u_save;           // forward: [L, B, D] input of every layer's conditioner (training), or null
     const void* cproj;       // hoisted plans: fp32 projections in fragment order (else null)
     FlowPlan plan;
     float tail_bound, min_w, min_h, min_d;

@@ -384,7 +384,7 @@ class NSFPosteriorFlow(nn.Module):
             any(t is not None and t.requires_grad for t in tensors)
             or any(p.requires_grad for p in self._ordered_parameters()))
 
-    def _forward_call(self, x, context, log_sigma, want_z=True, guard=True):
+    def _forward_call(self, x, context, log_sigma, want_z=True, guard=True, layer_inputs=None):
         if guard:
             dev, x, context = self._check_inputs(x, context, "NSFPosteriorFlow.forward")
         else:                       # already validated (and context blocks permuted) by the caller
@@ -399,9 +399,10 @@ class NSFPosteriorFlow(nn.Module):
         packed = self.packed_weights()
         desc = self._desc()
         ws, ws_bytes = self._ws(desc, B, dev)
-        _lib.check(_lib.lib().pf_flow_forward(
+        # layer_inputs: fp32 [L, B, D] that receives every conditioner's input (training forward)
+        _lib.check(_lib.lib().pf_flow_forward_train(
             desc, packed.data_ptr(), x.data_ptr(), _dev_ptr(context), _dev_ptr(perm),
-            _dev_ptr(log_sigma), B, _dev_ptr(z), logdet.data_ptr(), nll.data_ptr(),
+            _dev_ptr(log_sigma), B, _dev_ptr(z), logdet.data_ptr(), nll.data_ptr(), _dev_ptr(layer_inputs),
             _dev_ptr(ws), ws_bytes, torch.cuda.current_stream(dev).cuda_stream), "pf_flow_forward")
         return z, logdet, nll
 

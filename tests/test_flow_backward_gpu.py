@@ -1,0 +1,132 @@
+"""Backward of the flow on the GPU: the hand-written spline backward (pf_flow_rqs_backward) against
+float64 autograd through the oracle's spline, the layer inputs the training forward keeps, and the
+end-to-end gradients (HIP forward + HIP spline backward + layer-batched GEMMs) against autograd through
+the whole CPU oracle."""
+import pytest
+import torch
+
+from oracle import nflows_restated as nfr
+
+pytestmark = pytest.mark.gpu
+
+
+def _rqs_case(n, D, K, tb, seed, scale):
+    g = torch.Generator().manual_seed(seed)
+    u = (torch.rand(n, D, generator=g) * 2 - 1) * tb * 1.15             # ~13 % of the pairs in the tails
+    u[0, 0], u[1, 0] = -tb, tb                                          # exactly on the outer knots
+    params = torch.randn(n, D, 3 * K - 1, generator=g) * scale
+    gy = torch.randn(n, D, generator=g)
+    gl = torch.randn(n, generator=g)
+    return u, params, gy, gl
+
+
+@pytest.mark.parametrize("D,K,tb,scale", [(11, 16, 5.0, 1.0), (15, 16, 5.0, 3.0), (4, 8, 3.0, 2.0), (11, 2, 1.0, 1.0)])
+def test_rqs_backward_kernel_matches_float64_autograd(D, K, tb, scale):
+    from posteriflow_amd import _lib
+    from posteriflow_amd.flows import NSFPosteriorFlow
+    n = 700
+    u, params, gy, gl = _rqs_case(n, D, K, tb, seed=K + D, scale=scale)
+    ud, pd = u.double().requires_grad_(True), params.double().requires_grad_(True)
+    y, lad = nfr.unconstrained_rational_quadratic_spline(ud, pd[..., :K], pd[..., K:2 * K], pd[..., 2 * K:],
+                                                         tail_bound=tb)
+    ((y * gy.double()).sum() + (lad * gl.double()[:, None]).sum()).backward()
+    H = 16 * max(D, 4)
+    flow = NSFPosteriorFlow(features=D, context_features=0, hidden_features=64 if H <= 64 else 256,
+                            num_layers=2, num_bins=K, tail_bound=tb).cuda()
+    dev = [t.cuda().contiguous() for t in (u, params.reshape(n, -1), gy, gl)]
+    gparams, gu = torch.empty_like(dev[1]), torch.empty_like(dev[0])
+    _lib.check(_lib.lib().pf_flow_rqs_backward(flow._desc(), dev[0].data_ptr(), dev[1].data_ptr(), dev[2].data_ptr(),
+                                               dev[3].data_ptr(), n, gparams.data_ptr(), gu.data_ptr(),
+                                               torch.cuda.current_stream().cuda_stream), "rqs_backward")
+    want_p, want_u = pd.grad.reshape(n, -1), ud.grad
+    # the same autograd in float32 on the CPU: how well conditioned each pair is in single precision
+    uf, pf32 = u.clone().requires_grad_(True), params.clone().requires_grad_(True)
+    yf, ladf = nfr.unconstrained_rational_quadratic_spline(uf, pf32[..., :K], pf32[..., K:2 * K], pf32[..., 2 * K:],
+                                                           tail_bound=tb)
+    ((yf * gy).sum() + (ladf * gl[:, None]).sum()).backward()
+
+    def errors(got_u, got_p):     # relative to the largest gradient of the same pair
+        eu = (got_u.double() - want_u).abs() / want_u.abs().clamp_min(1.0)
+        scale_p = want_p.reshape(n, D, -1).abs().amax(-1, keepdim=True).clamp_min(1.0)
+        ep = (got_p.double() - want_p).reshape(n, D, -1).abs() / scale_p
+        return torch.cat([eu.flatten(), ep.flatten()])
+
+    err, cpu32 = errors(gu.cpu(), gparams.cpu()), errors(uf.grad, pf32.grad.reshape(n, -1))
+    q = torch.quantile(err, torch.tensor([0.5, 0.99], dtype=torch.float64))
+    q32 = torch.quantile(cpu32, torch.tensor([0.5, 0.99], dtype=torch.float64))
+    # tight for the bulk; pairs within float32 rounding of a knot are conditioned worse for ANY fp32
+    # evaluation, so the tail is gated against the CPU's own float32 autograd
+    assert q[0] < 1e-6 and q[1] < max(5e-5, 3 * q32[1]) and err.max() < max(1e-2, 5 * cpu32.max()), (q, q32, err.max(), cpu32.max())
+    tails = (u.abs() > tb)
+    assert torch.equal(gu.cpu()[tails], gy[tails])                                    # identity in the tails
+    assert (gparams.cpu().reshape(n, D, -1)[tails] == 0).all()
+
+
+def test_training_forward_keeps_every_conditioner_input():
+    from helpers import flow_inputs, make_pair
+    D, C, L = 11, 288, 4
+    ref, _, flow = make_pair(D, C, 256, L, 16, 5.0)
+    order = [3, 0, 7, 1, 10, 2, 9, 4, 8, 5, 6]
+    ref.set_autoregressive_order(order), flow.set_autoregressive_order(order)
+    x, ctx = flow_inputs(200, D, C, 5.0)
+    U = torch.empty(L, 200, D, device="cuda")
+    z, ld, _ = flow._forward_call(x.cuda(), ctx.cuda(), None, layer_inputs=U)
+    with torch.no_grad():
+        cur, want = x[:, ref._ar_perm], []
+        for t in ref.transform._transforms:
+            if isinstance(t, nfr.ReversePermutation):
+                cur, _ = t(cur, ctx)
+            else:
+                want.append(cur)
+                cur, _ = t(cur, ctx)
+    for l in range(L):
+        torch.testing.assert_close(U[l].cpu(), want[l], rtol=1e-5, atol=2e-5)
+    torch.testing.assert_close(z.cpu(), cur, rtol=1e-5, atol=2e-5)
+    # the plain entry point and the training one agree bit for bit
+    z2, ld2, _ = flow._forward_call(x.cuda(), ctx.cuda(), None)
+    assert torch.equal(z, z2) and torch.equal(ld, ld2)
+
+
+@pytest.mark.parametrize("D,C,H,L,order", [(11, 288, 256, 3, None), (15, 288, 256, 2, "perm"), (4, 0, 64, 3, None)])
+def test_flow_gradients_match_oracle_autograd(D, C, H, L, order):
+    from helpers import flow_inputs, make_pair
+    ref, _, flow = make_pair(D, C, H, L, 16, 5.0)
+    if order:
+        perm = torch.randperm(D, generator=torch.Generator().manual_seed(1)).tolist()
+        ref.set_autoregressive_order(perm), flow.set_autoregressive_order(perm)
+    B = 96
+    x, ctx = flow_inputs(B, D, C, 5.0)
+    g = torch.Generator().manual_seed(4)
+    w, ls = torch.rand(B, generator=g) + 0.5, torch.randn(B, D, generator=g) * 0.2
+    xr = x.clone().requires_grad_(True)
+    cr = ctx.clone().requires_grad_(True) if C else None
+    lr = ls.clone().requires_grad_(True)
+    (ref.compute_psd_aware_nll(xr, cr, lr) * w).sum().backward()
+    xg = x.cuda().requires_grad_(True)
+    cg = ctx.cuda().requires_grad_(True) if C else None
+    lg = ls.cuda().requires_grad_(True)
+    (flow.compute_psd_aware_nll(xg, cg, lg) * w.cuda()).sum().backward()
+    rel = lambda a, b: ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
+    assert rel(xg.grad.cpu(), xr.grad) < 2e-4 and rel(lg.grad.cpu(), lr.grad) < 2e-5
+    if C:
+        assert rel(cg.grad.cpu(), cr.grad) < 2e-4
+    ref_params = dict(ref.named_parameters())
+    n_checked = 0
+    for name, p in flow.named_parameters():
+        if name.startswith("transform.") and p.grad is not None:
+            assert rel(p.grad.cpu(), ref_params[name].grad) < 3e-4, name
+            n_checked += 1
+    assert n_checked == L * (18 if C else 12)
+    # forward() is differentiable too: gradients of z and logdet
+    for m in (ref, flow):
+        m.zero_grad()
+    xr.grad = None
+    xg.grad = None
+    zr, ldr = ref(xr, cr)
+    (zr.square().sum() + (ldr * w).sum()).backward()
+    zg, ldg = flow(xg, cg)
+    (zg.square().sum() + (ldg * w.cuda()).sum()).backward()
+    assert rel(xg.grad.cpu(), xr.grad) < 2e-4
+    for name, p in flow.named_parameters():
+        if name.startswith("transform.") and p.grad is not None:
+            assert rel(p.grad.cpu(), ref_params[name].grad) < 3e-4, name

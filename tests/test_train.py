@@ -1,5 +1,4 @@
-"""Gradients and the training step: the flow's interim backward against the CPU oracle's autograd
-(same weights), the trainer recipe, and the data-parallel gradient all-reduce (gloo, 2 ranks)."""
+"""The training step: the trainer recipe, and the data-parallel gradient all-reduce (gloo, 2 ranks)."""
 import math
 import os
 import subprocess
@@ -48,38 +47,6 @@ def test_gradient_allreduce_gloo_world2(tmp_path):
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.count("ok") == 2
-
-
-@pytest.mark.gpu
-def test_flow_gradients_match_oracle_autograd():
-    from helpers import flow_inputs, make_pair
-    D, C = 11, 288
-    ref, _, flow = make_pair(D, C, 256, 3, 16, 5.0)
-    x, ctx = flow_inputs(96, D, C, 5.0)
-    w = torch.rand(96) + 0.5
-    # oracle: autograd through the CPU restatement
-    xr, cr = x.clone().requires_grad_(True), ctx.clone().requires_grad_(True)
-    (ref.compute_psd_aware_nll(xr, cr, torch.zeros_like(x)) * w).sum().backward()
-    # product: HIP forward value, interim tensor-op backward
-    xg, cg = x.cuda().requires_grad_(True), ctx.cuda().requires_grad_(True)
-    nll = flow.compute_psd_aware_nll(xg, cg, None)
-    with torch.no_grad():
-        assert torch.allclose(nll.cpu(), ref.compute_psd_aware_nll(x, ctx, torch.zeros_like(x)), rtol=1e-5, atol=1e-4)
-    (nll * w.cuda()).sum().backward()
-    rel = lambda a, b: ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
-    assert rel(xg.grad.cpu(), xr.grad) < 1e-3 and rel(cg.grad.cpu(), cr.grad) < 1e-3
-    ref_params = dict(ref.named_parameters())
-    n_checked = 0
-    for name, p in flow.named_parameters():
-        if name.startswith("transform.") and p.grad is not None:
-            assert rel(p.grad.cpu(), ref_params[name].grad) < 2e-3, name
-            n_checked += 1
-    assert n_checked == 3 * 18          # 18 parameter tensors per layer
-    # forward() is differentiable too (z and logdet)
-    flow.zero_grad()
-    z, ld = flow(xg, cg)
-    (z.square().sum() + ld.sum()).backward()
-    assert torch.isfinite(xg.grad).all()
 
 
 @pytest.mark.gpu
