@@ -5,5 +5,7 @@ from .flows import FLOW_NORM_BOUND, NSFPosteriorFlow, PSDScaledNormal, create_fl
 from .npe import (PARAM_NAMES, CoherentEncoder, LeanNPE, LeanStrainEncoder, ParamScaler,  # noqa: F401
                   batch_nll)
 
-__all__ = ["NSFPosteriorFlow", "PSDScaledNormal", "create_flow_model", "FLOW_NORM_BOUND",
+from .remix import RemixDataset  # noqa: F401
+
+__all__ = ["RemixDataset", "NSFPosteriorFlow", "PSDScaledNormal", "create_flow_model", "FLOW_NORM_BOUND",
            "LeanNPE", "LeanStrainEncoder", "CoherentEncoder", "ParamScaler", "PARAM_NAMES", "batch_nll"]

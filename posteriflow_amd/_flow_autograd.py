@@ -115,10 +115,9 @@ def _rqs_backward(flow, u, params, gy, glad, gparams):
 
 
 @torch.no_grad()
-def flow_backward(flow, U, ctx, g_z, g_lad):
+def _flow_backward_batched(flow, U, ctx, g_z, g_lad):
     """U [L, B, D] conditioner inputs kept by the forward kernel; g_z [B, D] = dL/dz, g_lad [B] =
-    dL/dlogdet.  Returns (dL/dx [B, D], dL/dctx or None, parameter gradients in
-    ``flow._ordered_parameters()`` order)."""
+    dL/dlogdet.  Returns dL/dx [B, D], dL/dctx (or None) and the parameter gradients batched over layers."""
     nets = [t.autoregressive_net for t in flow._ar_transforms]
     Ln, B, D = U.shape
     nb = len(nets[0].blocks)
@@ -193,23 +192,38 @@ def flow_backward(flow, U, ctx, g_z, g_lad):
     gW1 = [torch.bmm(Gt1[j].transpose(1, 2), F.relu(hs[j])) * m1[j] for j in range(nb)]
     gW2 = [torch.bmm(Gt2[j].transpose(1, 2), F.relu(t1s[j])) * m2[j] for j in range(nb)]
     gb1, gb2 = [g.sum(1) for g in Gt1], [g.sum(1) for g in Gt2]
-    g_ctx = None
+    g_ctx = gWcat = gbcat = None
     if has_ctx:
         flat = Gc.permute(2, 0, 1, 3).reshape(B, -1)                            # [B, L (1+nb) H]
         gWcat = (flat.t() @ ctx).view(Ln, 1 + nb, H, C)
         gbcat = flat.sum(0).view(Ln, 1 + nb, H)
         g_ctx = flat @ Wcat.reshape(-1, C)
+    return dict(g_x=g_x, g_ctx=g_ctx, W0=gW0, b0=gb0, Wf=gWf, bf=gbf, W1=gW1, b1=gb1, W2=gW2, b2=gb2,
+                Wcat=gWcat if has_ctx else None, bcat=gbcat if has_ctx else None)
+
+
+def _per_parameter(flow, g):
+    """the layer-batched gradients as one tensor per parameter, in ``flow._ordered_parameters()`` order."""
+    has_ctx, nb = g["Wcat"] is not None, len(g["W1"])
     grads = []
-    for l in range(Ln):
-        grads += [gW0[l], gb0[l]]
+    for l in range(g["W0"].shape[0]):
+        grads += [g["W0"][l], g["b0"][l]]
         if has_ctx:
-            grads += [gWcat[l, 0], gbcat[l, 0]]
+            grads += [g["Wcat"][l, 0], g["bcat"][l, 0]]
         for j in range(nb):
             if has_ctx:
-                grads += [gWcat[l, 1 + j], gbcat[l, 1 + j]]
-            grads += [gW1[j][l], gb1[j][l], gW2[j][l], gb2[j][l]]
-        grads += [gWf[l], gbf[l]]
-    return g_x, g_ctx, grads
+                grads += [g["Wcat"][l, 1 + j], g["bcat"][l, 1 + j]]
+            grads += [g["W1"][j][l], g["b1"][j][l], g["W2"][j][l], g["b2"][j][l]]
+        grads += [g["Wf"][l], g["bf"][l]]
+    return grads
+
+
+def flow_backward(flow, U, ctx, g_z, g_lad):
+    """(dL/dx, dL/dctx or None, per-parameter gradients in ``flow._ordered_parameters()`` order).
+    (Replaying the chain from a captured hipGraph was tried: inside a training step the launches are
+    already hidden behind queued encoder work, so it bought nothing and was dropped.)"""
+    g = _flow_backward_batched(flow, U, ctx, g_z.contiguous().float(), g_lad.contiguous().float())
+    return g["g_x"], g["g_ctx"], _per_parameter(flow, g)
 
 
 def _fast(flow) -> bool:

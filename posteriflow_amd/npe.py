@@ -363,13 +363,16 @@ class LeanNPE(nn.Module):
 
 def batch_nll(model: LeanNPE, strain, params, nsig, asd_bands=None):
     """Mean per-signal NLL of a batch of events with up to ``max_signals`` signals each
-    (experiments/train_lean_npe.py:108-127), as ONE flow call: the (event, rank) pairs with
-    rank < nsig are flattened instead of looping over ranks with host syncs (SURVEY H6);
-    sum / count is identical."""
+    (experiments/train_lean_npe.py:108-127), as ONE flow call over all (event, rank) pairs with a
+    0/1 weight for rank < nsig, instead of looping over ranks with a boolean-index host sync per rank
+    (SURVEY H6): sum / count is identical, shapes are static (every step launches the same kernels) and nothing
+    waits on the host."""
     context = model.encode(strain, asd_bands)
     b, r_max = params.shape[0], params.shape[1]
     ranks = torch.arange(r_max, device=nsig.device)[None, :].expand(b, r_max)
-    keep = ranks < nsig[:, None]
-    ev = torch.arange(b, device=nsig.device)[:, None].expand(b, r_max)[keep]
-    rk = ranks[keep]
-    return model.nll(None, params[ev, rk], rk, context=context[ev]).mean()
+    keep = (ranks < nsig[:, None]).reshape(-1)
+    # rows of absent ranks are all-zero labels (remix_data.py:229): give them a valid stand-in (rank 0 of
+    # the same event) so that the unused rows stay finite; their weight is 0
+    rows = torch.where(keep[:, None], params.reshape(b * r_max, -1), params[:, :1].expand(-1, r_max, -1).reshape(b * r_max, -1))
+    nll = model.nll(None, rows, ranks.reshape(-1), context=context.repeat_interleave(r_max, dim=0))
+    return torch.where(keep, nll, torch.zeros_like(nll)).sum() / keep.sum().clamp_min(1)

@@ -60,6 +60,21 @@ def main():
             out[f"{tag}_snr"] = np.array([float(r[3]) for r in rows], dtype=np.float32)
             if kw.get("return_asd_bands"):
                 out[f"{tag}_asd_bands"] = np.stack([r[4].numpy() for r in rows])
+    # ---- cache builder: the reference's build_memmap_cache on synthetic pickle chunks ----------------
+    import hashlib
+    import json
+    with tempfile.TemporaryDirectory() as tmp:
+        recipe.pickle_chunks(os.path.join(tmp, "data"))
+        meta = ref.build_memmap_cache(os.path.join(tmp, "data"), "train", os.path.join(tmp, "cache"))
+        for name in ("noise", "signals", "params"):
+            arr = np.load(os.path.join(tmp, "cache", f"{name}.npy"))
+            out[f"cache_{name}_shape"] = np.array(arr.shape)
+            out[f"cache_{name}_sha256"] = np.frombuffer(hashlib.sha256(arr.tobytes()).digest(), dtype=np.uint8)
+        out["cache_params"] = np.load(os.path.join(tmp, "cache", "params.npy"))
+        out["cache_events"] = np.array(meta["events"])
+        out["cache_counts"] = np.array([meta["n_noise"], meta["n_signals"]])
+        with open(os.path.join(tmp, "cache", "events.json")) as fh:
+            assert json.load(fh) == meta
     path = os.path.join(HERE, "remix.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, {k: v.shape for k, v in out.items() if k.startswith("plain")})

@@ -131,3 +131,49 @@ def remix_cache(out_dir: str, seed: int = 5, n_noise: int = 7, with_real_bank: b
                 np.save(os.path.join(bank, f"{d}_{j:02d}_strain.npy"), seg)
                 np.save(os.path.join(bank, f"{d}_{j:02d}_asd.npy"), asd)
     return {"n_noise": n_noise, "n_signals": m, "events": events}
+
+
+def pickle_chunks(data_dir: str, split: str = "train", seed: int = 17) -> None:
+    """Two ``batch_*.pkl`` chunks in the v2 component-storage schema the dataset generator writes
+    (dataset_generator.py:340-389): per sample ``detector_data[det] = {strain, snr, noise (f16),
+    signals [f16, ...]}``, ``parameters`` (list of dicts), ``event_type``.  Covers: a pure-noise sample,
+    a sample stored without components (skipped by the cache builder), 1-, 2- and 6-signal events (the
+    last is truncated to 5), parameters missing a key, and loudness order different from storage order."""
+    import os
+    import pickle
+
+    import numpy as np
+
+    rng = np.random.default_rng(seed)
+    names = ["mass_1", "mass_2", "luminosity_distance", "ra", "dec", "theta_jn", "psi", "phase",
+             "geocent_time", "a1", "a2"]
+
+    def pars(k, drop=None):
+        p = {n: float(v) for n, v in zip(names, rng.uniform(0.1, 1.0, len(names)))}
+        p["mass_1"], p["mass_2"] = 10.0 + 7.0 * ((k * 5) % 7), 8.0 + 3.0 * (k % 4)
+        p["luminosity_distance"] = 200.0 + 450.0 * ((k * 3) % 5)
+        p["event_type"] = "BBH"
+        if drop:
+            p.pop(drop)
+        return p
+
+    def sample(n_sig, kind="BBH", components=True, drop=None):
+        dd = {}
+        for det in ("H1", "L1", "V1"):
+            e = {"strain": rng.standard_normal(REMIX_T).astype(np.float32), "snr": 9.0}
+            if components:
+                e["noise"] = rng.standard_normal(REMIX_T).astype(np.float16)
+                e["signals"] = [(0.1 * rng.standard_normal(REMIX_T)).astype(np.float16) for _ in range(n_sig)]
+            dd[det] = e
+        plist = [pars(k, drop if k == 0 else None) for k in range(n_sig)]
+        if kind == "noise":
+            plist = [{"event_type": "noise"}]
+        return {"detector_data": dd, "parameters": plist, "n_signals": n_sig, "event_type": kind}
+
+    chunks = [[sample(2), sample(0, kind="noise"), sample(1, components=False)],
+              [sample(6), sample(1, drop="a2"), sample(3)]]
+    out = os.path.join(data_dir, split)
+    os.makedirs(out, exist_ok=True)
+    for i, samples in enumerate(chunks):
+        with open(os.path.join(out, f"batch_{i:05d}.pkl"), "wb") as fh:
+            pickle.dump({"samples": samples, "batch_id": i, "n_samples": len(samples)}, fh)
