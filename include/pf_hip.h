@@ -10,6 +10,7 @@
  *                     (executes nflows CompositeTransform / MADE / RQS, flows.py:459-529)
  *   pf_flow_inverse   NSFPosteriorFlow.inverse (transform part) src/ahsd/models/flows.py:620-655
  *   pf_flow_pack      the per-call `weight * mask` of nflows MaskedLinear, done once
+ *   pf_embed_fusion_forward  LeanStrainEncoder fusion transformer + pool attention  lean_npe.py:226-229
  *   pf_remix_forward  RemixDataset.__getitem__ (algebra)      experiments/remix_data.py:218-299
  *   pf_embed_stem_forward  LeanStrainEncoder stem + energy windows  src/ahsd/models/lean_npe.py:207-217
  *
@@ -153,6 +154,25 @@ int64_t pf_embed_stem_workspace_bytes(int32_t precision, int64_t n_sequences);
 int pf_embed_stem_forward(int32_t precision, const void* packed, const float* strain,
                           int64_t n_sequences, float* tokens, float* log_energy,
                           void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- strain-embedding token mixer ---------------------------------------------------------
+ * The 3 pre-norm Transformer layers (d_model 192, 6 heads, FFN 768, GELU) over an event's tokens and
+ * the key/value side of the 8-query attention pool, eval mode: replaces `self.fusion(tok)` and the
+ * attention of `self.pool_attn(queries, tok, tok)` in LeanStrainEncoder._compute_feats
+ * (src/ahsd/models/lean_npe.py:226-229; modules built at :167-176).  bf16 MFMA, fp32 accumulate.
+ * tokens [n_events][n_tokens][192] fp32 (stem output + positional + detector embedding, geometry tokens
+ * prepended for the coherent encoder) is UPDATED IN PLACE to the Transformer output;
+ * pool_queries [8][192] = (pool_queries W_q^T + b_q) / sqrt(32) (input-independent, computed by the
+ * caller); pooled [n_events][8][192] = concatenated heads of the pool attention BEFORE its out_proj.
+ * Raw parameters: flat fp32, per layer l = 0..2: norm1.weight, norm1.bias, self_attn.in_proj_weight
+ * [576,192], self_attn.in_proj_bias, self_attn.out_proj.weight [192,192], .bias, norm2.weight, norm2.bias,
+ * linear1.weight [768,192], .bias, linear2.weight [192,768], .bias; then pool_attn.in_proj_weight[192:576]
+ * ([384,192], the K and V rows) and pool_attn.in_proj_bias[192:576]. */
+int64_t pf_embed_fusion_raw_param_count(void);
+int64_t pf_embed_fusion_packed_bytes(void);
+int pf_embed_fusion_pack(const float* raw, void* packed, void* stream);
+int pf_embed_fusion_forward(const void* packed, float* tokens, int32_t n_tokens, const float* pool_queries,
+                            int64_t n_events, float* pooled, void* stream);
 
 /* ---- training-example remix ------------------------------------------
  * The deterministic half of RemixDataset.__getitem__ (experiments/remix_data.py:218-299) for a

@@ -99,23 +99,35 @@ def stem_forward(w: Dict[str, torch.Tensor], x, return_stages=False):
     return (x, stages) if return_stages else x
 
 
-def _mha(q_in, kv_in, in_w, in_b, out_w, out_b, n_heads):
-    """torch.nn.MultiheadAttention, batch_first, no mask, eval."""
+def _same(t):
+    return t
+
+
+def _mha(q_in, kv_in, in_w, in_b, out_w, out_b, n_heads, rnd=_same):
+    """torch.nn.MultiheadAttention, batch_first, no mask, eval.  ``rnd`` is applied to every matrix-product
+    operand (identity by default; the GPU tests pass a bf16 round trip to mirror the kernel's operand
+    rounding -- products and sums stay fp32 either way)."""
     B, Lq, E = q_in.shape
     Lk = kv_in.shape[1]
-    q = F.linear(q_in, in_w[:E], in_b[:E])
-    k = F.linear(kv_in, in_w[E:2 * E], in_b[E:2 * E])
-    v = F.linear(kv_in, in_w[2 * E:], in_b[2 * E:])
+    q = F.linear(rnd(q_in), rnd(in_w[:E]), in_b[:E])
+    k = F.linear(rnd(kv_in), rnd(in_w[E:2 * E]), in_b[E:2 * E])
+    v = F.linear(rnd(kv_in), rnd(in_w[2 * E:]), in_b[2 * E:])
     hd = E // n_heads
-    q = q.reshape(B, Lq, n_heads, hd).transpose(1, 2)
+    q = q.reshape(B, Lq, n_heads, hd).transpose(1, 2) / math.sqrt(hd)
     k = k.reshape(B, Lk, n_heads, hd).transpose(1, 2)
     v = v.reshape(B, Lk, n_heads, hd).transpose(1, 2)
-    att = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(hd), dim=-1)
-    o = (att @ v).transpose(1, 2).reshape(B, Lq, E)
-    return F.linear(o, out_w, out_b)
+    o = _softmax_weighted(rnd(q) @ rnd(k).transpose(-1, -2), v, rnd).transpose(1, 2).reshape(B, Lq, E)
+    return F.linear(rnd(o), rnd(out_w), out_b)
 
 
-def fusion_forward(w, tokens, n_layers=3, n_heads=6):
+def _softmax_weighted(scores, v, rnd=_same):
+    """softmax(scores) @ v written as (exp(s - max) @ v) / sum(exp(s - max)): the same value, with the
+    matrix-product operand being the UN-normalised weights (where a reduced-precision kernel rounds)."""
+    e = torch.exp(scores - scores.amax(dim=-1, keepdim=True))
+    return (rnd(e) @ rnd(v)) / e.sum(dim=-1, keepdim=True)
+
+
+def fusion_forward(w, tokens, n_layers=3, n_heads=6, rnd=_same):
     """pre-norm TransformerEncoderLayer x n_layers, GELU FFN, eval (LN:167-172)."""
     x = tokens
     E = x.shape[-1]
@@ -123,10 +135,10 @@ def fusion_forward(w, tokens, n_layers=3, n_heads=6):
         p = f"fusion.layers.{l}."
         y = F.layer_norm(x, (E,), w[p + "norm1.weight"], w[p + "norm1.bias"], 1e-5)
         x = x + _mha(y, y, w[p + "self_attn.in_proj_weight"], w[p + "self_attn.in_proj_bias"],
-                     w[p + "self_attn.out_proj.weight"], w[p + "self_attn.out_proj.bias"], n_heads)
+                     w[p + "self_attn.out_proj.weight"], w[p + "self_attn.out_proj.bias"], n_heads, rnd)
         y = F.layer_norm(x, (E,), w[p + "norm2.weight"], w[p + "norm2.bias"], 1e-5)
-        y = F.linear(F.gelu(F.linear(y, w[p + "linear1.weight"], w[p + "linear1.bias"])),
-                     w[p + "linear2.weight"], w[p + "linear2.bias"])
+        y = F.linear(rnd(F.gelu(F.linear(rnd(y), rnd(w[p + "linear1.weight"]), w[p + "linear1.bias"]))),
+                     rnd(w[p + "linear2.weight"]), w[p + "linear2.bias"])
         x = x + y
     return x
 

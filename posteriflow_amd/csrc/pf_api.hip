@@ -15,6 +15,11 @@ void stem_build_pack_map(bool bf16, int32_t* map);
 int64_t stem_workspace_bytes(bool bf16, int64_t n_seq);
 int stem_forward(bool bf16, const char* packed, const float* strain, int64_t n_seq, float* tokens,
                  float* log_energy, char* ws, hipStream_t s);
+int64_t fusion_raw_count();
+int64_t fusion_packed_bytes();
+int fusion_pack(const float* raw, char* packed, hipStream_t s);
+int fusion_forward(const char* packed, float* tokens, int n_tokens, const float* pool_q, int64_t n_events,
+                   float* pooled, hipStream_t s);
 int64_t remix_workspace_bytes(int64_t batch);
 int remix_forward(const void* noise, int64_t n_noise, const void* signals, int64_t n_signals,
                   const int64_t* noise_row, const int64_t* sig_start, const int32_t* nsig, const float* scale,
@@ -233,6 +238,29 @@ int pf_embed_stem_forward(int32_t precision, const void* packed, const float* st
         return fail(PF_ERR_BAD_ARG, "packed/strain/tokens must be 16-byte, workspace 256-byte aligned");
     const int rc = pf::stem_forward(bf, static_cast<const char*>(packed), strain, n_sequences, tokens, log_energy,
                                     static_cast<char*>(workspace), static_cast<hipStream_t>(stream));
+    return rc == PF_OK ? rc : fail(rc, hipGetErrorString(hipGetLastError()));
+}
+
+// ---- strain-embedding token mixer (fusion transformer + attention pool) ------------------------
+int64_t pf_embed_fusion_raw_param_count(void) { return pf::fusion_raw_count(); }
+int64_t pf_embed_fusion_packed_bytes(void) { return pf::fusion_packed_bytes(); }
+int pf_embed_fusion_pack(const float* raw, void* packed, void* stream) {
+    if (!raw || !packed) return fail(PF_ERR_BAD_ARG, "null pointer");
+    if (misaligned(packed, 16) || misaligned(raw, 4)) return fail(PF_ERR_BAD_ARG, "packed must be 16-byte aligned");
+    const int rc = pf::fusion_pack(raw, static_cast<char*>(packed), static_cast<hipStream_t>(stream));
+    return rc == PF_OK ? rc : fail(rc, hipGetErrorString(hipGetLastError()));
+}
+int pf_embed_fusion_forward(const void* packed, float* tokens, int32_t n_tokens, const float* pool_queries,
+                            int64_t n_events, float* pooled, void* stream) {
+    if (n_events < 0) return fail(PF_ERR_BAD_ARG, "negative n_events");
+    if (n_events == 0) return PF_OK;
+    if (n_tokens < 1 || n_tokens > 192) return fail(PF_ERR_UNSUPPORTED, "1 <= n_tokens <= 192 tokens per event");
+    if (n_events > 0x7fffffff) return fail(PF_ERR_UNSUPPORTED, "too many events per call");
+    if (!packed || !tokens || !pool_queries || !pooled) return fail(PF_ERR_BAD_ARG, "null pointer");
+    if (misaligned(packed, 16) || misaligned(tokens, 16) || misaligned(pooled, 16) || misaligned(pool_queries, 4))
+        return fail(PF_ERR_BAD_ARG, "packed/tokens/pooled must be 16-byte aligned");
+    const int rc = pf::fusion_forward(static_cast<const char*>(packed), tokens, n_tokens, pool_queries, n_events, pooled,
+                                      static_cast<hipStream_t>(stream));
     return rc == PF_OK ? rc : fail(rc, hipGetErrorString(hipGetLastError()));
 }
 

@@ -1,0 +1,432 @@
+// pf_fusion.hip -- the strain encoder's token mixer on gfx950: the 3 pre-norm Transformer layers
+// (LayerNorm -> 6-head self-attention -> residual, LayerNorm -> 192-768-192 GELU FFN -> residual)
+// and the key/value side of the 8-query attention pool, fused in ONE kernel, ONE workgroup per event
+// (reference: LeanStrainEncoder.fusion / pool_attn, src/ahsd/models/lean_npe.py:167-176, 226-229,
+// executed through nn.TransformerEncoder / nn.MultiheadAttention in eval mode).
+//
+// An event is T <= 192 tokens x 192 features (183 for three detectors, +4 geometry tokens for the
+// coherent encoder): 12 token tiles of 16.  Everything is computed TRANSPOSED like the flow kernel,
+//   out^T[feature, token] = W[feature, k] . act^T[k, token]          (v_mfma_f32_16x16x32_bf16)
+// so the weights are the A operand, read straight from their packed fragment order in L2 (1 KiB per
+// fragment), and the activations are the
+// B operand, read from LDS where they live as bf16 [token][feature] rows (row stride 400 B: the 16
+// lanes of a fragment read hit 16 distinct 4-bank groups).  The fp32 residual stream stays in the
+// event's own 147 KB of global memory (L2 resident) and is read-modify-written by the wave that owns the
+// (feature block, token block): 2 round trips per layer.
+//   4 waves, one per SIMD with the whole 512-register budget; dense layers: wave = (feature block of 3
+//   tiles) x all 12 token tiles: 36 MFMAs per 3 weight + 12 activation fragment loads, every weight
+//   fragment is read by exactly one wave; per-head QKV: (3 of the head's 6 Q|K|V tiles) x (6 token tiles).
+//   attention, per (head, 16-query tile): S^T = K . Q^T is 12 MFMAs (the head dimension is one k-step),
+//   softmax over keys in registers (columns = queries: 4 rows per lane x 12 tiles, then two xor-shuffles),
+//   O^T = V^T . P^T with P taken from the S accumulators WITHOUT leaving registers: the k-step's key
+//   order is permuted to the accumulator layout (slot 8g+j <- key 32s+4g+j | 32s+16+4g+j-4) and V^T is
+//   read from LDS in the same order.  Each head's output goes through LDS once into the out-projection,
+//   which accumulates over heads in registers; the FFN hidden layer goes through LDS in 4 chunks of 192
+//   and never exists in full.  LDS: 76 800 (normalised tokens) + 76 800 (Q|K|V^T|O or hidden chunk).
+// bf16 operands, fp32 accumulation, fp32 LayerNorm / softmax / GELU (erf) / residual.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/pf_hip.h"
+
+namespace pf {
+namespace {
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int kE = 192, kHeads = 6, kHd = 32, kFF = 768, kLayers = 3, kPoolQ = 8;
+constexpr int kTok = 192, kTT = 12;                   // padded tokens, token tiles
+constexpr int kXS = 400, kQS = 80, kVS = 400;          // LDS byte strides: [tok][192], [tok][32], V^T [32][192]
+constexpr int kBuf = kTok * kXS;                       // 76 800
+constexpr int kLds = 2 * kBuf;
+constexpr int kFrag = 1024;
+
+// ---- packed parameter block --------------------------------------------------------------------
+// per layer: Wqkv 36 tiles x 6 k-steps | Wo 12 x 6 | W1 48 x 6 | W2 12 x 24 fragments, then fp32
+// ln1_g ln1_b bqkv bo ln2_g ln2_b b1 b2; after the layers: pool Wkv 24 x 6 fragments, bkv fp32.
+constexpr int64_t kWqkv = 0, kWo = kWqkv + 36 * 6 * kFrag, kW1 = kWo + 12 * 6 * kFrag, kW2 = kW1 + 48 * 6 * kFrag;
+constexpr int64_t kVec = kW2 + 12 * 24 * kFrag;
+constexpr int kVecFloats = 192 + 192 + 576 + 192 + 192 + 192 + 768 + 192;      // 2496
+constexpr int kLn1g = 0, kLn1b = 192, kBqkv = 384, kBo = 960, kLn2g = 1152, kLn2b = 1344, kB1 = 1536, kB2 = 2304;
+constexpr int64_t kLayerBytes = kVec + kVecFloats * 4;
+constexpr int64_t kPoolW = kLayers * kLayerBytes, kPoolB = kPoolW + 24 * 6 * kFrag;
+constexpr int64_t kPackedBytes = kPoolB + 384 * 4;
+// raw fp32 parameter order (state_dict order of the modules involved), per layer:
+//   norm1.weight norm1.bias self_attn.in_proj_weight[576,192] self_attn.in_proj_bias
+//   self_attn.out_proj.weight[192,192] .bias norm2.weight norm2.bias linear1.weight[768,192] .bias
+//   linear2.weight[192,768] .bias;  then pool_attn.in_proj_weight[192:576] and in_proj_bias[192:576]
+constexpr int64_t kRawLayer = 192 + 192 + 576 * 192 + 576 + 192 * 192 + 192 + 192 + 192 + 768 * 192 + 768 + 192 * 768 + 192;
+constexpr int64_t kRawCount = kLayers * kRawLayer + 384 * 192 + 384;
+
+struct FusionParams {
+    const char* packed;
+    float* x;                // [n_events][T][192] fp32, updated in place
+    const float* pool_q;     // [8][192] projected queries, already divided by sqrt(32)
+    float* pooled;           // [n_events][8][192] attention-pool output before its out-projection
+    int T;
+};
+
+template <int N> struct ic { static constexpr int value = N; };
+
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
+__device__ __forceinline__ f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ bf16x4 to_bf16(f32x4 v) {
+    bf16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+    return o;
+}
+
+__global__ __launch_bounds__(256) void fusion_kernel(FusionParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const xn = smem;                       // normalised tokens, bf16 [192][400 B]
+    char* const hb = smem + kBuf;                // FFN hidden chunk, bf16 [192][400 B]   (aliases the four below)
+    char* const qb = smem + kBuf;                // Q  [192][80 B]
+    char* const kb = qb + kTok * kQS;            // K  [192][80 B]
+    char* const vt = kb + kTok * kQS;            // V^T [32][400 B]
+    char* const ob = vt + kHd * kVS;             // O  [192][80 B]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int T = p.T;
+    float* const X = p.x + static_cast<int64_t>(blockIdx.x) * T * kE;
+    const int fblk = w;                          // dense layers: 4 feature blocks (3 tiles) x all 12 token tiles
+    const int fb2 = w & 1, tb2 = w >> 1;         // per-head projections: 2 feature blocks x 2 token blocks (6 tiles)
+
+    // tokens (global fp32) -> LDS bf16, optionally LayerNorm-ed; rows >= T are zero
+    auto stage_tokens = [&](const float* gamma, const float* beta) {
+        for (int t = w; t < kTok; t += 4) {
+            float v[3] = {0.f, 0.f, 0.f};
+            if (t < T) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) v[i] = X[t * kE + lane + 64 * i];
+                if (gamma) {
+                    float s = v[0] + v[1] + v[2];
+                    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+                    const float mean = s * (1.f / kE);
+                    float q = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) { v[i] -= mean; q += v[i] * v[i]; }
+                    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+                    const float rstd = rsqrtf(q * (1.f / kE) + 1e-5f);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) v[i] = v[i] * rstd * gamma[lane + 64 * i] + beta[lane + 64 * i];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) *reinterpret_cast<__bf16*>(xn + t * kXS + (lane + 64 * i) * 2) = (__bf16)v[i];
+        }
+    };
+    auto afrag = [&](const char* wbase, int tile, int ksteps, int ks) {
+        return *reinterpret_cast<const bf16x8*>(wbase + (static_cast<int64_t>(tile * ksteps + ks) * 64 + lane) * 16);
+    };
+    auto bx = [&](const char* buf, int tt, int ks) {           // [tok][192] buffers
+        return *reinterpret_cast<const bf16x8*>(buf + (16 * tt + c) * kXS + ks * 64 + g * 16);
+    };
+    auto bq = [&](const char* buf, int tt) {                   // [tok][32] buffers (also the A operand K)
+        return *reinterpret_cast<const bf16x8*>(buf + (16 * tt + c) * kQS + g * 16);
+    };
+    // dense block: acc[3][6] += W[tiles ft0..ft0+2][k-steps ks0..ks0+KS) . B
+    // dense block over NT token tiles starting at tile t0: acc[3][NT] += W[tiles ft0..ft0+2][k-steps] . B
+    auto dense = [&](auto& acc, int t0, const char* wbase, int ft0, int ksteps, int ks0, auto nks, auto&& bload) {
+        constexpr int NT = sizeof(acc[0]) / sizeof(f32x4);
+#pragma unroll 2
+        for (int ks = 0; ks < decltype(nks)::value; ++ks) {
+            bf16x8 a[3], b[NT];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) a[i] = afrag(wbase, ft0 + i, ksteps, ks0 + ks);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) b[j] = bload(t0 + j, ks);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = mfma(a[i], b[j], acc[i][j]);
+        }
+    };
+    auto zero36 = [&](f32x4 (&acc)[3][kTT]) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < kTT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    // X[tok][16 ft + 4g ..] += acc + bias for the wave's (feature block, token block)
+    auto residual = [&](const f32x4 (&acc)[3][kTT], const float* bias) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int f0 = 16 * (3 * fblk + i) + 4 * g;
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + f0);
+#pragma unroll
+            for (int j = 0; j < kTT; ++j) {
+                const int tok = 16 * j + c;
+                if (tok < T) {
+                    f32x4* px = reinterpret_cast<f32x4*>(X + tok * kE + f0);
+                    *px = *px + acc[i][j] + b4;
+                }
+            }
+        }
+    };
+    // one (head, 16-query tile): softmax(K Q^T) V with keys >= T masked; result O^T tiles (2 x f32x4)
+    auto attend = [&](int qt, f32x4 (&o)[2]) {
+        const bf16x8 qf = bq(qb, qt);
+        f32x4 s[kTT];
+        float m = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < kTT; ++kt) {
+            s[kt] = mfma(bq(kb, kt), qf, f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (16 * kt + 4 * g + e >= T) s[kt][e] = -INFINITY;
+                m = fmaxf(m, s[kt][e]);
+            }
+        }
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < kTT; ++kt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s[kt][e] = __expf(s[kt][e] - m); sum += s[kt][e]; }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        o[0] = o[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ss = 0; ss < kTT / 2; ++ss) {
+            bf16x8 pf;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { pf[e] = (__bf16)s[2 * ss][e]; pf[4 + e] = (__bf16)s[2 * ss + 1][e]; }
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const char* row = vt + (16 * dt + c) * kVS;
+                const bf16x4 lo = *reinterpret_cast<const bf16x4*>(row + (32 * ss + 4 * g) * 2);
+                const bf16x4 hi = *reinterpret_cast<const bf16x4*>(row + (32 * ss + 16 + 4 * g) * 2);
+                bf16x8 vf;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { vf[e] = lo[e]; vf[4 + e] = hi[e]; }
+                o[dt] = mfma(vf, pf, o[dt]);
+            }
+        }
+        const float inv = 1.f / sum;
+        o[0] = o[0] * inv;
+        o[1] = o[1] * inv;
+    };
+    // projection epilogues: a 16 x 16 tile of Q / K (token-major rows) or V (transposed)
+    auto put_qk = [&](char* buf, int dt, int tt, f32x4 v) {
+        *reinterpret_cast<bf16x4*>(buf + (16 * tt + c) * kQS + (16 * dt + 4 * g) * 2) = to_bf16(v);
+    };
+    auto put_vt = [&](int dt, int tt, f32x4 v) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            *reinterpret_cast<__bf16*>(vt + (16 * dt + 4 * g + e) * kVS + (16 * tt + c) * 2) = (__bf16)v[e];
+    };
+
+    f32x4 acc[3][kTT];
+    for (int l = 0; l < kLayers; ++l) {
+        const char* lw = p.packed + l * kLayerBytes;
+        const float* vec = reinterpret_cast<const float*>(lw + kVec);
+        // ================= self-attention block =================
+        stage_tokens(vec + kLn1g, vec + kLn1b);
+        __syncthreads();
+        zero36(acc);
+        for (int h = 0; h < kHeads; ++h) {
+            {   // Q | K | V of head h: this wave's 3 of the 6 tiles x its 3 token tiles
+                f32x4 t[3][6];
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) t[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                // tile index in the 36-tile in_proj: Q 2h,2h+1 | K 12+2h,12+2h+1 | V 24+2h,24+2h+1
+                int tile[3];
+                tile[0] = fb2 == 0 ? 2 * h : 12 + 2 * h + 1;
+                tile[1] = fb2 == 0 ? 2 * h + 1 : 24 + 2 * h;
+                tile[2] = fb2 == 0 ? 12 + 2 * h : 24 + 2 * h + 1;
+#pragma unroll 3
+                for (int ks = 0; ks < 6; ++ks) {
+                    bf16x8 a[3], b[6];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) a[i] = afrag(lw + kWqkv, tile[i], 6, ks);
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) b[j] = bx(xn, 6 * tb2 + j, ks);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) t[i][j] = mfma(a[i], b[j], t[i][j]);
+                }
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(vec + kBqkv + 16 * tile[i] + 4 * g);
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        const int tt = 6 * tb2 + j;
+                        const f32x4 v = t[i][j] + b4;
+                        if (fb2 == 0) {
+                            if (i == 0) put_qk(qb, 0, tt, v * 0.17677669529663687f);
+                            else if (i == 1) put_qk(qb, 1, tt, v * 0.17677669529663687f);
+                            else put_qk(kb, 0, tt, v);
+                        } else {
+                            if (i == 0) put_qk(kb, 1, tt, v);
+                            else put_vt(i - 1, tt, v);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            for (int qt = w; qt < kTT; qt += 4) {
+                f32x4 o[2];
+                attend(qt, o);
+                put_qk(ob, 0, qt, o[0]);
+                put_qk(ob, 1, qt, o[1]);
+            }
+            __syncthreads();
+            // out-projection, accumulated over heads: k-step h of Wo against this head's O
+            dense(acc, 0, lw + kWo, 3 * fblk, 6, h, ic<1>{}, [&](int tt, int) { return bq(ob, tt); });
+        }
+        residual(acc, vec + kBo);
+        __syncthreads();
+        // ================= feed-forward block =================
+        stage_tokens(vec + kLn2g, vec + kLn2b);
+        __syncthreads();
+        zero36(acc);
+        for (int ch = 0; ch < kFF / kE; ++ch) {
+            for (int half = 0; half < 2; ++half) {       // 6 token tiles at a time (register budget)
+                f32x4 t[3][6];
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) t[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                dense(t, 6 * half, lw + kW1, 12 * ch + 3 * fblk, 6, 0, ic<6>{}, [&](int tt, int ks) { return bx(xn, tt, ks); });
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const int f0 = 16 * (3 * fblk + i) + 4 * g;              // feature within the chunk
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(vec + kB1 + kE * ch + f0);
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        f32x4 v = t[i][j] + b4;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                        *reinterpret_cast<bf16x4*>(hb + (16 * (6 * half + j) + c) * kXS + f0 * 2) = to_bf16(v);
+                    }
+                }
+            }
+            __syncthreads();
+            dense(acc, 0, lw + kW2, 3 * fblk, 24, 6 * ch, ic<6>{}, [&](int tt, int ks) { return bx(hb, tt, ks); });
+            __syncthreads();
+        }
+        residual(acc, vec + kB2);
+        __syncthreads();
+    }
+
+    // ================= attention pool: keys / values of the final tokens, 8 projected queries ========
+    stage_tokens(nullptr, nullptr);
+    __syncthreads();
+    const float* bkv = reinterpret_cast<const float*>(p.packed + kPoolB);
+    for (int h = 0; h < kHeads; ++h) {
+        {   // K | V of head h: 2 tiles per wave x 3 token tiles (tile space: K 0..11 | V 12..23)
+            f32x4 t[2][6];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) t[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int tile0 = (fb2 == 0 ? 0 : 12) + 2 * h;
+#pragma unroll
+            for (int ks = 0; ks < 6; ++ks) {
+                bf16x8 a[2], b[6];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) a[i] = afrag(p.packed + kPoolW, tile0 + i, 6, ks);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) b[j] = bx(xn, 6 * tb2 + j, ks);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) t[i][j] = mfma(a[i], b[j], t[i][j]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(bkv + 16 * (tile0 + i) + 4 * g);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    if (fb2 == 0) put_qk(kb, i, 6 * tb2 + j, t[i][j] + b4);
+                    else put_vt(i, 6 * tb2 + j, t[i][j] + b4);
+                }
+            }
+            // the head's 8 queries (rows 8..15 of the tile are zero)
+            for (int i = tid; i < 16 * kHd; i += 256) {
+                const int q = i >> 5, d = i & 31;
+                const float v = q < kPoolQ ? p.pool_q[q * kE + kHd * h + d] : 0.f;
+                *reinterpret_cast<__bf16*>(qb + q * kQS + d * 2) = (__bf16)v;
+            }
+        }
+        __syncthreads();
+        if (w == 0) {
+            f32x4 o[2];
+            attend(0, o);
+            if (c < kPoolQ) {
+                float* dst = p.pooled + (static_cast<int64_t>(blockIdx.x) * kPoolQ + c) * kE + kHd * h + 4 * g;
+                *reinterpret_cast<f32x4*>(dst) = o[0];
+                *reinterpret_cast<f32x4*>(dst + 16) = o[1];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// raw fp32 [N][K] row-major -> bf16 A fragments: fragment (tile, ks), lane (g, r): W[16 tile + r][32 ks + 8 g ..+7]
+__global__ void pack_frags_kernel(const float* wsrc, int n_rows, int k, __bf16* out) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= static_cast<int64_t>(n_rows) * k) return;
+    const int ksteps = k / 32;
+    const int e = i & 7, lane = (i >> 3) & 63;
+    const int64_t f = i >> 9;
+    const int tile = static_cast<int>(f / ksteps), ks = static_cast<int>(f % ksteps);
+    out[i] = (__bf16)wsrc[static_cast<int64_t>(16 * tile + (lane & 15)) * k + 32 * ks + 8 * (lane >> 4) + e];
+}
+}  // namespace
+
+int64_t fusion_raw_count() { return kRawCount; }
+int64_t fusion_packed_bytes() { return kPackedBytes; }
+
+int fusion_pack(const float* raw, char* packed, hipStream_t s) {
+    auto frags = [&](const float* src, int n, int k, int64_t off) {
+        const int64_t tot = static_cast<int64_t>(n) * k;
+        pack_frags_kernel<<<dim3(static_cast<unsigned>((tot + 255) / 256)), dim3(256), 0, s>>>(
+            src, n, k, reinterpret_cast<__bf16*>(packed + off));
+    };
+    auto vec = [&](const float* src, int n, int64_t off) {
+        (void)hipMemcpyAsync(packed + off, src, static_cast<size_t>(n) * 4, hipMemcpyDeviceToDevice, s);
+    };
+    const float* r = raw;
+    for (int l = 0; l < kLayers; ++l) {
+        const int64_t base = l * kLayerBytes, vb = base + kVec;
+        vec(r, 192, vb + 4 * kLn1g); r += 192;
+        vec(r, 192, vb + 4 * kLn1b); r += 192;
+        frags(r, 576, 192, base + kWqkv); r += 576 * 192;
+        vec(r, 576, vb + 4 * kBqkv); r += 576;
+        frags(r, 192, 192, base + kWo); r += 192 * 192;
+        vec(r, 192, vb + 4 * kBo); r += 192;
+        vec(r, 192, vb + 4 * kLn2g); r += 192;
+        vec(r, 192, vb + 4 * kLn2b); r += 192;
+        frags(r, 768, 192, base + kW1); r += 768 * 192;
+        vec(r, 768, vb + 4 * kB1); r += 768;
+        frags(r, 192, 768, base + kW2); r += 192 * 768;
+        vec(r, 192, vb + 4 * kB2); r += 192;
+    }
+    frags(r, 384, 192, kPoolW); r += 384 * 192;
+    vec(r, 384, kPoolB);
+    return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
+}
+
+int fusion_forward(const char* packed, float* tokens, int n_tokens, const float* pool_q, int64_t n_events,
+                   float* pooled, hipStream_t s) {
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(fusion_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess)
+            return PF_ERR_HIP;
+        configured = true;
+    }
+    FusionParams p{packed, tokens, pool_q, pooled, n_tokens};
+    fusion_kernel<<<dim3(static_cast<unsigned>(n_events)), dim3(256), kLds, s>>>(p);
+    return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
+}
+}  // namespace pf

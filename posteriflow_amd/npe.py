@@ -195,6 +195,49 @@ class LeanStrainEncoder(nn.Module):
     def _fuse(self, tokens):
         return self.fusion(tokens)
 
+    # --- HIP token mixer: fusion transformer + pool attention in one kernel (bf16 mode, eval) ----------
+    def _mixer_params(self):
+        out = []
+        for layer in self.fusion.layers:
+            out += [layer.norm1.weight, layer.norm1.bias, layer.self_attn.in_proj_weight, layer.self_attn.in_proj_bias,
+                    layer.self_attn.out_proj.weight, layer.self_attn.out_proj.bias, layer.norm2.weight, layer.norm2.bias,
+                    layer.linear1.weight, layer.linear1.bias, layer.linear2.weight, layer.linear2.bias]
+        return out + [self.pool_attn.in_proj_weight, self.pool_attn.in_proj_bias]
+
+    def _mixer_supported(self) -> bool:
+        a = self.fusion.layers[0]
+        return (len(self.fusion.layers) == 3 and a.self_attn.embed_dim == 192 and a.self_attn.num_heads == 6
+                and a.linear1.out_features == 768 and self.pool_queries.shape == (8, 192)
+                and self.pool_attn.num_heads == 6 and self.fusion.norm is None)
+
+    def _mix_hip(self, tok):
+        """[B, 8 * 192] pooled features from tokens [B, T, 192] (T <= 192): one pf_embed_fusion_forward call
+        (3 Transformer layers + pool attention) and the pool's out-projection."""
+        L, dev = _lib.lib(), tok.device
+        params = self._mixer_params()
+        key = (dev, tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
+        st = self.__dict__.setdefault("_mixer_state", {})
+        if st.get("key") != key:
+            e = 192
+            raw = torch.cat([p.detach().reshape(-1).float() for p in params[:-2]]
+                            + [params[-2].detach()[e:].reshape(-1).float(), params[-1].detach()[e:].float()])
+            assert raw.numel() == L.pf_embed_fusion_raw_param_count()
+            if st.get("packed") is None or st["packed"].device != dev:
+                st["packed"] = torch.empty(L.pf_embed_fusion_packed_bytes(), dtype=torch.uint8, device=dev)
+            _lib.check(L.pf_embed_fusion_pack(raw.data_ptr(), st["packed"].data_ptr(),
+                                              torch.cuda.current_stream(dev).cuda_stream), "pf_embed_fusion_pack")
+            st["key"] = key
+        b, t, _ = tok.shape
+        tok = tok.float().contiguous()              # the kernel updates its token buffer in place
+        e = 192
+        w, bias = self.pool_attn.in_proj_weight, self.pool_attn.in_proj_bias
+        q = ((self.pool_queries.float() @ w[:e].float().t() + bias[:e].float()) * (1.0 / math.sqrt(32.0))).contiguous()
+        pooled = torch.empty(b, 8, e, dtype=torch.float32, device=dev)
+        _lib.check(L.pf_embed_fusion_forward(st["packed"].data_ptr(), tok.data_ptr(), t, q.data_ptr(), b,
+                                             pooled.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
+                   "pf_embed_fusion_forward")
+        return self.pool_attn.out_proj(pooled).reshape(b, -1)
+
     def _compute_feats(self, strain, asd_bands=None, extra_tokens=None):
         """[B, 8*d_model + 64 (+32)] pre-projection features and the sanitised strain (LN:199-243)."""
         b, d, _ = strain.shape
@@ -216,8 +259,13 @@ class LeanStrainEncoder(nn.Module):
         tok = tok.reshape(b, d * n_tok, e)
         if extra_tokens is not None:
             tok = torch.cat([extra_tokens, tok], dim=1)
-        tok = self._fuse(tok)
-        pooled, _ = self.pool_attn(self.pool_queries.unsqueeze(0).expand(b, -1, -1), tok, tok)
+        mixer_grad = torch.is_grad_enabled() and (tok.requires_grad or any(p.requires_grad for p in self._mixer_params()))
+        if (self.precision == "bf16" and tok.device.type == "cuda" and not self.training and not mixer_grad
+                and tok.shape[1] <= 192 and self._mixer_supported()):
+            pooled = self._mix_hip(tok)                    # fused HIP token mixer
+        else:      # fp32 parity mode, training (dropout, autograd) or another geometry: device tensor ops
+            tok = self._fuse(tok)
+            pooled, _ = self.pool_attn(self.pool_queries.unsqueeze(0).expand(b, -1, -1), tok, tok)
         parts = [pooled.reshape(b, -1), energy]
         if self.psd_bands > 0:
             if asd_bands is None:
