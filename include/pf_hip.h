@@ -160,8 +160,9 @@ int pf_embed_stem_forward(int32_t precision, const void* packed, const float* st
  * the key/value side of the 8-query attention pool, eval mode: replaces `self.fusion(tok)` and the
  * attention of `self.pool_attn(queries, tok, tok)` in LeanStrainEncoder._compute_feats
  * (src/ahsd/models/lean_npe.py:226-229; modules built at :167-176).  bf16 MFMA, fp32 accumulate.
- * tokens [n_events][n_tokens][192] fp32 (stem output + positional + detector embedding, geometry tokens
- * prepended for the coherent encoder) is UPDATED IN PLACE to the Transformer output;
+ * tokens [n_events][n_tokens][192] fp32 (stem output, geometry tokens prepended for the coherent
+ * encoder) is UPDATED IN PLACE to the Transformer output; token_bias [n_tokens][192] (or NULL) is added to
+ * every event's tokens first: the positional + detector embedding of lean_npe.py:218-222;
  * pool_queries [8][192] = (pool_queries W_q^T + b_q) / sqrt(32) (input-independent, computed by the
  * caller); pooled [n_events][8][192] = concatenated heads of the pool attention BEFORE its out_proj.
  * Raw parameters: flat fp32, per layer l = 0..2: norm1.weight, norm1.bias, self_attn.in_proj_weight
@@ -171,8 +172,8 @@ int pf_embed_stem_forward(int32_t precision, const void* packed, const float* st
 int64_t pf_embed_fusion_raw_param_count(void);
 int64_t pf_embed_fusion_packed_bytes(void);
 int pf_embed_fusion_pack(const float* raw, void* packed, void* stream);
-int pf_embed_fusion_forward(const void* packed, float* tokens, int32_t n_tokens, const float* pool_queries,
-                            int64_t n_events, float* pooled, void* stream);
+int pf_embed_fusion_forward(const void* packed, float* tokens, int32_t n_tokens, const float* token_bias,
+                            const float* pool_queries, int64_t n_events, float* pooled, void* stream);
 
 /* ---- training-example remix ------------------------------------------
  * The deterministic half of RemixDataset.__getitem__ (experiments/remix_data.py:218-299) for a

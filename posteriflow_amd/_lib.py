@@ -60,8 +60,8 @@ SYMBOLS = {
     "pf_embed_fusion_raw_param_count": (C.c_int64, []),
     "pf_embed_fusion_packed_bytes": (C.c_int64, []),
     "pf_embed_fusion_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
-    "pf_embed_fusion_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,
-                                          C.c_void_p]),
+    "pf_embed_fusion_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,
+                                          C.c_void_p, C.c_void_p]),
     "pf_remix_workspace_bytes": (C.c_int64, [C.c_int64]),
     "pf_remix_forward": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,

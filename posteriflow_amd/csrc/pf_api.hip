@@ -18,8 +18,8 @@ int stem_forward(bool bf16, const char* packed, const float* strain, int64_t n_s
 int64_t fusion_raw_count();
 int64_t fusion_packed_bytes();
 int fusion_pack(const float* raw, char* packed, hipStream_t s);
-int fusion_forward(const char* packed, float* tokens, int n_tokens, const float* pool_q, int64_t n_events,
-                   float* pooled, hipStream_t s);
+int fusion_forward(const char* packed, float* tokens, int n_tokens, const float* tok_bias, const float* pool_q,
+                   int64_t n_events, float* pooled, hipStream_t s);
 int64_t remix_workspace_bytes(int64_t batch);
 int remix_forward(const void* noise, int64_t n_noise, const void* signals, int64_t n_signals,
                   const int64_t* noise_row, const int64_t* sig_start, const int32_t* nsig, const float* scale,
@@ -250,16 +250,17 @@ int pf_embed_fusion_pack(const float* raw, void* packed, void* stream) {
     const int rc = pf::fusion_pack(raw, static_cast<char*>(packed), static_cast<hipStream_t>(stream));
     return rc == PF_OK ? rc : fail(rc, hipGetErrorString(hipGetLastError()));
 }
-int pf_embed_fusion_forward(const void* packed, float* tokens, int32_t n_tokens, const float* pool_queries,
-                            int64_t n_events, float* pooled, void* stream) {
+int pf_embed_fusion_forward(const void* packed, float* tokens, int32_t n_tokens, const float* token_bias,
+                            const float* pool_queries, int64_t n_events, float* pooled, void* stream) {
     if (n_events < 0) return fail(PF_ERR_BAD_ARG, "negative n_events");
     if (n_events == 0) return PF_OK;
     if (n_tokens < 1 || n_tokens > 192) return fail(PF_ERR_UNSUPPORTED, "1 <= n_tokens <= 192 tokens per event");
     if (n_events > 0x7fffffff) return fail(PF_ERR_UNSUPPORTED, "too many events per call");
     if (!packed || !tokens || !pool_queries || !pooled) return fail(PF_ERR_BAD_ARG, "null pointer");
-    if (misaligned(packed, 16) || misaligned(tokens, 16) || misaligned(pooled, 16) || misaligned(pool_queries, 4))
-        return fail(PF_ERR_BAD_ARG, "packed/tokens/pooled must be 16-byte aligned");
-    const int rc = pf::fusion_forward(static_cast<const char*>(packed), tokens, n_tokens, pool_queries, n_events, pooled,
+    if (misaligned(packed, 16) || misaligned(tokens, 16) || misaligned(pooled, 16) || misaligned(pool_queries, 4) ||
+        misaligned(token_bias, 16))
+        return fail(PF_ERR_BAD_ARG, "packed/tokens/token_bias/pooled must be 16-byte aligned");
+    const int rc = pf::fusion_forward(static_cast<const char*>(packed), tokens, n_tokens, token_bias, pool_queries, n_events, pooled,
                                       static_cast<hipStream_t>(stream));
     return rc == PF_OK ? rc : fail(rc, hipGetErrorString(hipGetLastError()));
 }

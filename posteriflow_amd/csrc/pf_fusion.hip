@@ -10,9 +10,12 @@
 // so the weights are the A operand, read straight from their packed fragment order in L2 (1 KiB per
 // fragment), and the activations are the
 // B operand, read from LDS where they live as bf16 [token][feature] rows (row stride 400 B: the 16
-// lanes of a fragment read hit 16 distinct 4-bank groups).  The fp32 residual stream stays in the
-// event's own 147 KB of global memory (L2 resident) and is read-modify-written by the wave that owns the
-// (feature block, token block): 2 round trips per layer.
+// lanes of a fragment read hit 16 distinct 4-bank groups).  The fp32 residual stream lives in REGISTERS for
+// the whole kernel, in the accumulator layout of the wave that owns the feature block (144 registers per
+// lane): the out-projection and the second FFN matmul accumulate straight into it, LayerNorm reads it from
+// there (token statistics cross the 4 waves through 6 KB of LDS), and global memory is touched only when the
+// tokens are loaded and when the result is stored (with one wave per SIMD every global round trip would be
+// fully exposed: the first version, with the residual in L2, spent 3/4 of its time waiting on it).
 //   4 waves, one per SIMD with the whole 512-register budget; dense layers: wave = (feature block of 3
 //   tiles) x all 12 token tiles: 36 MFMAs per 3 weight + 12 activation fragment loads, every weight
 //   fragment is read by exactly one wave; per-head QKV: (3 of the head's 6 Q|K|V tiles) x (6 token tiles).
@@ -40,7 +43,7 @@ constexpr int kE = 192, kHeads = 6, kHd = 32, kFF = 768, kLayers = 3, kPoolQ = 8
 constexpr int kTok = 192, kTT = 12;                   // padded tokens, token tiles
 constexpr int kXS = 400, kQS = 80, kVS = 400;          // LDS byte strides: [tok][192], [tok][32], V^T [32][192]
 constexpr int kBuf = kTok * kXS;                       // 76 800
-constexpr int kLds = 2 * kBuf;
+constexpr int kLds = 2 * kBuf + 4 * kTok * 8;         // + per-wave token statistics
 constexpr int kFrag = 1024;
 
 // ---- packed parameter block --------------------------------------------------------------------
@@ -63,6 +66,7 @@ constexpr int64_t kRawCount = kLayers * kRawLayer + 384 * 192 + 384;
 struct FusionParams {
     const char* packed;
     float* x;                // [n_events][T][192] fp32, updated in place
+    const float* tok_bias;   // [T][192] added to every event's tokens on load (positional + detector), or null
     const float* pool_q;     // [8][192] projected queries, already divided by sqrt(32)
     float* pooled;           // [n_events][8][192] attention-pool output before its out-projection
     int T;
@@ -70,7 +74,6 @@ struct FusionParams {
 
 template <int N> struct ic { static constexpr int value = N; };
 
-__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
 __device__ __forceinline__ f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
@@ -79,6 +82,28 @@ __device__ __forceinline__ bf16x4 to_bf16(f32x4 v) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
     return o;
+}
+// exact-form GELU 0.5 v (1 + erf(v / sqrt 2)) on 4 values, erf by Abramowitz & Stegun 7.1.26
+// (|error| <= 1.5e-7, far below the bf16 rounding the result gets).  Written on vectors so that the
+// polynomial runs on packed fp32 instructions; rcp / exp2 are the only per-element transcendental ops.
+// (erff costs ~40 instructions per value; the FFN evaluates 421 K GELUs per event.)
+__device__ __forceinline__ f32x4 gelu4(f32x4 v) {
+    f32x4 x, t, e;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = fabsf(v[k]);
+    x = x * 0.70710678118654752f;
+    const f32x4 d = x * 0.3275911f + 1.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t[k] = __builtin_amdgcn_rcpf(d[k]);
+    const f32x4 poly = t * (t * (t * (t * (t * 1.061405429f - 1.453152027f) + 1.421413741f) - 0.284496736f) + 0.254829592f);
+    const f32x4 a = x * x * -1.4426950408889634f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) e[k] = __builtin_amdgcn_exp2f(a[k]);
+    const f32x4 erf_abs = 1.f - poly * e;
+    f32x4 r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = copysignf(erf_abs[k], v[k]);
+    return v * 0.5f * (r + 1.f);
 }
 
 __global__ __launch_bounds__(256) void fusion_kernel(FusionParams p) {
@@ -89,34 +114,89 @@ __global__ __launch_bounds__(256) void fusion_kernel(FusionParams p) {
     char* const kb = qb + kTok * kQS;            // K  [192][80 B]
     char* const vt = kb + kTok * kQS;            // V^T [32][400 B]
     char* const ob = vt + kHd * kVS;             // O  [192][80 B]
+    float2* const stats = reinterpret_cast<float2*>(smem + 2 * kBuf);   // [4 waves][192 tokens] (sum, sum of squares)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
     const int T = p.T;
-    float* const X = p.x + static_cast<int64_t>(blockIdx.x) * T * kE;
+    float* const Xg = p.x + static_cast<int64_t>(blockIdx.x) * T * kE;
     const int fblk = w;                          // dense layers: 4 feature blocks (3 tiles) x all 12 token tiles
     const int fb2 = w & 1, tb2 = w >> 1;         // per-head projections: 2 feature blocks x 2 token blocks (6 tiles)
+    constexpr float kQScale = 0.17677669529663687f;      // 1 / sqrt(head dim), applied where torch applies it
+    constexpr float kLog2e = 1.4426950408889634f;
 
-    // tokens (global fp32) -> LDS bf16, optionally LayerNorm-ed; rows >= T are zero
-    auto stage_tokens = [&](const float* gamma, const float* beta) {
-        for (int t = w; t < kTok; t += 4) {
-            float v[3] = {0.f, 0.f, 0.f};
-            if (t < T) {
+    // ---- the fp32 residual stream lives in registers for the whole kernel: X[i][j] = features
+    // 16 (3 w + i) + 4 g .. +3 of token 16 j + c (the MFMA accumulator layout of this wave's block), so
+    // that the out-projection and the second FFN matmul accumulate straight into it
+    f32x4 X[3][kTT];
 #pragma unroll
-                for (int i = 0; i < 3; ++i) v[i] = X[t * kE + lane + 64 * i];
-                if (gamma) {
-                    float s = v[0] + v[1] + v[2];
-                    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-                    const float mean = s * (1.f / kE);
-                    float q = 0.f;
+    for (int i = 0; i < 3; ++i) {
+        const int f0 = 16 * (3 * fblk + i) + 4 * g;
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) { v[i] -= mean; q += v[i] * v[i]; }
-                    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
-                    const float rstd = rsqrtf(q * (1.f / kE) + 1e-5f);
+        for (int j = 0; j < kTT; ++j) {
+            const int tok = 16 * j + c;
+            X[i][j] = tok < T ? *reinterpret_cast<const f32x4*>(Xg + tok * kE + f0) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    if (p.tok_bias) {
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) v[i] = v[i] * rstd * gamma[lane + 64 * i] + beta[lane + 64 * i];
-                }
+        for (int i = 0; i < 3; ++i) {
+            const int f0 = 16 * (3 * fblk + i) + 4 * g;
+#pragma unroll
+            for (int j = 0; j < kTT; ++j) {
+                const int tok = 16 * j + c;
+                if (tok < T) X[i][j] = X[i][j] + *reinterpret_cast<const f32x4*>(p.tok_bias + tok * kE + f0);
             }
+        }
+    }
+
+    // residual (registers) -> LDS bf16 [token][feature], LayerNorm-ed when gamma is given; rows >= T zero.
+    // Token statistics need all 192 features = all 4 waves: per-wave partial (sum, sum of squares) through LDS.
+    auto stage_tokens = [&](const float* gamma, const float* beta) {
+        float mean[kTT], rstd[kTT];
+        if (gamma) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) *reinterpret_cast<__bf16*>(xn + t * kXS + (lane + 64 * i) * 2) = (__bf16)v[i];
+            for (int j = 0; j < kTT; ++j) {
+                float s = 0.f, q = 0.f;
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { s += X[i][j][e]; q += X[i][j][e] * X[i][j][e]; }
+                s += __shfl_xor(s, 16, 64); q += __shfl_xor(q, 16, 64);
+                s += __shfl_xor(s, 32, 64); q += __shfl_xor(q, 32, 64);
+                if (g == 0) stats[w * kTok + 16 * j + c] = make_float2(s, q);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < kTT; ++j) {
+                const int tok = 16 * j + c;
+                const float2 a0 = stats[tok], a1 = stats[kTok + tok], a2 = stats[2 * kTok + tok], a3 = stats[3 * kTok + tok];
+                const float m = ((a0.x + a1.x) + (a2.x + a3.x)) * (1.f / kE);
+                const float var = ((a0.y + a1.y) + (a2.y + a3.y)) * (1.f / kE) - m * m;
+                mean[j] = m;
+                rstd[j] = rsqrtf(fmaxf(var, 0.f) + 1e-5f);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int f0 = 16 * (3 * fblk + i) + 4 * g;
+            f32x4 ga = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f};
+            if (gamma) { ga = *reinterpret_cast<const f32x4*>(gamma + f0); be = *reinterpret_cast<const f32x4*>(beta + f0); }
+#pragma unroll
+            for (int j = 0; j < kTT; ++j) {
+                const int tok = 16 * j + c;
+                f32x4 v = X[i][j];
+                if (gamma) v = (v - mean[j]) * rstd[j] * ga + be;
+                if (tok >= T) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<bf16x4*>(xn + tok * kXS + f0 * 2) = to_bf16(v);
+            }
+        }
+        __syncthreads();
+    };
+    auto add_bias = [&](const float* bias) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + 16 * (3 * fblk + i) + 4 * g);
+#pragma unroll
+            for (int j = 0; j < kTT; ++j) X[i][j] = X[i][j] + b4;
         }
     };
     auto afrag = [&](const char* wbase, int tile, int ksteps, int ks) {
@@ -128,7 +208,6 @@ __global__ __launch_bounds__(256) void fusion_kernel(FusionParams p) {
     auto bq = [&](const char* buf, int tt) {                   // [tok][32] buffers (also the A operand K)
         return *reinterpret_cast<const bf16x8*>(buf + (16 * tt + c) * kQS + g * 16);
     };
-    // dense block: acc[3][6] += W[tiles ft0..ft0+2][k-steps ks0..ks0+KS) . B
     // dense block over NT token tiles starting at tile t0: acc[3][NT] += W[tiles ft0..ft0+2][k-steps] . B
     auto dense = [&](auto& acc, int t0, const char* wbase, int ft0, int ksteps, int ks0, auto nks, auto&& bload) {
         constexpr int NT = sizeof(acc[0]) / sizeof(f32x4);
@@ -145,29 +224,8 @@ __global__ __launch_bounds__(256) void fusion_kernel(FusionParams p) {
                 for (int j = 0; j < NT; ++j) acc[i][j] = mfma(a[i], b[j], acc[i][j]);
         }
     };
-    auto zero36 = [&](f32x4 (&acc)[3][kTT]) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < kTT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    };
-    // X[tok][16 ft + 4g ..] += acc + bias for the wave's (feature block, token block)
-    auto residual = [&](const f32x4 (&acc)[3][kTT], const float* bias) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int f0 = 16 * (3 * fblk + i) + 4 * g;
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + f0);
-#pragma unroll
-            for (int j = 0; j < kTT; ++j) {
-                const int tok = 16 * j + c;
-                if (tok < T) {
-                    f32x4* px = reinterpret_cast<f32x4*>(X + tok * kE + f0);
-                    *px = *px + acc[i][j] + b4;
-                }
-            }
-        }
-    };
-    // one (head, 16-query tile): softmax(K Q^T) V with keys >= T masked; result O^T tiles (2 x f32x4)
+    // one (head, 16-query tile): softmax(K Q^T) V with keys >= T masked; result O^T tiles (2 x f32x4).
+    // exp(s - m) = exp2(s log2e - m log2e): one packed fma + a bare v_exp_f32 per score.
     auto attend = [&](int qt, f32x4 (&o)[2]) {
         const bf16x8 qf = bq(qb, qt);
         f32x4 s[kTT];
@@ -175,19 +233,24 @@ __global__ __launch_bounds__(256) void fusion_kernel(FusionParams p) {
 #pragma unroll
         for (int kt = 0; kt < kTT; ++kt) {
             s[kt] = mfma(bq(kb, kt), qf, f32x4{0.f, 0.f, 0.f, 0.f});
+            if (16 * kt + 16 > T) {                 // (uniform) only the tiles that hold padded keys
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (16 * kt + 4 * g + e >= T) s[kt][e] = -INFINITY;
-                m = fmaxf(m, s[kt][e]);
+                for (int e = 0; e < 4; ++e)
+                    if (16 * kt + 4 * g + e >= T) s[kt][e] = -INFINITY;
             }
+            m = fmaxf(fmaxf(m, fmaxf(s[kt][0], s[kt][1])), fmaxf(s[kt][2], s[kt][3]));
         }
         m = fmaxf(m, __shfl_xor(m, 16, 64));
         m = fmaxf(m, __shfl_xor(m, 32, 64));
-        float sum = 0.f;
+        f32x4 sum4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kt = 0; kt < kTT; ++kt)
+        for (int kt = 0; kt < kTT; ++kt) {
+            s[kt] = s[kt] * kLog2e - m * kLog2e;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { s[kt][e] = __expf(s[kt][e] - m); sum += s[kt][e]; }
+            for (int e = 0; e < 4; ++e) s[kt][e] = __builtin_amdgcn_exp2f(s[kt][e]);
+            sum4 = sum4 + s[kt];
+        }
+        float sum = (sum4[0] + sum4[1]) + (sum4[2] + sum4[3]);
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
         o[0] = o[1] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -207,7 +270,7 @@ __global__ __launch_bounds__(256) void fusion_kernel(FusionParams p) {
                 o[dt] = mfma(vf, pf, o[dt]);
             }
         }
-        const float inv = 1.f / sum;
+        const float inv = __builtin_amdgcn_rcpf(sum);
         o[0] = o[0] * inv;
         o[1] = o[1] * inv;
     };
@@ -221,16 +284,14 @@ __global__ __launch_bounds__(256) void fusion_kernel(FusionParams p) {
             *reinterpret_cast<__bf16*>(vt + (16 * dt + 4 * g + e) * kVS + (16 * tt + c) * 2) = (__bf16)v[e];
     };
 
-    f32x4 acc[3][kTT];
     for (int l = 0; l < kLayers; ++l) {
         const char* lw = p.packed + l * kLayerBytes;
         const float* vec = reinterpret_cast<const float*>(lw + kVec);
         // ================= self-attention block =================
         stage_tokens(vec + kLn1g, vec + kLn1b);
-        __syncthreads();
-        zero36(acc);
+        add_bias(vec + kBo);
         for (int h = 0; h < kHeads; ++h) {
-            {   // Q | K | V of head h: this wave's 3 of the 6 tiles x its 3 token tiles
+            {   // Q | K | V of head h: this wave's 3 of the 6 tiles x its 6 token tiles
                 f32x4 t[3][6];
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
@@ -261,8 +322,8 @@ __global__ __launch_bounds__(256) void fusion_kernel(FusionParams p) {
                         const int tt = 6 * tb2 + j;
                         const f32x4 v = t[i][j] + b4;
                         if (fb2 == 0) {
-                            if (i == 0) put_qk(qb, 0, tt, v * 0.17677669529663687f);
-                            else if (i == 1) put_qk(qb, 1, tt, v * 0.17677669529663687f);
+                            if (i == 0) put_qk(qb, 0, tt, v * kQScale);
+                            else if (i == 1) put_qk(qb, 1, tt, v * kQScale);
                             else put_qk(kb, 0, tt, v);
                         } else {
                             if (i == 0) put_qk(kb, 1, tt, v);
@@ -279,15 +340,13 @@ __global__ __launch_bounds__(256) void fusion_kernel(FusionParams p) {
                 put_qk(ob, 1, qt, o[1]);
             }
             __syncthreads();
-            // out-projection, accumulated over heads: k-step h of Wo against this head's O
-            dense(acc, 0, lw + kWo, 3 * fblk, 6, h, ic<1>{}, [&](int tt, int) { return bq(ob, tt); });
+            // out-projection straight into the residual: k-step h of Wo against this head's O
+            dense(X, 0, lw + kWo, 3 * fblk, 6, h, ic<1>{}, [&](int tt, int) { return bq(ob, tt); });
         }
-        residual(acc, vec + kBo);
-        __syncthreads();
+        __syncthreads();                                   // ob / hb alias: all out-projections done
         // ================= feed-forward block =================
         stage_tokens(vec + kLn2g, vec + kLn2b);
-        __syncthreads();
-        zero36(acc);
+        add_bias(vec + kB2);
         for (int ch = 0; ch < kFF / kE; ++ch) {
             for (int half = 0; half < 2; ++half) {       // 6 token tiles at a time (register budget)
                 f32x4 t[3][6];
@@ -301,35 +360,38 @@ __global__ __launch_bounds__(256) void fusion_kernel(FusionParams p) {
                     const int f0 = 16 * (3 * fblk + i) + 4 * g;              // feature within the chunk
                     const f32x4 b4 = *reinterpret_cast<const f32x4*>(vec + kB1 + kE * ch + f0);
 #pragma unroll
-                    for (int j = 0; j < 6; ++j) {
-                        f32x4 v = t[i][j] + b4;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-                        *reinterpret_cast<bf16x4*>(hb + (16 * (6 * half + j) + c) * kXS + f0 * 2) = to_bf16(v);
-                    }
+                    for (int j = 0; j < 6; ++j)
+                        *reinterpret_cast<bf16x4*>(hb + (16 * (6 * half + j) + c) * kXS + f0 * 2) = to_bf16(gelu4(t[i][j] + b4));
                 }
             }
             __syncthreads();
-            dense(acc, 0, lw + kW2, 3 * fblk, 24, 6 * ch, ic<6>{}, [&](int tt, int ks) { return bx(hb, tt, ks); });
+            dense(X, 0, lw + kW2, 3 * fblk, 24, 6 * ch, ic<6>{}, [&](int tt, int ks) { return bx(hb, tt, ks); });
             __syncthreads();
         }
-        residual(acc, vec + kB2);
-        __syncthreads();
+    }
+    // the Transformer output (in-place contract of the entry point)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int f0 = 16 * (3 * fblk + i) + 4 * g;
+#pragma unroll
+        for (int j = 0; j < kTT; ++j) {
+            const int tok = 16 * j + c;
+            if (tok < T) *reinterpret_cast<f32x4*>(Xg + tok * kE + f0) = X[i][j];
+        }
     }
 
     // ================= attention pool: keys / values of the final tokens, 8 projected queries ========
     stage_tokens(nullptr, nullptr);
-    __syncthreads();
     const float* bkv = reinterpret_cast<const float*>(p.packed + kPoolB);
     for (int h = 0; h < kHeads; ++h) {
-        {   // K | V of head h: 2 tiles per wave x 3 token tiles (tile space: K 0..11 | V 12..23)
+        {   // K | V of head h: 2 tiles per wave x 6 token tiles (tile space: K 0..11 | V 12..23)
             f32x4 t[2][6];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 6; ++j) t[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             const int tile0 = (fb2 == 0 ? 0 : 12) + 2 * h;
-#pragma unroll
+#pragma unroll 3
             for (int ks = 0; ks < 6; ++ks) {
                 bf16x8 a[2], b[6];
 #pragma unroll
@@ -416,8 +478,8 @@ int fusion_pack(const float* raw, char* packed, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
 }
 
-int fusion_forward(const char* packed, float* tokens, int n_tokens, const float* pool_q, int64_t n_events,
-                   float* pooled, hipStream_t s) {
+int fusion_forward(const char* packed, float* tokens, int n_tokens, const float* tok_bias, const float* pool_q,
+                   int64_t n_events, float* pooled, hipStream_t s) {
     static bool configured = false;
     if (!configured) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(fusion_kernel),
@@ -425,7 +487,7 @@ int fusion_forward(const char* packed, float* tokens, int n_tokens, const float*
             return PF_ERR_HIP;
         configured = true;
     }
-    FusionParams p{packed, tokens, pool_q, pooled, n_tokens};
+    FusionParams p{packed, tokens, tok_bias, pool_q, pooled, n_tokens};
     fusion_kernel<<<dim3(static_cast<unsigned>(n_events)), dim3(256), kLds, s>>>(p);
     return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
 }

@@ -210,15 +210,16 @@ class LeanStrainEncoder(nn.Module):
                 and a.linear1.out_features == 768 and self.pool_queries.shape == (8, 192)
                 and self.pool_attn.num_heads == 6 and self.fusion.norm is None)
 
-    def _mix_hip(self, tok):
+    def _mix_hip(self, tok, token_bias=None):
         """[B, 8 * 192] pooled features from tokens [B, T, 192] (T <= 192): one pf_embed_fusion_forward call
-        (3 Transformer layers + pool attention) and the pool's out-projection."""
+        (token_bias add + 3 Transformer layers + pool attention) and the pool's out-projection.  ``tok`` is
+        overwritten with the Transformer output."""
         L, dev = _lib.lib(), tok.device
         params = self._mixer_params()
         key = (dev, tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
         st = self.__dict__.setdefault("_mixer_state", {})
+        e = 192
         if st.get("key") != key:
-            e = 192
             raw = torch.cat([p.detach().reshape(-1).float() for p in params[:-2]]
                             + [params[-2].detach()[e:].reshape(-1).float(), params[-1].detach()[e:].float()])
             assert raw.numel() == L.pf_embed_fusion_raw_param_count()
@@ -228,42 +229,52 @@ class LeanStrainEncoder(nn.Module):
                                               torch.cuda.current_stream(dev).cuda_stream), "pf_embed_fusion_pack")
             st["key"] = key
         b, t, _ = tok.shape
-        tok = tok.float().contiguous()              # the kernel updates its token buffer in place
-        e = 192
+        assert tok.dtype == torch.float32 and tok.is_contiguous()
         w, bias = self.pool_attn.in_proj_weight, self.pool_attn.in_proj_bias
-        q = ((self.pool_queries.float() @ w[:e].float().t() + bias[:e].float()) * (1.0 / math.sqrt(32.0))).contiguous()
+        with torch.autocast("cuda", enabled=False):
+            q = ((self.pool_queries.float() @ w[:e].float().t() + bias[:e].float()) * (1.0 / math.sqrt(32.0))).contiguous()
         pooled = torch.empty(b, 8, e, dtype=torch.float32, device=dev)
-        _lib.check(L.pf_embed_fusion_forward(st["packed"].data_ptr(), tok.data_ptr(), t, q.data_ptr(), b,
-                                             pooled.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
-                   "pf_embed_fusion_forward")
+        tb = None if token_bias is None else token_bias.float().contiguous()
+        _lib.check(L.pf_embed_fusion_forward(st["packed"].data_ptr(), tok.data_ptr(), t, 0 if tb is None else tb.data_ptr(),
+                                             q.data_ptr(), b, pooled.data_ptr(),
+                                             torch.cuda.current_stream(dev).cuda_stream), "pf_embed_fusion_forward")
         return self.pool_attn.out_proj(pooled).reshape(b, -1)
 
     def _compute_feats(self, strain, asd_bands=None, extra_tokens=None):
         """[B, 8*d_model + 64 (+32)] pre-projection features and the sanitised strain (LN:199-243)."""
         b, d, _ = strain.shape
-        clean = self._sanitize(strain)
         needs_grad = torch.is_grad_enabled() and (
             strain.requires_grad or any(p.requires_grad for p in self._stem_params()))
+        clean = None
         if self._allow_tensor_op_stem or (needs_grad and strain.device.type == "cuda"):
-            # interim backward path: the HIP stem has no backward kernels yet, so a differentiable
-            # call evaluates the stem with device tensor ops under autograd (DESIGN.md "Backward");
-            # _allow_tensor_op_stem additionally opens this path off the GPU for CPU wiring tests only
+            # differentiable call: the HIP stem has no backward kernels, so the stem is evaluated with
+            # device tensor ops under autograd (DESIGN.md 4.4); _allow_tensor_op_stem additionally opens
+            # this path off the GPU for CPU wiring tests only
+            clean = self._sanitize(strain)
             tok, log_energy = self._stem(clean), self._window_log_energy(clean)
         elif self.n_energy_windows != 16:
             raise NotImplementedError("pf_embed_stem_forward computes 16 energy windows")
         else:
-            tok, log_energy = self._stem_hip(strain)       # raises off the GPU: no CPU fallback
+            tok, log_energy = self._stem_hip(strain)       # sanitises in-kernel; raises off the GPU: no CPU fallback
         energy = self.energy_mlp(log_energy.reshape(b, -1))
         n_tok, e = tok.shape[1], tok.shape[2]
-        tok = (tok + self.pos(n_tok)).reshape(b, d, n_tok, e) + self.detector_embed.weight[None, :d, None, :]
-        tok = tok.reshape(b, d * n_tok, e)
-        if extra_tokens is not None:
-            tok = torch.cat([extra_tokens, tok], dim=1)
+        # positional + detector embedding of every token of an event (LN:218-222); geometry tokens get none
+        tok_bias = (self.pos(n_tok)[None] + self.detector_embed.weight[:d, None, :]).reshape(d * n_tok, e)
+        n_extra = 0 if extra_tokens is None else extra_tokens.shape[1]
+        n_total = d * n_tok + n_extra
         mixer_grad = torch.is_grad_enabled() and (tok.requires_grad or any(p.requires_grad for p in self._mixer_params()))
         if (self.precision == "bf16" and tok.device.type == "cuda" and not self.training and not mixer_grad
-                and tok.shape[1] <= 192 and self._mixer_supported()):
-            pooled = self._mix_hip(tok)                    # fused HIP token mixer (DESIGN.md 4.7)
+                and n_total <= 192 and self._mixer_supported()):
+            # fused HIP token mixer (DESIGN.md 4.7): embedding add + 3 Transformer layers + pool attention
+            tok = tok.float().reshape(b, d * n_tok, e)
+            if n_extra:
+                tok = torch.cat([extra_tokens.float(), tok], dim=1)
+                tok_bias = torch.cat([tok_bias.new_zeros(n_extra, e), tok_bias.float()], dim=0)
+            pooled = self._mix_hip(tok.contiguous(), tok_bias)
         else:      # fp32 parity mode, training (dropout, autograd) or another geometry: device tensor ops
+            tok = (tok.reshape(b, d, n_tok, e) + tok_bias.reshape(1, d, n_tok, e)).reshape(b, d * n_tok, e)
+            if extra_tokens is not None:
+                tok = torch.cat([extra_tokens, tok], dim=1)
             tok = self._fuse(tok)
             pooled, _ = self.pool_attn(self.pool_queries.unsqueeze(0).expand(b, -1, -1), tok, tok)
         parts = [pooled.reshape(b, -1), energy]

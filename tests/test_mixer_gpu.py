@@ -43,7 +43,7 @@ def F_linear(x, w, b):
     return torch.nn.functional.linear(x, w, b)
 
 
-def _run_kernel(enc, tok):
+def _run_kernel(enc, tok, tok_bias=None):
     from posteriflow_amd import _lib
     n_events, T, E = tok.shape
     enc = enc.cuda()
@@ -53,8 +53,10 @@ def _run_kernel(enc, tok):
     packed = enc.__dict__["_mixer_state"]["packed"]
     q = ((enc.pool_queries @ enc.pool_attn.in_proj_weight[:E].t() + enc.pool_attn.in_proj_bias[:E]) / math.sqrt(32)).contiguous()
     pooled = torch.empty(n_events, 8, E, device="cuda")
-    _lib.check(_lib.lib().pf_embed_fusion_forward(packed.data_ptr(), x.data_ptr(), T, q.data_ptr(), n_events,
-                                                  pooled.data_ptr(), torch.cuda.current_stream().cuda_stream), "fusion")
+    tb = None if tok_bias is None else tok_bias.cuda().contiguous()
+    _lib.check(_lib.lib().pf_embed_fusion_forward(packed.data_ptr(), x.data_ptr(), T, 0 if tb is None else tb.data_ptr(),
+                                                  q.data_ptr(), n_events, pooled.data_ptr(),
+                                                  torch.cuda.current_stream().cuda_stream), "fusion")
     return x.cpu(), pooled.cpu()
 
 
@@ -80,7 +82,8 @@ def test_one_layer_is_exact_up_to_rounding_boundary_flips(keep):
     tok = torch.randn(3, 183, 192, generator=torch.Generator().manual_seed(1)) * 0.7
     with torch.no_grad():
         out_emu, pool_emu = _oracle_mix(w, tok, bf16_rt)
-    got_out, got_pool = _run_kernel(enc, tok)
+    bias = torch.randn(183, 192, generator=torch.Generator().manual_seed(2)) * 0.3 if keep == "both" else None
+    got_out, got_pool = _run_kernel(enc, tok if bias is None else tok - bias, bias)     # token_bias is added on load
     assert (got_out - tok).abs().median() > 0.05                    # the block did something
     d_out, d_pool = (got_out - out_emu).abs(), (got_pool - pool_emu).abs()
     assert d_out.median() < 2e-6 and d_out.max() < 1.5e-2, (d_out.median(), d_out.max())
@@ -128,4 +131,4 @@ def test_encoder_bf16_uses_the_hip_mixer_and_agrees_with_fp32_mode():
         assert "_mixer_state" not in enc.__dict__
     with pytest.raises(NotImplementedError):
         from posteriflow_amd import _lib
-        _lib.check(_lib.lib().pf_embed_fusion_forward(1, 1, 200, 1, 1, 1, 0), "fusion")
+        _lib.check(_lib.lib().pf_embed_fusion_forward(1, 1, 200, 0, 1, 1, 1, 0), "fusion")
