@@ -10,6 +10,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpfhip.so")
+if os.environ.get("PF_LIBPFHIP"):          # kernel experiments: an alternative build of the same library
+    LIB_PATH = os.environ["PF_LIBPFHIP"]
 
 PF_OK, PF_ERR_BAD_ARG, PF_ERR_UNSUPPORTED, PF_ERR_HIP = 0, -1, -2, -3
 PF_PREC_F32, PF_PREC_BF16 = 0, 1
