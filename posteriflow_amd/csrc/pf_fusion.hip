@@ -121,7 +121,7 @@ __device__ __forceinline__ f32x4 gelu4(f32x4 v) {
     return v * 0.5f * (r + 1.f);
 }
 
-__global__ __launch_bounds__(256) void fusion_kernel(FusionParams p) {
+__global__ __launch_bounds__(512) void fusion_kernel(FusionParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const xn = smem;                       // normalised tokens, bf16 [192][384 B]
     char* const hb = smem + kBuf;                // FFN hidden chunk, bf16 [192][384 B]   (aliases the four below)
@@ -133,8 +133,8 @@ __global__ __launch_bounds__(256) void fusion_kernel(FusionParams p) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
     const int T = p.T;
     float* const Xg = p.x + static_cast<int64_t>(blockIdx.x) * T * kE;
-    const int fblk = w;                          // dense layers: 4 feature blocks (3 tiles) x all 12 token tiles
-    const int fb2 = w & 1, tb2 = w >> 1;         // per-head projections: 2 feature blocks x 2 token blocks (6 tiles)
+    const int fblk = w & 3, th = w >> 2;         // dense layers: 4 feature blocks (3 tiles) x 2 token halves (6 tiles)
+    const int fb2 = w & 1, tb4 = w >> 1;         // per-head projections: 2 feature blocks x 4 token blocks (3 tiles)
     constexpr float kQScale = 0.17677669529663687f;      // 1 / sqrt(head dim), applied where torch applies it
     constexpr float kLog2e = 1.4426950408889634f;
     const int gsw = g ^ ((c >> 1) & 7);
@@ -150,13 +150,14 @@ __global__ __launch_bounds__(256) void fusion_kernel(FusionParams p) {
     // ---- the fp32 residual stream lives in registers for the whole kernel: X[i][j] = features
     // 16 (3 w + i) + 4 g .. +3 of token 16 j + c (the MFMA accumulator layout of this wave's block), so
     // that the out-projection and the second FFN matmul accumulate straight into it
-    f32x4 X[3][kTT];
+    constexpr int kHT = kTT / 2;                 // token tiles per wave
+    f32x4 X[3][kHT];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int f0 = 16 * (3 * fblk + i) + 4 * g;
 #pragma unroll
-        for (int j = 0; j < kTT; ++j) {
-            const int tok = 16 * j + c;
+        for (int j = 0; j < kHT; ++j) {
+            const int tok = 16 * (kHT * th + j) + c;
             X[i][j] = tok < T ? *reinterpret_cast<const f32x4*>(Xg + tok * kE + f0) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
@@ -165,8 +166,8 @@ __global__ __launch_bounds__(256) void fusion_kernel(FusionParams p) {
         for (int i = 0; i < 3; ++i) {
             const int f0 = 16 * (3 * fblk + i) + 4 * g;
 #pragma unroll
-            for (int j = 0; j < kTT; ++j) {
-                const int tok = 16 * j + c;
+            for (int j = 0; j < kHT; ++j) {
+                const int tok = 16 * (kHT * th + j) + c;
                 if (tok < T) X[i][j] = X[i][j] + *reinterpret_cast<const f32x4*>(p.tok_bias + tok * kE + f0);
             }
         }
@@ -175,10 +176,10 @@ __global__ __launch_bounds__(256) void fusion_kernel(FusionParams p) {
     // residual (registers) -> LDS bf16 [token][feature], LayerNorm-ed when gamma is given; rows >= T zero.
     // Token statistics need all 192 features = all 4 waves: per-wave partial (sum, sum of squares) through LDS.
     auto stage_tokens = [&](const float* gamma, const float* beta) {
-        float mean[kTT], rstd[kTT];
+        float mean[kHT], rstd[kHT];
         if (gamma && !(kAbl & 16)) {
 #pragma unroll
-            for (int j = 0; j < kTT; ++j) {
+            for (int j = 0; j < kHT; ++j) {
                 float s = 0.f, q = 0.f;
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
@@ -186,12 +187,12 @@ __global__ __launch_bounds__(256) void fusion_kernel(FusionParams p) {
                     for (int e = 0; e < 4; ++e) { s += X[i][j][e]; q += X[i][j][e] * X[i][j][e]; }
                 s += __shfl_xor(s, 16, 64); q += __shfl_xor(q, 16, 64);
                 s += __shfl_xor(s, 32, 64); q += __shfl_xor(q, 32, 64);
-                if (g == 0) stats[w * kTok + 16 * j + c] = make_float2(s, q);
+                if (g == 0) stats[fblk * kTok + 16 * (kHT * th + j) + c] = make_float2(s, q);
             }
             __syncthreads();
 #pragma unroll
-            for (int j = 0; j < kTT; ++j) {
-                const int tok = 16 * j + c;
+            for (int j = 0; j < kHT; ++j) {
+                const int tok = 16 * (kHT * th + j) + c;
                 const float2 a0 = stats[tok], a1 = stats[kTok + tok], a2 = stats[2 * kTok + tok], a3 = stats[3 * kTok + tok];
                 const float m = ((a0.x + a1.x) + (a2.x + a3.x)) * (1.f / kE);
                 const float var = ((a0.y + a1.y) + (a2.y + a3.y)) * (1.f / kE) - m * m;
@@ -205,12 +206,12 @@ __global__ __launch_bounds__(256) void fusion_kernel(FusionParams p) {
             f32x4 ga = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f};
             if (gamma) { ga = *reinterpret_cast<const f32x4*>(gamma + f0); be = *reinterpret_cast<const f32x4*>(beta + f0); }
 #pragma unroll
-            for (int j = 0; j < kTT; ++j) {
-                const int tok = 16 * j + c;
+            for (int j = 0; j < kHT; ++j) {
+                const int tok = 16 * (kHT * th + j) + c;
                 f32x4 v = X[i][j];
                 if (gamma && !(kAbl & 16)) v = (v - mean[j]) * rstd[j] * ga + be;
                 if (tok >= T) v = f32x4{0.f, 0.f, 0.f, 0.f};
-                *reinterpret_cast<bf16x4*>(xn + j * (16 * kXS) + wx[i]) = to_bf16(v);
+                *reinterpret_cast<bf16x4*>(xn + (kHT * th + j) * (16 * kXS) + wx[i]) = to_bf16(v);
             }
         }
         __syncthreads();
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(256) void fusion_kernel(FusionParams p) {
         for (int i = 0; i < 3; ++i) {
             const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + 16 * (3 * fblk + i) + 4 * g);
 #pragma unroll
-            for (int j = 0; j < kTT; ++j) X[i][j] = X[i][j] + b4;
+            for (int j = 0; j < kHT; ++j) X[i][j] = X[i][j] + b4;
         }
     };
     auto afrag = [&](const char* wbase, int tile, int ksteps, int ks) {
@@ -326,11 +327,11 @@ __global__ __launch_bounds__(256) void fusion_kernel(FusionParams p) {
         add_bias(vec + kBo);
         for (int h = 0; h < kHeads; ++h) {
             {   // Q | K | V of head h: this wave's 3 of the 6 tiles x its 6 token tiles
-                f32x4 t[3][6];
+                f32x4 t[3][3];
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
-                    for (int j = 0; j < 6; ++j) t[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int j = 0; j < 3; ++j) t[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                 // tile index in the 36-tile in_proj: Q 2h,2h+1 | K 12+2h,12+2h+1 | V 24+2h,24+2h+1
                 int tile[3];
                 tile[0] = fb2 == 0 ? 2 * h : 12 + 2 * h + 1;
@@ -342,9 +343,9 @@ __global__ __launch_bounds__(256) void fusion_kernel(FusionParams p) {
                     for (int i = 0; i < 3; ++i) a[0][i] = afrag(lw + kWqkv, tile[i], 6, 0);
 #pragma unroll
                     for (int ks = 0; ks < 6; ++ks) {
-                        bf16x8 b[6];
+                        bf16x8 b[3];
 #pragma unroll
-                        for (int j = 0; j < 6; ++j) b[j] = bx(xn, 6 * tb2 + j, ks);
+                        for (int j = 0; j < 3; ++j) b[j] = bx(xn, 3 * tb4 + j, ks);
                         if (ks + 1 < 6) {
 #pragma unroll
                             for (int i = 0; i < 3; ++i) a[(ks + 1) & 1][i] = afrag(lw + kWqkv, tile[i], 6, ks + 1);
@@ -352,15 +353,15 @@ __global__ __launch_bounds__(256) void fusion_kernel(FusionParams p) {
 #pragma unroll
                         for (int i = 0; i < 3; ++i)
 #pragma unroll
-                            for (int j = 0; j < 6; ++j) t[i][j] = mfma(a[ks & 1][i], b[j], t[i][j]);
+                            for (int j = 0; j < 3; ++j) t[i][j] = mfma(a[ks & 1][i], b[j], t[i][j]);
                     }
                 }
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
                     const f32x4 b4 = *reinterpret_cast<const f32x4*>(vec + kBqkv + 16 * tile[i] + 4 * g);
 #pragma unroll
-                    for (int j = 0; j < 6; ++j) {
-                        const int tt = 6 * tb2 + j;
+                    for (int j = 0; j < 3; ++j) {
+                        const int tt = 3 * tb4 + j;
                         const f32x4 v = t[i][j] + b4;
                         if (fb2 == 0) {
                             if (i == 0) put_qk(qb, 0, tt, v * kQScale);
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(256) void fusion_kernel(FusionParams p) {
                 }
             }
             __syncthreads();
-            for (int qt = w; qt < kTT; qt += 4) {
+            for (int qt = w; qt < kTT; qt += 8) {
                 f32x4 o[2];
                 if constexpr (kAbl & 2) { o[0] = o[1] = f32x4{0.f, 0.f, 0.f, 0.f}; } else
                 attend(qt, o);
@@ -383,31 +384,31 @@ __global__ __launch_bounds__(256) void fusion_kernel(FusionParams p) {
             }
             __syncthreads();
             // out-projection straight into the residual: k-step h of Wo against this head's O
-            dense(X, 0, lw + kWo, 3 * fblk, 6, h, ic<1>{}, [&](int tt, int) { return bq(ob, tt); });
+            dense(X, kHT * th, lw + kWo, 3 * fblk, 6, h, ic<1>{}, [&](int tt, int) { return bq(ob, tt); });
         }
         __syncthreads();                                   // ob / hb alias: all out-projections done
         // ================= feed-forward block =================
         stage_tokens(vec + kLn2g, vec + kLn2b);
         add_bias(vec + kB2);
         for (int ch = 0; ch < kFF / kE; ++ch) {
-            for (int half = 0; half < 2; ++half) {       // 6 token tiles at a time (register budget)
-                f32x4 t[3][6];
+            {
+                f32x4 t[3][kHT];
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
-                    for (int j = 0; j < 6; ++j) t[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                dense(t, 6 * half, lw + kW1, 12 * ch + 3 * fblk, 6, 0, ic<6>{}, [&](int tt, int ks) { return bx(xn, tt, ks); });
+                    for (int j = 0; j < kHT; ++j) t[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                dense(t, kHT * th, lw + kW1, 12 * ch + 3 * fblk, 6, 0, ic<6>{}, [&](int tt, int ks) { return bx(xn, tt, ks); });
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
                     const int f0 = 16 * (3 * fblk + i) + 4 * g;              // feature within the chunk
                     const f32x4 b4 = *reinterpret_cast<const f32x4*>(vec + kB1 + kE * ch + f0);
 #pragma unroll
-                    for (int j = 0; j < 6; ++j)
-                        *reinterpret_cast<bf16x4*>(hb + (6 * half + j) * (16 * kXS) + wx[i]) = to_bf16((kAbl & 1) ? t[i][j] + b4 : gelu4(t[i][j] + b4));
+                    for (int j = 0; j < kHT; ++j)
+                        *reinterpret_cast<bf16x4*>(hb + (kHT * th + j) * (16 * kXS) + wx[i]) = to_bf16((kAbl & 1) ? t[i][j] + b4 : gelu4(t[i][j] + b4));
                 }
             }
             __syncthreads();
-            dense(X, 0, lw + kW2, 3 * fblk, 24, 6 * ch, ic<6>{}, [&](int tt, int ks) { return bx(hb, tt, ks); });
+            dense(X, kHT * th, lw + kW2, 3 * fblk, 24, 6 * ch, ic<6>{}, [&](int tt, int ks) { return bx(hb, tt, ks); });
             __syncthreads();
         }
     }
@@ -416,8 +417,8 @@ __global__ __launch_bounds__(256) void fusion_kernel(FusionParams p) {
     for (int i = 0; i < 3; ++i) {
         const int f0 = 16 * (3 * fblk + i) + 4 * g;
 #pragma unroll
-        for (int j = 0; j < kTT; ++j) {
-            const int tok = 16 * j + c;
+        for (int j = 0; j < kHT; ++j) {
+            const int tok = 16 * (kHT * th + j) + c;
             if (tok < T) *reinterpret_cast<f32x4*>(Xg + tok * kE + f0) = X[i][j];
         }
     }
@@ -427,35 +428,35 @@ __global__ __launch_bounds__(256) void fusion_kernel(FusionParams p) {
     const float* bkv = reinterpret_cast<const float*>(p.packed + kPoolB);
     for (int h = 0; h < kHeads; ++h) {
         {   // K | V of head h: 2 tiles per wave x 6 token tiles (tile space: K 0..11 | V 12..23)
-            f32x4 t[2][6];
+            f32x4 t[2][3];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 6; ++j) t[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < 3; ++j) t[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             const int tile0 = (fb2 == 0 ? 0 : 12) + 2 * h;
 #pragma unroll 3
             for (int ks = 0; ks < 6; ++ks) {
-                bf16x8 a[2], b[6];
+                bf16x8 a[2], b[3];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) a[i] = afrag(p.packed + kPoolW, tile0 + i, 6, ks);
 #pragma unroll
-                for (int j = 0; j < 6; ++j) b[j] = bx(xn, 6 * tb2 + j, ks);
+                for (int j = 0; j < 3; ++j) b[j] = bx(xn, 3 * tb4 + j, ks);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 6; ++j) t[i][j] = mfma(a[i], b[j], t[i][j]);
+                    for (int j = 0; j < 3; ++j) t[i][j] = mfma(a[i], b[j], t[i][j]);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const f32x4 b4 = *reinterpret_cast<const f32x4*>(bkv + 16 * (tile0 + i) + 4 * g);
 #pragma unroll
-                for (int j = 0; j < 6; ++j) {
-                    if (fb2 == 0) put_qk(kb, i, 6 * tb2 + j, t[i][j] + b4);
-                    else put_vt(i, 6 * tb2 + j, t[i][j] + b4);
+                for (int j = 0; j < 3; ++j) {
+                    if (fb2 == 0) put_qk(kb, i, 3 * tb4 + j, t[i][j] + b4);
+                    else put_vt(i, 3 * tb4 + j, t[i][j] + b4);
                 }
             }
             // the head's 8 queries (rows 8..15 of the tile are zero)
-            for (int i = tid; i < 16 * kHd; i += 256) {
+            for (int i = tid; i < 16 * kHd; i += 512) {
                 const int q = i >> 5, d = i & 31;
                 const float v = q < kPoolQ ? p.pool_q[q * kE + kHd * h + d] : 0.f;
                 *reinterpret_cast<__bf16*>(qb + qoff(q, d * 2)) = (__bf16)v;
@@ -530,7 +531,7 @@ int fusion_forward(const char* packed, float* tokens, int n_tokens, const float*
         configured = true;
     }
     FusionParams p{packed, tokens, tok_bias, pool_q, pooled, n_tokens};
-    fusion_kernel<<<dim3(static_cast<unsigned>(n_events)), dim3(256), kLds, s>>>(p);
+    fusion_kernel<<<dim3(static_cast<unsigned>(n_events)), dim3(512), kLds, s>>>(p);
     return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
 }
 }  // namespace pf
