@@ -139,6 +139,16 @@ def extras(flow, dev, batch):
     return out
 
 
+def pmc_traffic(args):
+    """bytes per launch at the L2's memory side from the committed PMC passes (rocprofv3 cannot run inside
+    this process): only for the configuration they were collected on, else null."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    if args.batch != 4096 or args.precision != "bf16" or not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        return json.load(fh)["bytes_per_launch"]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -288,7 +298,7 @@ def main():
                        "global_mean_nll": mean_nll,
                        "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                         "frac": ach / peak, "traffic": None,
+                         "frac": ach / peak, "traffic": pmc_traffic(args),
                          "kernel": "pf::flow_forward_kernel", "kernel_ms": kernel_ms,
                          "flop_per_sample": fl, "device_ms_per_step": dev_ms / args.steps},
         }
