@@ -130,7 +130,9 @@ def extras(flow, dev, batch):
         out["stem_events_per_s"] = batch / dt
         out["stem_tflops"] = batch * 3 * 34.98e6 * 2 / dt / 1e12          # 34.98 M MAC / detector
         out["stem_strain_read_GBps"] = batch * 3 * 16384 * 4 / dt / 1e9
-        dt = timed(lambda: [enc(strain[i:i + 512]) for i in range(0, batch, 512)], 1)
+        # fp32 parity mode evaluates the Transformer with tensor ops ([chunk, 183, 768] hidden): keep chunks small there
+        chunk = batch if flow.precision == "bf16" else 512
+        dt = timed(lambda: [enc(strain[i:i + chunk]) for i in range(0, batch, chunk)], 2)
         out["encoder_events_per_s"] = batch / dt
         nll = torch.empty(batch, device=dev)
         x, ctx = make_inputs(batch, 1, dev)

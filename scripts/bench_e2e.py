@@ -19,7 +19,8 @@ for prec in ("bf16", "fp32"):
     rank = torch.zeros(B, dtype=torch.long, device=dev)
     def step():
         with torch.no_grad():
-            return torch.cat([model.nll(strain[i:i + 1024], theta[i:i + 1024], rank[i:i + 1024]) for i in range(0, B, 1024)])
+            ck = B if prec == "bf16" else 1024
+            return torch.cat([model.nll(strain[i:i + ck], theta[i:i + ck], rank[i:i + ck]) for i in range(0, B, ck)])
     for _ in range(2): out = step()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(5): out = step()
