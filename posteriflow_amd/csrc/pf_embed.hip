@@ -28,6 +28,7 @@
 #include <cstdint>
 
 #include "../../include/pf_hip.h"
+#include "pf_math.h"
 
 namespace pf {
 
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_gemm_kernel(const ConvParams
                 x = (x != x) ? 0.f : x;                                    // nan -> 0
                 x = fminf(fmaxf(x, -100.f), 100.f);                        // +-inf -> +-100, clamp
                 if (i + e < P * S) sq[(i + e) >> 10] += x * x;             // own range: 2 windows of 1024
-                v[e] = asinhf(x);
+                v[e] = BF16 ? asinh_fast(x) : asinhf(x);
             }
             if (BF16) {
                 bf16x4 o;
@@ -215,8 +216,12 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_gemm_kernel(const ConvParams
             const int pos = p0 + 16 * cg + c;
             if (pos < LOUT) {
                 f32x4 v;
+                if constexpr (BF16) {
+                    v = gelu_erf_fast4(acc[cg] + b4);
+                } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = gelu_exact(acc[cg][e] + b4[e]);
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_exact(acc[cg][e] + b4[e]);
+                }
                 const size_t off = ((size_t)n * LOUT + pos) * COUT + tile * 16 + 4 * g;
                 if (BF16 && !LAST) {
                     bf16x4 o;

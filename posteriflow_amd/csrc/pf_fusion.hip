@@ -32,6 +32,7 @@
 #include <cstdint>
 
 #include "../../include/pf_hip.h"
+#include "pf_math.h"
 
 #ifndef PF_FUSION_ABLATE
 #define PF_FUSION_ABLATE 0      // timing experiments only: 1 no GELU, 2 no attention, 4 no dense matmuls, 8 no QKV projection, 16 no LN
@@ -96,29 +97,6 @@ __device__ __forceinline__ int xoff(int row, int byte) {
 }
 __device__ __forceinline__ int qoff(int row, int byte) {
     return row * kQS + ((((byte >> 4) ^ ((4 - ((row >> 2) & 3)) & 3)) << 4) | (byte & 15));
-}
-
-// exact-form GELU 0.5 v (1 + erf(v / sqrt 2)) on 4 values, erf by Abramowitz & Stegun 7.1.26
-// (|error| <= 1.5e-7, far below the bf16 rounding the result gets).  Written on vectors so that the
-// polynomial runs on packed fp32 instructions; rcp / exp2 are the only per-element transcendental ops.
-// (erff costs ~40 instructions per value; the FFN evaluates 421 K GELUs per event.)
-__device__ __forceinline__ f32x4 gelu4(f32x4 v) {
-    f32x4 x, t, e;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) x[k] = fabsf(v[k]);
-    x = x * 0.70710678118654752f;
-    const f32x4 d = x * 0.3275911f + 1.f;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) t[k] = __builtin_amdgcn_rcpf(d[k]);
-    const f32x4 poly = t * (t * (t * (t * (t * 1.061405429f - 1.453152027f) + 1.421413741f) - 0.284496736f) + 0.254829592f);
-    const f32x4 a = x * x * -1.4426950408889634f;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) e[k] = __builtin_amdgcn_exp2f(a[k]);
-    const f32x4 erf_abs = 1.f - poly * e;
-    f32x4 r;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) r[k] = copysignf(erf_abs[k], v[k]);
-    return v * 0.5f * (r + 1.f);
 }
 
 __global__ __launch_bounds__(512) void fusion_kernel(FusionParams p) {
@@ -404,7 +382,7 @@ __global__ __launch_bounds__(512) void fusion_kernel(FusionParams p) {
                     const f32x4 b4 = *reinterpret_cast<const f32x4*>(vec + kB1 + kE * ch + f0);
 #pragma unroll
                     for (int j = 0; j < kHT; ++j)
-                        *reinterpret_cast<bf16x4*>(hb + (kHT * th + j) * (16 * kXS) + wx[i]) = to_bf16((kAbl & 1) ? t[i][j] + b4 : gelu4(t[i][j] + b4));
+                        *reinterpret_cast<bf16x4*>(hb + (kHT * th + j) * (16 * kXS) + wx[i]) = to_bf16((kAbl & 1) ? t[i][j] + b4 : gelu_erf_fast4(t[i][j] + b4));
                 }
             }
             __syncthreads();
