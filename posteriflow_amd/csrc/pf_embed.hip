@@ -60,6 +60,9 @@ __device__ __forceinline__ float gelu_exact(float x) {         // nn.GELU() defa
     return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
 }
 
+// slot swizzle of a 64-byte LDS row (4 slots of 16 B): (4 - (row >> 2)) & 3, see the staging code
+__device__ __forceinline__ int row_swz(int q) { return (4 - ((q >> 2) & 3)) & 3; }
+
 // One workgroup: CG*16 output positions of one sequence; wave w owns channel tiles w*TPW..
 template <bool BF16, int LAYER, int CG, int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64) void conv_gemm_kernel(const ConvParams p) {
@@ -90,6 +93,8 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_gemm_kernel(const ConvParams
         // this workgroup "owns", asinh, store as a contiguous signal in LDS
         const float* src = reinterpret_cast<const float*>(p.in) + n * LIN;
         float sq[2] = {0.f, 0.f};
+        // (one chunk per iteration on purpose: this layer runs 16 small workgroups per CU, which hide the load
+        // latency; requesting all chunks first costs registers = occupancy and measured 1.5x slower here)
         for (int i = tid * 4; i < SPAN; i += NWAVES * 64 * 4) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (in0 + i + 3 < LIN) v = *reinterpret_cast<const f32x4*>(src + in0 + i);
@@ -135,13 +140,30 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_gemm_kernel(const ConvParams
         constexpr int Q = (SPAN + S - 1) / S + 1;      // rows per (r, block)
         const char* src = reinterpret_cast<const char*>(p.in) + ((size_t)n * LIN) * CIN * ESZ;
         constexpr int CHUNKS = CIN * ESZ / 16;         // 16-byte chunks per position
-        for (int i = tid; i < SPAN * CHUNKS; i += NWAVES * 64) {
+        // all of a thread's 16-byte chunks are requested before the first one is stored: a loop that loads
+        // and stores one chunk per iteration pays one HBM latency per chunk (17 in a row for conv2)
+        constexpr int NTHR = NWAVES * 64;
+        constexpr int ITERS = (SPAN * CHUNKS + NTHR - 1) / NTHR;
+        u32x4 v[ITERS];
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int i = tid + it * NTHR;
             const int pos = i / CHUNKS, ch16 = i - pos * CHUNKS;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (in0 + pos < LIN) v = *reinterpret_cast<const u32x4*>(src + ((size_t)(in0 + pos) * CIN * ESZ) + ch16 * 16);
-            const int r = pos % S, q = pos / S;
-            const int cb = ch16 / 4, sub = ch16 & 3;   // 4 chunks per 64-byte row
-            *reinterpret_cast<u32x4*>(smem + ((size_t)((r * CB + cb) * Q + q) * 64) + sub * 16) = v;
+            v[it] = u32x4{0u, 0u, 0u, 0u};
+            if (i < SPAN * CHUNKS && in0 + pos < LIN)
+                v[it] = *reinterpret_cast<const u32x4*>(src + ((size_t)(in0 + pos) * CIN * ESZ) + ch16 * 16);
+        }
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int i = tid + it * NTHR;
+            if (i < SPAN * CHUNKS) {
+                const int pos = i / CHUNKS, ch16 = i - pos * CHUNKS;
+                const int r = pos % S, q = pos / S;
+                const int cb = ch16 / 4, sub = ch16 & 3;   // 4 chunks per 64-byte row
+                // 16-byte slot XOR-swizzled by the row: ds_read_b128 serves lanes in the groups {0-3,12-15,20-27}, ...
+                // (8 lanes of k-group g, 8 of g+1), which collide pairwise on plain 64-byte rows
+                *reinterpret_cast<u32x4*>(smem + ((size_t)((r * CB + cb) * Q + q) * 64) + ((sub ^ row_swz(q)) << 4)) = v[it];
+            }
         }
         __syncthreads();
     }
@@ -159,7 +181,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_gemm_kernel(const ConvParams
             const int kk0 = KSTEP * ks;                // kk = tap * CIN + ch
             const int tap = kk0 / CIN, cb = (kk0 % CIN) / CHB;
             const int r = tap % S, q = 16 * cg + c + tap / S;
-            return *reinterpret_cast<const u32x4*>(smem + ((size_t)((r * CB + cb) * Q + q) * 64) + g * 16);
+            return *reinterpret_cast<const u32x4*>(smem + ((size_t)((r * CB + cb) * Q + q) * 64) + ((g ^ row_swz(q)) << 4));
         }
     };
 
