@@ -158,9 +158,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=4096, help="rows per GPU")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a HIP graph")
+    ap.add_argument("--graph", action="store_true", help="N = 1: replay one HIP graph per step instead of one pre-bound launch")
+    ap.add_argument("--no-graph", action="store_true", help="(default now; kept for older command lines)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the sampling / embedding side measurements")
+    ap.add_argument("--collective", action="store_true", help="run the N > 1 step (with its all-reduce) on a single rank")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N > 1 path on fewer GPUs than ranks (collective through the host)")
     args = ap.parse_args()
@@ -174,9 +176,11 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    collective = world > 1 or args.collective            # --collective: rehearse the N > 1 step on one rank
+    if collective:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -187,47 +191,59 @@ def main():
     log("weights packed")
     x, ctx = make_inputs(args.batch, 1 + rank, dev)
     nll = torch.empty(args.batch, device=dev)
-    # N > 1: (sum nll, count) all-reduced every step over RCCL -- the path's only exchange.  One
-    # reduction kernel per step; the 8-byte collective is launched asynchronously and double-buffered
-    # so that it overlaps the next step's flow kernel (it is latency-, not bandwidth-bound).
-    red = torch.zeros(2, 2, device=dev, dtype=torch.float32)
-    red[:, 1] = float(args.batch)
-    works = [None, None]
+    # N > 1: (sum nll, count) all-reduced every step over RCCL -- the path's only exchange.  The flow
+    # kernel reduces the pair itself (wave shuffle + one pair of atomics per workgroup) and zeroes the
+    # accumulator of the NEXT step, so a step is exactly one kernel launch (a pre-bound C call: the Python
+    # wrapper's per-call work would make the loop host-bound at ~250 us) and one asynchronous 8-byte
+    # all-reduce that overlaps the next steps' kernels (three rotating accumulators).
+    NBUF = 3
+    red = [torch.zeros(2, device=dev, dtype=torch.float32) for _ in range(NBUF)]
+    works = [None] * NBUF
     state = {"k": 0}
-
-    def step():
-        flow.nll_into(x, ctx, nll)
-        if world > 1:
-            k = state["k"] & 1
-            if works[k] is not None:
-                works[k].wait()                           # stream-side wait: the buffer is free again
-            torch.sum(nll, dim=0, out=red[k, 0])
-            if args.backend == "nccl":
-                works[k] = dist.all_reduce(red[k], async_op=True)
-            else:
-                host = red[k].cpu()
-                dist.all_reduce(host)
-                red[k].copy_(host); red[k, 1] = float(args.batch)
-            state["k"] += 1
 
     def drain():
         for w in works:
             if w is not None:
                 w.wait()
 
-    # one HIP graph per step on N=1 (the step is a single ~100 us kernel: eager launch
-    # overhead would otherwise be inside the measurement); eager with collectives
-    use_graph = not args.no_graph and world == 1
+    # One pre-bound launch per step (a few microseconds of host time: the device queue stays full, measured
+    # 113.0 us/step against 116.7 us/step for replaying a one-kernel HIP graph per step, --graph), plus, for
+    # N > 1, one asynchronous all-reduce per step.
+    use_graph = args.graph and not collective
     graph = None
     stream = torch.cuda.Stream(dev)
     with torch.cuda.stream(stream):
+        plain = flow.bind_nll(x, ctx, nll, stream=stream)
+        reduce_launch = flow.bind_nll(x, ctx, nll, sum_count=red, stream=stream) if collective else None
+
+        def step():
+            if not collective:
+                plain()
+                return
+            i = state["k"]
+            nxt = (i + 1) % NBUF
+            if works[nxt] is not None:
+                works[nxt].wait()                         # stream-side: its all-reduce is done before this launch zeroes it
+                works[nxt] = None
+            reduce_launch(i)
+            if os.environ.get("PF_BENCH_SKIP_ALLREDUCE"):           # timing experiment only
+                pass
+            elif args.backend == "nccl":
+                works[i % NBUF] = dist.all_reduce(red[i % NBUF], async_op=True)
+            else:                                         # gloo rehearsal on CPU tensors
+                host = red[i % NBUF].cpu()
+                dist.all_reduce(host)
+                red[i % NBUF].copy_(host)
+            state["k"] = i + 1
+
         step()
+        drain()
         stream.synchronize()
         if use_graph:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=stream):
                 step()
-        log("step captured" if use_graph else "eager steps")
+        log("step captured" if use_graph else "one pre-bound launch per step" + (" + async all-reduce" if collective else ""))
         run = graph.replay if graph is not None else step
         for _ in range(args.warmup):
             run()
@@ -275,9 +291,9 @@ def main():
     log(f"kernel-only: {kernel_ms * 1e3:.2f} us")
 
     mean_nll = None
-    if world > 1:
-        last = red[(state["k"] - 1) & 1].cpu()
-        mean_nll = (last[0] / (last[1] if args.backend == "nccl" else args.batch * world)).item()
+    if collective:
+        last = red[(state["k"] - 1) % NBUF].cpu()    # (sum nll, count) over all ranks, both all-reduced
+        mean_nll = (last[0] / last[1]).item()
     if rank == 0:
         fl = flops_per_sample()
         ach = args.batch * fl / (kernel_ms * 1e-3) / 1e12
@@ -296,7 +312,7 @@ def main():
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "rows_per_workgroup": int(__import__("posteriflow_amd")._lib.lib().pf_flow_rows_per_workgroup(
                            flow._desc(), args.batch)),
-                       "launch": "hipGraph" if graph is not None else "eager + async all-reduce",
+                       "launch": "hipGraph" if graph is not None else ("pre-bound launch + async all-reduce" if collective else "pre-bound launch"),
                        "global_mean_nll": mean_nll,
                        "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
@@ -309,7 +325,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(flow, args.batch)
         print(json.dumps(out))
-    if world > 1:
+    if collective:
         dist.destroy_process_group()
 
 

@@ -119,6 +119,17 @@ int pf_flow_forward_train(const PfFlowDesc* desc, const void* packed,
                           const float* log_sigma, int64_t batch,
                           float* z, float* logdet, float* nll, float* layer_inputs,
                           void* workspace, int64_t workspace_bytes, void* stream);
+/* pf_flow_forward_reduce: pf_flow_forward for a loss -- nll (may be NULL) as there, and
+ * nll_sum_count[0] += sum of nll over the batch, nll_sum_count[1] += batch (float atomics, one pair per
+ * workgroup after a wave shuffle reduction): the 8-byte vector a data-parallel rank all-reduces
+ * (train_lean_npe.py:108-127 computes sum / count on the host).  The accumulator must be zero before the
+ * launch: either the caller zeroes it, or an EARLIER launch did through zero_pair (float[2] or NULL, set to
+ * zero by this launch; must differ from nll_sum_count) -- with three rotating pairs a step of a
+ * data-parallel loop is exactly one kernel launch and one asynchronous all-reduce. */
+int pf_flow_forward_reduce(const PfFlowDesc* desc, const void* packed,
+                           const float* x, const float* ctx, const int32_t* ar_perm,
+                           const float* log_sigma, int64_t batch, float* nll, float* nll_sum_count,
+                           float* zero_pair, void* workspace, int64_t workspace_bytes, void* stream);
 int pf_flow_rqs_backward(const PfFlowDesc* desc, const float* u, const float* params,
                          const float* grad_y, const float* grad_logabsdet, int64_t rows,
                          float* grad_params, float* grad_u, void* stream);

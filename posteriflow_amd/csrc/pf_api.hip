@@ -106,10 +106,10 @@ static int project_context(const pf::FlowPlan& L, pf::FwdParams& p, void* worksp
     return PF_OK;
 }
 
-int pf_flow_forward_train(const PfFlowDesc* desc, const void* packed, const float* x, const float* ctx,
-                          const int32_t* ar_perm, const float* log_sigma, int64_t batch, float* z,
-                          float* logdet, float* nll, float* layer_inputs, void* workspace,
-                          int64_t workspace_bytes, void* stream) {
+static int flow_forward_impl(const PfFlowDesc* desc, const void* packed, const float* x, const float* ctx,
+                             const int32_t* ar_perm, const float* log_sigma, int64_t batch, float* z,
+                             float* logdet, float* nll, float* layer_inputs, float* nll_sum, float* zero_pair,
+                             void* workspace, int64_t workspace_bytes, void* stream) {
     pf::FlowPlan L;
     int rc = layout_of(desc, L);
     if (rc != PF_OK) return rc;
@@ -121,7 +121,7 @@ int pf_flow_forward_train(const PfFlowDesc* desc, const void* packed, const floa
     pf::FwdParams p{};
     p.packed = static_cast<const char*>(packed);
     p.x = x; p.ctx = ctx; p.ar_perm = ar_perm; p.log_sigma = log_sigma; p.z = z; p.logdet = logdet; p.nll = nll;
-    p.batch = batch; p.ctx_rows = batch; p.fail_flags = nullptr; p.plan = L; p.u_save = layer_inputs;
+    p.batch = batch; p.ctx_rows = batch; p.fail_flags = nullptr; p.plan = L; p.u_save = layer_inputs; p.nll_sum = nll_sum; p.zero_pair = zero_pair;
     p.tail_bound = desc->tail_bound; p.min_w = desc->min_bin_width; p.min_h = desc->min_bin_height;
     p.min_d = desc->min_derivative;
     p.deriv_const = (float)std::log(std::exp(1.0 - (double)desc->min_derivative) - 1.0);
@@ -131,6 +131,22 @@ int pf_flow_forward_train(const PfFlowDesc* desc, const void* packed, const floa
     return rc == PF_OK ? rc : fail(rc, rc == PF_ERR_HIP ? hipGetErrorString(hipGetLastError()) : "unsupported launch shape");
 }
 
+int pf_flow_forward_train(const PfFlowDesc* desc, const void* packed, const float* x, const float* ctx,
+                          const int32_t* ar_perm, const float* log_sigma, int64_t batch, float* z,
+                          float* logdet, float* nll, float* layer_inputs, void* workspace,
+                          int64_t workspace_bytes, void* stream) {
+    return flow_forward_impl(desc, packed, x, ctx, ar_perm, log_sigma, batch, z, logdet, nll, layer_inputs, nullptr,
+                             nullptr, workspace, workspace_bytes, stream);
+}
+int pf_flow_forward_reduce(const PfFlowDesc* desc, const void* packed, const float* x, const float* ctx,
+                           const int32_t* ar_perm, const float* log_sigma, int64_t batch, float* nll,
+                           float* nll_sum_count, float* zero_pair, void* workspace, int64_t workspace_bytes,
+                           void* stream) {
+    if (!nll_sum_count) return fail(PF_ERR_BAD_ARG, "nll_sum_count is null");
+    if (zero_pair == nll_sum_count) return fail(PF_ERR_BAD_ARG, "zero_pair must not be the accumulator of this launch");
+    return flow_forward_impl(desc, packed, x, ctx, ar_perm, log_sigma, batch, nullptr, nullptr, nll, nullptr,
+                             nll_sum_count, zero_pair, workspace, workspace_bytes, stream);
+}
 int pf_flow_forward(const PfFlowDesc* desc, const void* packed, const float* x, const float* ctx,
                     const int32_t* ar_perm, const float* log_sigma, int64_t batch, float* z,
                     float* logdet, float* nll, void* workspace, int64_t workspace_bytes, void* stream) {

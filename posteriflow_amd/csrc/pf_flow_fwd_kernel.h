@@ -696,6 +696,8 @@ __global__ __launch_bounds__(NT * 32) void flow_kernel(const FwdParams p) {
         }
     } else {
     const float* zfin = (L.L & 1) ? s_xb1 : s_xb0;     // stored reversed (see above)
+    float my_nll = 0.f, my_cnt = 0.f;                  // this lane's row for the in-kernel loss reduction
+    if (p.zero_pair && blockIdx.x == 0 && tid == 0) { p.zero_pair[0] = 0.f; p.zero_pair[1] = 0.f; }
     if (tid < COLS) {
         const int64_t row = row0 + tid;
         if (row < p.batch) {
@@ -714,8 +716,17 @@ __global__ __launch_bounds__(NT * 32) void flow_kernel(const FwdParams p) {
             }
             if (p.logdet) p.logdet[row] = ld;
             // nll = -(log N(z; 0, diag(e^ls)^2) + logdet)
-            if (p.nll) p.nll[row] = 0.5f * (q + 2.f * sls + (float)D * 1.8378770664093453f) - ld;
+            my_nll = 0.5f * (q + 2.f * sls + (float)D * 1.8378770664093453f) - ld;
+            my_cnt = 1.f;
+            if (p.nll) p.nll[row] = my_nll;
         }
+    }
+    // (sum nll, rows) += this workgroup's rows: the rows sit in the first COLS <= 32 lanes of wave 0;
+    // wave shuffle reduction, then one pair of float atomics per workgroup
+    if (p.nll_sum && tid < 64) {
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) { my_nll += __shfl_xor(my_nll, o, 64); my_cnt += __shfl_xor(my_cnt, o, 64); }
+        if (tid == 0) { atomicAdd(p.nll_sum, my_nll); atomicAdd(p.nll_sum + 1, my_cnt); }
     }
     }
 }

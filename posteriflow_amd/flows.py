@@ -259,10 +259,12 @@ class NSFPosteriorFlow(nn.Module):
         return self
 
     def nll_into(self, x: torch.Tensor, context: Optional[torch.Tensor], out: torch.Tensor,
-                 log_sigma: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 log_sigma: Optional[torch.Tensor] = None, sum_count: Optional[torch.Tensor] = None) -> torch.Tensor:
         """compute_psd_aware_nll into a preallocated fp32 ``out[B]`` with no allocation and no
         host-side checks beyond shapes: the call a serving / benchmark loop (or a HIP-graph
-        capture) issues.  Inputs must already be contiguous fp32 on the flow's device."""
+        capture) issues.  Inputs must already be contiguous fp32 on the flow's device.
+        ``sum_count`` (fp32 [2], zeroed by the caller): the kernel also adds (sum of nll, B) to it --
+        the 8-byte vector a data-parallel rank all-reduces."""
         B = x.shape[0]
         if x.shape[1] != self.features or out.shape[0] != B or not x.is_contiguous():
             raise ValueError("nll_into: bad shapes / non-contiguous input")
@@ -273,11 +275,55 @@ class NSFPosteriorFlow(nn.Module):
         perm, _ = self._perms(dev)
         desc = self._desc()
         ws, ws_bytes = self._ws(desc, B, dev)
+        if sum_count is not None:
+            if sum_count.dtype != torch.float32 or sum_count.numel() != 2 or not sum_count.is_contiguous():
+                raise ValueError("nll_into: sum_count must be a contiguous fp32 tensor of 2 elements")
+            _lib.check(_lib.lib().pf_flow_forward_reduce(
+                desc, self.packed_weights().data_ptr(), x.data_ptr(), _dev_ptr(context),
+                _dev_ptr(perm), _dev_ptr(log_sigma), B, out.data_ptr(), sum_count.data_ptr(), None,
+                _dev_ptr(ws), ws_bytes, torch.cuda.current_stream(dev).cuda_stream), "pf_flow_forward_reduce")
+            return out
         _lib.check(_lib.lib().pf_flow_forward(
             desc, self.packed_weights().data_ptr(), x.data_ptr(), _dev_ptr(context),
             _dev_ptr(perm), _dev_ptr(log_sigma), B, None, None, out.data_ptr(),
             _dev_ptr(ws), ws_bytes, torch.cuda.current_stream(dev).cuda_stream), "pf_flow_forward")
         return out
+
+    def bind_nll(self, x: torch.Tensor, context: Optional[torch.Tensor], out: torch.Tensor,
+                 sum_count: Optional[List[torch.Tensor]] = None, stream: Optional[torch.cuda.Stream] = None):
+        """A launcher with every argument of ``nll_into`` resolved once (descriptor, packed weights,
+        workspace, pointers): ``launch(i)`` is one C call, a few microseconds of host time, for loops whose
+        step is a single ~100 us kernel.  ``sum_count``: rotating fp32 [2] accumulators; launch i adds
+        (sum nll, B) to ``sum_count[i % n]`` and zeroes ``sum_count[(i + 1) % n]`` for the next launch
+        (``n >= 2``; the caller zeroes ``sum_count[0]`` before launch 0).  The tensors must stay alive and
+        the weights frozen (``freeze_packed``) while the launcher is used."""
+        self.nll_into(x, context, out)                          # validates shapes once
+        dev = x.device
+        perm, _ = self._perms(dev)
+        desc = self._desc()
+        ws, ws_bytes = self._ws(desc, x.shape[0], dev)
+        packed = self.packed_weights()
+        fn = _lib.lib().pf_flow_forward_reduce if sum_count else _lib.lib().pf_flow_forward
+        st = (stream or torch.cuda.current_stream(dev)).cuda_stream
+        keep = (x, context, out, perm, ws, packed, desc, sum_count)
+        base = (desc, packed.data_ptr(), x.data_ptr(), _dev_ptr(context), _dev_ptr(perm), None, x.shape[0])
+        if sum_count:
+            n = len(sum_count)
+            ptrs = [t.data_ptr() for t in sum_count]
+            tail = (_dev_ptr(ws), ws_bytes, st)
+
+            def launch(i: int, _keep=keep):
+                rc = fn(*base, out.data_ptr(), ptrs[i % n], ptrs[(i + 1) % n], *tail)
+                if rc:
+                    _lib.check(rc, "pf_flow_forward_reduce")
+        else:
+            args = (*base, None, None, out.data_ptr(), _dev_ptr(ws), ws_bytes, st)
+
+            def launch(i: int = 0, _keep=keep):
+                rc = fn(*args)
+                if rc:
+                    _lib.check(rc, "pf_flow_forward")
+        return launch
 
     # ---- plumbing -------------------------------------------------------------
     def _desc(self, precision: Optional[str] = None, inverse: bool = False) -> _lib.PfFlowDesc:

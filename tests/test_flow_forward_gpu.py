@@ -219,3 +219,24 @@ def test_masked_context_conditioner_a14():
     xr_ = x[:32].clone().requires_grad_(True)
     ref.compute_psd_aware_nll(xr_, ctx[:32], torch.zeros(32, D)).sum().backward()
     assert ((xg.grad.cpu() - xr_.grad).abs().max() / xr_.grad.abs().max()) < 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [1, 37, 4096, 5000])
+def test_in_kernel_loss_reduction(B):
+    """pf_flow_forward_reduce: (sum nll, rows) accumulated by the kernel (wave shuffle + atomics) equals the
+    sum of the per-row nll it also returns, for batches that do and do not fill the last workgroup."""
+    from helpers import flow_inputs, make_pair
+    _, _, flow = make_pair(11, 288, 256, 3, 16, 5.0)
+    x, ctx = flow_inputs(B, 11, 288, 5.0)
+    x, ctx = x.cuda().contiguous(), ctx.cuda().contiguous()
+    nll = torch.empty(B, device="cuda")
+    acc = torch.zeros(2, device="cuda")
+    flow.nll_into(x, ctx, nll, sum_count=acc)
+    flow.nll_into(x, ctx, nll, sum_count=acc)                 # accumulates
+    want = flow.compute_psd_aware_nll(x, ctx, None)
+    assert torch.equal(nll, want)
+    assert acc[1].item() == 2 * B
+    assert abs(acc[0].item() - 2 * want.double().sum().item()) <= 2e-5 * want.double().abs().sum().item() + 1e-3
+    with pytest.raises(ValueError):
+        flow.nll_into(x, ctx, nll, sum_count=torch.zeros(3, device="cuda"))
