@@ -29,7 +29,7 @@ for prec in ("bf16", "fp32"):
     with torch.no_grad():
         sample_event(model, strain[:1], num_samples=4096, seed=0)
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        res = sample_event(model, strain[:1], num_samples=100000, seed=0, batch_size=25000)
+        res = sample_event(model, strain[:1], num_samples=100000, seed=0)
         torch.cuda.synchronize(); ts = time.perf_counter() - t0
     print(f"{prec}: LeanNPE.nll batch {B}: {dt*1e3:.1f} ms = {B/dt:.0f} events/s | single event, 1e5 draws + log q: "
           f"{ts*1e3:.0f} ms = {1e5/ts:.0f} draws/s", flush=True)
