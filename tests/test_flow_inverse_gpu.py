@@ -110,3 +110,32 @@ def test_sampling_api_and_nonfinite_context():
     assert torch.allclose(got.cpu(), want, atol=1e-4)
     pen = flow.compute_endpoint_loss(torch.zeros(3, D).cuda(), ctx.cuda())
     assert pen.ndim == 0 and torch.isfinite(pen)
+
+
+def test_sharded_draw_statistics_match_the_oracle():
+    """SURVEY 8d, config 5 in miniature: draws produced shard by shard (per-rank generators, as the 8-GPU
+    sampling run does) against the CPU oracle's OWN independent draws for the same context -- per-dimension
+    quantiles within binomial noise and a two-sample Kolmogorov-Smirnov test per dimension."""
+    from scipy.stats import ks_2samp
+    from posteriflow_amd.dist import rank_generator, shard_bounds
+    D, C, n = 8, 40, 24000
+    ref, _, flow = make_pair(D, C, 128, 3, 16, 3.0)
+    ctx = torch.randn(1, C, generator=torch.Generator().manual_seed(5))
+    world, parts = 4, []
+    for rank in range(world):                                  # what each rank of a sampling job does
+        lo, hi = shard_bounds(n, rank, world)
+        z = torch.randn(hi - lo, D, device="cuda", generator=rank_generator(100, rank, "cuda"))
+        parts.append(flow.inverse(z, ctx.cuda())[0].cpu())
+    got = torch.cat(parts)
+    with torch.no_grad():
+        want, _ = ref.inverse(torch.randn(n, D, generator=torch.Generator().manual_seed(7)), ctx.expand(n, -1))
+    assert got.shape == want.shape == (n, D)
+    qs = torch.tensor([0.05, 0.25, 0.5, 0.75, 0.95])
+    for d in range(D):
+        a, b = got[:, d].double(), want[:, d].double()
+        assert ks_2samp(a.numpy(), b.numpy()).pvalue > 1e-4, d
+        scale = b.std().item()
+        assert abs(a.mean().item() - b.mean().item()) < 6 * scale * (2.0 / n) ** 0.5
+        assert abs(a.std().item() / scale - 1.0) < 0.05
+        # a quantile estimate has standard error sqrt(q (1 - q) / n) / pdf; bound the pdf from below crudely
+        assert (torch.quantile(a, qs.double()) - torch.quantile(b, qs.double())).abs().max().item() < 0.08 * scale
