@@ -387,6 +387,15 @@ class LeanNPE(nn.Module):
                                      use_masked_context=False)
         self.flow.temperature.requires_grad_(False)                     # LN:297
 
+    def set_precision(self, precision: str) -> "LeanNPE":
+        """"fp32" (default: f32 MFMA + fp32 tensor ops, matches the CPU path to ~1e-5) or "bf16" (throughput:
+        bf16 MFMA operands with fp32 accumulation in the stem, the token mixer and the flow)."""
+        if precision not in ("fp32", "bf16"):
+            raise ValueError(f"precision must be 'fp32' or 'bf16', got {precision!r}")
+        self.encoder.precision = precision
+        self.flow.precision = precision
+        return self
+
     def _full_context(self, context: torch.Tensor, rank: torch.Tensor) -> torch.Tensor:
         return torch.cat([context, self.rank_embed(rank)], dim=1)
 
