@@ -282,6 +282,12 @@ __global__ __launch_bounds__(NT * 32) void flow_kernel(const FwdParams p) {
         }
     };
 
+    // prologue of the weight stream: first window of layer 0, requested before the staging loads so that
+    // its L2 latency runs under theirs
+    static_for<0, W>([&](auto e) {
+        constexpr int E = decltype(e)::value;
+        if constexpr (E < NF) win[E] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, lbase + E * kFragBytes, 0);
+    });
     // ---- stage context (B-fragment order), x^T and layer 0's biases -------------------
     for (int s = tid; s < CKM * R * 64; s += NW * 64) {
         const int ln = s & 63, r = (s >> 6) % R, ks = s / (64 * R);
@@ -333,11 +339,6 @@ __global__ __launch_bounds__(NT * 32) void flow_kernel(const FwdParams p) {
         for (int s = tid; s < NT * kBiasFloatsPerTile; s += NW * 64) s_bias[s] = b0[s];
     }
     for (int s = tid; s < D * COLS; s += NW * 64) s_ldb[s] = 0.f;
-    // prologue of the weight stream: first window of layer 0
-    static_for<0, W>([&](auto e) {
-        constexpr int E = decltype(e)::value;
-        if constexpr (E < NF) win[E] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, lbase + E * kFragBytes, 0);
-    });
     __syncthreads();
 
     // B fragments of one LDS buffer -> registers
