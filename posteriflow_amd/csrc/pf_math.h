@@ -7,23 +7,29 @@
 namespace pf {
 typedef __attribute__((ext_vector_type(4))) float pf_f32x4;
 
-// GELU in its erf form, 0.5 v (1 + erf(v / sqrt 2)), erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7).
+// GELU in its erf form, 0.5 v (1 + erf(v / sqrt 2)), with erf by Abramowitz & Stegun 7.1.28:
+//   erf(x) = 1 - (1 + a1 x + ... + a6 x^6)^-16,  x >= 0,  |error| <= 3e-7
+// -- a degree-6 Horner, four squarings and ONE hardware reciprocal per value, all on packed fp32
+// instructions (7.1.26, used first, needs a reciprocal AND an exponential: the two quarter-rate
+// transcendental ops were 2/3 of its cost).  p^16 overflows to +inf for |v| > ~13, where 1/inf = 0 gives erf = 1.
 __device__ __forceinline__ pf_f32x4 gelu_erf_fast4(pf_f32x4 v) {
-    pf_f32x4 x, t, e, r;
+    pf_f32x4 x, r, e;
 #pragma unroll
     for (int k = 0; k < 4; ++k) x[k] = fabsf(v[k]);
     x = x * 0.70710678118654752f;
-    const pf_f32x4 d = x * 0.3275911f + 1.f;
+    pf_f32x4 p = x * 0.0000430638f + 0.0002765672f;
+    p = p * x + 0.0001520143f;
+    p = p * x + 0.0092705272f;
+    p = p * x + 0.0422820123f;
+    p = p * x + 0.0705230784f;
+    p = p * x + 1.f;
+    p = p * p; p = p * p; p = p * p; p = p * p;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) t[k] = __builtin_amdgcn_rcpf(d[k]);
-    const pf_f32x4 poly = t * (t * (t * (t * (t * 1.061405429f - 1.453152027f) + 1.421413741f) - 0.284496736f) + 0.254829592f);
-    const pf_f32x4 a = x * x * -1.4426950408889634f;
+    for (int k = 0; k < 4; ++k) r[k] = __builtin_amdgcn_rcpf(p[k]);
+    const pf_f32x4 erf_abs = 1.f - r;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) e[k] = __builtin_amdgcn_exp2f(a[k]);
-    const pf_f32x4 erf_abs = 1.f - poly * e;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) r[k] = copysignf(erf_abs[k], v[k]);
-    return v * 0.5f * (r + 1.f);
+    for (int k = 0; k < 4; ++k) e[k] = copysignf(erf_abs[k], v[k]);
+    return v * 0.5f * (e + 1.f);
 }
 
 // asinh(x) = sign(x) log(|x| + sqrt(x^2 + 1)); below 1e-3 the identity (error x^3 / 6) avoids the
