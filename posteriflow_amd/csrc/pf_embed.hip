@@ -198,7 +198,9 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_gemm_kernel(const ConvParams
         u32x4 a0[CH], a1[CH];
 #pragma unroll
         for (int k = 0; k < CH; ++k) a0[k] = wf[(size_t)k * 64];
-#pragma unroll 1
+        // fully unrolled: with the k-step a compile-time constant the LDS address of every B fragment is an
+        // immediate offset from one per-lane base (tap / channel-block arithmetic folds away)
+#pragma unroll
         for (int k0 = 0; k0 < NKS; k0 += 2 * CH) {
             if (k0 + CH < NKS) {
 #pragma unroll
