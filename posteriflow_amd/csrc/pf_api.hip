@@ -40,7 +40,8 @@ int layout_of(const PfFlowDesc* d, pf::FlowPlan& L) {
     if (!d) return fail(PF_ERR_BAD_ARG, "desc is null");
     const int rc = pf::make_plan(*d, L);
     if (rc != PF_OK)
-        return fail(rc, "unsupported flow shape (need D<=H/16, H in {64,128,192,256}, K<=16, num_blocks=2)");
+        return fail(rc, "unsupported flow shape (need D<=H/16, H in {64,128,192,256}, K<=16, num_blocks=2; in-layer context: C<=288, "
+                    "or <=576 in bf16 at H=256 -- wider contexts need PF_FLAG_HOIST_CTX, C<=1024 / 2048 in bf16)");
     if (!(d->tail_bound > 0.f)) return fail(PF_ERR_BAD_ARG, "tail_bound must be positive");
     if (d->min_bin_width * d->num_bins > 1.f || d->min_bin_height * d->num_bins > 1.f)
         return fail(PF_ERR_BAD_ARG, "minimal bin size too large for the number of bins");

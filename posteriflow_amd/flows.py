@@ -332,9 +332,21 @@ class NSFPosteriorFlow(nn.Module):
         flags = _lib.PF_FLAG_HOIST_CTX if (hoist and self.context_features > 0) else 0
         if self.use_masked_context:
             flags = _lib.PF_FLAG_HOIST_CTX | _lib.PF_FLAG_MASKED_CONTEXT
-        return _lib.PfFlowDesc(self.features, self.context_features, self.hidden_features,
-                               self.num_bins, self.num_layers, 2, float(self._tail_bound),
-                               _MIN_BIN, _MIN_BIN, _MIN_BIN, prec, flags)
+        make = lambda fl: _lib.PfFlowDesc(self.features, self.context_features, self.hidden_features,
+                                          self.num_bins, self.num_layers, 2, float(self._tail_bound),
+                                          _MIN_BIN, _MIN_BIN, _MIN_BIN, prec, fl)
+        desc = make(flags)
+        if self.hoist_context is None and not flags and self.context_features > 0:
+            # auto mode: the in-layer context kernels cover C <= 288 (576 in bf16 at H = 256); wider contexts
+            # go through the hoisted projection kernel, which has no such limit
+            key = ("inlayer_ok", prec)
+            ok = self.__dict__.setdefault("_plan_cache", {}).get(key)
+            if ok is None:
+                ok = _lib.lib().pf_flow_pack_map_len(desc) >= 0
+                self._plan_cache[key] = ok
+            if not ok:
+                desc = make(_lib.PF_FLAG_HOIST_CTX)
+        return desc
 
     def _ws(self, desc, ctx_rows: int, dev):
         """Caller-owned scratch for the hoisted context projections (grown on demand)."""

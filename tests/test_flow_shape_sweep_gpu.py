@@ -1,0 +1,57 @@
+"""Seeded sweep over flow shapes the reference could be built with (features, context width, hidden width,
+bins, layers, tail bound, batch, permuted order): forward / log-density, gradient-free inverse round trip and
+the pack map, each against the CPU oracle, in fp32 mode.  Complements the hand-picked configurations of the
+other GPU tests with shapes nobody picked."""
+import random
+
+import pytest
+import torch
+
+from helpers import flow_inputs, make_pair
+
+pytestmark = pytest.mark.gpu
+
+
+def _configs(n=12, seed=2024):
+    rng = random.Random(seed)
+    out = []
+    for i in range(n):
+        H = rng.choice([64, 128, 192, 256])
+        D = rng.randint(2, min(16, H // 16))
+        C = rng.choice([0, 1, 7, 32, 33, 96, 288, 300])
+        K = rng.choice([2, 5, 8, 13, 16])
+        L = rng.randint(1, 5)
+        tb = rng.choice([1.0, 3.0, 5.0])
+        B = rng.choice([1, 15, 16, 17, 100, 257])
+        out.append((D, C, H, K, L, tb, B, rng.random() < 0.5, 1000 + i))
+    return out
+
+
+@pytest.mark.parametrize("D,C,H,K,L,tb,B,permute,seed", _configs(),
+                         ids=lambda v: str(v) if not isinstance(v, bool) else ("perm" if v else "id"))
+def test_random_shape_matches_oracle(D, C, H, K, L, tb, B, permute, seed):
+    ref, ref64, flow = make_pair(D, C, H, L, K, tb, seed=seed)
+    if permute:
+        order = list(range(D))
+        random.Random(seed).shuffle(order)
+        for m in (ref, ref64, flow):
+            m.set_autoregressive_order(order)
+    x, ctx = flow_inputs(B, D, C, tb, seed=seed + 1)
+    with torch.no_grad():
+        z64, ld64 = ref64(x.double(), None if ctx is None else ctx.double())
+        z32, ld32 = ref(x, ctx)
+        zg, ldg = flow(x.cuda(), None if ctx is None else ctx.cuda())
+    # fp32 kernel vs fp64 oracle, bounded by a small multiple of the CPU fp32 path's own error
+    for got, w32, w64 in ((zg.cpu(), z32, z64), (ldg.cpu(), ld32, ld64)):
+        err = (got.double() - w64).abs()
+        cpu = (w32.double() - w64).abs()
+        scale = w64.abs().clamp_min(1.0)
+        assert (err / scale).max() < max(2e-5, 6 * (cpu / scale).max().item()), ((err / scale).max(), (cpu / scale).max())
+    # inverse round trip through the kernels
+    with torch.no_grad():
+        xb, ldi = flow.flow_inverse_raw(zg, None if ctx is None else ctx.cuda()) if hasattr(flow, "flow_inverse_raw") \
+            else flow.inverse(zg, None if ctx is None else ctx.cuda())
+    inside = (x.abs() < 3.0).all(dim=1)                      # inverse() clamps to +-3 like the reference
+    if inside.any():
+        back = xb.cpu()[inside]
+        assert (back - x[inside]).abs().max() < 5e-3, (back - x[inside]).abs().max()
