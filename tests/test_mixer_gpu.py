@@ -132,3 +132,19 @@ def test_encoder_bf16_uses_the_hip_mixer_and_agrees_with_fp32_mode():
     with pytest.raises(NotImplementedError):
         from posteriflow_amd import _lib
         _lib.check(_lib.lib().pf_embed_fusion_forward(1, 1, 200, 0, 1, 1, 1, 0), "fusion")
+
+
+@pytest.mark.parametrize("n_det", [1, 2])
+def test_fewer_detectors_bf16_vs_fp32(n_det):
+    """config 2 of BASELINE (single-detector strain): 61 / 122 tokens through the same kernels."""
+    from posteriflow_amd import npe
+    torch.manual_seed(3)
+    enc = npe.LeanStrainEncoder(n_detectors=n_det).cuda().eval()
+    strain = recipe.strain_batch(3, n_det, seed=11).cuda()
+    with torch.no_grad():
+        enc.precision = "fp32"
+        want = enc(strain)
+        enc.precision = "bf16"
+        got = enc(strain)
+    assert "_mixer_state" in enc.__dict__
+    assert (got - want).abs().max() / want.abs().max() < 4e-2
