@@ -92,3 +92,32 @@ def test_random_shape_bf16_and_gradients(D, C, H, K, L, tb, B, permute, seed):
     assert torch.isfinite(got).all()
     err = (got - nll_ref.detach()).abs() / nll_ref.detach().abs().clamp_min(1.0)
     assert err.median() < 2e-2 and err.max() < 0.5, (err.median(), err.max())
+
+
+@pytest.mark.parametrize("D,block,H,K,L", [(4, 5, 64, 8, 2), (7, 16, 128, 16, 3), (12, 3, 192, 13, 2), (15, 20, 256, 16, 2)])
+def test_masked_context_variant_shapes(D, block, H, K, L):
+    """the reference's masked-context conditioner (flows.py:112-360, auto-on when C % D == 0) on other shapes
+    than the one of test_flow_forward_gpu.py: forward / log-det against the fp64 oracle, with a permuted order."""
+    from helpers import oracle_state_for_product
+    from oracle.flow_ref import NSFPosteriorFlowRef
+    from posteriflow_amd import NSFPosteriorFlow
+    C, tb = D * block, 3.0
+    torch.manual_seed(D)
+    ref = NSFPosteriorFlowRef(D, C, H, L, K, tb, temperature_scale=1.0, use_masked_context=True)
+    ref64 = NSFPosteriorFlowRef(D, C, H, L, K, tb, temperature_scale=1.0, use_masked_context=True).double()
+    ref64.load_state_dict(ref.state_dict())
+    flow = NSFPosteriorFlow(D, C, H, L, K, tb, temperature_scale=1.0)
+    assert flow.use_masked_context
+    flow.load_state_dict(oracle_state_for_product(ref))
+    flow = flow.cuda()
+    order = list(range(D))
+    random.Random(D).shuffle(order)
+    for f in (ref, ref64, flow):
+        f.set_autoregressive_order(order)
+    x, ctx = flow_inputs(90, D, C, tb, seed=D)
+    with torch.no_grad():
+        z64, ld64 = ref64(x.double(), ctx.double())
+        z32, ld32 = ref(x, ctx)
+        z, ld = flow(x.cuda(), ctx.cuda())
+    assert (z.cpu().double() - z64).abs().max() < max(6 * (z32.double() - z64).abs().max().item(), 3e-5)
+    assert (ld.cpu().double() - ld64).abs().max() < max(6 * (ld32.double() - ld64).abs().max().item(), 1e-4)
