@@ -3,7 +3,7 @@ Synthetic pools (2048 noise rows, 4096 signal rows = 1.2 GB fp16), 1024 and 8192
 2 signals per example on average (algorithmic bytes: 98 KB fp16 per pool row read + 196 KB fp32 out)."""
 import json, os, sys, tempfile, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from posteriflow_amd.remix import RemixDataset, T_LEN
 
 dev = torch.device("cuda")
