@@ -26,6 +26,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 
 #include "../../include/pf_hip.h"
 #include "pf_math.h"
@@ -52,8 +53,10 @@ struct ConvParams {
     const u32x4* wfrags;    // [cout/16][ksteps][64 lanes]
     const float* bias;      // [cout]
     void* out;              // [N][lout][cout]  (LAST: fp32)
-    float* log_energy;      // FIRST: [N][16]
+    float* log_energy;      // FIRST / FUSE: [N][16]
     int64_t n_seq;
+    const u32x4* wfrags0;   // FUSE (conv1 computed inside conv2's staging): conv1's fragments, bias; `in` is the strain
+    const float* bias0;
 };
 
 __device__ __forceinline__ float gelu_exact(float x) {         // nn.GELU() default: erf form
@@ -64,8 +67,9 @@ __device__ __forceinline__ float gelu_exact(float x) {         // nn.GELU() defa
 __device__ __forceinline__ int row_swz(int q) { return (4 - ((q >> 2) & 3)) & 3; }
 
 // One workgroup: CG*16 output positions of one sequence; wave w owns channel tiles w*TPW..
-template <bool BF16, int LAYER, int CG, int NWAVES>
+template <bool BF16, int LAYER, int CG, int NWAVES, bool FUSE = false>
 __global__ __launch_bounds__(NWAVES * 64) void conv_gemm_kernel(const ConvParams p) {
+    static_assert(!FUSE || LAYER == 1, "only conv1 -> conv2 is fused");
     constexpr StemLayer SL = stem_layer(LAYER);
     constexpr bool FIRST = LAYER == 0, LAST = LAYER == kStemLayers - 1;
     constexpr int CIN = SL.cin, COUT = SL.cout, KW = SL.kw, S = SL.stride, LIN = SL.lin, LOUT = SL.lout;
@@ -132,6 +136,121 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_gemm_kernel(const ConvParams
         __syncthreads();
         if (tid < 2 && p.log_energy) {
             const int w = 2 * blockIdx.x + tid;
+            if (w < 16) p.log_energy[n * 16 + w] = logf(s_e[tid] * (1.f / 1024.f) + 1e-8f);
+        }
+    } else if constexpr (FUSE) {
+        // conv1 (+ sanitise, asinh, log-energy windows, GELU) evaluated HERE for the SPAN conv1 outputs this
+        // workgroup's conv2 positions need, written straight into conv2's LDS input image: the 1.6 GB conv1
+        // activation never exists in HBM.  (1) strain span -> contiguous signal in LDS, (2) conv1 as MFMA over
+        // 16-position tiles (both channel tiles per wave, weights in registers), (3) image rows.
+        constexpr StemLayer L0 = stem_layer(0);
+        constexpr int S0 = L0.stride, KW0 = L0.kw, LIN0 = L0.lin, LOUT0 = L0.lout;
+        constexpr int CB = CIN / CHB;
+        constexpr int Q = (SPAN + S - 1) / S + 1;
+        constexpr int NPT = (SPAN + 15) / 16;                       // conv1 position tiles
+        constexpr int NSIG = (16 * NPT - 1) * S0 + KW0;             // strain samples those tiles read
+        constexpr int NKS0 = KW0 / KSTEP;
+        constexpr size_t IMG = (size_t)S * CB * Q * 64;
+        char* sig = smem + IMG;
+        float* s_e = reinterpret_cast<float*>(sig + (((size_t)NSIG * ESZ + 15) & ~(size_t)15));
+        const float* src = reinterpret_cast<const float*>(p.in) + n * LIN0;
+        const int s0 = in0 * S0;                                   // first strain sample of the span
+        constexpr int OWN = P * S * S0;                            // samples this workgroup owns (energy windows)
+        constexpr int NWIN = OWN / 1024;
+        float sq[NWIN];
+#pragma unroll
+        for (int w = 0; w < NWIN; ++w) sq[w] = 0.f;
+        for (int i = tid * 4; i < NSIG; i += NWAVES * 64 * 4) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (s0 + i + 3 < LIN0) v = *reinterpret_cast<const f32x4*>(src + s0 + i);
+            else
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (s0 + i + e < LIN0) v[e] = src[s0 + i + e];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = v[e];
+                x = (x != x) ? 0.f : x;
+                x = fminf(fmaxf(x, -100.f), 100.f);
+#pragma unroll
+                for (int w = 0; w < NWIN; ++w) if (((i + e) >> 10) == w && i + e < OWN) sq[w] += x * x;
+                v[e] = BF16 ? asinh_fast(x) : asinhf(x);
+            }
+            if (BF16) {
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+                *reinterpret_cast<bf16x4*>(sig + (size_t)i * 2) = o;
+            } else {
+                *reinterpret_cast<f32x4*>(sig + (size_t)i * 4) = v;
+            }
+        }
+        if (tid < NWIN) s_e[tid] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < NWIN; ++w) {
+            float v = sq[w];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+            if (lane == 0) atomicAdd(&s_e[w], v);
+        }
+        // conv1 on the staged signal
+        u32x4 a1f[2][NKS0];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int ks = 0; ks < NKS0; ++ks) a1f[t][ks] = p.wfrags0[(size_t)(t * NKS0 + ks) * 64 + lane];
+        f32x4 b1[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) b1[t] = *reinterpret_cast<const f32x4*>(p.bias0 + 16 * t + 4 * g);
+        for (int pt = wave; pt < NPT; pt += NWAVES) {
+            f32x4 acc1[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int ks = 0; ks < NKS0; ++ks) {
+                const int idx = S0 * (16 * pt + c) + KSTEP * ks + (KSTEP / 4) * g;
+                const u32x4 b = *reinterpret_cast<const u32x4*>(sig + (size_t)idx * ESZ);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    if (BF16) {
+                        acc1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8, a1f[t][ks]), __builtin_bit_cast(bf16x8, b), acc1[t], 0, 0, 0);
+                    } else {
+                        const f32x4 af = __builtin_bit_cast(f32x4, a1f[t][ks]), bf = __builtin_bit_cast(f32x4, b);
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4)
+                            acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q4], bf[q4], acc1[t], 0, 0, 0);
+                    }
+                }
+            }
+            const int pos = 16 * pt + c;                            // conv1 output position within the span
+            const int r = pos % S, q = pos / S;
+            if (q < Q) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    f32x4 v;
+                    if constexpr (BF16) {
+                        v = gelu_erf_fast4(acc1[t] + b1[t]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_exact(acc1[t][e] + b1[t][e]);
+                    }
+                    if (in0 + pos >= LOUT0) v = f32x4{0.f, 0.f, 0.f, 0.f};      // beyond conv1's output: zero padding
+                    const int ch = 16 * t + 4 * g;                                  // first of this lane's 4 channels
+                    const int cb = ch / CHB, byte = (ch % CHB) * ESZ;
+                    char* dst = smem + ((size_t)((r * CB + cb) * Q + q) * 64) + ((((byte >> 4) ^ row_swz(q)) << 4) | (byte & 15));
+                    if constexpr (BF16) {
+                        bf16x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+                        *reinterpret_cast<bf16x4*>(dst) = o;
+                    } else {
+                        *reinterpret_cast<f32x4*>(dst) = v;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < NWIN && p.log_energy) {
+            const int w = NWIN * blockIdx.x + tid;
             if (w < 16) p.log_energy[n * 16 + w] = logf(s_e[tid] * (1.f / 1024.f) + 1e-8f);
         }
     } else {
@@ -268,6 +387,14 @@ constexpr StemGeom stem_geom(int layer) {
                                                                                        : StemGeom{4, 12};
 }
 
+constexpr int kFuseCG = 8;       // conv1 -> conv2 fused: 128 conv2 positions per workgroup (LDS: image + signal)
+static size_t stem_lds_fused(bool bf16) {
+    const StemLayer L = stem_layer(1), L0 = stem_layer(0);
+    const int esz = bf16 ? 2 : 4, P = kFuseCG * 16, span = (P - 1) * L.stride + L.kw;
+    const int chb = 64 / esz, cb = L.cin / chb, q = (span + L.stride - 1) / L.stride + 1;
+    const int npt = (span + 15) / 16, nsig = (16 * npt - 1) * L0.stride + L0.kw;
+    return (size_t)L.stride * cb * q * 64 + (((size_t)nsig * esz + 15) & ~(size_t)15) + 64;
+}
 static size_t stem_lds(int layer, bool bf16) {
     const StemLayer L = stem_layer(layer);
     const StemGeom G = stem_geom(layer);
@@ -352,6 +479,18 @@ static int launch_layer(const ConvParams& p, hipStream_t s) {
 }
 
 template <bool BF16>
+static int launch_fused12(const ConvParams& p, hipStream_t s) {
+    constexpr StemLayer L = stem_layer(1);
+    const size_t lds = stem_lds_fused(BF16);
+    auto k = conv_gemm_kernel<BF16, 1, kFuseCG, 4, true>;
+    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PF_ERR_HIP;
+    const unsigned gx = (L.lout + kFuseCG * 16 - 1) / (kFuseCG * 16);
+    hipLaunchKernelGGL(k, dim3(gx, (unsigned)p.n_seq), dim3(4 * 64), lds, s, p);
+    return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
+}
+
+template <bool BF16>
 static int stem_forward_t(const char* packed, const float* strain, int64_t n_seq, float* tokens,
                           float* log_energy, char* ws, hipStream_t s) {
     int64_t w_off[kStemLayers], b_off[kStemLayers];
@@ -366,8 +505,19 @@ static int stem_forward_t(const char* packed, const float* strain, int64_t n_seq
         p.bias = reinterpret_cast<const float*>(packed + b_off[l]); p.log_energy = l == 0 ? log_energy : nullptr;
     };
     int rc;
-    set(0, strain, act0);  if ((rc = launch_layer<BF16, 0>(p, s)) != PF_OK) return rc;
-    set(1, act0, act1);    if ((rc = launch_layer<BF16, 1>(p, s)) != PF_OK) return rc;
+    // bf16: conv1 inside conv2's staging (2.56 -> 2.13 ms per 12 288 sequences, tokens bit-identical to the
+    // 4-launch path; $PF_STEM_UNFUSED keeps that path testable).  fp32: the fused image + signal need 84 KB of LDS =
+    // one workgroup per CU and measured slower (9.4 -> 10.4 ms), so the parity mode keeps four launches.
+    if (BF16 && !std::getenv("PF_STEM_UNFUSED")) {
+        set(1, strain, act1);
+        p.wfrags0 = reinterpret_cast<const u32x4*>(packed + w_off[0]);
+        p.bias0 = reinterpret_cast<const float*>(packed + b_off[0]);
+        p.log_energy = log_energy;
+        if ((rc = launch_fused12<BF16>(p, s)) != PF_OK) return rc;
+    } else {
+        set(0, strain, act0);  if ((rc = launch_layer<BF16, 0>(p, s)) != PF_OK) return rc;
+        set(1, act0, act1);    if ((rc = launch_layer<BF16, 1>(p, s)) != PF_OK) return rc;
+    }
     set(2, act1, act0);    if ((rc = launch_layer<BF16, 2>(p, s)) != PF_OK) return rc;
     set(3, act0, tokens);  return launch_layer<BF16, 3>(p, s);
 }
