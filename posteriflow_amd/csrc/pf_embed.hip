@@ -387,7 +387,7 @@ constexpr StemGeom stem_geom(int layer) {
                                                                                        : StemGeom{4, 12};
 }
 
-constexpr int kFuseCG = 8;       // conv1 -> conv2 fused: 128 conv2 positions per workgroup (LDS: image + signal)
+constexpr int kFuseCG = 4;       // conv1 -> conv2 fused: 64 conv2 positions per workgroup (32: 2.23 ms, 64: 2.07, 128: 2.13)
 static size_t stem_lds_fused(bool bf16) {
     const StemLayer L = stem_layer(1), L0 = stem_layer(0);
     const int esz = bf16 ? 2 : 4, P = kFuseCG * 16, span = (P - 1) * L.stride + L.kw;
