@@ -23,16 +23,34 @@ size_t fwd_lds_bytes_host(const FlowPlan& L, int R) {
          + (size_t)(3 * 16 * 16 * R + 2 * L.NT * kBiasFloatsPerTile + L.D * 16 * R) * sizeof(float);
 }
 
-int rows_per_workgroup(const FlowPlan& L, int64_t batch) {
-    // B <= 256 CUs * 16 rows: one 16-row group per CU; larger batches amortise each streamed
-    // fragment (and every instruction around it) over R = 2 column groups.
+static int rows_per_workgroup_dir(const FlowPlan& L, int64_t batch, bool inverse) {
+    // A workgroup streams the whole weight set whatever its row count, so more rows per workgroup (R groups
+    // of 16) amortise the stream -- but a launch costs ceil(workgroups / 256 CUs) rounds, and a round of
+    // R = 1 / 2 / 3 groups takes 108 / 142 / 195 us (forward, measured): pick the R with the cheapest launch.
+    // R = 3 exists for the bf16, H = 256, in-layer-context forward kernel only (registers).
     int R = 1;
-    if (const char* f = getenv("PF_FORCE_R")) R = atoi(f) == 2 ? 2 : 1;   // test knob
-    else if (batch > 256 * 16) R = 2;
+    if (const char* f = getenv("PF_FORCE_R")) {          // test knob
+        R = atoi(f);
+        R = R < 1 ? 1 : (R > 3 ? 3 : R);
+    } else if (inverse) {
+        if (batch > 256 * 16) R = 2;
+    } else {
+        const bool r3 = L.bf16 && L.NT == 16 && !L.hoist;
+        const double t[4] = {0.0, 1.0, 1.32, 1.81};
+        double best = 1e300;
+        for (int r = 1; r <= (r3 ? 3 : 2); ++r) {
+            const int64_t wgs = (batch + 16 * r - 1) / (16 * r);
+            const double cost = (double)((wgs + 255) / 256) * t[r];
+            if (cost < best - 1e-9) { best = cost; R = r; }
+        }
+    }
+    const bool r3_built = !inverse && L.bf16 && L.NT == 16 && !L.hoist;
+    if (R == 3 && !r3_built) R = 2;
     if (L.dense) R = 1;
-    while (R > 1 && fwd_lds_bytes_host(L, R) > 160 * 1024) R >>= 1;
+    while (R > 1 && fwd_lds_bytes_host(L, R) > 160 * 1024) --R;
     return 16 * R;
 }
+int rows_per_workgroup(const FlowPlan& L, int64_t batch) { return rows_per_workgroup_dir(L, batch, false); }
 
 int launch_flow_forward(const FwdParams& p_in, hipStream_t s) {
     if (p_in.batch == 0) return PF_OK;
@@ -51,7 +69,7 @@ int launch_flow_forward(const FwdParams& p_in, hipStream_t s) {
 
 int launch_flow_inverse(const FwdParams& p, hipStream_t s) {
     if (p.batch == 0) return PF_OK;
-    const int R = rows_per_workgroup(p.plan, p.batch) / 16;
+    const int R = rows_per_workgroup_dir(p.plan, p.batch, true) / 16;
 #define PF_CASE(P, N) case N: return launch_flow_inverse_p##P##_nt##N(p, R, s);
     if (p.plan.bf16) {
         switch (p.plan.NT) { PF_CASE(1, 4) PF_CASE(1, 8) PF_CASE(1, 12) PF_CASE(1, 16) }

@@ -724,9 +724,10 @@ __global__ __launch_bounds__(NT * 32) void flow_kernel(const FwdParams p) {
     }
     // (sum nll, rows) += this workgroup's rows: the rows sit in the first COLS <= 32 lanes of wave 0;
     // wave shuffle reduction, then one pair of float atomics per workgroup
+    static_assert(COLS <= 64, "the loss reduction assumes the rows sit in wave 0");
     if (p.nll_sum && tid < 64) {
 #pragma unroll
-        for (int o = 16; o > 0; o >>= 1) { my_nll += __shfl_xor(my_nll, o, 64); my_cnt += __shfl_xor(my_cnt, o, 64); }
+        for (int o = 32; o > 0; o >>= 1) { my_nll += __shfl_xor(my_nll, o, 64); my_cnt += __shfl_xor(my_cnt, o, 64); }
         if (tid == 0) { atomicAdd(p.nll_sum, my_nll); atomicAdd(p.nll_sum + 1, my_cnt); }
     }
     }
@@ -756,7 +757,10 @@ inline int launch_variant(const FwdParams& p, hipStream_t s) {
 template <bool BF16, int NT, int CKM, bool INV>
 inline int launch_ckm(const FwdParams& p, int R, hipStream_t s) {
     if (p.plan.dense) return launch_variant<BF16, NT, 1, CKM, true, INV>(p, s);
-    if (R == 2) return launch_variant<BF16, NT, 2, CKM, false, INV>(p, s);
+    if constexpr (BF16 && NT == 16 && !INV) {            // large batches, LeanNPE-sized hidden width: 48 rows per workgroup
+        if (R == 3) return launch_variant<BF16, NT, 3, CKM, false, INV>(p, s);
+    }
+    if (R >= 2) return launch_variant<BF16, NT, 2, CKM, false, INV>(p, s);
     return launch_variant<BF16, NT, 1, CKM, false, INV>(p, s);
 }
 

@@ -240,3 +240,30 @@ def test_in_kernel_loss_reduction(B):
     assert abs(acc[0].item() - 2 * want.double().sum().item()) <= 2e-5 * want.double().abs().sum().item() + 1e-3
     with pytest.raises(ValueError):
         flow.nll_into(x, ctx, nll, sum_count=torch.zeros(3, device="cuda"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,rows", [(4096, 16), (5000, 32), (12288, 48), (12289, 32), (36864, 48), (65536, 32)])
+def test_rows_per_workgroup_choice_and_parity(B, rows):
+    """the launch picks 16 / 32 / 48 rows per workgroup by rounds x round time; every choice gives the same
+    log-density as the CPU oracle on a sample of rows and the same values as the 16-row kernel everywhere."""
+    import os
+    from helpers import flow_inputs, make_pair
+    from posteriflow_amd import _lib
+    ref, _, flow = make_pair(15, 288, 256, 2, 16, 5.0)
+    flow.precision = "bf16"
+    assert _lib.lib().pf_flow_rows_per_workgroup(flow._desc(), B) == rows
+    x, ctx = flow_inputs(B, 15, 288, 5.0)
+    xg, cg = x.cuda(), ctx.cuda()
+    with torch.no_grad():
+        got = flow.compute_psd_aware_nll(xg, cg, None)
+        os.environ["PF_FORCE_R"] = "1"
+        try:
+            base = flow.compute_psd_aware_nll(xg, cg, None)
+        finally:
+            del os.environ["PF_FORCE_R"]
+        assert torch.equal(got, base)                      # rows per workgroup does not change any row's arithmetic
+        idx = torch.linspace(0, B - 1, 64).long()
+        want = ref.compute_psd_aware_nll(x[idx], ctx[idx], torch.zeros(64, 15))
+    err = (got.cpu()[idx] - want).abs() / want.abs().clamp_min(1.0)
+    assert err.median() < 2e-2 and err.max() < 0.3
