@@ -1,0 +1,44 @@
+"""bench.py end to end on the GPU: the default single-GPU step and the N > 1 step (in-kernel loss reduction +
+asynchronous all-reduce over a real NCCL/RCCL communicator, rehearsed with one rank), checked for the JSON
+contract and for the loss the collective path reports."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+        "vs_baseline", "dtype", "data", "config", "roofline"}
+
+
+def _run(*flags):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "3",
+                          "--no-extras", "--no-cpu-baseline", *flags],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                   # exactly one JSON line on stdout
+    return json.loads(lines[0])
+
+
+def test_default_step_contract():
+    d = _run()
+    assert KEYS <= set(d) and d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 3
+    assert d["unit"] == "samples/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["config"]["workload"].startswith("BASELINE config 3") and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["unit"] == "TFLOP/s"
+    assert d["value"] > 1e7 and abs(d["value"] - 4096 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+
+
+def test_collective_step_reports_the_same_loss():
+    d = _run("--collective")
+    assert d["config"]["launch"] == "pre-bound launch + async all-reduce"
+    loss = d["config"]["global_mean_nll"]
+    assert loss is not None and 50.0 < loss < 500.0          # mean NLL of the synthetic batch (134.9 for seed 1)
+    assert d["value"] > 5e6
