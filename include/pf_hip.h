@@ -149,6 +149,26 @@ int pf_flow_inverse(const PfFlowDesc* desc, const void* packed,
                     float* x, float* logdet, uint32_t* fail_flags,
                     void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- incremental inverse (bf16) -----------------------------------------------------------------
+ * Same result as pf_flow_inverse (the transform.inverse call of flows.py:637), with ONE masked conditioner
+ * evaluation per layer instead of D dense ones: pass i computes only the hidden units of degree i (2-3 tiles per
+ * hidden stage, hidden units sorted by degree) from the activations of the earlier passes, which stay in LDS.
+ * 32 draws per workgroup.  The caller prepares, per layer l (bytes: pf_flow_inc_layer_bytes):
+ *   A fragments (pf_pack_bf16_frags of the masked weights, rows / columns of hidden units in degree-sorted
+ *   order): W0 [H][32] (columns f and 16 + f both = initial_layer.weight[:, f]: the input enters as a bf16
+ *   hi | lo pair), W1 / W2 of block 0, W1 / W2 of block 1 [H][H], final layer [D * 48][H] (per feature 16
+ *   width rows, 16 height rows, 16 derivative rows, zero padded), then fp32: b0 | b1_0 | b2_0 | b1_1 | b2_1
+ *   (H each, sorted) | final bias [D][48];
+ *   ctx_proj [ctx_rows][L][3][H] fp32 = context_layer / block-0 / block-1 context projections (with their
+ *   biases, before ReLU / sigmoid), sorted-unit order, or NULL for a context-free flow;
+ *   units_upto_degree (host int32[D + 1]): number of hidden units with degree <= i.
+ * z, x, logdet, fail_flags, ar_inv_perm, ctx_rows as in pf_flow_inverse. */
+int pf_pack_bf16_frags(const float* src, int32_t n_rows, int32_t k, void* out, void* stream);
+int64_t pf_flow_inc_layer_bytes(const PfFlowDesc* desc);
+int pf_flow_inverse_inc(const PfFlowDesc* desc, const int32_t* units_upto_degree, const void* packed,
+                        const float* ctx_proj, int64_t ctx_rows, const float* z, const int32_t* ar_inv_perm,
+                        int64_t batch, float* x, float* logdet, uint32_t* fail_flags, void* stream);
+
 /* ---- strain-embedding stem ------------------------------------------------------
  * tokens[N,61,192], log_energy[N,16] = stem(strain[N,16384]) for N = batch * n_detectors
  * sequences: replaces lean_npe.py:207 (sanitise), :210-212 (window log-energy) and :216-217

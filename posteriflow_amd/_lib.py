@@ -54,6 +54,10 @@ SYMBOLS = {
     "pf_flow_inverse": (C.c_int, [_P, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                   C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_int64, C.c_void_p]),
+    "pf_pack_bf16_frags": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "pf_flow_inc_layer_bytes": (C.c_int64, [_P]),
+    "pf_flow_inverse_inc": (C.c_int, [_P, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                      C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pf_embed_stem_raw_param_count": (C.c_int64, []),
     "pf_embed_stem_packed_bytes": (C.c_int64, [C.c_int32]),
     "pf_embed_stem_pack_map_len": (C.c_int64, [C.c_int32]),

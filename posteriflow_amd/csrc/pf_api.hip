@@ -20,6 +20,11 @@ int64_t fusion_packed_bytes();
 int fusion_pack(const float* raw, char* packed, hipStream_t s);
 int fusion_forward(const char* packed, float* tokens, int n_tokens, const float* tok_bias, const float* pool_q,
                    int64_t n_events, float* pooled, hipStream_t s);
+int inc_pack_frags(const float* src, int n_rows, int k, void* out, hipStream_t s);
+int64_t inc_layer_bytes(int D, int H);
+int flow_inverse_inc(const PfFlowDesc& d, float deriv_const, const int32_t* u1, const void* packed, const float* proj,
+                     int64_t ctx_rows, const float* z, const int32_t* inv_perm, int64_t batch, float* x, float* logdet,
+                     uint32_t* fail, hipStream_t s);
 int64_t remix_workspace_bytes(int64_t batch);
 int remix_forward(const void* noise, int64_t n_noise, const void* signals, int64_t n_signals,
                   const int64_t* noise_row, const int64_t* sig_start, const int32_t* nsig, const float* scale,
@@ -255,6 +260,42 @@ int pf_embed_stem_forward(int32_t precision, const void* packed, const float* st
         return fail(PF_ERR_BAD_ARG, "packed/strain/tokens must be 16-byte, workspace 256-byte aligned");
     const int rc = pf::stem_forward(bf, static_cast<const char*>(packed), strain, n_sequences, tokens, log_energy,
                                     static_cast<char*>(workspace), static_cast<hipStream_t>(stream));
+    return rc == PF_OK ? rc : fail(rc, hipGetErrorString(hipGetLastError()));
+}
+
+// ---- incremental inverse ------------------------------------------------------------------------
+int pf_pack_bf16_frags(const float* src, int32_t n_rows, int32_t k, void* out, void* stream) {
+    if (!src || !out) return fail(PF_ERR_BAD_ARG, "null pointer");
+    if (n_rows <= 0 || k <= 0 || n_rows % 16 || k % 32) return fail(PF_ERR_BAD_ARG, "rows must be a multiple of 16, k of 32");
+    if (misaligned(out, 16)) return fail(PF_ERR_BAD_ARG, "out must be 16-byte aligned");
+    const int rc = pf::inc_pack_frags(src, n_rows, k, out, static_cast<hipStream_t>(stream));
+    return rc == PF_OK ? rc : fail(rc, hipGetErrorString(hipGetLastError()));
+}
+int64_t pf_flow_inc_layer_bytes(const PfFlowDesc* desc) {
+    if (!desc || desc->hidden_features % 32 || desc->hidden_features < 64 || desc->hidden_features > 256) return -1;
+    return pf::inc_layer_bytes(desc->features, desc->hidden_features);
+}
+int pf_flow_inverse_inc(const PfFlowDesc* desc, const int32_t* units_upto_degree, const void* packed,
+                        const float* ctx_proj, int64_t ctx_rows, const float* z, const int32_t* ar_inv_perm,
+                        int64_t batch, float* x, float* logdet, uint32_t* fail_flags, void* stream) {
+    if (!desc) return fail(PF_ERR_BAD_ARG, "desc is null");
+    const int D = desc->features, H = desc->hidden_features;
+    if (H % 32 || H < 64 || H > 256 || D < 1 || D > 16 || D > H / 16 || desc->num_bins < 2 || desc->num_bins > 16 ||
+        desc->num_blocks != 2)
+        return fail(PF_ERR_UNSUPPORTED, "incremental inverse: need H in 64..256 (multiple of 32), D <= min(16, H/16), K <= 16");
+    if (desc->precision != PF_PREC_BF16) return fail(PF_ERR_UNSUPPORTED, "incremental inverse is built for PF_PREC_BF16");
+    if (!(desc->tail_bound > 0.f)) return fail(PF_ERR_BAD_ARG, "tail_bound must be positive");
+    if (batch < 0) return fail(PF_ERR_BAD_ARG, "negative batch");
+    if (batch == 0) return PF_OK;
+    if (!units_upto_degree || !packed || !z || !x) return fail(PF_ERR_BAD_ARG, "null pointer");
+    if (ctx_proj && (ctx_rows < 1 || batch % ctx_rows != 0)) return fail(PF_ERR_BAD_ARG, "ctx_rows must be >= 1 and divide batch");
+    if (misaligned(packed, 16) || misaligned(ctx_proj, 16)) return fail(PF_ERR_BAD_ARG, "packed / ctx_proj must be 16-byte aligned");
+    if (units_upto_degree[0] != 0 || units_upto_degree[D] > H) return fail(PF_ERR_BAD_ARG, "units_upto_degree[0] must be 0 and [D] <= H");
+    for (int i = 0; i < D; ++i)
+        if (units_upto_degree[i] > units_upto_degree[i + 1]) return fail(PF_ERR_BAD_ARG, "units_upto_degree must be non-decreasing");
+    const float dc = (float)std::log(std::exp(1.0 - (double)desc->min_derivative) - 1.0);
+    const int rc = pf::flow_inverse_inc(*desc, dc, units_upto_degree, packed, ctx_proj, ctx_proj ? ctx_rows : batch, z,
+                                        ar_inv_perm, batch, x, logdet, fail_flags, static_cast<hipStream_t>(stream));
     return rc == PF_OK ? rc : fail(rc, hipGetErrorString(hipGetLastError()));
 }
 

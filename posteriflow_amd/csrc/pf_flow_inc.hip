@@ -1,0 +1,288 @@
+// pf_flow_inc.hip -- incremental inverse (sampling direction) of the masked-autoregressive spline flow.
+//
+// nflows inverts an autoregressive layer with D full conditioner passes (AutoregressiveTransform.inverse,
+// executed under src/ahsd/models/flows.py:637), and so does pf_flow_inverse: every pass streams the whole
+// layer (~0.45 MB of fragments) although feature i's spline parameters only need the hidden units of
+// degree <= i, and of those only the units of degree exactly i are NEW in pass i (their inputs -- x_0..x_{i-1}
+// and the units of lower degree -- were final one pass earlier).  Here a pass computes just those units:
+// with the hidden units sorted by degree they are a contiguous range of 2-3 sixteen-unit tiles per hidden
+// layer (H / (D - 1) units), whose reduction runs over the units of degree <= i only, and the activations
+// of all five hidden stages of the layer stay in LDS (bf16, 5 x 32 rows x H) between passes.  Summed over the
+// D passes the work is ONE masked conditioner evaluation per layer ("exact incremental
+// algorithm") instead of D dense ones.  The result is the same x: no approximation is involved.
+//
+// One workgroup = 32 draws (two 16-row MFMA column tiles), 8 waves.  Transposed MFMA form as everywhere:
+// out^T[unit, row] = W[unit, k] . act^T[k, row]; a task = (unit tile, column tile), its fp32 residual value
+// h lives in the owning wave's registers through the five stages of a pass; stages are separated by a
+// workgroup barrier (the next stage reads the tile just written).  bf16 operands / fp32 accumulation, the
+// input features enter the first masked layer as a bf16 hi + lo pair, context enters as per-context-row
+// projections computed once by the caller (C = 0: none).  Spline inversion: rqs_pair_inverse of the D-pass
+// kernel, one lane per row.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "pf_flow_fwd_kernel.h"
+
+namespace pf {
+namespace {
+constexpr int kRows = 32;                  // draws per workgroup
+constexpr int kMaxTasks = 4;               // (unit tile, column tile) tasks per wave: 16 tiles x 2 / 8 waves
+constexpr int kParS = kParStride;          // floats per row in the spline-parameter transpose (52)
+
+struct IncParams {
+    FwdParams sp;              // spline scalars only: tail_bound, min_w, min_h, min_d, deriv_const
+    const char* w;             // L layer blocks (see pf_hip.h, pf_flow_inverse_inc)
+    const float* proj;         // [ctx_rows][L][3][H] fp32 in sorted-unit order, or null when C = 0
+    const float* z;            // [batch][D]
+    float* x;                  // [batch][D]
+    float* logdet;             // [batch] or null
+    uint32_t* fail;            // [batch] or null
+    const int32_t* inv_perm;   // [D] or null
+    int64_t batch, ctx_rows, layer_bytes;
+    int64_t off_w1[2], off_w2[2], off_wf, off_bias;      // byte offsets inside a layer block (W0 at 0)
+    int D, H, K, L;
+    int u1[17];                // number of hidden units (sorted order) with degree <= i
+};
+
+__device__ __forceinline__ f32x4 mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ bf16x4 bf16_of(f32x4 v) {
+    bf16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+    return o;
+}
+__device__ __forceinline__ f32x4 relu4(f32x4 v) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+    return v;
+}
+__device__ __forceinline__ f32x4 sigmoid4(f32x4 v) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_rcpf(1.f + __expf(-v[e]));
+    return v;
+}
+
+// acc = sum_{ks < ks1} A(ks) . B(ks): all weight fragments are requested before the first MFMA (a loop that
+// loads and multiplies one k-step at a time pays one L2 latency per k-step); H <= 256 -> at most 8 k-steps
+__device__ __forceinline__ f32x4 gemm_tile(const char* wb, const char* src, int ks1) {
+    bf16x8 a[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+        if (ks < ks1) a[ks] = *reinterpret_cast<const bf16x8*>(wb + (size_t)ks * 1024);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+        if (ks < ks1) v = mfma_bf16(a[ks], *reinterpret_cast<const bf16x8*>(src + ks * 64), v);
+    return v;
+}
+
+__global__ __launch_bounds__(512) void flow_inverse_inc_kernel(const IncParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int D = p.D, H = p.H, HK = H / 32;
+    const int AS = H * 2 + 16;                                   // byte stride of an activation row (bank spread)
+    char* const act = smem;                                      // 5 stages x [32 rows][H] bf16
+    char* const xb = act + (size_t)5 * kRows * AS;               // [32][32] bf16: x hi (0..15) | lo (16..31)
+    float* const xs = reinterpret_cast<float*>(xb + kRows * 64); // [32][16] current layer's input, fp32
+    float* const ys = xs + kRows * 16;                           // [32][16] current layer's output
+    float* const par = ys + kRows * 16;                          // [32][52] spline parameters of one feature
+    float* const ldacc = par + kRows * kParS;                    // [32]
+    uint32_t* const badf = reinterpret_cast<uint32_t*>(ldacc + kRows);
+
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t row0 = (int64_t)blockIdx.x * kRows;
+    auto act_of = [&](int s) { return act + (size_t)s * kRows * AS; };
+
+    // ---- initial state: y = z (coordinates of the last layer's output), log-det 0 --------------------
+    for (int s = tid; s < kRows * 16; s += 512) {
+        const int r = s >> 4, d = s & 15;
+        int64_t row = row0 + r;
+        if (row >= p.batch) row = p.batch - 1;
+        ys[s] = d < D ? p.z[row * D + d] : 0.f;
+    }
+    if (tid < kRows) { ldacc[tid] = 0.f; badf[tid] = 0u; }
+    // activations of units not computed yet are read through zero (masked) weights: they must be finite
+    for (int s = tid * 16; s < 5 * kRows * AS; s += 512 * 16) *reinterpret_cast<f32x4*>(act + s) = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+
+    for (int l = p.L - 1; l >= 0; --l) {
+        const char* lw = p.w + (size_t)l * p.layer_bytes;
+        const float* bias = reinterpret_cast<const float*>(lw + p.off_bias);   // b0 | b1_0 | b2_0 | b1_1 | b2_1 | bf[D][48]
+        // x estimate of this layer starts at zero (only solved features are ever read through non-zero weights)
+        for (int s = tid; s < kRows * 32; s += 512) reinterpret_cast<__bf16*>(xb)[s] = (__bf16)0.f;
+        for (int s = tid; s < kRows * 16; s += 512) xs[s] = 0.f;
+        __syncthreads();
+
+        for (int i = 0; i < D; ++i) {                  // solve feature i (autoregressive position, degree i + 1)
+            const int ulo = i >= 1 ? p.u1[i - 1] : 0, uhi = p.u1[i];     // new hidden units: degree == i
+            const int t_lo = ulo / 16, t_hi = (uhi + 15) / 16;           // their tiles
+            const int ntile = i >= 1 ? t_hi - t_lo : 0;
+            const int ks1 = (uhi + 31) / 32;                             // reduction over units of degree <= i
+            if (ntile > 0) {
+                // this wave's tasks: (tile, column) = task / 2, task % 2 for task = wave, wave + 8, ...
+                f32x4 h[kMaxTasks], pg[2][kMaxTasks];
+                // ---- stage a: h0 = W0 . (x hi|lo) + b0 + relu(pc); act0 = relu(h0) ----
+#pragma unroll
+                for (int q = 0; q < kMaxTasks; ++q) {
+                    const int task = wave + 8 * q;
+                    if (task < 2 * ntile) {
+                        const int t = t_lo + (task >> 1), c2 = task & 1;
+                        const bf16x8 a = *reinterpret_cast<const bf16x8*>(lw + ((size_t)t * 64 + lane) * 16);
+                        const bf16x8 b = *reinterpret_cast<const bf16x8*>(xb + (16 * c2 + c) * 64 + g * 16);
+                        f32x4 v = mfma_bf16(a, b, f32x4{0.f, 0.f, 0.f, 0.f});
+                        const int u = 16 * t + 4 * g;
+                        v = v + *reinterpret_cast<const f32x4*>(bias + u);
+                        pg[0][q] = pg[1][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (p.proj) {
+                            int64_t row = row0 + 16 * c2 + c;
+                            if (row >= p.batch) row = p.batch - 1;
+                            const int64_t cr = row / (p.batch / p.ctx_rows);
+                            const float* pr = p.proj + ((cr * p.L + l) * 3) * (int64_t)H + u;
+                            v = v + relu4(*reinterpret_cast<const f32x4*>(pr));
+                            pg[0][q] = *reinterpret_cast<const f32x4*>(pr + H);
+                            pg[1][q] = *reinterpret_cast<const f32x4*>(pr + 2 * H);
+                        }
+                        h[q] = v;
+                        *reinterpret_cast<bf16x4*>(act_of(0) + (16 * c2 + c) * AS + u * 2) = bf16_of(relu4(v));
+                    }
+                }
+                __syncthreads();
+                // ---- stages b..e: the two residual blocks ----
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk) {
+                    // t1 = W1 . act[2 blk] + b1 ; act[2 blk + 1] = relu(t1)
+#pragma unroll
+                    for (int q = 0; q < kMaxTasks; ++q) {
+                        const int task = wave + 8 * q;
+                        if (task < 2 * ntile) {
+                            const int t = t_lo + (task >> 1), c2 = task & 1;
+                            const char* wb = lw + p.off_w1[blk] + ((size_t)t * HK * 64 + lane) * 16;
+                            const char* src = act_of(2 * blk) + (16 * c2 + c) * AS + g * 16;
+                            f32x4 v = gemm_tile(wb, src, ks1);
+                            const int u = 16 * t + 4 * g;
+                            v = v + *reinterpret_cast<const f32x4*>(bias + (1 + 2 * blk) * H + u);
+                            *reinterpret_cast<bf16x4*>(act_of(2 * blk + 1) + (16 * c2 + c) * AS + u * 2) = bf16_of(relu4(v));
+                        }
+                    }
+                    __syncthreads();
+                    // t2 = W2 . act[2 blk + 1] + b2 ; h += t2 * sigmoid(pg) ; act[2 blk + 2] = relu(h) (block 0) | h (block 1)
+#pragma unroll
+                    for (int q = 0; q < kMaxTasks; ++q) {
+                        const int task = wave + 8 * q;
+                        if (task < 2 * ntile) {
+                            const int t = t_lo + (task >> 1), c2 = task & 1;
+                            const char* wb = lw + p.off_w2[blk] + ((size_t)t * HK * 64 + lane) * 16;
+                            const char* src = act_of(2 * blk + 1) + (16 * c2 + c) * AS + g * 16;
+                            f32x4 v = gemm_tile(wb, src, ks1);
+                            const int u = 16 * t + 4 * g;
+                            v = v + *reinterpret_cast<const f32x4*>(bias + (2 + 2 * blk) * H + u);
+                            if (p.proj) v = v * sigmoid4(pg[blk][q]);
+                            h[q] = h[q] + v;
+                            *reinterpret_cast<bf16x4*>(act_of(2 * blk + 2) + (16 * c2 + c) * AS + u * 2) =
+                                bf16_of(blk == 0 ? relu4(h[q]) : h[q]);
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+            // ---- stage f: the 3K-1 raw spline parameters of feature i (3 row tiles: widths | heights | derivatives) ----
+            if (wave < 6) {
+                const int t3 = wave >> 1, c2 = wave & 1;
+                const char* wb = lw + p.off_wf + ((size_t)(3 * i + t3) * HK * 64 + lane) * 16;
+                const char* src = act_of(4) + (16 * c2 + c) * AS + g * 16;
+                f32x4 v = gemm_tile(wb, src, ks1);
+                v = v + *reinterpret_cast<const f32x4*>(bias + 5 * H + 48 * i + 16 * t3 + 4 * g);
+                *reinterpret_cast<f32x4*>(par + (16 * c2 + c) * kParS + 16 * t3 + 4 * g) = v;
+            }
+            __syncthreads();
+            if (tid < kRows) {
+                float xv, ld;
+                bool bad;
+                rqs_pair_inverse<true>(par + tid * kParS, ys[tid * 16 + i], p.K, p.sp, xv, ld, bad);
+                xs[tid * 16 + i] = xv;
+                const __bf16 hi = (__bf16)xv;
+                reinterpret_cast<__bf16*>(xb)[tid * 32 + i] = hi;
+                reinterpret_cast<__bf16*>(xb)[tid * 32 + 16 + i] = (__bf16)(xv - (float)hi);
+                ldacc[tid] += ld;
+                if (bad) badf[tid] = 1u;
+            }
+            __syncthreads();
+        }
+        // this layer's input is the previous layer's output, reversed (ReversePermutation precedes every layer)
+        for (int s = tid; s < kRows * 16; s += 512) {
+            const int r = s >> 4, d = s & 15;
+            ys[s] = d < D ? xs[r * 16 + (D - 1 - d)] : 0.f;
+        }
+        __syncthreads();
+    }
+    // ---- ys now holds x[:, ar_perm]; undo the autoregressive order and store ------------------------------
+    if (tid < kRows) {
+        const int64_t row = row0 + tid;
+        if (row < p.batch) {
+            for (int d = 0; d < D; ++d) {
+                const int src = p.inv_perm ? p.inv_perm[d] : d;
+                p.x[row * D + d] = ys[tid * 16 + src];
+            }
+            if (p.logdet) p.logdet[row] = ldacc[tid];
+            if (p.fail && badf[tid]) atomicOr(p.fail + row, 1u);
+        }
+    }
+}
+
+// raw fp32 [N][K] row-major -> bf16 A fragments: fragment (tile, ks), lane (g, r): W[16 tile + r][32 ks + 8 g ..+7]
+__global__ void inc_pack_frags_kernel(const float* wsrc, int n_rows, int k, __bf16* out) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= static_cast<int64_t>(n_rows) * k) return;
+    const int ksteps = k / 32;
+    const int e = i & 7, lane = (i >> 3) & 63;
+    const int64_t f = i >> 9;
+    const int tile = static_cast<int>(f / ksteps), ks = static_cast<int>(f % ksteps);
+    out[i] = (__bf16)wsrc[static_cast<int64_t>(16 * tile + (lane & 15)) * k + 32 * ks + 8 * (lane >> 4) + e];
+}
+}  // namespace
+
+int inc_pack_frags(const float* src, int n_rows, int k, void* out, hipStream_t s) {
+    const int64_t tot = static_cast<int64_t>(n_rows) * k;
+    inc_pack_frags_kernel<<<dim3(static_cast<unsigned>((tot + 255) / 256)), dim3(256), 0, s>>>(
+        src, n_rows, k, static_cast<__bf16*>(out));
+    return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
+}
+
+int64_t inc_layer_bytes(int D, int H) {
+    const int64_t NT = H / 16, HK = H / 32;
+    return (NT + 4 * NT * HK + 3 * (int64_t)D * HK) * 1024 + (5 * (int64_t)H + 48 * (int64_t)D) * 4;
+}
+
+int flow_inverse_inc(const PfFlowDesc& d, float deriv_const, const int32_t* u1, const void* packed, const float* proj,
+                     int64_t ctx_rows, const float* z, const int32_t* inv_perm, int64_t batch, float* x, float* logdet,
+                     uint32_t* fail, hipStream_t s) {
+    IncParams p{};
+    p.sp.tail_bound = d.tail_bound; p.sp.min_w = d.min_bin_width; p.sp.min_h = d.min_bin_height;
+    p.sp.min_d = d.min_derivative; p.sp.deriv_const = deriv_const;
+    p.w = static_cast<const char*>(packed); p.proj = proj; p.z = z; p.x = x; p.logdet = logdet; p.fail = fail;
+    p.inv_perm = inv_perm; p.batch = batch; p.ctx_rows = ctx_rows;
+    p.D = d.features; p.H = d.hidden_features; p.K = d.num_bins; p.L = d.num_layers;
+    const int64_t NT = p.H / 16, HK = p.H / 32;
+    p.off_w1[0] = NT * 1024;
+    p.off_w2[0] = p.off_w1[0] + NT * HK * 1024;
+    p.off_w1[1] = p.off_w2[0] + NT * HK * 1024;
+    p.off_w2[1] = p.off_w1[1] + NT * HK * 1024;
+    p.off_wf = p.off_w2[1] + NT * HK * 1024;
+    p.off_bias = p.off_wf + 3 * (int64_t)p.D * HK * 1024;
+    p.layer_bytes = inc_layer_bytes(p.D, p.H);
+    for (int i = 0; i <= p.D; ++i) p.u1[i] = u1[i];
+    const size_t lds = (size_t)5 * kRows * (p.H * 2 + 16) + kRows * 64 + (size_t)kRows * (16 + 16 + kParS + 2) * 4;
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(flow_inverse_inc_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
+            return PF_ERR_HIP;
+        configured = true;
+    }
+    flow_inverse_inc_kernel<<<dim3(static_cast<unsigned>((batch + kRows - 1) / kRows)), dim3(512), lds, s>>>(p);
+    return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
+}
+}  // namespace pf

@@ -530,6 +530,79 @@ class NSFPosteriorFlow(nn.Module):
         return torch.relu(lo - params_norm).mean() + torch.relu(params_norm - hi).mean()
 
     # ---- inverse / sampling ------------------------------------------------------------------
+    # ---- incremental inverse (bf16): one masked conditioner evaluation per layer instead of D dense ones ----
+    incremental_inverse: Optional[bool] = None      # None: on in bf16 mode for the plain conditioner; False: D-pass kernel
+
+    def _use_incremental(self) -> bool:
+        if self.incremental_inverse is False or self.use_masked_context or self.precision != "bf16":
+            return False
+        return self.hidden_features % 32 == 0 and self.features <= min(16, self.hidden_features // 16)
+
+    def _inc_state(self, dev):
+        """Weights of every layer in the layout of pf_flow_inverse_inc (hidden units sorted by degree, masks
+        applied, bf16 MFMA A-fragments) + the stacked context-projection weights; rebuilt when a parameter changed."""
+        params = self._ordered_parameters()
+        key = (dev, tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
+        st = self.__dict__.setdefault("_inc", {})
+        if st.get("key") == key and (self._frozen or True):
+            return st
+        L_, D, H, K = _lib.lib(), self.features, self.hidden_features, self.num_bins
+        desc = self._desc("bf16", inverse=True)
+        deg = _hidden_degrees(H, D).to(dev)
+        perm = torch.argsort(deg, stable=True)
+        deg_sorted = deg[perm]
+        u1 = (_lib.C.c_int32 * (D + 1))(*[int((deg_sorted <= i).sum()) for i in range(D + 1)])
+        layer_bytes = L_.pf_flow_inc_layer_bytes(desc)
+        if layer_bytes <= 0:
+            _lib.check(_lib.PF_ERR_UNSUPPORTED, "pf_flow_inc_layer_bytes")
+        nl = self.num_layers
+        buf = torch.empty(nl * layer_bytes, dtype=torch.uint8, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        nt, hk = H // 16, H // 32
+        wc, bc = [], []
+        with torch.no_grad():
+            for l, layer in enumerate(self._ar_transforms):
+                net = layer.autoregressive_net
+                off = l * layer_bytes
+
+                def pack(mat, off):
+                    mat = mat.float().contiguous()
+                    _lib.check(L_.pf_pack_bf16_frags(mat.data_ptr(), mat.shape[0], mat.shape[1],
+                                                     buf.data_ptr() + off, stream), "pf_pack_bf16_frags")
+                    return off + mat.shape[0] * mat.shape[1] * 2
+
+                w0 = (net.initial_layer.weight * net.initial_layer.mask)[perm]
+                a0 = torch.zeros(H, 32, device=dev)
+                a0[:, :D] = w0
+                a0[:, 16:16 + D] = w0
+                off = pack(a0, off)
+                biases = [net.initial_layer.bias[perm]]
+                for blk in net.blocks:
+                    for lin in blk.linear_layers:
+                        off = pack((lin.weight * lin.mask)[perm][:, perm], off)
+                        biases.append(lin.bias[perm])
+                wf = (net.final_layer.weight * net.final_layer.mask)[:, perm].reshape(D, 3 * K - 1, H)
+                wf48 = torch.zeros(D, 48, H, device=dev)
+                wf48[:, 0:K] = wf[:, 0:K]
+                wf48[:, 16:16 + K] = wf[:, K:2 * K]
+                wf48[:, 32:32 + K - 1] = wf[:, 2 * K:]
+                off = pack(wf48.reshape(D * 48, H), off)
+                bf = net.final_layer.bias.reshape(D, 3 * K - 1)
+                bf48 = torch.zeros(D, 48, device=dev)
+                bf48[:, 0:K] = bf[:, 0:K]
+                bf48[:, 16:16 + K] = bf[:, K:2 * K]
+                bf48[:, 32:32 + K - 1] = bf[:, 2 * K:]
+                vec = torch.cat([b.float() for b in biases] + [bf48.reshape(-1)]).contiguous()
+                assert off + vec.numel() * 4 == (l + 1) * layer_bytes
+                buf[off:off + vec.numel() * 4].copy_(vec.view(torch.uint8))
+                if self.context_features > 0:
+                    wc.append(torch.stack([net.context_layer.weight[perm]] + [b.context_layer.weight[perm] for b in net.blocks]))
+                    bc.append(torch.stack([net.context_layer.bias[perm]] + [b.context_layer.bias[perm] for b in net.blocks]))
+            st.update(key=key, buf=buf, u1=u1,
+                      wcat=torch.stack(wc).reshape(-1, self.context_features).float().contiguous() if wc else None,
+                      bcat=torch.stack(bc).reshape(-1).float().contiguous() if bc else None)
+        return st
+
     def _inverse_call(self, z, context, ctx_rows):
         dev = self._device()
         B = z.shape[0]
@@ -537,6 +610,17 @@ class NSFPosteriorFlow(nn.Module):
         logdet = torch.empty(B, dtype=torch.float32, device=dev)
         flags = torch.zeros(B, dtype=torch.int32, device=dev)
         _, inv_perm = self._perms(dev)
+        if self._use_incremental():
+            st = self._inc_state(dev)
+            proj = None
+            if st["wcat"] is not None:
+                with torch.no_grad():       # [ctx_rows, L * 3 * H]: one GEMM for every layer's three context projections
+                    proj = torch.addmm(st["bcat"], context.float(), st["wcat"].t()).contiguous()
+            _lib.check(_lib.lib().pf_flow_inverse_inc(
+                self._desc("bf16", inverse=True), st["u1"], st["buf"].data_ptr(), _dev_ptr(proj), ctx_rows,
+                z.data_ptr(), _dev_ptr(inv_perm), B, x.data_ptr(), logdet.data_ptr(), flags.data_ptr(),
+                torch.cuda.current_stream(dev).cuda_stream), "pf_flow_inverse_inc")
+            return x, logdet, flags
         desc = self._desc(inverse=True)
         ws, ws_bytes = self._ws(desc, ctx_rows, dev)
         _lib.check(_lib.lib().pf_flow_inverse(
