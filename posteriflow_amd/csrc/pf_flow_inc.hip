@@ -121,81 +121,165 @@ __global__ __launch_bounds__(512) void flow_inverse_inc_kernel(const IncParams p
             const int t_lo = ulo / 16, t_hi = (uhi + 15) / 16;           // their tiles
             const int ntile = i >= 1 ? t_hi - t_lo : 0;
             const int ks1 = (uhi + 31) / 32;                             // reduction over units of degree <= i
-            if (ntile > 0) {
-                // this wave's tasks: (tile, column) = task / 2, task % 2 for task = wave, wave + 8, ...
-                f32x4 h[kMaxTasks], pg[2][kMaxTasks];
-                // ---- stage a: h0 = W0 . (x hi|lo) + b0 + relu(pc); act0 = relu(h0) ----
+            if (2 * ntile <= 8) {
+                // ---- usual case (2-3 new tiles): one task per wave; the weight fragments of stage s + 1 are
+                // requested before stage s is computed (two register buffers), so every load has a whole stage
+                // (compute + barrier) to arrive instead of being waited for at the top of its stage
+                const bool mine = ntile > 0 && wave < 2 * ntile;
+                const int t = t_lo + (wave >> 1), c2 = wave & 1, u = 16 * t + 4 * g;
+                const int arow = (16 * c2 + c) * AS;
+                bf16x8 bufA[8], bufB[8];
+                auto fetch = [&](bf16x8 (&buf)[8], int64_t off, int tile, bool on) {
+                    const char* wb = lw + off + ((size_t)tile * HK * 64 + lane) * 16;
 #pragma unroll
-                for (int q = 0; q < kMaxTasks; ++q) {
-                    const int task = wave + 8 * q;
-                    if (task < 2 * ntile) {
-                        const int t = t_lo + (task >> 1), c2 = task & 1;
+                    for (int ks = 0; ks < 8; ++ks)
+                        if (on && ks < ks1) buf[ks] = *reinterpret_cast<const bf16x8*>(wb + (size_t)ks * 1024);
+                };
+                auto gemm_regs = [&](const bf16x8 (&a)[8], const char* src) {
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks)
+                        if (ks < ks1) v = mfma_bf16(a[ks], *reinterpret_cast<const bf16x8*>(src + ks * 64), v);
+                    return v;
+                };
+                f32x4 h = {0.f, 0.f, 0.f, 0.f}, pg0 = h, pg1 = h;
+                // every bias of the pass is requested now too (a load issued where its value is needed costs an
+                // L2 round trip per stage: they were 2/3 of a pass)
+                f32x4 bb[5], bfin = h;
+#pragma unroll
+                for (int q = 0; q < 5; ++q) bb[q] = mine ? *reinterpret_cast<const f32x4*>(bias + q * H + u) : h;
+                if (wave < 6) bfin = *reinterpret_cast<const f32x4*>(bias + 5 * H + 48 * i + 16 * (wave >> 1) + 4 * g);
+                if (ntile > 0) {
+                    fetch(bufA, p.off_w1[0], t, mine);                              // stage b's weights
+                    if (mine) {                                                     // ---- stage a
                         const bf16x8 a = *reinterpret_cast<const bf16x8*>(lw + ((size_t)t * 64 + lane) * 16);
-                        const bf16x8 b = *reinterpret_cast<const bf16x8*>(xb + (16 * c2 + c) * 64 + g * 16);
-                        f32x4 v = mfma_bf16(a, b, f32x4{0.f, 0.f, 0.f, 0.f});
-                        const int u = 16 * t + 4 * g;
-                        v = v + *reinterpret_cast<const f32x4*>(bias + u);
-                        pg[0][q] = pg[1][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        const bf16x8 bx0 = *reinterpret_cast<const bf16x8*>(xb + (16 * c2 + c) * 64 + g * 16);
+                        f32x4 v = mfma_bf16(a, bx0, f32x4{0.f, 0.f, 0.f, 0.f});
+                        v = v + bb[0];
                         if (p.proj) {
                             int64_t row = row0 + 16 * c2 + c;
                             if (row >= p.batch) row = p.batch - 1;
                             const int64_t cr = row / (p.batch / p.ctx_rows);
                             const float* pr = p.proj + ((cr * p.L + l) * 3) * (int64_t)H + u;
                             v = v + relu4(*reinterpret_cast<const f32x4*>(pr));
-                            pg[0][q] = *reinterpret_cast<const f32x4*>(pr + H);
-                            pg[1][q] = *reinterpret_cast<const f32x4*>(pr + 2 * H);
+                            pg0 = *reinterpret_cast<const f32x4*>(pr + H);
+                            pg1 = *reinterpret_cast<const f32x4*>(pr + 2 * H);
                         }
-                        h[q] = v;
-                        *reinterpret_cast<bf16x4*>(act_of(0) + (16 * c2 + c) * AS + u * 2) = bf16_of(relu4(v));
+                        h = v;
+                        *reinterpret_cast<bf16x4*>(act_of(0) + arow + u * 2) = bf16_of(relu4(v));
                     }
+                    __syncthreads();
+                    fetch(bufB, p.off_w2[0], t, mine);
+                    if (mine) {                                                     // ---- stage b
+                        f32x4 v = gemm_regs(bufA, act_of(0) + arow + g * 16) + bb[1];
+                        *reinterpret_cast<bf16x4*>(act_of(1) + arow + u * 2) = bf16_of(relu4(v));
+                    }
+                    __syncthreads();
+                    fetch(bufA, p.off_w1[1], t, mine);
+                    if (mine) {                                                     // ---- stage c
+                        f32x4 v = gemm_regs(bufB, act_of(1) + arow + g * 16) + bb[2];
+                        if (p.proj) v = v * sigmoid4(pg0);
+                        h = h + v;
+                        *reinterpret_cast<bf16x4*>(act_of(2) + arow + u * 2) = bf16_of(relu4(h));
+                    }
+                    __syncthreads();
+                    fetch(bufB, p.off_w2[1], t, mine);
+                    if (mine) {                                                     // ---- stage d
+                        f32x4 v = gemm_regs(bufA, act_of(2) + arow + g * 16) + bb[3];
+                        *reinterpret_cast<bf16x4*>(act_of(3) + arow + u * 2) = bf16_of(relu4(v));
+                    }
+                    __syncthreads();
                 }
-                __syncthreads();
-                // ---- stages b..e: the two residual blocks ----
-#pragma unroll
-                for (int blk = 0; blk < 2; ++blk) {
-                    // t1 = W1 . act[2 blk] + b1 ; act[2 blk + 1] = relu(t1)
-#pragma unroll
+                fetch(bufA, p.off_wf, 3 * i + (wave >> 1), wave < 6);               // the parameter rows of feature i
+                if (mine) {                                                         // ---- stage e
+                    f32x4 v = gemm_regs(bufB, act_of(3) + arow + g * 16) + bb[4];
+                    if (p.proj) v = v * sigmoid4(pg1);
+                    h = h + v;
+                    *reinterpret_cast<bf16x4*>(act_of(4) + arow + u * 2) = bf16_of(h);
+                }
+                if (ntile > 0) __syncthreads();
+                if (wave < 6) {                                                     // ---- stage f
+                    const int t3 = wave >> 1;
+                    f32x4 v = gemm_regs(bufA, act_of(4) + arow + g * 16) + bfin;
+                    *reinterpret_cast<f32x4*>(par + (16 * c2 + c) * kParS + 16 * t3 + 4 * g) = v;
+                }
+            } else {
+                if (ntile > 0) {
+                    // this wave's tasks: (tile, column) = task / 2, task % 2 for task = wave, wave + 8, ...
+                    f32x4 h[kMaxTasks], pg[2][kMaxTasks];
+                    // ---- stage a: h0 = W0 . (x hi|lo) + b0 + relu(pc); act0 = relu(h0) ----
+    #pragma unroll
                     for (int q = 0; q < kMaxTasks; ++q) {
                         const int task = wave + 8 * q;
                         if (task < 2 * ntile) {
                             const int t = t_lo + (task >> 1), c2 = task & 1;
-                            const char* wb = lw + p.off_w1[blk] + ((size_t)t * HK * 64 + lane) * 16;
-                            const char* src = act_of(2 * blk) + (16 * c2 + c) * AS + g * 16;
-                            f32x4 v = gemm_tile(wb, src, ks1);
+                            const bf16x8 a = *reinterpret_cast<const bf16x8*>(lw + ((size_t)t * 64 + lane) * 16);
+                            const bf16x8 b = *reinterpret_cast<const bf16x8*>(xb + (16 * c2 + c) * 64 + g * 16);
+                            f32x4 v = mfma_bf16(a, b, f32x4{0.f, 0.f, 0.f, 0.f});
                             const int u = 16 * t + 4 * g;
-                            v = v + *reinterpret_cast<const f32x4*>(bias + (1 + 2 * blk) * H + u);
-                            *reinterpret_cast<bf16x4*>(act_of(2 * blk + 1) + (16 * c2 + c) * AS + u * 2) = bf16_of(relu4(v));
+                            v = v + *reinterpret_cast<const f32x4*>(bias + u);
+                            pg[0][q] = pg[1][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                            if (p.proj) {
+                                int64_t row = row0 + 16 * c2 + c;
+                                if (row >= p.batch) row = p.batch - 1;
+                                const int64_t cr = row / (p.batch / p.ctx_rows);
+                                const float* pr = p.proj + ((cr * p.L + l) * 3) * (int64_t)H + u;
+                                v = v + relu4(*reinterpret_cast<const f32x4*>(pr));
+                                pg[0][q] = *reinterpret_cast<const f32x4*>(pr + H);
+                                pg[1][q] = *reinterpret_cast<const f32x4*>(pr + 2 * H);
+                            }
+                            h[q] = v;
+                            *reinterpret_cast<bf16x4*>(act_of(0) + (16 * c2 + c) * AS + u * 2) = bf16_of(relu4(v));
                         }
                     }
                     __syncthreads();
-                    // t2 = W2 . act[2 blk + 1] + b2 ; h += t2 * sigmoid(pg) ; act[2 blk + 2] = relu(h) (block 0) | h (block 1)
-#pragma unroll
-                    for (int q = 0; q < kMaxTasks; ++q) {
-                        const int task = wave + 8 * q;
-                        if (task < 2 * ntile) {
-                            const int t = t_lo + (task >> 1), c2 = task & 1;
-                            const char* wb = lw + p.off_w2[blk] + ((size_t)t * HK * 64 + lane) * 16;
-                            const char* src = act_of(2 * blk + 1) + (16 * c2 + c) * AS + g * 16;
-                            f32x4 v = gemm_tile(wb, src, ks1);
-                            const int u = 16 * t + 4 * g;
-                            v = v + *reinterpret_cast<const f32x4*>(bias + (2 + 2 * blk) * H + u);
-                            if (p.proj) v = v * sigmoid4(pg[blk][q]);
-                            h[q] = h[q] + v;
-                            *reinterpret_cast<bf16x4*>(act_of(2 * blk + 2) + (16 * c2 + c) * AS + u * 2) =
-                                bf16_of(blk == 0 ? relu4(h[q]) : h[q]);
+                    // ---- stages b..e: the two residual blocks ----
+    #pragma unroll
+                    for (int blk = 0; blk < 2; ++blk) {
+                        // t1 = W1 . act[2 blk] + b1 ; act[2 blk + 1] = relu(t1)
+    #pragma unroll
+                        for (int q = 0; q < kMaxTasks; ++q) {
+                            const int task = wave + 8 * q;
+                            if (task < 2 * ntile) {
+                                const int t = t_lo + (task >> 1), c2 = task & 1;
+                                const char* wb = lw + p.off_w1[blk] + ((size_t)t * HK * 64 + lane) * 16;
+                                const char* src = act_of(2 * blk) + (16 * c2 + c) * AS + g * 16;
+                                f32x4 v = gemm_tile(wb, src, ks1);
+                                const int u = 16 * t + 4 * g;
+                                v = v + *reinterpret_cast<const f32x4*>(bias + (1 + 2 * blk) * H + u);
+                                *reinterpret_cast<bf16x4*>(act_of(2 * blk + 1) + (16 * c2 + c) * AS + u * 2) = bf16_of(relu4(v));
+                            }
                         }
+                        __syncthreads();
+                        // t2 = W2 . act[2 blk + 1] + b2 ; h += t2 * sigmoid(pg) ; act[2 blk + 2] = relu(h) (block 0) | h (block 1)
+    #pragma unroll
+                        for (int q = 0; q < kMaxTasks; ++q) {
+                            const int task = wave + 8 * q;
+                            if (task < 2 * ntile) {
+                                const int t = t_lo + (task >> 1), c2 = task & 1;
+                                const char* wb = lw + p.off_w2[blk] + ((size_t)t * HK * 64 + lane) * 16;
+                                const char* src = act_of(2 * blk + 1) + (16 * c2 + c) * AS + g * 16;
+                                f32x4 v = gemm_tile(wb, src, ks1);
+                                const int u = 16 * t + 4 * g;
+                                v = v + *reinterpret_cast<const f32x4*>(bias + (2 + 2 * blk) * H + u);
+                                if (p.proj) v = v * sigmoid4(pg[blk][q]);
+                                h[q] = h[q] + v;
+                                *reinterpret_cast<bf16x4*>(act_of(2 * blk + 2) + (16 * c2 + c) * AS + u * 2) =
+                                    bf16_of(blk == 0 ? relu4(h[q]) : h[q]);
+                            }
+                        }
+                        __syncthreads();
                     }
-                    __syncthreads();
                 }
-            }
-            // ---- stage f: the 3K-1 raw spline parameters of feature i (3 row tiles: widths | heights | derivatives) ----
-            if (wave < 6) {
-                const int t3 = wave >> 1, c2 = wave & 1;
-                const char* wb = lw + p.off_wf + ((size_t)(3 * i + t3) * HK * 64 + lane) * 16;
-                const char* src = act_of(4) + (16 * c2 + c) * AS + g * 16;
-                f32x4 v = gemm_tile(wb, src, ks1);
-                v = v + *reinterpret_cast<const f32x4*>(bias + 5 * H + 48 * i + 16 * t3 + 4 * g);
-                *reinterpret_cast<f32x4*>(par + (16 * c2 + c) * kParS + 16 * t3 + 4 * g) = v;
+                // ---- stage f: the 3K-1 raw spline parameters of feature i (3 row tiles: widths | heights | derivatives) ----
+                if (wave < 6) {
+                    const int t3 = wave >> 1, c2 = wave & 1;
+                    const char* wb = lw + p.off_wf + ((size_t)(3 * i + t3) * HK * 64 + lane) * 16;
+                    const char* src = act_of(4) + (16 * c2 + c) * AS + g * 16;
+                    f32x4 v = gemm_tile(wb, src, ks1);
+                    v = v + *reinterpret_cast<const f32x4*>(bias + 5 * H + 48 * i + 16 * t3 + 4 * g);
+                    *reinterpret_cast<f32x4*>(par + (16 * c2 + c) * kParS + 16 * t3 + 4 * g) = v;
+                }
             }
             __syncthreads();
             if (tid < kRows) {
