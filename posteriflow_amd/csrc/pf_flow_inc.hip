@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 #include "pf_flow_fwd_kernel.h"
 
@@ -43,6 +44,7 @@ struct IncParams {
     int64_t off_w1[2], off_w2[2], off_wf, off_bias;      // byte offsets inside a layer block (W0 at 0)
     int D, H, K, L;
     int u1[17];                // number of hidden units (sorted order) with degree <= i
+    int ablate;                // timing experiments ($PF_INC_ABLATE): 1 no spline, 2 no barriers between stages
 };
 
 __device__ __forceinline__ f32x4 mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
@@ -63,6 +65,72 @@ __device__ __forceinline__ f32x4 sigmoid4(f32x4 v) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_rcpf(1.f + __expf(-v[e]));
     return v;
+}
+
+// ---- lane-parallel spline inverse: 16 lanes (one DPP row) per draw, lane j = bin j ------------------------
+// With one lane per draw the inversion is ~600 dependent instructions on a single wave while the other seven
+// wait (28 % of the kernel); with a lane per bin the softmax sums, the knot prefix sums and the bin selection
+// are 4-step DPP row operations and the chain is ~5x shorter.  Same formulas as rqs_pair_inverse; the prefix
+// sums associate as a scan instead of left to right (fp32 rounding only).
+template <int CTRL>
+__device__ __forceinline__ float row_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row_sum(float v) {
+    v += row_dpp<0xB1>(v); v += row_dpp<0x4E>(v); v += row_dpp<0x141>(v); v += row_dpp<0x140>(v);
+    return v;
+}
+__device__ __forceinline__ float row_max(float v) {
+    v = fmaxf(v, row_dpp<0xB1>(v)); v = fmaxf(v, row_dpp<0x4E>(v));
+    v = fmaxf(v, row_dpp<0x141>(v)); v = fmaxf(v, row_dpp<0x140>(v));
+    return v;
+}
+__device__ __forceinline__ float row_scan(float v) {            // inclusive prefix sum over the 16 lanes of a row
+    v += row_dpp<0x111>(v); v += row_dpp<0x112>(v); v += row_dpp<0x114>(v); v += row_dpp<0x118>(v);
+    return v;
+}
+__device__ __forceinline__ void rqs_row16_inverse(const float* par, float yin, int K, const FwdParams& p, int j,
+                                                  float& x, float& ld, bool& bad) {
+    const bool live = j < K;
+    const float uw = live ? par[j] : -INFINITY, uh = live ? par[16 + j] : -INFINITY;
+    const float ud = par[32 + j];                                   // raw derivative at the RIGHT knot of bin j (j < K - 1)
+    const float tb = p.tail_bound, span = 2.f * tb;
+    // (every DPP reduction is evaluated OUTSIDE conditionals: inside `live ? ... : ...` the compiler may run it with
+    // the non-live lanes masked off, and a DPP read of a disabled lane is not the lane's value)
+    const float mw = row_max(uw), mh = row_max(uh);
+    const float ew = live ? __expf(uw - mw) : 0.f, eh = live ? __expf(uh - mh) : 0.f;
+    const float cw = __fdividef(1.f - p.min_w * (float)K, row_sum(ew));
+    const float ch = __fdividef(1.f - p.min_h * (float)K, row_sum(eh));
+    const float wj = live ? p.min_w + cw * ew : 0.f, hj = live ? p.min_h + ch * eh : 0.f;
+    const float cumw = row_scan(wj), cumh = row_scan(hj);
+    const bool last = j == K - 1;
+    const float kr = last ? tb : span * cumw - tb, hr = last ? tb : span * cumh - tb;       // right knots of bin j
+    const float dr_raw = last ? p.deriv_const : ud;
+    // left knots / derivative = the right ones of bin j - 1 (row_shr:1), the interval's ends for bin 0
+    float kl = row_dpp<0x111>(kr), hl = row_dpp<0x111>(hr), dl_raw = row_dpp<0x111>(dr_raw);
+    if (j == 0) { kl = -tb; hl = -tb; dl_raw = p.deriv_const; }
+    // searchsorted on the heights: bin j holds y if y >= its left knot and not >= its right knot (last knot + 1e-6)
+    const bool ge_r = yin >= (last ? tb + 1e-6f : hr);
+    const bool ge_l = j == 0 ? true : yin >= hl;
+    const bool sel = live && ge_l && !ge_r;
+    const float w = kr - kl, hh = hr - hl;
+    const float dl = p.min_d + pf_softplus<true>(dl_raw), dr = p.min_d + pf_softplus<true>(dr_raw);
+    const float delta = __fdividef(hh, w);
+    const float dy = yin - hl, s2 = dl + dr - 2.f * delta;
+    const float a = dy * s2 + hh * (delta - dl), b = hh * dl - dy * s2, c0 = -delta * dy;
+    const float disc = b * b - 4.f * a * c0;
+    const float root = __fdividef(2.f * c0, -b - sqrtf(fmaxf(disc, 0.f)));
+    const float tt = root * (1.f - root), den = delta + s2 * tt, omt = 1.f - root;
+    const float dnum = delta * delta * (dr * root * root + 2.f * delta * tt + dl * omt * omt);
+    const bool inside = (yin >= -tb) && (yin <= tb);
+    // exactly one bin is selected inside the interval: its values reach every lane of the row through a sum
+    const float xsel = sel ? root * w + kl : 0.f;
+    const float lsel = sel ? -(__logf(dnum) - 2.f * __logf(den)) : 0.f;
+    const float bsel = (sel && !(disc >= 0.f)) ? 1.f : 0.f;
+    const float xs = row_sum(xsel), ls = row_sum(lsel), bs = row_sum(bsel);
+    x = inside ? xs : yin;
+    ld = inside ? ls : 0.f;
+    bad = inside && bs > 0.f;
 }
 
 // acc = sum_{ks < ks1} A(ks) . B(ks): all weight fragments are requested before the first MFMA (a loop that
@@ -282,16 +350,20 @@ __global__ __launch_bounds__(512) void flow_inverse_inc_kernel(const IncParams p
                 }
             }
             __syncthreads();
-            if (tid < kRows) {
+            {   // all 512 threads: draw = tid / 16, bin = tid % 16
+                const int r = tid >> 4, j = tid & 15;
                 float xv, ld;
                 bool bad;
-                rqs_pair_inverse<true>(par + tid * kParS, ys[tid * 16 + i], p.K, p.sp, xv, ld, bad);
-                xs[tid * 16 + i] = xv;
-                const __bf16 hi = (__bf16)xv;
-                reinterpret_cast<__bf16*>(xb)[tid * 32 + i] = hi;
-                reinterpret_cast<__bf16*>(xb)[tid * 32 + 16 + i] = (__bf16)(xv - (float)hi);
-                ldacc[tid] += ld;
-                if (bad) badf[tid] = 1u;
+                if (p.ablate & 1) { xv = ys[r * 16 + i] * 0.5f + par[r * kParS]; ld = 0.f; bad = false; } else
+                rqs_row16_inverse(par + r * kParS, ys[r * 16 + i], p.K, p.sp, j, xv, ld, bad);
+                if (j == 0) {
+                    xs[r * 16 + i] = xv;
+                    const __bf16 hi = (__bf16)xv;
+                    reinterpret_cast<__bf16*>(xb)[r * 32 + i] = hi;
+                    reinterpret_cast<__bf16*>(xb)[r * 32 + 16 + i] = (__bf16)(xv - (float)hi);
+                    ldacc[r] += ld;
+                    if (bad) badf[r] = 1u;
+                }
             }
             __syncthreads();
         }
@@ -358,6 +430,7 @@ int flow_inverse_inc(const PfFlowDesc& d, float deriv_const, const int32_t* u1, 
     p.off_bias = p.off_wf + 3 * (int64_t)p.D * HK * 1024;
     p.layer_bytes = inc_layer_bytes(p.D, p.H);
     for (int i = 0; i <= p.D; ++i) p.u1[i] = u1[i];
+    if (const char* a = std::getenv("PF_INC_ABLATE")) p.ablate = std::atoi(a);
     const size_t lds = (size_t)5 * kRows * (p.H * 2 + 16) + kRows * 64 + (size_t)kRows * (16 + 16 + kParS + 2) * 4;
     static bool configured = false;
     if (!configured) {

@@ -599,7 +599,7 @@ class NSFPosteriorFlow(nn.Module):
                     wc.append(torch.stack([net.context_layer.weight[perm]] + [b.context_layer.weight[perm] for b in net.blocks]))
                     bc.append(torch.stack([net.context_layer.bias[perm]] + [b.context_layer.bias[perm] for b in net.blocks]))
             st.update(key=key, buf=buf, u1=u1,
-                      wcat=torch.stack(wc).reshape(-1, self.context_features).float().contiguous() if wc else None,
+                      wcat=torch.stack(wc).reshape(-1, self.context_features).to(torch.bfloat16).float().contiguous() if wc else None,
                       bcat=torch.stack(bc).reshape(-1).float().contiguous() if bc else None)
         return st
 
@@ -614,8 +614,11 @@ class NSFPosteriorFlow(nn.Module):
             st = self._inc_state(dev)
             proj = None
             if st["wcat"] is not None:
-                with torch.no_grad():       # [ctx_rows, L * 3 * H]: one GEMM for every layer's three context projections
-                    proj = torch.addmm(st["bcat"], context.float(), st["wcat"].t()).contiguous()
+                with torch.no_grad():
+                    # [ctx_rows, L * 3 * H]: one GEMM for every layer's three context projections, with the operand
+                    # rounding of the bf16 forward kernel (context and weights to bf16, fp32 accumulation) so that
+                    # forward(inverse(z)) sees the same conditioner
+                    proj = torch.addmm(st["bcat"], context.to(torch.bfloat16).float(), st["wcat"].t()).contiguous()
             _lib.check(_lib.lib().pf_flow_inverse_inc(
                 self._desc("bf16", inverse=True), st["u1"], st["buf"].data_ptr(), _dev_ptr(proj), ctx_rows,
                 z.data_ptr(), _dev_ptr(inv_perm), B, x.data_ptr(), logdet.data_ptr(), flags.data_ptr(),
