@@ -11,9 +11,10 @@
 // D passes the work is ONE masked conditioner evaluation per layer ("exact incremental
 // algorithm") instead of D dense ones.  The result is the same x: no approximation is involved.
 //
-// One workgroup = 32 draws (two 16-row MFMA column tiles), 8 waves.  Transposed MFMA form as everywhere:
-// out^T[unit, row] = W[unit, k] . act^T[k, row]; a task = (unit tile, column tile), its fp32 residual value
-// h lives in the owning wave's registers through the five stages of a pass; stages are separated by a
+// One workgroup = 16 / 32 / 48 draws (1-3 sixteen-row MFMA column tiles), 8 waves.  Transposed MFMA form as
+// everywhere: out^T[unit, row] = W[unit, k] . act^T[k, row]; a wave owns a new unit tile across all column
+// tiles (one set of weight fragments, one MFMA chain per column), its fp32 residual values h live in its
+// registers through the five stages of a pass; stages are separated by a
 // workgroup barrier (the next stage reads the tile just written).  bf16 operands / fp32 accumulation, the
 // input features enter the first masked layer as a bf16 hi + lo pair, context enters as per-context-row
 // projections computed once by the caller (C = 0: none).  Spline inversion: rqs_pair_inverse of the D-pass
@@ -27,8 +28,8 @@
 
 namespace pf {
 namespace {
-constexpr int kRows = 32;                  // draws per workgroup
-constexpr int kMaxTasks = 4;               // (unit tile, column tile) tasks per wave: 16 tiles x 2 / 8 waves
+// draws per workgroup = 16 x COLS column tiles, COLS in {1, 2, 3} (5 x 48 x H bf16 of LDS state: 127 KB at H = 256);
+// a pass has a fixed latency, so more rows per workgroup raise throughput until the launch has fewer workgroups than CUs
 constexpr int kParS = kParStride;          // floats per row in the spline-parameter transpose (52)
 
 struct IncParams {
@@ -147,16 +148,18 @@ __device__ __forceinline__ f32x4 gemm_tile(const char* wb, const char* src, int 
     return v;
 }
 
+template <int kCols>
 __global__ __launch_bounds__(512) void flow_inverse_inc_kernel(const IncParams p) {
+    constexpr int kRows = 16 * kCols;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int D = p.D, H = p.H, HK = H / 32;
     const int AS = H * 2 + 16;                                   // byte stride of an activation row (bank spread)
-    char* const act = smem;                                      // 5 stages x [32 rows][H] bf16
-    char* const xb = act + (size_t)5 * kRows * AS;               // [32][32] bf16: x hi (0..15) | lo (16..31)
-    float* const xs = reinterpret_cast<float*>(xb + kRows * 64); // [32][16] current layer's input, fp32
-    float* const ys = xs + kRows * 16;                           // [32][16] current layer's output
-    float* const par = ys + kRows * 16;                          // [32][52] spline parameters of one feature
-    float* const ldacc = par + kRows * kParS;                    // [32]
+    char* const act = smem;                                      // 5 stages x [kRows][H] bf16
+    char* const xb = act + (size_t)5 * kRows * AS;               // [kRows][32] bf16: x hi (0..15) | lo (16..31)
+    float* const xs = reinterpret_cast<float*>(xb + kRows * 64); // [kRows][16] current layer's input, fp32
+    float* const ys = xs + kRows * 16;                           // [kRows][16] current layer's output
+    float* const par = ys + kRows * 16;                          // [kRows][52] spline parameters of one feature
+    float* const ldacc = par + kRows * kParS;                    // [kRows]
     uint32_t* const badf = reinterpret_cast<uint32_t*>(ldacc + kRows);
 
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
@@ -176,6 +179,15 @@ __global__ __launch_bounds__(512) void flow_inverse_inc_kernel(const IncParams p
     for (int s = tid * 16; s < 5 * kRows * AS; s += 512 * 16) *reinterpret_cast<f32x4*>(act + s) = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
 
+    // this lane's context rows (one per column tile) are fixed for the whole kernel
+    int64_t crow[kCols];
+#pragma unroll
+    for (int cc = 0; cc < kCols; ++cc) {
+        int64_t row = row0 + 16 * cc + c;
+        if (row >= p.batch) row = p.batch - 1;
+        crow[cc] = p.proj ? row / (p.batch / p.ctx_rows) : 0;
+    }
+
     for (int l = p.L - 1; l >= 0; --l) {
         const char* lw = p.w + (size_t)l * p.layer_bytes;
         const float* bias = reinterpret_cast<const float*>(lw + p.off_bias);   // b0 | b1_0 | b2_0 | b1_1 | b2_1 | bf[D][48]
@@ -189,180 +201,122 @@ __global__ __launch_bounds__(512) void flow_inverse_inc_kernel(const IncParams p
             const int t_lo = ulo / 16, t_hi = (uhi + 15) / 16;           // their tiles
             const int ntile = i >= 1 ? t_hi - t_lo : 0;
             const int ks1 = (uhi + 31) / 32;                             // reduction over units of degree <= i
-            if (2 * ntile <= 8) {
-                // ---- usual case (2-3 new tiles): one task per wave; the weight fragments of stage s + 1 are
-                // requested before stage s is computed (two register buffers), so every load has a whole stage
-                // (compute + barrier) to arrive instead of being waited for at the top of its stage
-                const bool mine = ntile > 0 && wave < 2 * ntile;
-                const int t = t_lo + (wave >> 1), c2 = wave & 1, u = 16 * t + 4 * g;
-                const int arow = (16 * c2 + c) * AS;
+            // A wave owns unit tiles t_lo + wave (+ 8 when more than 8 tiles are new: only for D = 2..3) across
+            // ALL column tiles: one set of weight fragments, kCols independent MFMA chains.
+            auto fetch = [&](bf16x8 (&buf)[8], int64_t off, int tile, bool on) {
+                const char* wb = lw + off + ((size_t)tile * HK * 64 + lane) * 16;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks)
+                    if (on && ks < ks1) buf[ks] = *reinterpret_cast<const bf16x8*>(wb + (size_t)ks * 1024);
+            };
+            auto gemm = [&](const bf16x8 (&a)[8], const char* src, f32x4 (&v)[kCols]) {
+#pragma unroll
+                for (int cc = 0; cc < kCols; ++cc) v[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks)
+                    if (ks < ks1) {
+#pragma unroll
+                        for (int cc = 0; cc < kCols; ++cc)
+                            v[cc] = mfma_bf16(a[ks], *reinterpret_cast<const bf16x8*>(src + (16 * cc + c) * AS + g * 16 + ks * 64), v[cc]);
+                    }
+            };
+            for (int tq = 0; tq < ntile; tq += 8) {   // one trip unless more than 8 tiles are new
+                const bool mine = tq + wave < ntile;
+                const int t = t_lo + tq + wave, u = 16 * t + 4 * g;
                 bf16x8 bufA[8], bufB[8];
-                auto fetch = [&](bf16x8 (&buf)[8], int64_t off, int tile, bool on) {
-                    const char* wb = lw + off + ((size_t)tile * HK * 64 + lane) * 16;
+                f32x4 h[kCols], pg0[kCols], pg1[kCols], v[kCols];
+                // every bias of the pass is requested now (a load issued where its value is needed costs an L2
+                // round trip per stage), the weights of stage s + 1 before stage s is computed (two buffers)
+                f32x4 bb[5];
 #pragma unroll
-                    for (int ks = 0; ks < 8; ++ks)
-                        if (on && ks < ks1) buf[ks] = *reinterpret_cast<const bf16x8*>(wb + (size_t)ks * 1024);
-                };
-                auto gemm_regs = [&](const bf16x8 (&a)[8], const char* src) {
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                for (int q = 0; q < 5; ++q) bb[q] = mine ? *reinterpret_cast<const f32x4*>(bias + q * H + u) : f32x4{0.f, 0.f, 0.f, 0.f};
+                fetch(bufA, p.off_w1[0], t, mine);
+                if (mine) {                                                         // ---- stage a: h0 = W0 . (x hi|lo) + b0 + relu(pc)
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(lw + ((size_t)t * 64 + lane) * 16);
 #pragma unroll
-                    for (int ks = 0; ks < 8; ++ks)
-                        if (ks < ks1) v = mfma_bf16(a[ks], *reinterpret_cast<const bf16x8*>(src + ks * 64), v);
-                    return v;
-                };
-                f32x4 h = {0.f, 0.f, 0.f, 0.f}, pg0 = h, pg1 = h;
-                // every bias of the pass is requested now too (a load issued where its value is needed costs an
-                // L2 round trip per stage: they were 2/3 of a pass)
-                f32x4 bb[5], bfin = h;
-#pragma unroll
-                for (int q = 0; q < 5; ++q) bb[q] = mine ? *reinterpret_cast<const f32x4*>(bias + q * H + u) : h;
-                if (wave < 6) bfin = *reinterpret_cast<const f32x4*>(bias + 5 * H + 48 * i + 16 * (wave >> 1) + 4 * g);
-                if (ntile > 0) {
-                    fetch(bufA, p.off_w1[0], t, mine);                              // stage b's weights
-                    if (mine) {                                                     // ---- stage a
-                        const bf16x8 a = *reinterpret_cast<const bf16x8*>(lw + ((size_t)t * 64 + lane) * 16);
-                        const bf16x8 bx0 = *reinterpret_cast<const bf16x8*>(xb + (16 * c2 + c) * 64 + g * 16);
-                        f32x4 v = mfma_bf16(a, bx0, f32x4{0.f, 0.f, 0.f, 0.f});
-                        v = v + bb[0];
+                    for (int cc = 0; cc < kCols; ++cc) {
+                        const bf16x8 bx0 = *reinterpret_cast<const bf16x8*>(xb + (16 * cc + c) * 64 + g * 16);
+                        f32x4 w0 = mfma_bf16(a, bx0, f32x4{0.f, 0.f, 0.f, 0.f}) + bb[0];
+                        pg0[cc] = pg1[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
                         if (p.proj) {
-                            int64_t row = row0 + 16 * c2 + c;
-                            if (row >= p.batch) row = p.batch - 1;
-                            const int64_t cr = row / (p.batch / p.ctx_rows);
-                            const float* pr = p.proj + ((cr * p.L + l) * 3) * (int64_t)H + u;
-                            v = v + relu4(*reinterpret_cast<const f32x4*>(pr));
-                            pg0 = *reinterpret_cast<const f32x4*>(pr + H);
-                            pg1 = *reinterpret_cast<const f32x4*>(pr + 2 * H);
+                            const float* pr = p.proj + ((crow[cc] * p.L + l) * 3) * (int64_t)H + u;
+                            w0 = w0 + relu4(*reinterpret_cast<const f32x4*>(pr));
+                            pg0[cc] = *reinterpret_cast<const f32x4*>(pr + H);
+                            pg1[cc] = *reinterpret_cast<const f32x4*>(pr + 2 * H);
                         }
-                        h = v;
-                        *reinterpret_cast<bf16x4*>(act_of(0) + arow + u * 2) = bf16_of(relu4(v));
-                    }
-                    __syncthreads();
-                    fetch(bufB, p.off_w2[0], t, mine);
-                    if (mine) {                                                     // ---- stage b
-                        f32x4 v = gemm_regs(bufA, act_of(0) + arow + g * 16) + bb[1];
-                        *reinterpret_cast<bf16x4*>(act_of(1) + arow + u * 2) = bf16_of(relu4(v));
-                    }
-                    __syncthreads();
-                    fetch(bufA, p.off_w1[1], t, mine);
-                    if (mine) {                                                     // ---- stage c
-                        f32x4 v = gemm_regs(bufB, act_of(1) + arow + g * 16) + bb[2];
-                        if (p.proj) v = v * sigmoid4(pg0);
-                        h = h + v;
-                        *reinterpret_cast<bf16x4*>(act_of(2) + arow + u * 2) = bf16_of(relu4(h));
-                    }
-                    __syncthreads();
-                    fetch(bufB, p.off_w2[1], t, mine);
-                    if (mine) {                                                     // ---- stage d
-                        f32x4 v = gemm_regs(bufA, act_of(2) + arow + g * 16) + bb[3];
-                        *reinterpret_cast<bf16x4*>(act_of(3) + arow + u * 2) = bf16_of(relu4(v));
-                    }
-                    __syncthreads();
-                }
-                fetch(bufA, p.off_wf, 3 * i + (wave >> 1), wave < 6);               // the parameter rows of feature i
-                if (mine) {                                                         // ---- stage e
-                    f32x4 v = gemm_regs(bufB, act_of(3) + arow + g * 16) + bb[4];
-                    if (p.proj) v = v * sigmoid4(pg1);
-                    h = h + v;
-                    *reinterpret_cast<bf16x4*>(act_of(4) + arow + u * 2) = bf16_of(h);
-                }
-                if (ntile > 0) __syncthreads();
-                if (wave < 6) {                                                     // ---- stage f
-                    const int t3 = wave >> 1;
-                    f32x4 v = gemm_regs(bufA, act_of(4) + arow + g * 16) + bfin;
-                    *reinterpret_cast<f32x4*>(par + (16 * c2 + c) * kParS + 16 * t3 + 4 * g) = v;
-                }
-            } else {
-                if (ntile > 0) {
-                    // this wave's tasks: (tile, column) = task / 2, task % 2 for task = wave, wave + 8, ...
-                    f32x4 h[kMaxTasks], pg[2][kMaxTasks];
-                    // ---- stage a: h0 = W0 . (x hi|lo) + b0 + relu(pc); act0 = relu(h0) ----
-    #pragma unroll
-                    for (int q = 0; q < kMaxTasks; ++q) {
-                        const int task = wave + 8 * q;
-                        if (task < 2 * ntile) {
-                            const int t = t_lo + (task >> 1), c2 = task & 1;
-                            const bf16x8 a = *reinterpret_cast<const bf16x8*>(lw + ((size_t)t * 64 + lane) * 16);
-                            const bf16x8 b = *reinterpret_cast<const bf16x8*>(xb + (16 * c2 + c) * 64 + g * 16);
-                            f32x4 v = mfma_bf16(a, b, f32x4{0.f, 0.f, 0.f, 0.f});
-                            const int u = 16 * t + 4 * g;
-                            v = v + *reinterpret_cast<const f32x4*>(bias + u);
-                            pg[0][q] = pg[1][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-                            if (p.proj) {
-                                int64_t row = row0 + 16 * c2 + c;
-                                if (row >= p.batch) row = p.batch - 1;
-                                const int64_t cr = row / (p.batch / p.ctx_rows);
-                                const float* pr = p.proj + ((cr * p.L + l) * 3) * (int64_t)H + u;
-                                v = v + relu4(*reinterpret_cast<const f32x4*>(pr));
-                                pg[0][q] = *reinterpret_cast<const f32x4*>(pr + H);
-                                pg[1][q] = *reinterpret_cast<const f32x4*>(pr + 2 * H);
-                            }
-                            h[q] = v;
-                            *reinterpret_cast<bf16x4*>(act_of(0) + (16 * c2 + c) * AS + u * 2) = bf16_of(relu4(v));
-                        }
-                    }
-                    __syncthreads();
-                    // ---- stages b..e: the two residual blocks ----
-    #pragma unroll
-                    for (int blk = 0; blk < 2; ++blk) {
-                        // t1 = W1 . act[2 blk] + b1 ; act[2 blk + 1] = relu(t1)
-    #pragma unroll
-                        for (int q = 0; q < kMaxTasks; ++q) {
-                            const int task = wave + 8 * q;
-                            if (task < 2 * ntile) {
-                                const int t = t_lo + (task >> 1), c2 = task & 1;
-                                const char* wb = lw + p.off_w1[blk] + ((size_t)t * HK * 64 + lane) * 16;
-                                const char* src = act_of(2 * blk) + (16 * c2 + c) * AS + g * 16;
-                                f32x4 v = gemm_tile(wb, src, ks1);
-                                const int u = 16 * t + 4 * g;
-                                v = v + *reinterpret_cast<const f32x4*>(bias + (1 + 2 * blk) * H + u);
-                                *reinterpret_cast<bf16x4*>(act_of(2 * blk + 1) + (16 * c2 + c) * AS + u * 2) = bf16_of(relu4(v));
-                            }
-                        }
-                        __syncthreads();
-                        // t2 = W2 . act[2 blk + 1] + b2 ; h += t2 * sigmoid(pg) ; act[2 blk + 2] = relu(h) (block 0) | h (block 1)
-    #pragma unroll
-                        for (int q = 0; q < kMaxTasks; ++q) {
-                            const int task = wave + 8 * q;
-                            if (task < 2 * ntile) {
-                                const int t = t_lo + (task >> 1), c2 = task & 1;
-                                const char* wb = lw + p.off_w2[blk] + ((size_t)t * HK * 64 + lane) * 16;
-                                const char* src = act_of(2 * blk + 1) + (16 * c2 + c) * AS + g * 16;
-                                f32x4 v = gemm_tile(wb, src, ks1);
-                                const int u = 16 * t + 4 * g;
-                                v = v + *reinterpret_cast<const f32x4*>(bias + (2 + 2 * blk) * H + u);
-                                if (p.proj) v = v * sigmoid4(pg[blk][q]);
-                                h[q] = h[q] + v;
-                                *reinterpret_cast<bf16x4*>(act_of(2 * blk + 2) + (16 * c2 + c) * AS + u * 2) =
-                                    bf16_of(blk == 0 ? relu4(h[q]) : h[q]);
-                            }
-                        }
-                        __syncthreads();
+                        h[cc] = w0;
+                        *reinterpret_cast<bf16x4*>(act_of(0) + (16 * cc + c) * AS + u * 2) = bf16_of(relu4(w0));
                     }
                 }
-                // ---- stage f: the 3K-1 raw spline parameters of feature i (3 row tiles: widths | heights | derivatives) ----
-                if (wave < 6) {
-                    const int t3 = wave >> 1, c2 = wave & 1;
-                    const char* wb = lw + p.off_wf + ((size_t)(3 * i + t3) * HK * 64 + lane) * 16;
-                    const char* src = act_of(4) + (16 * c2 + c) * AS + g * 16;
-                    f32x4 v = gemm_tile(wb, src, ks1);
-                    v = v + *reinterpret_cast<const f32x4*>(bias + 5 * H + 48 * i + 16 * t3 + 4 * g);
-                    *reinterpret_cast<f32x4*>(par + (16 * c2 + c) * kParS + 16 * t3 + 4 * g) = v;
+                __syncthreads();
+                fetch(bufB, p.off_w2[0], t, mine);
+                if (mine) {                                                         // ---- stage b: act1 = relu(W1 . act0 + b1)
+                    gemm(bufA, act_of(0), v);
+#pragma unroll
+                    for (int cc = 0; cc < kCols; ++cc)
+                        *reinterpret_cast<bf16x4*>(act_of(1) + (16 * cc + c) * AS + u * 2) = bf16_of(relu4(v[cc] + bb[1]));
                 }
+                __syncthreads();
+                fetch(bufA, p.off_w1[1], t, mine);
+                if (mine) {                                                         // ---- stage c: h1 = h0 + (W2 . act1 + b2) sigmoid(pg0)
+                    gemm(bufB, act_of(1), v);
+#pragma unroll
+                    for (int cc = 0; cc < kCols; ++cc) {
+                        f32x4 d = v[cc] + bb[2];
+                        if (p.proj) d = d * sigmoid4(pg0[cc]);
+                        h[cc] = h[cc] + d;
+                        *reinterpret_cast<bf16x4*>(act_of(2) + (16 * cc + c) * AS + u * 2) = bf16_of(relu4(h[cc]));
+                    }
+                }
+                __syncthreads();
+                fetch(bufB, p.off_w2[1], t, mine);
+                if (mine) {                                                         // ---- stage d
+                    gemm(bufA, act_of(2), v);
+#pragma unroll
+                    for (int cc = 0; cc < kCols; ++cc)
+                        *reinterpret_cast<bf16x4*>(act_of(3) + (16 * cc + c) * AS + u * 2) = bf16_of(relu4(v[cc] + bb[3]));
+                }
+                __syncthreads();
+                if (mine) {                                                         // ---- stage e: h2 = h1 + (W2 . act3 + b2) sigmoid(pg1)
+                    gemm(bufB, act_of(3), v);
+#pragma unroll
+                    for (int cc = 0; cc < kCols; ++cc) {
+                        f32x4 d = v[cc] + bb[4];
+                        if (p.proj) d = d * sigmoid4(pg1[cc]);
+                        h[cc] = h[cc] + d;
+                        *reinterpret_cast<bf16x4*>(act_of(4) + (16 * cc + c) * AS + u * 2) = bf16_of(h[cc]);
+                    }
+                }
+                __syncthreads();
+            }
+            // ---- stage f: the 3K-1 raw spline parameters of feature i (3 row tiles: widths | heights | derivatives) ----
+            if (wave < 3) {
+                bf16x8 bufF[8];
+                f32x4 v[kCols];
+                fetch(bufF, p.off_wf, 3 * i + wave, true);
+                const f32x4 bfin = *reinterpret_cast<const f32x4*>(bias + 5 * H + 48 * i + 16 * wave + 4 * g);
+                gemm(bufF, act_of(4), v);
+#pragma unroll
+                for (int cc = 0; cc < kCols; ++cc)
+                    *reinterpret_cast<f32x4*>(par + (16 * cc + c) * kParS + 16 * wave + 4 * g) = v[cc] + bfin;
             }
             __syncthreads();
-            {   // all 512 threads: draw = tid / 16, bin = tid % 16
-                const int r = tid >> 4, j = tid & 15;
-                float xv, ld;
-                bool bad;
-                if (p.ablate & 1) { xv = ys[r * 16 + i] * 0.5f + par[r * kParS]; ld = 0.f; bad = false; } else
-                rqs_row16_inverse(par + r * kParS, ys[r * 16 + i], p.K, p.sp, j, xv, ld, bad);
-                if (j == 0) {
-                    xs[r * 16 + i] = xv;
-                    const __bf16 hi = (__bf16)xv;
-                    reinterpret_cast<__bf16*>(xb)[r * 32 + i] = hi;
-                    reinterpret_cast<__bf16*>(xb)[r * 32 + 16 + i] = (__bf16)(xv - (float)hi);
-                    ldacc[r] += ld;
-                    if (bad) badf[r] = 1u;
+            // ---- spline inversion: 16 lanes per draw (lane = bin), 32 draws per sweep of the 512 threads ----
+            for (int r0 = 0; r0 < kRows; r0 += 32) {
+                const int r = r0 + (tid >> 4), j = tid & 15;
+                if (r < kRows) {                                   // (uniform per 16-lane row)
+                    float xv, ld;
+                    bool bad;
+                    if (p.ablate & 1) { xv = ys[r * 16 + i] * 0.5f + par[r * kParS]; ld = 0.f; bad = false; } else
+                    rqs_row16_inverse(par + r * kParS, ys[r * 16 + i], p.K, p.sp, j, xv, ld, bad);
+                    if (j == 0) {
+                        xs[r * 16 + i] = xv;
+                        const __bf16 hi = (__bf16)xv;
+                        reinterpret_cast<__bf16*>(xb)[r * 32 + i] = hi;
+                        reinterpret_cast<__bf16*>(xb)[r * 32 + 16 + i] = (__bf16)(xv - (float)hi);
+                        ldacc[r] += ld;
+                        if (bad) badf[r] = 1u;
+                    }
                 }
             }
             __syncthreads();
@@ -431,15 +385,39 @@ int flow_inverse_inc(const PfFlowDesc& d, float deriv_const, const int32_t* u1, 
     p.layer_bytes = inc_layer_bytes(p.D, p.H);
     for (int i = 0; i <= p.D; ++i) p.u1[i] = u1[i];
     if (const char* a = std::getenv("PF_INC_ABLATE")) p.ablate = std::atoi(a);
-    const size_t lds = (size_t)5 * kRows * (p.H * 2 + 16) + kRows * 64 + (size_t)kRows * (16 + 16 + kParS + 2) * 4;
+    // rows per workgroup: the launch with the fewest rounds x time per round (0.55 / 0.68 / 0.85 ms per round of 16 / 32 /
+    // 48-row workgroups on 256 CUs, measured at D = 15, L = 8)
+    int cols = 1;
+    if (const char* f = std::getenv("PF_INC_COLS")) {
+        cols = std::atoi(f);
+        cols = cols < 1 ? 1 : (cols > 3 ? 3 : cols);
+    } else {
+        const double t[4] = {0.0, 0.55, 0.68, 0.85};
+        double best = 1e300;
+        for (int cc = 1; cc <= 3; ++cc) {
+            const int64_t wgs = (batch + 16 * cc - 1) / (16 * cc);
+            const double cost = (double)((wgs + 255) / 256) * t[cc];
+            if (cost < best - 1e-12) { best = cost; cols = cc; }
+        }
+    }
+    auto lds_of = [&](int cc) {
+        const size_t rows = 16 * (size_t)cc;
+        return 5 * rows * (p.H * 2 + 16) + rows * 64 + rows * (16 + 16 + kParS + 2) * 4;
+    };
+    while (cols > 1 && lds_of(cols) > 160 * 1024) --cols;
+    const size_t lds = lds_of(cols);
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(flow_inverse_inc_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(flow_inverse_inc_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(flow_inverse_inc_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(flow_inverse_inc_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return PF_ERR_HIP;
         configured = true;
     }
-    flow_inverse_inc_kernel<<<dim3(static_cast<unsigned>((batch + kRows - 1) / kRows)), dim3(512), lds, s>>>(p);
+    const dim3 grid(static_cast<unsigned>((batch + 16 * cols - 1) / (16 * cols)));
+    if (cols == 1) flow_inverse_inc_kernel<1><<<grid, dim3(512), lds, s>>>(p);
+    else if (cols == 2) flow_inverse_inc_kernel<2><<<grid, dim3(512), lds, s>>>(p);
+    else flow_inverse_inc_kernel<3><<<grid, dim3(512), lds, s>>>(p);
     return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
 }
 }  // namespace pf
