@@ -134,20 +134,6 @@ __device__ __forceinline__ void rqs_row16_inverse(const float* par, float yin, i
     bad = inside && bs > 0.f;
 }
 
-// acc = sum_{ks < ks1} A(ks) . B(ks): all weight fragments are requested before the first MFMA (a loop that
-// loads and multiplies one k-step at a time pays one L2 latency per k-step); H <= 256 -> at most 8 k-steps
-__device__ __forceinline__ f32x4 gemm_tile(const char* wb, const char* src, int ks1) {
-    bf16x8 a[8];
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks)
-        if (ks < ks1) a[ks] = *reinterpret_cast<const bf16x8*>(wb + (size_t)ks * 1024);
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks)
-        if (ks < ks1) v = mfma_bf16(a[ks], *reinterpret_cast<const bf16x8*>(src + ks * 64), v);
-    return v;
-}
-
 template <int kCols>
 __global__ __launch_bounds__(512) void flow_inverse_inc_kernel(const IncParams p) {
     constexpr int kRows = 16 * kCols;
