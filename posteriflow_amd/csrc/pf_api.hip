@@ -296,6 +296,7 @@ int pf_flow_inverse_inc(const PfFlowDesc* desc, const int32_t* units_upto_degree
     const float dc = (float)std::log(std::exp(1.0 - (double)desc->min_derivative) - 1.0);
     const int rc = pf::flow_inverse_inc(*desc, dc, units_upto_degree, packed, ctx_proj, ctx_proj ? ctx_rows : batch, z,
                                         ar_inv_perm, batch, x, logdet, fail_flags, static_cast<hipStream_t>(stream));
+    if (rc == PF_ERR_UNSUPPORTED) return fail(rc, "incremental inverse: more than 8 sixteen-unit tiles hold the units of one degree");
     return rc == PF_OK ? rc : fail(rc, hipGetErrorString(hipGetLastError()));
 }
 

@@ -21,8 +21,12 @@
 // kernel, one lane per row.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
+#include <type_traits>
+#include <vector>
 
 #include "pf_flow_fwd_kernel.h"
 
@@ -30,7 +34,9 @@ namespace pf {
 namespace {
 // draws per workgroup = 16 x COLS column tiles, COLS in {1, 2, 3} (5 x 48 x H bf16 of LDS state: 127 KB at H = 256);
 // a pass has a fixed latency, so more rows per workgroup raise throughput until the launch has fewer workgroups than CUs
-constexpr int kParS = kParStride;          // floats per row in the spline-parameter transpose (52)
+constexpr int kParS = kParStride;
+// ms per round of a full chip: three co-resident 16-draw workgroups per CU | one 32-draw | one 48-draw workgroup
+constexpr double kIncRoundMs[3] = {0.60, 0.68, 0.85};          // floats per row in the spline-parameter transpose (52)
 
 struct IncParams {
     FwdParams sp;              // spline scalars only: tail_bound, min_w, min_h, min_d, deriv_const
@@ -45,7 +51,7 @@ struct IncParams {
     int64_t off_w1[2], off_w2[2], off_wf, off_bias;      // byte offsets inside a layer block (W0 at 0)
     int D, H, K, L;
     int u1[17];                // number of hidden units (sorted order) with degree <= i
-    int ablate;                // timing experiments ($PF_INC_ABLATE): 1 no spline, 2 no barriers between stages
+    unsigned long long* trace; // $PF_INC_TRACE: stage timestamps of workgroup 0 / wave 0 (debug)
 };
 
 __device__ __forceinline__ f32x4 mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
@@ -134,8 +140,11 @@ __device__ __forceinline__ void rqs_row16_inverse(const float* par, float yin, i
     bad = inside && bs > 0.f;
 }
 
-template <int kCols>
-__global__ __launch_bounds__(512) void flow_inverse_inc_kernel(const IncParams p) {
+#define PF_TR(k) do { if (p.trace && blockIdx.x == 0 && tid == 0) p.trace[((p.L - 1 - l) * 16 + i) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+
+template <int kCols, int kThreads, bool kCtx>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(kThreads == 256 ? 3 : 1, kThreads == 256 ? 3 : 2)))
+void flow_inverse_inc_kernel(const IncParams p) {
     constexpr int kRows = 16 * kCols;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int D = p.D, H = p.H, HK = H / 32;
@@ -154,7 +163,7 @@ __global__ __launch_bounds__(512) void flow_inverse_inc_kernel(const IncParams p
     auto act_of = [&](int s) { return act + (size_t)s * kRows * AS; };
 
     // ---- initial state: y = z (coordinates of the last layer's output), log-det 0 --------------------
-    for (int s = tid; s < kRows * 16; s += 512) {
+    for (int s = tid; s < kRows * 16; s += kThreads) {
         const int r = s >> 4, d = s & 15;
         int64_t row = row0 + r;
         if (row >= p.batch) row = p.batch - 1;
@@ -162,7 +171,7 @@ __global__ __launch_bounds__(512) void flow_inverse_inc_kernel(const IncParams p
     }
     if (tid < kRows) { ldacc[tid] = 0.f; badf[tid] = 0u; }
     // activations of units not computed yet are read through zero (masked) weights: they must be finite
-    for (int s = tid * 16; s < 5 * kRows * AS; s += 512 * 16) *reinterpret_cast<f32x4*>(act + s) = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = tid * 16; s < 5 * kRows * AS; s += kThreads * 16) *reinterpret_cast<f32x4*>(act + s) = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
 
     // this lane's context rows (one per column tile) are fixed for the whole kernel
@@ -178,122 +187,94 @@ __global__ __launch_bounds__(512) void flow_inverse_inc_kernel(const IncParams p
         const char* lw = p.w + (size_t)l * p.layer_bytes;
         const float* bias = reinterpret_cast<const float*>(lw + p.off_bias);   // b0 | b1_0 | b2_0 | b1_1 | b2_1 | bf[D][48]
         // x estimate of this layer starts at zero (only solved features are ever read through non-zero weights)
-        for (int s = tid; s < kRows * 32; s += 512) reinterpret_cast<__bf16*>(xb)[s] = (__bf16)0.f;
-        for (int s = tid; s < kRows * 16; s += 512) xs[s] = 0.f;
+        for (int s = tid; s < kRows * 32; s += kThreads) reinterpret_cast<__bf16*>(xb)[s] = (__bf16)0.f;
+        for (int s = tid; s < kRows * 16; s += kThreads) xs[s] = 0.f;
         __syncthreads();
 
-        for (int i = 0; i < D; ++i) {                  // solve feature i (autoregressive position, degree i + 1)
-            const int ulo = i >= 1 ? p.u1[i - 1] : 0, uhi = p.u1[i];     // new hidden units: degree == i
-            const int t_lo = ulo / 16, t_hi = (uhi + 15) / 16;           // their tiles
-            const int ntile = i >= 1 ? t_hi - t_lo : 0;
-            const int ks1 = (uhi + 31) / 32;                             // reduction over units of degree <= i
-            // A wave owns unit tiles t_lo + wave (+ 8 when more than 8 tiles are new: only for D = 2..3) across
-            // ALL column tiles: one set of weight fragments, kCols independent MFMA chains.
-            auto fetch = [&](bf16x8 (&buf)[8], int64_t off, int tile, bool on) {
-                const char* wb = lw + off + ((size_t)tile * HK * 64 + lane) * 16;
+        // Every global load of a pass is issued one stage (0.4-0.5 us, about an L2 round trip) before its value is
+        // used, in straight-line code with a FIXED number of loads per stage, so that the compiler can wait for exactly
+        // the fragments a stage needs while the next stage's are in flight (with a load count that depends on a branch
+        // it drains everything before each MFMA chain; a k-step under a branch puts an LDS round trip between
+        // consecutive MFMAs).  The reduction always runs over 8 k-steps; those beyond the units of degree <= i have
+        // masked-zero weights (never fetched, see fetch).  Two fragment
+        // buffers X / Y alternate; the head of pass i + 1 (biases, context projections, W0 and the first hidden
+        // matrix) is requested while pass i computes its spline parameters, so the buffers swap roles every pass.
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(lw), 0, (int)p.layer_bytes, 0x00020000);
+        // fragments of k-steps >= kmax are masked zeros: their loads carry an out-of-range offset, which returns
+        // zeros without touching memory (the load count stays fixed, the L1 / L2 traffic stays triangular)
+        auto fetch = [&](bf16x8 (&buf)[8], int64_t off, int tile, int kmax) {
+            const int base = (int)off + tile * HK * 1024;
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks)
-                    if (on && ks < ks1) buf[ks] = *reinterpret_cast<const bf16x8*>(wb + (size_t)ks * 1024);
-            };
-            auto gemm = [&](const bf16x8 (&a)[8], const char* src, f32x4 (&v)[kCols]) {
+            for (int ks = 0; ks < 8; ++ks)
+                buf[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                    rsrc, ks < kmax ? lane * 16 : 0x80000000u, base + ks * 1024, 0));
+        };
+        auto gemm = [&](const bf16x8 (&a)[8], const char* src, f32x4 (&v)[kCols]) {
 #pragma unroll
-                for (int cc = 0; cc < kCols; ++cc) v[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int cc = 0; cc < kCols; ++cc) {
+                // (k-steps >= kmax multiply zero weights -- see fetch -- with whatever finite activations the row holds;
+                // k-steps >= H / 32 re-read the row's last one)
+                const char* brow = src + (16 * cc + c) * AS + g * 16;
+                f32x4 v0{0.f, 0.f, 0.f, 0.f}, v1{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks)
-                    if (ks < ks1) {
+                for (int k0 = 0; k0 < 8; k0 += 4) {          // four operand reads in flight (register budget of the 4-wave variant)
+                    bf16x8 b[4];
 #pragma unroll
-                        for (int cc = 0; cc < kCols; ++cc)
-                            v[cc] = mfma_bf16(a[ks], *reinterpret_cast<const bf16x8*>(src + (16 * cc + c) * AS + g * 16 + ks * 64), v[cc]);
-                    }
-            };
-            for (int tq = 0; tq < ntile; tq += 8) {   // one trip unless more than 8 tiles are new
-                const bool mine = tq + wave < ntile;
-                const int t = t_lo + tq + wave, u = 16 * t + 4 * g;
-                bf16x8 bufA[8], bufB[8];
-                f32x4 h[kCols], pg0[kCols], pg1[kCols], v[kCols];
-                // every bias of the pass is requested now (a load issued where its value is needed costs an L2
-                // round trip per stage), the weights of stage s + 1 before stage s is computed (two buffers)
-                f32x4 bb[5];
-#pragma unroll
-                for (int q = 0; q < 5; ++q) bb[q] = mine ? *reinterpret_cast<const f32x4*>(bias + q * H + u) : f32x4{0.f, 0.f, 0.f, 0.f};
-                fetch(bufA, p.off_w1[0], t, mine);
-                if (mine) {                                                         // ---- stage a: h0 = W0 . (x hi|lo) + b0 + relu(pc)
-                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(lw + ((size_t)t * 64 + lane) * 16);
-#pragma unroll
-                    for (int cc = 0; cc < kCols; ++cc) {
-                        const bf16x8 bx0 = *reinterpret_cast<const bf16x8*>(xb + (16 * cc + c) * 64 + g * 16);
-                        f32x4 w0 = mfma_bf16(a, bx0, f32x4{0.f, 0.f, 0.f, 0.f}) + bb[0];
-                        pg0[cc] = pg1[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        if (p.proj) {
-                            const float* pr = p.proj + ((crow[cc] * p.L + l) * 3) * (int64_t)H + u;
-                            w0 = w0 + relu4(*reinterpret_cast<const f32x4*>(pr));
-                            pg0[cc] = *reinterpret_cast<const f32x4*>(pr + H);
-                            pg1[cc] = *reinterpret_cast<const f32x4*>(pr + 2 * H);
-                        }
-                        h[cc] = w0;
-                        *reinterpret_cast<bf16x4*>(act_of(0) + (16 * cc + c) * AS + u * 2) = bf16_of(relu4(w0));
-                    }
+                    for (int ks = 0; ks < 4; ++ks)
+                        b[ks] = *reinterpret_cast<const bf16x8*>(brow + (k0 + ks < HK ? k0 + ks : HK - 1) * 64);
+                    v0 = mfma_bf16(a[k0], b[0], v0);
+                    v1 = mfma_bf16(a[k0 + 1], b[1], v1);
+                    v0 = mfma_bf16(a[k0 + 2], b[2], v0);
+                    v1 = mfma_bf16(a[k0 + 3], b[3], v1);
+                    if (kThreads == 256) __builtin_amdgcn_sched_barrier(0);
                 }
-                __syncthreads();
-                fetch(bufB, p.off_w2[0], t, mine);
-                if (mine) {                                                         // ---- stage b: act1 = relu(W1 . act0 + b1)
-                    gemm(bufA, act_of(0), v);
-#pragma unroll
-                    for (int cc = 0; cc < kCols; ++cc)
-                        *reinterpret_cast<bf16x4*>(act_of(1) + (16 * cc + c) * AS + u * 2) = bf16_of(relu4(v[cc] + bb[1]));
-                }
-                __syncthreads();
-                fetch(bufA, p.off_w1[1], t, mine);
-                if (mine) {                                                         // ---- stage c: h1 = h0 + (W2 . act1 + b2) sigmoid(pg0)
-                    gemm(bufB, act_of(1), v);
-#pragma unroll
-                    for (int cc = 0; cc < kCols; ++cc) {
-                        f32x4 d = v[cc] + bb[2];
-                        if (p.proj) d = d * sigmoid4(pg0[cc]);
-                        h[cc] = h[cc] + d;
-                        *reinterpret_cast<bf16x4*>(act_of(2) + (16 * cc + c) * AS + u * 2) = bf16_of(relu4(h[cc]));
-                    }
-                }
-                __syncthreads();
-                fetch(bufB, p.off_w2[1], t, mine);
-                if (mine) {                                                         // ---- stage d
-                    gemm(bufA, act_of(2), v);
-#pragma unroll
-                    for (int cc = 0; cc < kCols; ++cc)
-                        *reinterpret_cast<bf16x4*>(act_of(3) + (16 * cc + c) * AS + u * 2) = bf16_of(relu4(v[cc] + bb[3]));
-                }
-                __syncthreads();
-                if (mine) {                                                         // ---- stage e: h2 = h1 + (W2 . act3 + b2) sigmoid(pg1)
-                    gemm(bufB, act_of(3), v);
-#pragma unroll
-                    for (int cc = 0; cc < kCols; ++cc) {
-                        f32x4 d = v[cc] + bb[4];
-                        if (p.proj) d = d * sigmoid4(pg1[cc]);
-                        h[cc] = h[cc] + d;
-                        *reinterpret_cast<bf16x4*>(act_of(4) + (16 * cc + c) * AS + u * 2) = bf16_of(h[cc]);
-                    }
-                }
-                __syncthreads();
+                v[cc] = v0 + v1;
             }
-            // ---- stage f: the 3K-1 raw spline parameters of feature i (3 row tiles: widths | heights | derivatives) ----
+        };
+        // head registers of the coming pass
+        // (a stage's bias travels with its weights: bX / bY belong to the fragment buffers X / Y)
+        f32x4 b0, bA, bB, pr0[kCols], pg0[kCols], pg1[kCols];
+        bf16x8 a0;
+        const int wf = wave < 3 ? wave : 2;
+
+        // stage f of pass i (spline parameters of feature i from the last hidden state) + the spline inversion;
+        // X holds the stage's weights, Y receives the first hidden matrix of pass i + 1
+        auto tail = [&](int i, bf16x8 (&X)[8], f32x4& bX, bf16x8 (&Y)[8], f32x4& bY) {
             if (wave < 3) {
-                bf16x8 bufF[8];
                 f32x4 v[kCols];
-                fetch(bufF, p.off_wf, 3 * i + wave, true);
-                const f32x4 bfin = *reinterpret_cast<const f32x4*>(bias + 5 * H + 48 * i + 16 * wave + 4 * g);
-                gemm(bufF, act_of(4), v);
+                gemm(X, act_of(4), v);
 #pragma unroll
                 for (int cc = 0; cc < kCols; ++cc)
-                    *reinterpret_cast<f32x4*>(par + (16 * cc + c) * kParS + 16 * wave + 4 * g) = v[cc] + bfin;
+                    *reinterpret_cast<f32x4*>(par + (16 * cc + c) * kParS + 16 * wf + 4 * g) = v[cc] + bX;
+            }
+            // head of pass i + 1, requested after the stage's own operands have been consumed: a conditional load
+            // between another load and its use makes the compiler drain the whole queue at that use
+            if (i + 1 < D) {
+                const int t_lo = p.u1[i] / 16, ntile = (p.u1[i + 1] + 15) / 16 - t_lo;
+                if (wave < ntile) {
+                    const int t = t_lo + wave, u = 16 * t + 4 * g;
+                    b0 = *reinterpret_cast<const f32x4*>(bias + u);
+                    bY = *reinterpret_cast<const f32x4*>(bias + H + u);
+                    if constexpr (kCtx) {
+#pragma unroll
+                        for (int cc = 0; cc < kCols; ++cc) {
+                            const float* pr = p.proj + ((crow[cc] * p.L + l) * 3) * (int64_t)H + u;
+                            pr0[cc] = *reinterpret_cast<const f32x4*>(pr);
+                            pg0[cc] = *reinterpret_cast<const f32x4*>(pr + H);
+                        }
+                    }
+                    a0 = *reinterpret_cast<const bf16x8*>(lw + ((size_t)t * 64 + lane) * 16);
+                    fetch(Y, p.off_w1[0], t, (p.u1[i + 1] + 31) / 32);
+                }
             }
             __syncthreads();
-            // ---- spline inversion: 16 lanes per draw (lane = bin), 32 draws per sweep of the 512 threads ----
-            for (int r0 = 0; r0 < kRows; r0 += 32) {
+            PF_TR(6);
+            // ---- spline inversion: 16 lanes per draw (lane = bin), kThreads / 16 draws per sweep ----
+            for (int r0 = 0; r0 < kRows; r0 += kThreads / 16) {
                 const int r = r0 + (tid >> 4), j = tid & 15;
                 if (r < kRows) {                                   // (uniform per 16-lane row)
                     float xv, ld;
                     bool bad;
-                    if (p.ablate & 1) { xv = ys[r * 16 + i] * 0.5f + par[r * kParS]; ld = 0.f; bad = false; } else
                     rqs_row16_inverse(par + r * kParS, ys[r * 16 + i], p.K, p.sp, j, xv, ld, bad);
                     if (j == 0) {
                         xs[r * 16 + i] = xv;
@@ -306,9 +287,98 @@ __global__ __launch_bounds__(512) void flow_inverse_inc_kernel(const IncParams p
                 }
             }
             __syncthreads();
+            PF_TR(7);
+        };
+        // pass i >= 1: the new hidden units (degree == i) through the five hidden stages, then the tail.
+        // X holds the first hidden matrix on entry and stage f's weights on exit.
+        auto pass = [&](int i, bf16x8 (&X)[8], f32x4& bX, bf16x8 (&Y)[8], f32x4& bY) {
+            PF_TR(0);
+            const int t_lo = p.u1[i - 1] / 16, ntile = (p.u1[i] + 15) / 16 - t_lo;
+            const int kmax = (p.u1[i] + 31) / 32;
+            const bool mine = wave < ntile;                  // a wave owns a new tile across all column tiles
+            const int t = t_lo + wave, u = 16 * t + 4 * g;
+            f32x4 h[kCols], v[kCols];
+            if (mine) {                                                             // ---- stage a: h0 = W0 . (x hi|lo) + b0 + relu(pc)
+#pragma unroll
+                for (int cc = 0; cc < kCols; ++cc) {
+                    const bf16x8 bx0 = *reinterpret_cast<const bf16x8*>(xb + (16 * cc + c) * 64 + g * 16);
+                    f32x4 w0 = mfma_bf16(a0, bx0, f32x4{0.f, 0.f, 0.f, 0.f}) + b0;
+                    if constexpr (kCtx) w0 = w0 + relu4(pr0[cc]);
+                    h[cc] = w0;
+                    *reinterpret_cast<bf16x4*>(act_of(0) + (16 * cc + c) * AS + u * 2) = bf16_of(relu4(w0));
+                }
+            }
+            __syncthreads();
+            PF_TR(1);
+            if (mine) {                                                             // ---- stage b: act1 = relu(W1 . act0 + b1)
+                fetch(Y, p.off_w2[0], t, kmax);
+                bY = *reinterpret_cast<const f32x4*>(bias + 2 * H + u);
+                gemm(X, act_of(0), v);
+#pragma unroll
+                for (int cc = 0; cc < kCols; ++cc)
+                    *reinterpret_cast<bf16x4*>(act_of(1) + (16 * cc + c) * AS + u * 2) = bf16_of(relu4(v[cc] + bX));
+            }
+            __syncthreads();
+            PF_TR(2);
+            if (mine) {                                                             // ---- stage c: h1 = h0 + (W2 . act1 + b2) sigmoid(pg0)
+                fetch(X, p.off_w1[1], t, kmax);
+                bX = *reinterpret_cast<const f32x4*>(bias + 3 * H + u);
+                if constexpr (kCtx) {
+#pragma unroll
+                    for (int cc = 0; cc < kCols; ++cc)
+                        pg1[cc] = *reinterpret_cast<const f32x4*>(p.proj + ((crow[cc] * p.L + l) * 3 + 2) * (int64_t)H + u);
+                }
+                gemm(Y, act_of(1), v);
+#pragma unroll
+                for (int cc = 0; cc < kCols; ++cc) {
+                    f32x4 d = v[cc] + bY;
+                    if constexpr (kCtx) d = d * sigmoid4(pg0[cc]);
+                    h[cc] = h[cc] + d;
+                    *reinterpret_cast<bf16x4*>(act_of(2) + (16 * cc + c) * AS + u * 2) = bf16_of(relu4(h[cc]));
+                }
+            }
+            __syncthreads();
+            PF_TR(3);
+            if (mine) {                                                             // ---- stage d
+                fetch(Y, p.off_w2[1], t, kmax);
+                bY = *reinterpret_cast<const f32x4*>(bias + 4 * H + u);
+                gemm(X, act_of(2), v);
+#pragma unroll
+                for (int cc = 0; cc < kCols; ++cc)
+                    *reinterpret_cast<bf16x4*>(act_of(3) + (16 * cc + c) * AS + u * 2) = bf16_of(relu4(v[cc] + bX));
+            }
+            __syncthreads();
+            PF_TR(4);
+            // stage f's weights, one stage ahead; unconditional (out of range for waves >= 3): it sits between the
+            // fetch of Y and its use
+            fetch(X, p.off_wf, 3 * i + wf, wave < 3 ? kmax : 0);
+            bX = *reinterpret_cast<const f32x4*>(bias + 5 * H + 48 * i + 16 * wf + 4 * g);
+            if (mine) {                                                             // ---- stage e: h2 = h1 + (W2 . act3 + b2) sigmoid(pg1)
+                gemm(Y, act_of(3), v);
+#pragma unroll
+                for (int cc = 0; cc < kCols; ++cc) {
+                    f32x4 d = v[cc] + bY;
+                    if constexpr (kCtx) d = d * sigmoid4(pg1[cc]);
+                    h[cc] = h[cc] + d;
+                    *reinterpret_cast<bf16x4*>(act_of(4) + (16 * cc + c) * AS + u * 2) = bf16_of(h[cc]);
+                }
+            }
+            __syncthreads();
+            PF_TR(5);
+            tail(i, X, bX, Y, bY);
+        };
+        bf16x8 bufA[8], bufB[8];
+        // feature 0 depends on no hidden unit that is new: its parameters are the bias (+ masked zeros)
+        fetch(bufA, p.off_wf, wf, 0);
+        bA = *reinterpret_cast<const f32x4*>(bias + 5 * H + 16 * wf + 4 * g);
+        { const int i = 0; PF_TR(0); }
+        tail(0, bufA, bA, bufB, bB);
+        for (int i = 1; i < D; i += 2) {
+            pass(i, bufB, bB, bufA, bA);
+            if (i + 1 < D) pass(i + 1, bufA, bA, bufB, bB);
         }
         // this layer's input is the previous layer's output, reversed (ReversePermutation precedes every layer)
-        for (int s = tid; s < kRows * 16; s += 512) {
+        for (int s = tid; s < kRows * 16; s += kThreads) {
             const int r = s >> 4, d = s & 15;
             ys[s] = d < D ? xs[r * 16 + (D - 1 - d)] : 0.f;
         }
@@ -370,40 +440,70 @@ int flow_inverse_inc(const PfFlowDesc& d, float deriv_const, const int32_t* u1, 
     p.off_bias = p.off_wf + 3 * (int64_t)p.D * HK * 1024;
     p.layer_bytes = inc_layer_bytes(p.D, p.H);
     for (int i = 0; i <= p.D; ++i) p.u1[i] = u1[i];
-    if (const char* a = std::getenv("PF_INC_ABLATE")) p.ablate = std::atoi(a);
-    // rows per workgroup: the launch with the fewest rounds x time per round (0.55 / 0.68 / 0.85 ms per round of 16 / 32 /
-    // 48-row workgroups on 256 CUs, measured at D = 15, L = 8)
-    int cols = 1;
-    if (const char* f = std::getenv("PF_INC_COLS")) {
-        cols = std::atoi(f);
+    // Draws per workgroup.  A pass is a chain of seven barrier-separated stages whose cost is latency, not bandwidth,
+    // so the CU is filled either with one 8-wave workgroup of 32 / 48 draws (one weight fetch for 2-3 MFMA chains) or
+    // with up to three independent 4-wave workgroups of 16 draws (49 KB of LDS, <= 168 VGPRs each) whose barriers
+    // overlap.  The launch with the fewest rounds x time per round wins (ms per round at D = 15, L = 8, measured).
+    auto lds_of = [&](int cc) {
+        const size_t rows = 16 * (size_t)cc;
+        return 5 * rows * (p.H * 2 + 16) + rows * 64 + rows * (16 + 16 + kParS + 2) * 4 + 64;
+    };
+    int cols = 1, threads = 256;
+    const char* fc = std::getenv("PF_INC_COLS");
+    const char* ft = std::getenv("PF_INC_THREADS");
+    if (fc) {
+        cols = std::atoi(fc);
         cols = cols < 1 ? 1 : (cols > 3 ? 3 : cols);
     } else {
-        const double t[4] = {0.0, 0.55, 0.68, 0.85};
         double best = 1e300;
         for (int cc = 1; cc <= 3; ++cc) {
+            if (cc > 1 && lds_of(cc) > 160 * 1024) break;
             const int64_t wgs = (batch + 16 * cc - 1) / (16 * cc);
-            const double cost = (double)((wgs + 255) / 256) * t[cc];
+            const int64_t per_cu = cc == 1 ? std::max<int64_t>(1, std::min<int64_t>(3, (160 * 1024) / (int64_t)lds_of(1))) : 1;
+            const int64_t rounds = (wgs + 256 * per_cu - 1) / (256 * per_cu);
+            const double cost = (double)rounds * kIncRoundMs[cc - 1];
             if (cost < best - 1e-12) { best = cost; cols = cc; }
         }
     }
-    auto lds_of = [&](int cc) {
-        const size_t rows = 16 * (size_t)cc;
-        return 5 * rows * (p.H * 2 + 16) + rows * 64 + rows * (16 + 16 + kParS + 2) * 4;
-    };
+    // a wave owns one new tile per pass: at most 4 (8) sixteen-unit tiles may hold the units of one degree
+    int max_tiles = 0;
+    for (int i = 1; i < p.D; ++i) max_tiles = std::max(max_tiles, (u1[i] + 15) / 16 - u1[i - 1] / 16);
+    if (max_tiles > 8) return PF_ERR_UNSUPPORTED;
+    threads = cols == 1 && max_tiles <= 4 ? 256 : 512;
+    if (ft && cols == 1 && max_tiles <= 4) threads = std::atoi(ft) == 512 ? 512 : 256;
     while (cols > 1 && lds_of(cols) > 160 * 1024) --cols;
     const size_t lds = lds_of(cols);
+    const int variant = (cols == 1 ? (threads == 256 ? 0 : 1) : cols) * 2 + (proj ? 1 : 0);
+    using Kern = void (*)(const IncParams);
+    static const Kern kerns[8] = {
+        flow_inverse_inc_kernel<1, 256, false>, flow_inverse_inc_kernel<1, 256, true>,
+        flow_inverse_inc_kernel<1, 512, false>, flow_inverse_inc_kernel<1, 512, true>,
+        flow_inverse_inc_kernel<2, 512, false>, flow_inverse_inc_kernel<2, 512, true>,
+        flow_inverse_inc_kernel<3, 512, false>, flow_inverse_inc_kernel<3, 512, true>};
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(flow_inverse_inc_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(flow_inverse_inc_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(flow_inverse_inc_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return PF_ERR_HIP;
+        for (const Kern k : kerns)
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return PF_ERR_HIP;
         configured = true;
     }
+    const bool tracing = std::getenv("PF_INC_TRACE") != nullptr;
+    if (tracing && hipMalloc(&p.trace, p.L * 16 * 8 * sizeof(unsigned long long)) != hipSuccess) return PF_ERR_HIP;
     const dim3 grid(static_cast<unsigned>((batch + 16 * cols - 1) / (16 * cols)));
-    if (cols == 1) flow_inverse_inc_kernel<1><<<grid, dim3(512), lds, s>>>(p);
-    else if (cols == 2) flow_inverse_inc_kernel<2><<<grid, dim3(512), lds, s>>>(p);
-    else flow_inverse_inc_kernel<3><<<grid, dim3(512), lds, s>>>(p);
+    kerns[variant]<<<grid, dim3(threads), lds, s>>>(p);
+    if (tracing) {                   // debug: 100 MHz timestamps -> 10 ns units per stage, layers 0 and 1 as launched
+        std::vector<unsigned long long> t(p.L * 16 * 8);
+        if (hipStreamSynchronize(s) != hipSuccess ||
+            hipMemcpy(t.data(), p.trace, t.size() * sizeof(t[0]), hipMemcpyDeviceToHost) != hipSuccess) return PF_ERR_HIP;
+        (void)hipFree(p.trace);
+        for (int l = 0; l < 2 && l < p.L; ++l)
+            for (int i = 0; i < p.D; ++i) {
+                const unsigned long long* r = &t[(l * 16 + i) * 8];
+                std::fprintf(stderr, "inc trace layer %d pass %2d:", l, i);
+                for (int k = 1; k < 8; ++k) std::fprintf(stderr, " %5lld", (long long)(r[k] - r[k - 1]));
+                std::fprintf(stderr, "  | pass %lld\n", (long long)(r[7] - r[0]));
+            }
+    }
     return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
 }
 }  // namespace pf

@@ -619,11 +619,16 @@ class NSFPosteriorFlow(nn.Module):
                     # rounding of the bf16 forward kernel (context and weights to bf16, fp32 accumulation) so that
                     # forward(inverse(z)) sees the same conditioner
                     proj = torch.addmm(st["bcat"], context.to(torch.bfloat16).float(), st["wcat"].t()).contiguous()
-            _lib.check(_lib.lib().pf_flow_inverse_inc(
+            rc = _lib.lib().pf_flow_inverse_inc(
                 self._desc("bf16", inverse=True), st["u1"], st["buf"].data_ptr(), _dev_ptr(proj), ctx_rows,
                 z.data_ptr(), _dev_ptr(inv_perm), B, x.data_ptr(), logdet.data_ptr(), flags.data_ptr(),
-                torch.cuda.current_stream(dev).cuda_stream), "pf_flow_inverse_inc")
-            return x, logdet, flags
+                torch.cuda.current_stream(dev).cuda_stream)
+            if rc != _lib.PF_ERR_UNSUPPORTED:
+                _lib.check(rc, "pf_flow_inverse_inc")
+                return x, logdet, flags
+            # more than 8 sixteen-unit tiles of one degree (H / (D - 1) > 112: few features, where the D-pass
+            # kernel needs only 2-3 passes anyway): the D-pass kernel below handles every shape
+            self.incremental_inverse = False
         desc = self._desc(inverse=True)
         ws, ws_bytes = self._ws(desc, ctx_rows, dev)
         _lib.check(_lib.lib().pf_flow_inverse(
