@@ -54,8 +54,11 @@ struct IncParams {
     unsigned long long* trace; // $PF_INC_TRACE: stage timestamps of workgroup 0 / wave 0 (debug)
 };
 
-__device__ __forceinline__ f32x4 mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+// MFMA operands travel as four dwords: a <8 x bfloat> that lives across a branch is split into halves and re-packed
+// (v_bfi) right behind its load, which makes the load synchronous
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+__device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 __device__ __forceinline__ bf16x4 bf16_of(f32x4 v) {
     bf16x4 o;
@@ -174,15 +177,23 @@ void flow_inverse_inc_kernel(const IncParams p) {
     for (int s = tid * 16; s < 5 * kRows * AS; s += kThreads * 16) *reinterpret_cast<f32x4*>(act + s) = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
 
-    // this lane's context rows (one per column tile) are fixed for the whole kernel
-    int64_t crow[kCols];
+    // this lane's context rows (one per column tile) are fixed for the whole kernel: byte offsets of their projection
+    // blocks relative to the workgroup's first context row (32-bit, through a buffer resource: one VGPR per column)
+    const int64_t per = p.proj ? p.batch / p.ctx_rows : 1;
+    const int64_t crow_first = p.proj ? (row0 < p.batch ? row0 : p.batch - 1) / per : 0;
+    const int proj_row_bytes = p.L * 3 * H * 4;
+    int poff[kCols];
 #pragma unroll
     for (int cc = 0; cc < kCols; ++cc) {
         int64_t row = row0 + 16 * cc + c;
         if (row >= p.batch) row = p.batch - 1;
-        crow[cc] = p.proj ? row / (p.batch / p.ctx_rows) : 0;
+        poff[cc] = (int)(row / per - crow_first) * proj_row_bytes;
     }
-
+    const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.proj ? p.proj + crow_first * (int64_t)(p.L * 3 * H) : nullptr), 0, kCtx ? kRows * proj_row_bytes : 0, 0x00020000);
+    auto proj_load = [&](int cc, int l, int which, int u) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prsrc, poff[cc] + u * 4, ((l * 3 + which) * H) * 4, 0));
+    };
     for (int l = p.L - 1; l >= 0; --l) {
         const char* lw = p.w + (size_t)l * p.layer_bytes;
         const float* bias = reinterpret_cast<const float*>(lw + p.off_bias);   // b0 | b1_0 | b2_0 | b1_1 | b2_1 | bf[D][48]
@@ -202,14 +213,13 @@ void flow_inverse_inc_kernel(const IncParams p) {
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(lw), 0, (int)p.layer_bytes, 0x00020000);
         // fragments of k-steps >= kmax are masked zeros: their loads carry an out-of-range offset, which returns
         // zeros without touching memory (the load count stays fixed, the L1 / L2 traffic stays triangular)
-        auto fetch = [&](bf16x8 (&buf)[8], int64_t off, int tile, int kmax) {
+        auto fetch = [&](u32x4 (&buf)[8], int64_t off, int tile, int kmax) {
             const int base = (int)off + tile * HK * 1024;
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks)
-                buf[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
-                    rsrc, ks < kmax ? lane * 16 : 0x80000000u, base + ks * 1024, 0));
+                buf[ks] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ks < kmax ? lane * 16 : 0x80000000u, base + ks * 1024, 0);
         };
-        auto gemm = [&](const bf16x8 (&a)[8], const char* src, f32x4 (&v)[kCols]) {
+        auto gemm = [&](const u32x4 (&a)[8], const char* src, f32x4 (&v)[kCols]) {
 #pragma unroll
             for (int cc = 0; cc < kCols; ++cc) {
                 // (k-steps >= kmax multiply zero weights -- see fetch -- with whatever finite activations the row holds;
@@ -218,10 +228,10 @@ void flow_inverse_inc_kernel(const IncParams p) {
                 f32x4 v0{0.f, 0.f, 0.f, 0.f}, v1{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int k0 = 0; k0 < 8; k0 += 4) {          // four operand reads in flight (register budget of the 4-wave variant)
-                    bf16x8 b[4];
+                    u32x4 b[4];
 #pragma unroll
                     for (int ks = 0; ks < 4; ++ks)
-                        b[ks] = *reinterpret_cast<const bf16x8*>(brow + (k0 + ks < HK ? k0 + ks : HK - 1) * 64);
+                        b[ks] = *reinterpret_cast<const u32x4*>(brow + (k0 + ks < HK ? k0 + ks : HK - 1) * 64);
                     v0 = mfma_bf16(a[k0], b[0], v0);
                     v1 = mfma_bf16(a[k0 + 1], b[1], v1);
                     v0 = mfma_bf16(a[k0 + 2], b[2], v0);
@@ -234,12 +244,12 @@ void flow_inverse_inc_kernel(const IncParams p) {
         // head registers of the coming pass
         // (a stage's bias travels with its weights: bX / bY belong to the fragment buffers X / Y)
         f32x4 b0, bA, bB, pr0[kCols], pg0[kCols], pg1[kCols];
-        bf16x8 a0;
+        u32x4 a0;
         const int wf = wave < 3 ? wave : 2;
 
         // stage f of pass i (spline parameters of feature i from the last hidden state) + the spline inversion;
         // X holds the stage's weights, Y receives the first hidden matrix of pass i + 1
-        auto tail = [&](int i, bf16x8 (&X)[8], f32x4& bX, bf16x8 (&Y)[8], f32x4& bY) {
+        auto tail = [&](int i, u32x4 (&X)[8], f32x4& bX, u32x4 (&Y)[8], f32x4& bY) {
             if (wave < 3) {
                 f32x4 v[kCols];
                 gemm(X, act_of(4), v);
@@ -258,12 +268,11 @@ void flow_inverse_inc_kernel(const IncParams p) {
                     if constexpr (kCtx) {
 #pragma unroll
                         for (int cc = 0; cc < kCols; ++cc) {
-                            const float* pr = p.proj + ((crow[cc] * p.L + l) * 3) * (int64_t)H + u;
-                            pr0[cc] = *reinterpret_cast<const f32x4*>(pr);
-                            pg0[cc] = *reinterpret_cast<const f32x4*>(pr + H);
+                            pr0[cc] = proj_load(cc, l, 0, u);
+                            pg0[cc] = proj_load(cc, l, 1, u);
                         }
                     }
-                    a0 = *reinterpret_cast<const bf16x8*>(lw + ((size_t)t * 64 + lane) * 16);
+                    a0 = *reinterpret_cast<const u32x4*>(lw + ((size_t)t * 64 + lane) * 16);
                     fetch(Y, p.off_w1[0], t, (p.u1[i + 1] + 31) / 32);
                 }
             }
@@ -291,7 +300,7 @@ void flow_inverse_inc_kernel(const IncParams p) {
         };
         // pass i >= 1: the new hidden units (degree == i) through the five hidden stages, then the tail.
         // X holds the first hidden matrix on entry and stage f's weights on exit.
-        auto pass = [&](int i, bf16x8 (&X)[8], f32x4& bX, bf16x8 (&Y)[8], f32x4& bY) {
+        auto pass = [&](int i, u32x4 (&X)[8], f32x4& bX, u32x4 (&Y)[8], f32x4& bY) {
             PF_TR(0);
             const int t_lo = p.u1[i - 1] / 16, ntile = (p.u1[i] + 15) / 16 - t_lo;
             const int kmax = (p.u1[i] + 31) / 32;
@@ -301,7 +310,7 @@ void flow_inverse_inc_kernel(const IncParams p) {
             if (mine) {                                                             // ---- stage a: h0 = W0 . (x hi|lo) + b0 + relu(pc)
 #pragma unroll
                 for (int cc = 0; cc < kCols; ++cc) {
-                    const bf16x8 bx0 = *reinterpret_cast<const bf16x8*>(xb + (16 * cc + c) * 64 + g * 16);
+                    const u32x4 bx0 = *reinterpret_cast<const u32x4*>(xb + (16 * cc + c) * 64 + g * 16);
                     f32x4 w0 = mfma_bf16(a0, bx0, f32x4{0.f, 0.f, 0.f, 0.f}) + b0;
                     if constexpr (kCtx) w0 = w0 + relu4(pr0[cc]);
                     h[cc] = w0;
@@ -326,7 +335,7 @@ void flow_inverse_inc_kernel(const IncParams p) {
                 if constexpr (kCtx) {
 #pragma unroll
                     for (int cc = 0; cc < kCols; ++cc)
-                        pg1[cc] = *reinterpret_cast<const f32x4*>(p.proj + ((crow[cc] * p.L + l) * 3 + 2) * (int64_t)H + u);
+                        pg1[cc] = proj_load(cc, l, 2, u);
                 }
                 gemm(Y, act_of(1), v);
 #pragma unroll
@@ -367,7 +376,7 @@ void flow_inverse_inc_kernel(const IncParams p) {
             PF_TR(5);
             tail(i, X, bX, Y, bY);
         };
-        bf16x8 bufA[8], bufB[8];
+        u32x4 bufA[8], bufB[8];
         // feature 0 depends on no hidden unit that is new: its parameters are the bias (+ masked zeros)
         fetch(bufA, p.off_wf, wf, 0);
         bA = *reinterpret_cast<const f32x4*>(bias + 5 * H + 16 * wf + 4 * g);
