@@ -7,18 +7,29 @@
 // and the units of lower degree -- were final one pass earlier).  Here a pass computes just those units:
 // with the hidden units sorted by degree they are a contiguous range of 2-3 sixteen-unit tiles per hidden
 // layer (H / (D - 1) units), whose reduction runs over the units of degree <= i only, and the activations
-// of all five hidden stages of the layer stay in LDS (bf16, 5 x 32 rows x H) between passes.  Summed over the
+// of all five hidden stages of the layer stay in LDS (bf16, 5 x 16 rows x 256) between passes.  Summed over the
 // D passes the work is ONE masked conditioner evaluation per layer ("exact incremental
 // algorithm") instead of D dense ones.  The result is the same x: no approximation is involved.
 //
-// One workgroup = 16 / 32 / 48 draws (1-3 sixteen-row MFMA column tiles), 8 waves.  Transposed MFMA form as
-// everywhere: out^T[unit, row] = W[unit, k] . act^T[k, row]; a wave owns a new unit tile across all column
-// tiles (one set of weight fragments, one MFMA chain per column), its fp32 residual values h live in its
-// registers through the five stages of a pass; stages are separated by a
-// workgroup barrier (the next stage reads the tile just written).  bf16 operands / fp32 accumulation, the
-// input features enter the first masked layer as a bf16 hi + lo pair, context enters as per-context-row
-// projections computed once by the caller (C = 0: none).  Spline inversion: rqs_pair_inverse of the D-pass
-// kernel, one lane per row.
+// One workgroup = 16 draws (one sixteen-row MFMA column tile), 4 waves, 49 KB of LDS, <= 168 VGPRs: three of them share
+// a CU.  A pass is a chain of seven barrier-separated stages (six dependent GEMV-like stages + the spline) whose
+// cost is latency, so independent workgroups on the same CU are what fills it; 32 / 48-draw workgroups sharing one
+// weight fetch measured 25-30 % slower per draw.  Transposed MFMA form as everywhere:
+// out^T[unit, row] = W[unit, k] . act^T[k, row]; a wave owns a new unit tile, its fp32 residual values h live in its
+// registers through the five stages of a pass.  bf16 operands / fp32 accumulation, the input features enter the first
+// masked layer as a bf16 hi + lo pair, context enters as per-context-row projections computed once by the caller
+// (C = 0: none).  Spline inversion: 16 lanes per draw (lane = bin), DPP row reductions.
+//
+// Latency rules the code follows (each measured with the stage timestamps of $PF_INC_TRACE, scripts/trace_inc.py):
+//   - every global load is issued one stage before its value is used, in straight-line code with a fixed number of
+//     loads per stage (fragments beyond the units of degree <= i are fetched through a buffer resource that ends
+//     before them: zeros, no traffic); a conditional load between another load and its use makes the compiler drain
+//     the whole queue at that use;
+//   - the head of pass i + 1 (biases, context projections, W0, first hidden matrix) is requested under the spline of
+//     pass i, the two fragment buffers swap roles every pass (passes are unrolled by two);
+//   - MFMA operands live in registers as dword vectors: a <8 x bfloat> that crosses a branch is split and re-packed
+//     right behind its load;
+//   - LDS rows have a fixed stride, so operand addresses are one VGPR + an instruction immediate.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -32,11 +43,8 @@
 
 namespace pf {
 namespace {
-// draws per workgroup = 16 x COLS column tiles, COLS in {1, 2, 3} (5 x 48 x H bf16 of LDS state: 127 KB at H = 256);
-// a pass has a fixed latency, so more rows per workgroup raise throughput until the launch has fewer workgroups than CUs
-constexpr int kParS = kParStride;
-// ms per round of a full chip: three co-resident 16-draw workgroups per CU | one 32-draw | one 48-draw workgroup
-constexpr double kIncRoundMs[3] = {0.60, 0.68, 0.85};          // floats per row in the spline-parameter transpose (52)
+constexpr int kParS = kParStride;          // floats per row in the spline-parameter transpose (52)
+constexpr int kActStride = 256 * 2 + 16;   // bytes per activation row in LDS: 8 k-steps of bf16 + bank spread, whatever H is
 
 struct IncParams {
     FwdParams sp;              // spline scalars only: tail_bound, min_w, min_h, min_d, deriv_const
@@ -73,7 +81,7 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v) {
 }
 __device__ __forceinline__ f32x4 sigmoid4(f32x4 v) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_rcpf(1.f + __expf(-v[e]));
+    for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(v[e] * -1.44269504f));
     return v;
 }
 
@@ -90,11 +98,29 @@ __device__ __forceinline__ float row_sum(float v) {
     v += row_dpp<0xB1>(v); v += row_dpp<0x4E>(v); v += row_dpp<0x141>(v); v += row_dpp<0x140>(v);
     return v;
 }
-__device__ __forceinline__ float row_max(float v) {
-    v = fmaxf(v, row_dpp<0xB1>(v)); v = fmaxf(v, row_dpp<0x4E>(v));
-    v = fmaxf(v, row_dpp<0x141>(v)); v = fmaxf(v, row_dpp<0x140>(v));
-    return v;
+// max over the 16 lanes of a row for two values at once: v_max_f32_dpp directly (through fmaxf every step costs a DPP
+// move plus two NaN-quieting v_max); a VGPR written by a VALU instruction needs two wait states before a DPP read
+__device__ __forceinline__ void row_max2(float& a, float& b) {
+    asm volatile(
+        "s_nop 1\n"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+        "v_max_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+        "s_nop 0\n"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+        "v_max_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+        "s_nop 0\n"
+        "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n"
+        "v_max_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n"
+        "s_nop 0\n"
+        "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n"
+        "v_max_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n"
+        "s_nop 1\n"
+        : "+v"(a), "+v"(b));
 }
+// raw transcendental instructions (1 ulp, no denormal-range fix-ups: every argument here is a normal number)
+__device__ __forceinline__ float exp_raw(float v) { return __builtin_amdgcn_exp2f(v * 1.44269504f); }
+__device__ __forceinline__ float log_raw(float v) { return __builtin_amdgcn_logf(v) * 0.693147181f; }
+__device__ __forceinline__ float softplus_raw(float u) { return u > 20.f ? u : log_raw(1.f + exp_raw(u)); }
 __device__ __forceinline__ float row_scan(float v) {            // inclusive prefix sum over the 16 lanes of a row
     v += row_dpp<0x111>(v); v += row_dpp<0x112>(v); v += row_dpp<0x114>(v); v += row_dpp<0x118>(v);
     return v;
@@ -107,10 +133,11 @@ __device__ __forceinline__ void rqs_row16_inverse(const float* par, float yin, i
     const float tb = p.tail_bound, span = 2.f * tb;
     // (every DPP reduction is evaluated OUTSIDE conditionals: inside `live ? ... : ...` the compiler may run it with
     // the non-live lanes masked off, and a DPP read of a disabled lane is not the lane's value)
-    const float mw = row_max(uw), mh = row_max(uh);
-    const float ew = live ? __expf(uw - mw) : 0.f, eh = live ? __expf(uh - mh) : 0.f;
-    const float cw = __fdividef(1.f - p.min_w * (float)K, row_sum(ew));
-    const float ch = __fdividef(1.f - p.min_h * (float)K, row_sum(eh));
+    float mw = uw, mh = uh;
+    row_max2(mw, mh);
+    const float ew = live ? exp_raw(uw - mw) : 0.f, eh = live ? exp_raw(uh - mh) : 0.f;
+    const float cw = (1.f - p.min_w * (float)K) * __builtin_amdgcn_rcpf(row_sum(ew));
+    const float ch = (1.f - p.min_h * (float)K) * __builtin_amdgcn_rcpf(row_sum(eh));
     const float wj = live ? p.min_w + cw * ew : 0.f, hj = live ? p.min_h + ch * eh : 0.f;
     const float cumw = row_scan(wj), cumh = row_scan(hj);
     const bool last = j == K - 1;
@@ -124,18 +151,18 @@ __device__ __forceinline__ void rqs_row16_inverse(const float* par, float yin, i
     const bool ge_l = j == 0 ? true : yin >= hl;
     const bool sel = live && ge_l && !ge_r;
     const float w = kr - kl, hh = hr - hl;
-    const float dl = p.min_d + pf_softplus<true>(dl_raw), dr = p.min_d + pf_softplus<true>(dr_raw);
-    const float delta = __fdividef(hh, w);
+    const float dl = p.min_d + softplus_raw(dl_raw), dr = p.min_d + softplus_raw(dr_raw);
+    const float delta = hh * __builtin_amdgcn_rcpf(w);
     const float dy = yin - hl, s2 = dl + dr - 2.f * delta;
     const float a = dy * s2 + hh * (delta - dl), b = hh * dl - dy * s2, c0 = -delta * dy;
     const float disc = b * b - 4.f * a * c0;
-    const float root = __fdividef(2.f * c0, -b - sqrtf(fmaxf(disc, 0.f)));
+    const float root = 2.f * c0 * __builtin_amdgcn_rcpf(-b - __builtin_amdgcn_sqrtf(fmaxf(disc, 0.f)));
     const float tt = root * (1.f - root), den = delta + s2 * tt, omt = 1.f - root;
     const float dnum = delta * delta * (dr * root * root + 2.f * delta * tt + dl * omt * omt);
     const bool inside = (yin >= -tb) && (yin <= tb);
     // exactly one bin is selected inside the interval: its values reach every lane of the row through a sum
     const float xsel = sel ? root * w + kl : 0.f;
-    const float lsel = sel ? -(__logf(dnum) - 2.f * __logf(den)) : 0.f;
+    const float lsel = sel ? -(log_raw(dnum) - 2.f * log_raw(den)) : 0.f;
     const float bsel = (sel && !(disc >= 0.f)) ? 1.f : 0.f;
     const float xs = row_sum(xsel), ls = row_sum(lsel), bs = row_sum(bsel);
     x = inside ? xs : yin;
@@ -151,7 +178,8 @@ void flow_inverse_inc_kernel(const IncParams p) {
     constexpr int kRows = 16 * kCols;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int D = p.D, H = p.H, HK = H / 32;
-    const int AS = H * 2 + 16;                                   // byte stride of an activation row (bank spread)
+    constexpr int AS = kActStride;                               // byte stride of an activation row: 8 k-steps + bank spread,
+                                                                 // whatever H is (LDS offsets are then instruction immediates)
     char* const act = smem;                                      // 5 stages x [kRows][H] bf16
     char* const xb = act + (size_t)5 * kRows * AS;               // [kRows][32] bf16: x hi (0..15) | lo (16..31)
     float* const xs = reinterpret_cast<float*>(xb + kRows * 64); // [kRows][16] current layer's input, fp32
@@ -164,6 +192,7 @@ void flow_inverse_inc_kernel(const IncParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t row0 = (int64_t)blockIdx.x * kRows;
     auto act_of = [&](int s) { return act + (size_t)s * kRows * AS; };
+    const int lane16 = lane * 16, lane16hi = lane * 16 + 4096;
 
     // ---- initial state: y = z (coordinates of the last layer's output), log-det 0 --------------------
     for (int s = tid; s < kRows * 16; s += kThreads) {
@@ -210,20 +239,21 @@ void flow_inverse_inc_kernel(const IncParams p) {
         // masked-zero weights (never fetched, see fetch).  Two fragment
         // buffers X / Y alternate; the head of pass i + 1 (biases, context projections, W0 and the first hidden
         // matrix) is requested while pass i computes its spline parameters, so the buffers swap roles every pass.
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(lw), 0, (int)p.layer_bytes, 0x00020000);
-        // fragments of k-steps >= kmax are masked zeros: their loads carry an out-of-range offset, which returns
-        // zeros without touching memory (the load count stays fixed, the L1 / L2 traffic stays triangular)
+        // fragments of k-steps >= kmax are masked zeros: the buffer resource of a fetch ends after kmax fragments, the
+        // loads beyond it return zeros without touching memory (the load count stays fixed, the L1 / L2 traffic
+        // triangular); offsets are lane * 16 (+ 4096) + an instruction immediate
         auto fetch = [&](u32x4 (&buf)[8], int64_t off, int tile, int kmax) {
-            const int base = (int)off + tile * HK * 1024;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<char*>(lw) + off + (int64_t)tile * HK * 1024, 0, kmax * 1024, 0x00020000);
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks)
-                buf[ks] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ks < kmax ? lane * 16 : 0x80000000u, base + ks * 1024, 0);
+                buf[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs, (ks < 4 ? lane16 : lane16hi) + (ks & 3) * 1024, 0, 0);
         };
         auto gemm = [&](const u32x4 (&a)[8], const char* src, f32x4 (&v)[kCols]) {
 #pragma unroll
             for (int cc = 0; cc < kCols; ++cc) {
-                // (k-steps >= kmax multiply zero weights -- see fetch -- with whatever finite activations the row holds;
-                // k-steps >= H / 32 re-read the row's last one)
+                // (k-steps >= kmax multiply zero weights -- see fetch -- with whatever finite activations the row holds:
+                // zeros beyond H)
                 const char* brow = src + (16 * cc + c) * AS + g * 16;
                 f32x4 v0{0.f, 0.f, 0.f, 0.f}, v1{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -231,7 +261,7 @@ void flow_inverse_inc_kernel(const IncParams p) {
                     u32x4 b[4];
 #pragma unroll
                     for (int ks = 0; ks < 4; ++ks)
-                        b[ks] = *reinterpret_cast<const u32x4*>(brow + (k0 + ks < HK ? k0 + ks : HK - 1) * 64);
+                        b[ks] = *reinterpret_cast<const u32x4*>(brow + (k0 + ks) * 64);
                     v0 = mfma_bf16(a[k0], b[0], v0);
                     v1 = mfma_bf16(a[k0 + 1], b[1], v1);
                     v0 = mfma_bf16(a[k0 + 2], b[2], v0);
@@ -449,56 +479,33 @@ int flow_inverse_inc(const PfFlowDesc& d, float deriv_const, const int32_t* u1, 
     p.off_bias = p.off_wf + 3 * (int64_t)p.D * HK * 1024;
     p.layer_bytes = inc_layer_bytes(p.D, p.H);
     for (int i = 0; i <= p.D; ++i) p.u1[i] = u1[i];
-    // Draws per workgroup.  A pass is a chain of seven barrier-separated stages whose cost is latency, not bandwidth,
-    // so the CU is filled either with one 8-wave workgroup of 32 / 48 draws (one weight fetch for 2-3 MFMA chains) or
-    // with up to three independent 4-wave workgroups of 16 draws (49 KB of LDS, <= 168 VGPRs each) whose barriers
-    // overlap.  The launch with the fewest rounds x time per round wins (ms per round at D = 15, L = 8, measured).
-    auto lds_of = [&](int cc) {
-        const size_t rows = 16 * (size_t)cc;
-        return 5 * rows * (p.H * 2 + 16) + rows * 64 + rows * (16 + 16 + kParS + 2) * 4 + 64;
-    };
-    int cols = 1, threads = 256;
-    const char* fc = std::getenv("PF_INC_COLS");
-    const char* ft = std::getenv("PF_INC_THREADS");
-    if (fc) {
-        cols = std::atoi(fc);
-        cols = cols < 1 ? 1 : (cols > 3 ? 3 : cols);
-    } else {
-        double best = 1e300;
-        for (int cc = 1; cc <= 3; ++cc) {
-            if (cc > 1 && lds_of(cc) > 160 * 1024) break;
-            const int64_t wgs = (batch + 16 * cc - 1) / (16 * cc);
-            const int64_t per_cu = cc == 1 ? std::max<int64_t>(1, std::min<int64_t>(3, (160 * 1024) / (int64_t)lds_of(1))) : 1;
-            const int64_t rounds = (wgs + 256 * per_cu - 1) / (256 * per_cu);
-            const double cost = (double)rounds * kIncRoundMs[cc - 1];
-            if (cost < best - 1e-12) { best = cost; cols = cc; }
-        }
-    }
-    // a wave owns one new tile per pass: at most 4 (8) sixteen-unit tiles may hold the units of one degree
+    // One workgroup = 16 draws.  A pass is a chain of seven barrier-separated stages whose cost is latency, not
+    // bandwidth, so the CU is filled with three independent 4-wave workgroups (49 KB of LDS, <= 168 VGPRs each) whose
+    // stalls overlap; wider workgroups (32 / 48 draws sharing one weight fetch) measured 25-30 % slower per draw.
+    // A wave owns one new tile per pass: at most 4 (8 with the 8-wave variant) sixteen-unit tiles may hold the
+    // units of one degree.
     int max_tiles = 0;
     for (int i = 1; i < p.D; ++i) max_tiles = std::max(max_tiles, (u1[i] + 15) / 16 - u1[i - 1] / 16);
     if (max_tiles > 8) return PF_ERR_UNSUPPORTED;
-    threads = cols == 1 && max_tiles <= 4 ? 256 : 512;
-    if (ft && cols == 1 && max_tiles <= 4) threads = std::atoi(ft) == 512 ? 512 : 256;
-    while (cols > 1 && lds_of(cols) > 160 * 1024) --cols;
-    const size_t lds = lds_of(cols);
-    const int variant = (cols == 1 ? (threads == 256 ? 0 : 1) : cols) * 2 + (proj ? 1 : 0);
+    int threads = max_tiles <= 4 ? 256 : 512;
+    if (const char* ft = std::getenv("PF_INC_THREADS")) {
+        if (std::atoi(ft) == 512) threads = 512;
+    }
+    constexpr size_t lds = 5 * 16 * kActStride + 16 * 64 + 16 * (16 + 16 + kParS + 2) * 4;
     using Kern = void (*)(const IncParams);
-    static const Kern kerns[8] = {
-        flow_inverse_inc_kernel<1, 256, false>, flow_inverse_inc_kernel<1, 256, true>,
-        flow_inverse_inc_kernel<1, 512, false>, flow_inverse_inc_kernel<1, 512, true>,
-        flow_inverse_inc_kernel<2, 512, false>, flow_inverse_inc_kernel<2, 512, true>,
-        flow_inverse_inc_kernel<3, 512, false>, flow_inverse_inc_kernel<3, 512, true>};
+    static const Kern kerns[4] = {flow_inverse_inc_kernel<1, 256, false>, flow_inverse_inc_kernel<1, 256, true>,
+                                  flow_inverse_inc_kernel<1, 512, false>, flow_inverse_inc_kernel<1, 512, true>};
     static bool configured = false;
     if (!configured) {
         for (const Kern k : kerns)
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess)
                 return PF_ERR_HIP;
         configured = true;
     }
+    const int variant = (threads == 256 ? 0 : 2) + (proj ? 1 : 0);
     const bool tracing = std::getenv("PF_INC_TRACE") != nullptr;
     if (tracing && hipMalloc(&p.trace, p.L * 16 * 8 * sizeof(unsigned long long)) != hipSuccess) return PF_ERR_HIP;
-    const dim3 grid(static_cast<unsigned>((batch + 16 * cols - 1) / (16 * cols)));
+    const dim3 grid(static_cast<unsigned>((batch + 15) / 16));
     kerns[variant]<<<grid, dim3(threads), lds, s>>>(p);
     if (tracing) {                   // debug: 100 MHz timestamps -> 10 ns units per stage, layers 0 and 1 as launched
         std::vector<unsigned long long> t(p.L * 16 * 8);
