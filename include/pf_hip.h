@@ -153,7 +153,9 @@ int pf_flow_inverse(const PfFlowDesc* desc, const void* packed,
  * Same result as pf_flow_inverse (the transform.inverse call of flows.py:637), with ONE masked conditioner
  * evaluation per layer instead of D dense ones: pass i computes only the hidden units of degree i (2-3 tiles per
  * hidden stage, hidden units sorted by degree) from the activations of the earlier passes, which stay in LDS.
- * 48 draws per workgroup.  The caller prepares, per layer l (bytes: pf_flow_inc_layer_bytes):
+ * 16 draws per workgroup, three workgroups per CU.  Returns PF_ERR_UNSUPPORTED when more than 8 sixteen-unit tiles hold
+ * the hidden units of one degree (H / (D - 1) > 112: use pf_flow_inverse).  The caller prepares, per layer l (bytes:
+ * pf_flow_inc_layer_bytes):
  *   A fragments (pf_pack_bf16_frags of the masked weights, rows / columns of hidden units in degree-sorted
  *   order): W0 [H][32] (columns f and 16 + f both = initial_layer.weight[:, f]: the input enters as a bf16
  *   hi | lo pair), W1 / W2 of block 0, W1 / W2 of block 1 [H][H], final layer [D * 48][H] (per feature 16
