@@ -25,7 +25,7 @@ def lib():
 
 def test_library_exports_every_declared_symbol(lib):
     header = open(os.path.join(ROOT, "include", "pf_hip.h")).read()
-    declared = set(re.findall(r"\b(pf_[a-z_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(pf_[a-z0-9_]+)\s*\(", header))
     assert declared == set(lib.SYMBOLS), declared ^ set(lib.SYMBOLS)
     handle = lib.lib()
     for name in declared:
