@@ -21,7 +21,7 @@ int fusion_pack(const float* raw, char* packed, hipStream_t s);
 int fusion_forward(const char* packed, float* tokens, int n_tokens, const float* tok_bias, const float* pool_q,
                    int64_t n_events, float* pooled, hipStream_t s);
 int inc_pack_frags(const float* src, int n_rows, int k, void* out, hipStream_t s);
-int64_t inc_layer_bytes(int D, int H);
+int64_t inc_layer_bytes(int D, int H, bool f32);
 int flow_inverse_inc(const PfFlowDesc& d, float deriv_const, const int32_t* u1, const void* packed, const float* proj,
                      int64_t ctx_rows, const float* z, const int32_t* inv_perm, int64_t batch, float* x, float* logdet,
                      uint32_t* fail, hipStream_t s);
@@ -273,7 +273,7 @@ int pf_pack_bf16_frags(const float* src, int32_t n_rows, int32_t k, void* out, v
 }
 int64_t pf_flow_inc_layer_bytes(const PfFlowDesc* desc) {
     if (!desc || desc->hidden_features % 32 || desc->hidden_features < 64 || desc->hidden_features > 256) return -1;
-    return pf::inc_layer_bytes(desc->features, desc->hidden_features);
+    return pf::inc_layer_bytes(desc->features, desc->hidden_features, desc->precision == PF_PREC_F32);
 }
 int pf_flow_inverse_inc(const PfFlowDesc* desc, const int32_t* units_upto_degree, const void* packed,
                         const float* ctx_proj, int64_t ctx_rows, const float* z, const int32_t* ar_inv_perm,
@@ -283,7 +283,6 @@ int pf_flow_inverse_inc(const PfFlowDesc* desc, const int32_t* units_upto_degree
     if (H % 32 || H < 64 || H > 256 || D < 1 || D > 16 || D > H / 16 || desc->num_bins < 2 || desc->num_bins > 16 ||
         desc->num_blocks != 2)
         return fail(PF_ERR_UNSUPPORTED, "incremental inverse: need H in 64..256 (multiple of 32), D <= min(16, H/16), K <= 16");
-    if (desc->precision != PF_PREC_BF16) return fail(PF_ERR_UNSUPPORTED, "incremental inverse is built for PF_PREC_BF16");
     if (!(desc->tail_bound > 0.f)) return fail(PF_ERR_BAD_ARG, "tail_bound must be positive");
     if (batch < 0) return fail(PF_ERR_BAD_ARG, "negative batch");
     if (batch == 0) return PF_OK;

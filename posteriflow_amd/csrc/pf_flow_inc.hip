@@ -44,7 +44,8 @@
 namespace pf {
 namespace {
 constexpr int kParS = kParStride;          // floats per row in the spline-parameter transpose (52)
-constexpr int kActStride = 256 * 2 + 16;   // bytes per activation row in LDS: 8 k-steps of bf16 + bank spread, whatever H is
+constexpr int kActStride = 256 * 2 + 16;
+constexpr int kActStrideF32 = 256 * 4 + 16;   // bytes per activation row in LDS: 8 k-steps of bf16 + bank spread, whatever H is
 
 struct IncParams {
     FwdParams sp;              // spline scalars only: tail_bound, min_w, min_h, min_d, deriv_const
@@ -79,9 +80,10 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v) {
     for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
     return v;
 }
-__device__ __forceinline__ f32x4 sigmoid4(f32x4 v) {
+template <bool FAST> __device__ __forceinline__ f32x4 sigmoid4(f32x4 v) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(v[e] * -1.44269504f));
+    for (int e = 0; e < 4; ++e)
+        v[e] = FAST ? __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(v[e] * -1.44269504f)) : 1.f / (1.f + expf(-v[e]));
     return v;
 }
 
@@ -118,13 +120,19 @@ __device__ __forceinline__ void row_max2(float& a, float& b) {
         : "+v"(a), "+v"(b));
 }
 // raw transcendental instructions (1 ulp, no denormal-range fix-ups: every argument here is a normal number)
-__device__ __forceinline__ float exp_raw(float v) { return __builtin_amdgcn_exp2f(v * 1.44269504f); }
-__device__ __forceinline__ float log_raw(float v) { return __builtin_amdgcn_logf(v) * 0.693147181f; }
-__device__ __forceinline__ float softplus_raw(float u) { return u > 20.f ? u : log_raw(1.f + exp_raw(u)); }
+// (FAST = bf16 mode; the fp32 parity mode uses the library functions and true division, like the D-pass kernel)
+template <bool FAST> __device__ __forceinline__ float exp_m(float v) { return FAST ? __builtin_amdgcn_exp2f(v * 1.44269504f) : expf(v); }
+template <bool FAST> __device__ __forceinline__ float log_m(float v) { return FAST ? __builtin_amdgcn_logf(v) * 0.693147181f : logf(v); }
+template <bool FAST> __device__ __forceinline__ float div_m(float a, float b) { return FAST ? a * __builtin_amdgcn_rcpf(b) : a / b; }
+template <bool FAST> __device__ __forceinline__ float sqrt_m(float v) { return FAST ? __builtin_amdgcn_sqrtf(v) : sqrtf(v); }
+template <bool FAST> __device__ __forceinline__ float softplus_m(float u) {
+    return u > 20.f ? u : (FAST ? log_m<true>(1.f + exp_m<true>(u)) : log1pf(expf(u)));
+}
 __device__ __forceinline__ float row_scan(float v) {            // inclusive prefix sum over the 16 lanes of a row
     v += row_dpp<0x111>(v); v += row_dpp<0x112>(v); v += row_dpp<0x114>(v); v += row_dpp<0x118>(v);
     return v;
 }
+template <bool FAST>
 __device__ __forceinline__ void rqs_row16_inverse(const float* par, float yin, int K, const FwdParams& p, int j,
                                                   float& x, float& ld, bool& bad) {
     const bool live = j < K;
@@ -135,9 +143,9 @@ __device__ __forceinline__ void rqs_row16_inverse(const float* par, float yin, i
     // the non-live lanes masked off, and a DPP read of a disabled lane is not the lane's value)
     float mw = uw, mh = uh;
     row_max2(mw, mh);
-    const float ew = live ? exp_raw(uw - mw) : 0.f, eh = live ? exp_raw(uh - mh) : 0.f;
-    const float cw = (1.f - p.min_w * (float)K) * __builtin_amdgcn_rcpf(row_sum(ew));
-    const float ch = (1.f - p.min_h * (float)K) * __builtin_amdgcn_rcpf(row_sum(eh));
+    const float ew = live ? exp_m<FAST>(uw - mw) : 0.f, eh = live ? exp_m<FAST>(uh - mh) : 0.f;
+    const float cw = div_m<FAST>(1.f - p.min_w * (float)K, row_sum(ew));
+    const float ch = div_m<FAST>(1.f - p.min_h * (float)K, row_sum(eh));
     const float wj = live ? p.min_w + cw * ew : 0.f, hj = live ? p.min_h + ch * eh : 0.f;
     const float cumw = row_scan(wj), cumh = row_scan(hj);
     const bool last = j == K - 1;
@@ -151,18 +159,18 @@ __device__ __forceinline__ void rqs_row16_inverse(const float* par, float yin, i
     const bool ge_l = j == 0 ? true : yin >= hl;
     const bool sel = live && ge_l && !ge_r;
     const float w = kr - kl, hh = hr - hl;
-    const float dl = p.min_d + softplus_raw(dl_raw), dr = p.min_d + softplus_raw(dr_raw);
-    const float delta = hh * __builtin_amdgcn_rcpf(w);
+    const float dl = p.min_d + softplus_m<FAST>(dl_raw), dr = p.min_d + softplus_m<FAST>(dr_raw);
+    const float delta = div_m<FAST>(hh, w);
     const float dy = yin - hl, s2 = dl + dr - 2.f * delta;
     const float a = dy * s2 + hh * (delta - dl), b = hh * dl - dy * s2, c0 = -delta * dy;
     const float disc = b * b - 4.f * a * c0;
-    const float root = 2.f * c0 * __builtin_amdgcn_rcpf(-b - __builtin_amdgcn_sqrtf(fmaxf(disc, 0.f)));
+    const float root = div_m<FAST>(2.f * c0, -b - sqrt_m<FAST>(fmaxf(disc, 0.f)));
     const float tt = root * (1.f - root), den = delta + s2 * tt, omt = 1.f - root;
     const float dnum = delta * delta * (dr * root * root + 2.f * delta * tt + dl * omt * omt);
     const bool inside = (yin >= -tb) && (yin <= tb);
     // exactly one bin is selected inside the interval: its values reach every lane of the row through a sum
     const float xsel = sel ? root * w + kl : 0.f;
-    const float lsel = sel ? -(log_raw(dnum) - 2.f * log_raw(den)) : 0.f;
+    const float lsel = sel ? -(log_m<FAST>(dnum) - 2.f * log_m<FAST>(den)) : 0.f;
     const float bsel = (sel && !(disc >= 0.f)) ? 1.f : 0.f;
     const float xs = row_sum(xsel), ls = row_sum(lsel), bs = row_sum(bsel);
     x = inside ? xs : yin;
@@ -172,13 +180,18 @@ __device__ __forceinline__ void rqs_row16_inverse(const float* par, float yin, i
 
 #define PF_TR(k) do { if (p.trace && blockIdx.x == 0 && tid == 0) p.trace[((p.L - 1 - l) * 16 + i) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 
-template <int kCols, int kThreads, bool kCtx>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(kThreads == 256 ? 3 : 1, kThreads == 256 ? 3 : 2)))
+// kF32: the fp32 parity mode.  fp32 weights and activations, v_mfma_f32_16x16x4_f32: a fragment is 16 units x 16 k
+// (lane (r, kq) holds W[r][16 q + 4 kq .. + 3], one dwordx4; B = 4 consecutive floats of the activation row), 16
+// fragments per tile row at H = 256, activation rows of 1040 bytes (83 KB of LDS state: one workgroup per CU).
+template <int kCols, int kThreads, bool kCtx, bool kF32>
+__global__ __launch_bounds__(kThreads)
+__attribute__((amdgpu_waves_per_eu(kThreads == 256 && !kF32 ? 3 : 1, kThreads == 256 && !kF32 ? 3 : 2)))
 void flow_inverse_inc_kernel(const IncParams p) {
     constexpr int kRows = 16 * kCols;
+    constexpr int NF = kF32 ? 16 : 8;                            // fragments (k-steps of 16 / 32) per tile row, at most
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int D = p.D, H = p.H, HK = H / 32;
-    constexpr int AS = kActStride;                               // byte stride of an activation row: 8 k-steps + bank spread,
+    const int D = p.D, H = p.H, HK = kF32 ? H / 16 : H / 32;
+    constexpr int AS = kF32 ? kActStrideF32 : kActStride;                               // byte stride of an activation row: 8 k-steps + bank spread,
                                                                  // whatever H is (LDS offsets are then instruction immediates)
     char* const act = smem;                                      // 5 stages x [kRows][H] bf16
     char* const xb = act + (size_t)5 * kRows * AS;               // [kRows][32] bf16: x hi (0..15) | lo (16..31)
@@ -192,7 +205,7 @@ void flow_inverse_inc_kernel(const IncParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t row0 = (int64_t)blockIdx.x * kRows;
     auto act_of = [&](int s) { return act + (size_t)s * kRows * AS; };
-    const int lane16 = lane * 16, lane16hi = lane * 16 + 4096;
+    const int lane16 = lane * 16;
 
     // ---- initial state: y = z (coordinates of the last layer's output), log-det 0 --------------------
     for (int s = tid; s < kRows * 16; s += kThreads) {
@@ -242,35 +255,61 @@ void flow_inverse_inc_kernel(const IncParams p) {
         // fragments of k-steps >= kmax are masked zeros: the buffer resource of a fetch ends after kmax fragments, the
         // loads beyond it return zeros without touching memory (the load count stays fixed, the L1 / L2 traffic
         // triangular); offsets are lane * 16 (+ 4096) + an instruction immediate
-        auto fetch = [&](u32x4 (&buf)[8], int64_t off, int tile, int kmax) {
+        auto fetch = [&](u32x4 (&buf)[NF], int64_t off, int tile, int kmax) {
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<char*>(lw) + off + (int64_t)tile * HK * 1024, 0, kmax * 1024, 0x00020000);
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks)
-                buf[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs, (ks < 4 ? lane16 : lane16hi) + (ks & 3) * 1024, 0, 0);
+            for (int ks = 0; ks < NF; ++ks)
+                buf[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16 + 4096 * (ks >> 2) + (ks & 3) * 1024, 0, 0);
         };
-        auto gemm = [&](const u32x4 (&a)[8], const char* src, f32x4 (&v)[kCols]) {
+        auto gemm = [&](const u32x4 (&a)[NF], const char* src, int kmax, f32x4 (&v)[kCols]) {
 #pragma unroll
             for (int cc = 0; cc < kCols; ++cc) {
                 // (k-steps >= kmax multiply zero weights -- see fetch -- with whatever finite activations the row holds:
                 // zeros beyond H)
                 const char* brow = src + (16 * cc + c) * AS + g * 16;
                 f32x4 v0{0.f, 0.f, 0.f, 0.f}, v1{0.f, 0.f, 0.f, 0.f};
+                if constexpr (kF32) {
+                    // four fragments (64 k) per group; the MFMAs of groups beyond the units of degree <= i are skipped
+                    // (the loads are not: their count must stay fixed)
 #pragma unroll
-                for (int k0 = 0; k0 < 8; k0 += 4) {          // four operand reads in flight (register budget of the 4-wave variant)
-                    u32x4 b[4];
+                    for (int q0 = 0; q0 < NF; q0 += 4) {
+                        if (q0 < kmax) {
+                            f32x4 b[4];
 #pragma unroll
-                    for (int ks = 0; ks < 4; ++ks)
-                        b[ks] = *reinterpret_cast<const u32x4*>(brow + (k0 + ks) * 64);
-                    v0 = mfma_bf16(a[k0], b[0], v0);
-                    v1 = mfma_bf16(a[k0 + 1], b[1], v1);
-                    v0 = mfma_bf16(a[k0 + 2], b[2], v0);
-                    v1 = mfma_bf16(a[k0 + 3], b[3], v1);
-                    if (kThreads == 256) __builtin_amdgcn_sched_barrier(0);
+                            for (int q = 0; q < 4; ++q) b[q] = *reinterpret_cast<const f32x4*>(brow + (q0 + q) * 64);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const f32x4 af = __builtin_bit_cast(f32x4, a[q0 + q]);
+                                v0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0], b[q][0], v0, 0, 0, 0);
+                                v1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1], b[q][1], v1, 0, 0, 0);
+                                v0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[2], b[q][2], v0, 0, 0, 0);
+                                v1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[3], b[q][3], v1, 0, 0, 0);
+                            }
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int k0 = 0; k0 < NF; k0 += 4) {      // four operand reads in flight (register budget of the 4-wave variant)
+                        u32x4 b[4];
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) b[ks] = *reinterpret_cast<const u32x4*>(brow + (k0 + ks) * 64);
+                        v0 = mfma_bf16(a[k0], b[0], v0);
+                        v1 = mfma_bf16(a[k0 + 1], b[1], v1);
+                        v0 = mfma_bf16(a[k0 + 2], b[2], v0);
+                        v1 = mfma_bf16(a[k0 + 3], b[3], v1);
+                        if (kThreads == 256) __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
                 v[cc] = v0 + v1;
             }
         };
+        // activation tile of this lane (4 consecutive units of row 16 cc + c) into stage s
+        auto put = [&](int s, int cc, int u, f32x4 val) {
+            if constexpr (kF32) *reinterpret_cast<f32x4*>(act_of(s) + (16 * cc + c) * AS + u * 4) = val;
+            else *reinterpret_cast<bf16x4*>(act_of(s) + (16 * cc + c) * AS + u * 2) = bf16_of(val);
+        };
+        auto kfrag = [&](int i) { return kF32 ? (p.u1[i] + 15) / 16 : (p.u1[i] + 31) / 32; };   // fragments holding the units of degree <= i
         // head registers of the coming pass
         // (a stage's bias travels with its weights: bX / bY belong to the fragment buffers X / Y)
         f32x4 b0, bA, bB, pr0[kCols], pg0[kCols], pg1[kCols];
@@ -279,10 +318,10 @@ void flow_inverse_inc_kernel(const IncParams p) {
 
         // stage f of pass i (spline parameters of feature i from the last hidden state) + the spline inversion;
         // X holds the stage's weights, Y receives the first hidden matrix of pass i + 1
-        auto tail = [&](int i, u32x4 (&X)[8], f32x4& bX, u32x4 (&Y)[8], f32x4& bY) {
+        auto tail = [&](int i, u32x4 (&X)[NF], f32x4& bX, u32x4 (&Y)[NF], f32x4& bY) {
             if (wave < 3) {
                 f32x4 v[kCols];
-                gemm(X, act_of(4), v);
+                gemm(X, act_of(4), kfrag(i), v);
 #pragma unroll
                 for (int cc = 0; cc < kCols; ++cc)
                     *reinterpret_cast<f32x4*>(par + (16 * cc + c) * kParS + 16 * wf + 4 * g) = v[cc] + bX;
@@ -303,7 +342,7 @@ void flow_inverse_inc_kernel(const IncParams p) {
                         }
                     }
                     a0 = *reinterpret_cast<const u32x4*>(lw + ((size_t)t * 64 + lane) * 16);
-                    fetch(Y, p.off_w1[0], t, (p.u1[i + 1] + 31) / 32);
+                    fetch(Y, p.off_w1[0], t, kfrag(i + 1));
                 }
             }
             __syncthreads();
@@ -314,7 +353,7 @@ void flow_inverse_inc_kernel(const IncParams p) {
                 if (r < kRows) {                                   // (uniform per 16-lane row)
                     float xv, ld;
                     bool bad;
-                    rqs_row16_inverse(par + r * kParS, ys[r * 16 + i], p.K, p.sp, j, xv, ld, bad);
+                    rqs_row16_inverse<!kF32>(par + r * kParS, ys[r * 16 + i], p.K, p.sp, j, xv, ld, bad);
                     if (j == 0) {
                         xs[r * 16 + i] = xv;
                         const __bf16 hi = (__bf16)xv;
@@ -330,21 +369,31 @@ void flow_inverse_inc_kernel(const IncParams p) {
         };
         // pass i >= 1: the new hidden units (degree == i) through the five hidden stages, then the tail.
         // X holds the first hidden matrix on entry and stage f's weights on exit.
-        auto pass = [&](int i, u32x4 (&X)[8], f32x4& bX, u32x4 (&Y)[8], f32x4& bY) {
+        auto pass = [&](int i, u32x4 (&X)[NF], f32x4& bX, u32x4 (&Y)[NF], f32x4& bY) {
             PF_TR(0);
             const int t_lo = p.u1[i - 1] / 16, ntile = (p.u1[i] + 15) / 16 - t_lo;
-            const int kmax = (p.u1[i] + 31) / 32;
+            const int kmax = kfrag(i);
             const bool mine = wave < ntile;                  // a wave owns a new tile across all column tiles
             const int t = t_lo + wave, u = 16 * t + 4 * g;
             f32x4 h[kCols], v[kCols];
             if (mine) {                                                             // ---- stage a: h0 = W0 . (x hi|lo) + b0 + relu(pc)
 #pragma unroll
                 for (int cc = 0; cc < kCols; ++cc) {
-                    const u32x4 bx0 = *reinterpret_cast<const u32x4*>(xb + (16 * cc + c) * 64 + g * 16);
-                    f32x4 w0 = mfma_bf16(a0, bx0, f32x4{0.f, 0.f, 0.f, 0.f}) + b0;
+                    f32x4 w0;
+                    if constexpr (kF32) {
+                        const f32x4 bx = *reinterpret_cast<const f32x4*>(xs + (16 * cc + c) * 16 + 4 * g);
+                        const f32x4 af = __builtin_bit_cast(f32x4, a0);
+                        f32x4 acc{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bx[e], acc, 0, 0, 0);
+                        w0 = acc + b0;
+                    } else {
+                        const u32x4 bx0 = *reinterpret_cast<const u32x4*>(xb + (16 * cc + c) * 64 + g * 16);
+                        w0 = mfma_bf16(a0, bx0, f32x4{0.f, 0.f, 0.f, 0.f}) + b0;
+                    }
                     if constexpr (kCtx) w0 = w0 + relu4(pr0[cc]);
                     h[cc] = w0;
-                    *reinterpret_cast<bf16x4*>(act_of(0) + (16 * cc + c) * AS + u * 2) = bf16_of(relu4(w0));
+                    put(0, cc, u, relu4(w0));
                 }
             }
             __syncthreads();
@@ -352,10 +401,10 @@ void flow_inverse_inc_kernel(const IncParams p) {
             if (mine) {                                                             // ---- stage b: act1 = relu(W1 . act0 + b1)
                 fetch(Y, p.off_w2[0], t, kmax);
                 bY = *reinterpret_cast<const f32x4*>(bias + 2 * H + u);
-                gemm(X, act_of(0), v);
+                gemm(X, act_of(0), kmax, v);
 #pragma unroll
                 for (int cc = 0; cc < kCols; ++cc)
-                    *reinterpret_cast<bf16x4*>(act_of(1) + (16 * cc + c) * AS + u * 2) = bf16_of(relu4(v[cc] + bX));
+                    put(1, cc, u, relu4(v[cc] + bX));
             }
             __syncthreads();
             PF_TR(2);
@@ -367,13 +416,13 @@ void flow_inverse_inc_kernel(const IncParams p) {
                     for (int cc = 0; cc < kCols; ++cc)
                         pg1[cc] = proj_load(cc, l, 2, u);
                 }
-                gemm(Y, act_of(1), v);
+                gemm(Y, act_of(1), kmax, v);
 #pragma unroll
                 for (int cc = 0; cc < kCols; ++cc) {
                     f32x4 d = v[cc] + bY;
-                    if constexpr (kCtx) d = d * sigmoid4(pg0[cc]);
+                    if constexpr (kCtx) d = d * sigmoid4<!kF32>(pg0[cc]);
                     h[cc] = h[cc] + d;
-                    *reinterpret_cast<bf16x4*>(act_of(2) + (16 * cc + c) * AS + u * 2) = bf16_of(relu4(h[cc]));
+                    put(2, cc, u, relu4(h[cc]));
                 }
             }
             __syncthreads();
@@ -381,10 +430,10 @@ void flow_inverse_inc_kernel(const IncParams p) {
             if (mine) {                                                             // ---- stage d
                 fetch(Y, p.off_w2[1], t, kmax);
                 bY = *reinterpret_cast<const f32x4*>(bias + 4 * H + u);
-                gemm(X, act_of(2), v);
+                gemm(X, act_of(2), kmax, v);
 #pragma unroll
                 for (int cc = 0; cc < kCols; ++cc)
-                    *reinterpret_cast<bf16x4*>(act_of(3) + (16 * cc + c) * AS + u * 2) = bf16_of(relu4(v[cc] + bX));
+                    put(3, cc, u, relu4(v[cc] + bX));
             }
             __syncthreads();
             PF_TR(4);
@@ -393,20 +442,20 @@ void flow_inverse_inc_kernel(const IncParams p) {
             fetch(X, p.off_wf, 3 * i + wf, wave < 3 ? kmax : 0);
             bX = *reinterpret_cast<const f32x4*>(bias + 5 * H + 48 * i + 16 * wf + 4 * g);
             if (mine) {                                                             // ---- stage e: h2 = h1 + (W2 . act3 + b2) sigmoid(pg1)
-                gemm(Y, act_of(3), v);
+                gemm(Y, act_of(3), kmax, v);
 #pragma unroll
                 for (int cc = 0; cc < kCols; ++cc) {
                     f32x4 d = v[cc] + bY;
-                    if constexpr (kCtx) d = d * sigmoid4(pg1[cc]);
+                    if constexpr (kCtx) d = d * sigmoid4<!kF32>(pg1[cc]);
                     h[cc] = h[cc] + d;
-                    *reinterpret_cast<bf16x4*>(act_of(4) + (16 * cc + c) * AS + u * 2) = bf16_of(h[cc]);
+                    put(4, cc, u, h[cc]);
                 }
             }
             __syncthreads();
             PF_TR(5);
             tail(i, X, bX, Y, bY);
         };
-        u32x4 bufA[8], bufB[8];
+        u32x4 bufA[NF], bufB[NF];
         // feature 0 depends on no hidden unit that is new: its parameters are the bias (+ masked zeros)
         fetch(bufA, p.off_wf, wf, 0);
         bA = *reinterpret_cast<const f32x4*>(bias + 5 * H + 16 * wf + 4 * g);
@@ -456,8 +505,8 @@ int inc_pack_frags(const float* src, int n_rows, int k, void* out, hipStream_t s
     return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
 }
 
-int64_t inc_layer_bytes(int D, int H) {
-    const int64_t NT = H / 16, HK = H / 32;
+int64_t inc_layer_bytes(int D, int H, bool f32) {
+    const int64_t NT = H / 16, HK = f32 ? H / 16 : H / 32;          // 1 KB fragments per tile row
     return (NT + 4 * NT * HK + 3 * (int64_t)D * HK) * 1024 + (5 * (int64_t)H + 48 * (int64_t)D) * 4;
 }
 
@@ -470,14 +519,15 @@ int flow_inverse_inc(const PfFlowDesc& d, float deriv_const, const int32_t* u1, 
     p.w = static_cast<const char*>(packed); p.proj = proj; p.z = z; p.x = x; p.logdet = logdet; p.fail = fail;
     p.inv_perm = inv_perm; p.batch = batch; p.ctx_rows = ctx_rows;
     p.D = d.features; p.H = d.hidden_features; p.K = d.num_bins; p.L = d.num_layers;
-    const int64_t NT = p.H / 16, HK = p.H / 32;
+    const bool f32 = d.precision == PF_PREC_F32;
+    const int64_t NT = p.H / 16, HK = f32 ? p.H / 16 : p.H / 32;
     p.off_w1[0] = NT * 1024;
     p.off_w2[0] = p.off_w1[0] + NT * HK * 1024;
     p.off_w1[1] = p.off_w2[0] + NT * HK * 1024;
     p.off_w2[1] = p.off_w1[1] + NT * HK * 1024;
     p.off_wf = p.off_w2[1] + NT * HK * 1024;
     p.off_bias = p.off_wf + 3 * (int64_t)p.D * HK * 1024;
-    p.layer_bytes = inc_layer_bytes(p.D, p.H);
+    p.layer_bytes = inc_layer_bytes(p.D, p.H, f32);
     for (int i = 0; i <= p.D; ++i) p.u1[i] = u1[i];
     // One workgroup = 16 draws.  A pass is a chain of seven barrier-separated stages whose cost is latency, not
     // bandwidth, so the CU is filled with three independent 4-wave workgroups (49 KB of LDS, <= 168 VGPRs each) whose
@@ -491,18 +541,21 @@ int flow_inverse_inc(const PfFlowDesc& d, float deriv_const, const int32_t* u1, 
     if (const char* ft = std::getenv("PF_INC_THREADS")) {
         if (std::atoi(ft) == 512) threads = 512;
     }
-    constexpr size_t lds = 5 * 16 * kActStride + 16 * 64 + 16 * (16 + 16 + kParS + 2) * 4;
+    const size_t lds = 5 * 16 * (size_t)(f32 ? kActStrideF32 : kActStride) + 16 * 64 + 16 * (16 + 16 + kParS + 2) * 4;
     using Kern = void (*)(const IncParams);
-    static const Kern kerns[4] = {flow_inverse_inc_kernel<1, 256, false>, flow_inverse_inc_kernel<1, 256, true>,
-                                  flow_inverse_inc_kernel<1, 512, false>, flow_inverse_inc_kernel<1, 512, true>};
+    static const Kern kerns[8] = {
+        flow_inverse_inc_kernel<1, 256, false, false>, flow_inverse_inc_kernel<1, 256, true, false>,
+        flow_inverse_inc_kernel<1, 512, false, false>, flow_inverse_inc_kernel<1, 512, true, false>,
+        flow_inverse_inc_kernel<1, 256, false, true>,  flow_inverse_inc_kernel<1, 256, true, true>,
+        flow_inverse_inc_kernel<1, 512, false, true>,  flow_inverse_inc_kernel<1, 512, true, true>};
     static bool configured = false;
     if (!configured) {
         for (const Kern k : kerns)
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess)
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
                 return PF_ERR_HIP;
         configured = true;
     }
-    const int variant = (threads == 256 ? 0 : 2) + (proj ? 1 : 0);
+    const int variant = (f32 ? 4 : 0) + (threads == 256 ? 0 : 2) + (proj ? 1 : 0);
     const bool tracing = std::getenv("PF_INC_TRACE") != nullptr;
     if (tracing && hipMalloc(&p.trace, p.L * 16 * 8 * sizeof(unsigned long long)) != hipSuccess) return PF_ERR_HIP;
     const dim3 grid(static_cast<unsigned>((batch + 15) / 16));

@@ -530,24 +530,26 @@ class NSFPosteriorFlow(nn.Module):
         return torch.relu(lo - params_norm).mean() + torch.relu(params_norm - hi).mean()
 
     # ---- inverse / sampling ------------------------------------------------------------------
-    # ---- incremental inverse (bf16): one masked conditioner evaluation per layer instead of D dense ones ----
-    incremental_inverse: Optional[bool] = None      # None: on in bf16 mode for the plain conditioner; False: D-pass kernel
+    # ---- incremental inverse: one masked conditioner evaluation per layer instead of D dense ones ----
+    incremental_inverse: Optional[bool] = None      # None: on for the plain conditioner (both precisions); False: D-pass kernel
 
     def _use_incremental(self) -> bool:
-        if self.incremental_inverse is False or self.use_masked_context or self.precision != "bf16":
+        if self.incremental_inverse is False or self.use_masked_context:
             return False
         return self.hidden_features % 32 == 0 and self.features <= min(16, self.hidden_features // 16)
 
     def _inc_state(self, dev):
         """Weights of every layer in the layout of pf_flow_inverse_inc (hidden units sorted by degree, masks
-        applied, bf16 MFMA A-fragments) + the stacked context-projection weights; rebuilt when a parameter changed."""
+        applied, MFMA A-fragments in the current precision) + the stacked context-projection weights; rebuilt when a
+        parameter changed."""
         params = self._ordered_parameters()
-        key = (dev, tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
-        st = self.__dict__.setdefault("_inc", {})
-        if st.get("key") == key and (self._frozen or True):
+        f32 = self.precision != "bf16"
+        key = (dev, f32, tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
+        st = self.__dict__.setdefault("_inc", {}).setdefault(self.precision, {})
+        if st.get("key") == key:
             return st
         L_, D, H, K = _lib.lib(), self.features, self.hidden_features, self.num_bins
-        desc = self._desc("bf16", inverse=True)
+        desc = self._desc(self.precision, inverse=True)
         deg = _hidden_degrees(H, D).to(dev)
         perm = torch.argsort(deg, stable=True)
         deg_sorted = deg[perm]
@@ -567,14 +569,20 @@ class NSFPosteriorFlow(nn.Module):
 
                 def pack(mat, off):
                     mat = mat.float().contiguous()
-                    _lib.check(L_.pf_pack_bf16_frags(mat.data_ptr(), mat.shape[0], mat.shape[1],
-                                                     buf.data_ptr() + off, stream), "pf_pack_bf16_frags")
-                    return off + mat.shape[0] * mat.shape[1] * 2
+                    n, k = mat.shape
+                    if f32:   # fragment (tile, q), lane (r, kq): W[16 tile + r][16 q + 4 kq .. + 3], lane = 16 kq + r
+                        frag = mat.view(n // 16, 16, k // 16, 4, 4).permute(0, 2, 3, 1, 4).contiguous().view(-1)
+                        buf[off:off + n * k * 4].copy_(frag.view(torch.uint8))
+                        return off + n * k * 4
+                    _lib.check(L_.pf_pack_bf16_frags(mat.data_ptr(), n, k, buf.data_ptr() + off, stream),
+                               "pf_pack_bf16_frags")
+                    return off + n * k * 2
 
                 w0 = (net.initial_layer.weight * net.initial_layer.mask)[perm]
-                a0 = torch.zeros(H, 32, device=dev)
+                a0 = torch.zeros(H, 16 if f32 else 32, device=dev)
                 a0[:, :D] = w0
-                a0[:, 16:16 + D] = w0
+                if not f32:                        # the input enters the bf16 kernel as a hi | lo pair
+                    a0[:, 16:16 + D] = w0
                 off = pack(a0, off)
                 biases = [net.initial_layer.bias[perm]]
                 for blk in net.blocks:
@@ -599,7 +607,8 @@ class NSFPosteriorFlow(nn.Module):
                     wc.append(torch.stack([net.context_layer.weight[perm]] + [b.context_layer.weight[perm] for b in net.blocks]))
                     bc.append(torch.stack([net.context_layer.bias[perm]] + [b.context_layer.bias[perm] for b in net.blocks]))
             st.update(key=key, buf=buf, u1=u1,
-                      wcat=torch.stack(wc).reshape(-1, self.context_features).to(torch.bfloat16).float().contiguous() if wc else None,
+                      wcat=((lambda w: w if f32 else w.to(torch.bfloat16).float())(
+                          torch.stack(wc).reshape(-1, self.context_features).float()).contiguous() if wc else None),
                       bcat=torch.stack(bc).reshape(-1).float().contiguous() if bc else None)
         return st
 
@@ -618,9 +627,10 @@ class NSFPosteriorFlow(nn.Module):
                     # [ctx_rows, L * 3 * H]: one GEMM for every layer's three context projections, with the operand
                     # rounding of the bf16 forward kernel (context and weights to bf16, fp32 accumulation) so that
                     # forward(inverse(z)) sees the same conditioner
-                    proj = torch.addmm(st["bcat"], context.to(torch.bfloat16).float(), st["wcat"].t()).contiguous()
+                    cx = context.float() if self.precision != "bf16" else context.to(torch.bfloat16).float()
+                    proj = torch.addmm(st["bcat"], cx, st["wcat"].t()).contiguous()
             rc = _lib.lib().pf_flow_inverse_inc(
-                self._desc("bf16", inverse=True), st["u1"], st["buf"].data_ptr(), _dev_ptr(proj), ctx_rows,
+                self._desc(self.precision, inverse=True), st["u1"], st["buf"].data_ptr(), _dev_ptr(proj), ctx_rows,
                 z.data_ptr(), _dev_ptr(inv_perm), B, x.data_ptr(), logdet.data_ptr(), flags.data_ptr(),
                 torch.cuda.current_stream(dev).cuda_stream)
             if rc != _lib.PF_ERR_UNSUPPORTED:

@@ -3,8 +3,11 @@ autoregressive inverse, plus the size-independent round-trip property.
 
 Tolerances: fp32 mode -- |x - x_oracle64| within 4x the CPU fp32 path's own error against
 fp64 (floor 5e-5: the inverse of a contracting map amplifies rounding), inverse log-det
-likewise; round trip forward(inverse(z)) == z to 2e-4 and logdet_fwd + logdet_inv == 0 to
-2e-3 on well-conditioned weights.  bf16 mode -- round trip within 0.1 (statistical)."""
+likewise; round trip forward(inverse(z)) == z to 5e-4 and logdet_fwd + logdet_inv == 0 to
+2e-3 on well-conditioned weights (the incremental inverse sums in a different order than the
+forward kernel, so their rounding no longer cancels in the round trip: 1.9e-4 at the 99th
+percentile against 1.0e-4 for the D-pass kernel, while against the fp64 oracle it is the closer
+of the two -- test_incremental_fp32_is_as_close_to_the_oracle_as_the_d_pass_kernel).  bf16 mode -- round trip within 0.1 (statistical)."""
 import pytest
 import torch
 
@@ -47,7 +50,29 @@ def test_inverse_fp32_parity(name, hoist):
     assert (xw.cpu().double() - x64.clamp(-3.0, 3.0)).abs().max() < max(4 * ex_ref, 5e-5)
 
 
-@pytest.mark.parametrize("precision,tol_x,tol_ld", [("fp32", 2e-4, 2e-3), ("bf16", 0.1, 1.0)])
+def test_incremental_fp32_is_as_close_to_the_oracle_as_the_d_pass_kernel():
+    # BASELINE config 3 flow; both fp32 kernels against the fp64 oracle on the same draws
+    D, C, H, L, K, tb, B = 15, 288, 256, 8, 16, 5.0, 128
+    _, ref64, flow = make_pair(D, C, H, L, K, tb)
+    g = torch.Generator().manual_seed(5)
+    z = torch.randn(B, D, generator=g) * 1.2
+    ctx = torch.randn(B, C, generator=g)
+    err = {}
+    with torch.no_grad():
+        x64, ld64 = ref64.inverse_raw(z.double(), ctx.double())
+        for name, inc in (("inc", None), ("dpass", False)):
+            flow.incremental_inverse = inc
+            x, ld, flags = flow._inverse_call(z.cuda(), ctx.cuda(), B)
+            assert int(flags.sum()) == 0
+            ex, el = (x.cpu().double() - x64).abs().flatten(), (ld.cpu().double() - ld64).abs()
+            err[name] = (ex.median().item(), ex.quantile(0.99).item(), el.median().item(), el.max().item())
+            print(f"\n[{name}] |x-x64| median {err[name][0]:.2e} q99 {err[name][1]:.2e}  |ld-ld64| median {err[name][2]:.2e} max {err[name][3]:.2e}")
+    for a, b in zip(err["inc"], err["dpass"]):
+        assert a < 2.0 * b + 1e-6
+    assert err["inc"][0] < 5e-6 and err["inc"][2] < 2e-4
+
+
+@pytest.mark.parametrize("precision,tol_x,tol_ld", [("fp32", 5e-4, 2e-3), ("bf16", 0.1, 1.0)])
 def test_round_trip_full_size(precision, tol_x, tol_ld):
     # BASELINE-sized batch, property only (the CPU oracle would need minutes for the D-pass inverse)
     D, C = 15, 288
@@ -82,6 +107,16 @@ def test_grouped_and_expanded_context_and_order():
         a, ald = flow.inverse(z.cuda(), rep.cuda())                       # one context row per sample
         b, bld = flow.inverse(z.cuda(), ctx.cuda())                       # 4 rows grouped over 128 samples
         c1, _ = flow.inverse(z[:32].cuda(), ctx[:1].cuda().expand(32, -1))  # stride-0 expand, pipeline.py:171
+    assert torch.allclose(a.cpu(), want, atol=1e-4) and torch.allclose(ald.cpu(), wld, atol=1e-3)
+    # incremental kernel: the projections of 4, of 128 and of 1 context rows come from differently tiled fp32 GEMMs
+    assert (a - b).abs().max() < 1e-4 and (ald - bld).abs().max() < 1e-3
+    assert (c1 - a[:32]).abs().max() < 1e-4
+    # D-pass kernel (context handled inside the kernel): bit-identical
+    flow.incremental_inverse = False
+    with torch.no_grad():
+        a, ald = flow.inverse(z.cuda(), rep.cuda())
+        b, bld = flow.inverse(z.cuda(), ctx.cuda())
+        c1, _ = flow.inverse(z[:32].cuda(), ctx[:1].cuda().expand(32, -1))
     assert torch.allclose(a.cpu(), want, atol=1e-4) and torch.allclose(ald.cpu(), wld, atol=1e-3)
     assert torch.equal(a, b) and torch.equal(ald, bld)
     assert torch.equal(c1, a[:32])
@@ -151,14 +186,15 @@ INC_CONFIGS = {
 }
 
 
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
 @pytest.mark.parametrize("name", list(INC_CONFIGS))
-def test_incremental_inverse_matches_dpass_and_oracle(name):
+def test_incremental_inverse_matches_dpass_and_oracle(name, precision):
     """pf_flow_inverse_inc (one masked conditioner evaluation per layer) against pf_flow_inverse (D dense passes
-    per layer, the nflows algorithm) in the same bf16 arithmetic, and both against the fp64 oracle: the two
-    kernels differ by bf16 rounding-boundary noise only, and the incremental one is no further from the oracle."""
+    per layer, the nflows algorithm) in the same arithmetic (bf16 operands or fp32), and both against the fp64
+    oracle: the two kernels differ by rounding noise only, and the incremental one is no further from the oracle."""
     D, C, H, L, K, tb, B = INC_CONFIGS[name]
     ref, ref64, flow = make_pair(D, C, H, L, K, tb)
-    flow.precision = "bf16"
+    flow.precision = precision
     order = list(range(D))
     import random
     random.Random(3).shuffle(order)
