@@ -133,6 +133,11 @@ def extras(flow, dev, batch):
             z = torch.randn(n, D, device=dev)
             dt = timed(lambda: flow.inverse(z, ctx1), 5 if n <= 4096 else 2)
             out[f"inverse_draws_per_s_{n}"] = n / dt
+        if flow.precision == "bf16":           # the same draws in the fp32 parity mode (fp32 incremental inverse)
+            prec, flow.precision = flow.precision, "fp32"
+            dt = timed(lambda: flow.inverse(z, ctx1), 2)
+            out["inverse_draws_per_s_fp32_131072"] = z.shape[0] / dt
+            flow.precision = prec
         enc = npe.LeanStrainEncoder().to(dev).eval()
         enc.precision = flow.precision
         strain = torch.randn(batch, 3, 16384, device=dev)

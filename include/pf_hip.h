@@ -149,7 +149,7 @@ int pf_flow_inverse(const PfFlowDesc* desc, const void* packed,
                     float* x, float* logdet, uint32_t* fail_flags,
                     void* workspace, int64_t workspace_bytes, void* stream);
 
-/* ---- incremental inverse (bf16) -----------------------------------------------------------------
+/* ---- incremental inverse -------------------------------------------------------------------------
  * Same result as pf_flow_inverse (the transform.inverse call of flows.py:637), with ONE masked conditioner
  * evaluation per layer instead of D dense ones: pass i computes only the hidden units of degree i (2-3 tiles per
  * hidden stage, hidden units sorted by degree) from the activations of the earlier passes, which stay in LDS.
@@ -164,6 +164,9 @@ int pf_flow_inverse(const PfFlowDesc* desc, const void* packed,
  *   ctx_proj [ctx_rows][L][3][H] fp32 = context_layer / block-0 / block-1 context projections (with their
  *   biases, before ReLU / sigmoid), sorted-unit order, or NULL for a context-free flow;
  *   units_upto_degree (host int32[D + 1]): number of hidden units with degree <= i.
+ * PF_PREC_F32 (parity mode, v_mfma_f32_16x16x4_f32): the same blocks with fp32 fragments of 16 units x 16 k --
+ *   fragment (tile, q), lane (r = lane & 15, kq = lane >> 4): W[16 tile + r][16 q + 4 kq .. + 3] -- , W0 [H][16]
+ *   (column f = initial_layer.weight[:, f]); the caller packs them (a reshape / permute, posteriflow_amd/flows.py).
  * z, x, logdet, fail_flags, ar_inv_perm, ctx_rows as in pf_flow_inverse. */
 int pf_pack_bf16_frags(const float* src, int32_t n_rows, int32_t k, void* out, void* stream);
 int64_t pf_flow_inc_layer_bytes(const PfFlowDesc* desc);
