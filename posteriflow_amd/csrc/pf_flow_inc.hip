@@ -44,8 +44,13 @@
 namespace pf {
 namespace {
 constexpr int kParS = kParStride;          // floats per row in the spline-parameter transpose (52)
-constexpr int kActStride = 256 * 2 + 16;
-constexpr int kActStrideF32 = 256 * 4 + 16;   // bytes per activation row in LDS: 8 k-steps of bf16 + bank spread, whatever H is
+// Bytes per activation row in LDS: 256 units whatever H is (LDS offsets are then instruction immediates).  Inside a row
+// the 16-byte chunk q sits at chunk (q & ~15) | ((q ^ row) & 15): a ds_read_b128 serves lanes {0-3, 12-15, 20-27}, ... in
+// one pass -- every row 0..15 once, with g = lane >> 4 in {0, 1} or {2, 3} -- and this XOR sends those 16 lanes to
+// the 16 different 16-byte slots of the 256-byte bank window (rows padded by 16 bytes collide on one slot per pass:
+// 45 % of the LDS cycles of the padded version were bank conflicts, profiles/r01_inc_pmc.txt).
+constexpr int kActStride = 256 * 2;
+constexpr int kActStrideF32 = 256 * 4;
 
 struct IncParams {
     FwdParams sp;              // spline scalars only: tail_bound, min_w, min_h, min_d, deriv_const
@@ -191,8 +196,7 @@ void flow_inverse_inc_kernel(const IncParams p) {
     constexpr int NF = kF32 ? 16 : 8;                            // fragments (k-steps of 16 / 32) per tile row, at most
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int D = p.D, H = p.H, HK = kF32 ? H / 16 : H / 32;
-    constexpr int AS = kF32 ? kActStrideF32 : kActStride;                               // byte stride of an activation row: 8 k-steps + bank spread,
-                                                                 // whatever H is (LDS offsets are then instruction immediates)
+    constexpr int AS = kF32 ? kActStrideF32 : kActStride;
     char* const act = smem;                                      // 5 stages x [kRows][H] bf16
     char* const xb = act + (size_t)5 * kRows * AS;               // [kRows][32] bf16: x hi (0..15) | lo (16..31)
     float* const xs = reinterpret_cast<float*>(xb + kRows * 64); // [kRows][16] current layer's input, fp32
@@ -206,6 +210,10 @@ void flow_inverse_inc_kernel(const IncParams p) {
     const int64_t row0 = (int64_t)blockIdx.x * kRows;
     auto act_of = [&](int s) { return act + (size_t)s * kRows * AS; };
     const int lane16 = lane * 16;
+    // B-operand read of k-step ks (chunk 4 ks + g of row c): swz[ks & 3] + (ks >> 2) * 256 -- see kActStride
+    int swz[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) swz[j] = c * AS + (((c ^ g) << 4) ^ (j << 6));
 
     // ---- initial state: y = z (coordinates of the last layer's output), log-det 0 --------------------
     for (int s = tid; s < kRows * 16; s += kThreads) {
@@ -267,7 +275,7 @@ void flow_inverse_inc_kernel(const IncParams p) {
             for (int cc = 0; cc < kCols; ++cc) {
                 // (k-steps >= kmax multiply zero weights -- see fetch -- with whatever finite activations the row holds:
                 // zeros beyond H)
-                const char* brow = src + (16 * cc + c) * AS + g * 16;
+                const char* brow = src + 16 * cc * AS;
                 f32x4 v0{0.f, 0.f, 0.f, 0.f}, v1{0.f, 0.f, 0.f, 0.f};
                 if constexpr (kF32) {
                     // four fragments (64 k) per group; the MFMAs of groups beyond the units of degree <= i are skipped
@@ -277,7 +285,7 @@ void flow_inverse_inc_kernel(const IncParams p) {
                         if (q0 < kmax) {
                             f32x4 b[4];
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) b[q] = *reinterpret_cast<const f32x4*>(brow + (q0 + q) * 64);
+                            for (int q = 0; q < 4; ++q) b[q] = *reinterpret_cast<const f32x4*>(brow + swz[q] + (q0 >> 2) * 256);
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
                                 const f32x4 af = __builtin_bit_cast(f32x4, a[q0 + q]);
@@ -293,7 +301,7 @@ void flow_inverse_inc_kernel(const IncParams p) {
                     for (int k0 = 0; k0 < NF; k0 += 4) {      // four operand reads in flight (register budget of the 4-wave variant)
                         u32x4 b[4];
 #pragma unroll
-                        for (int ks = 0; ks < 4; ++ks) b[ks] = *reinterpret_cast<const u32x4*>(brow + (k0 + ks) * 64);
+                        for (int ks = 0; ks < 4; ++ks) b[ks] = *reinterpret_cast<const u32x4*>(brow + swz[ks] + (k0 >> 2) * 256);
                         v0 = mfma_bf16(a[k0], b[0], v0);
                         v1 = mfma_bf16(a[k0 + 1], b[1], v1);
                         v0 = mfma_bf16(a[k0 + 2], b[2], v0);
@@ -306,8 +314,14 @@ void flow_inverse_inc_kernel(const IncParams p) {
         };
         // activation tile of this lane (4 consecutive units of row 16 cc + c) into stage s
         auto put = [&](int s, int cc, int u, f32x4 val) {
-            if constexpr (kF32) *reinterpret_cast<f32x4*>(act_of(s) + (16 * cc + c) * AS + u * 4) = val;
-            else *reinterpret_cast<bf16x4*>(act_of(s) + (16 * cc + c) * AS + u * 2) = bf16_of(val);
+            char* row = act_of(s) + (16 * cc + c) * AS;
+            if constexpr (kF32) {
+                const int q = u >> 2;                                               // 16-byte chunk of units u .. u + 3
+                *reinterpret_cast<f32x4*>(row + (((q ^ c) & 15) << 4) + (q >> 4) * 256) = val;
+            } else {
+                const int q = u >> 3;                                               // 8 units per chunk
+                *reinterpret_cast<bf16x4*>(row + (((q ^ c) & 15) << 4) + (q >> 4) * 256 + (u & 4) * 2) = bf16_of(val);
+            }
         };
         auto kfrag = [&](int i) { return kF32 ? (p.u1[i] + 15) / 16 : (p.u1[i] + 31) / 32; };   // fragments holding the units of degree <= i
         // head registers of the coming pass
