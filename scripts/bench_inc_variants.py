@@ -1,5 +1,5 @@
 """Incremental-inverse variants: draws/s of pf_flow_inverse_inc at several batch sizes (config 3 flow, D = 15, L = 8,
-one context row).  Variants are chosen through $PF_INC_COLS / $PF_INC_THREADS by the caller."""
+one context row).  $PF_INC_THREADS=512 selects the 8-wave variant."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
@@ -15,4 +15,4 @@ for n in [int(a) for a in sys.argv[1:]] or [4096, 12288, 32768, 131072]:
         for _ in range(5): flow.inverse(z, ctx1)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
     out.append(f"{n}: {dt*1e3:.3f} ms {n/dt/1e6:.2f} M/s")
-print(os.environ.get("PF_INC_COLS"), os.environ.get("PF_INC_THREADS"), " | ".join(out))
+print("threads", os.environ.get("PF_INC_THREADS", "256"), "|", " | ".join(out))
