@@ -97,10 +97,17 @@ def cpu_baseline(flow, batch, budget_s=15.0):
             times.append(time.perf_counter() - t0)
             if len(times) % 10 == 1:
                 log(f"cpu baseline iter {len(times)}: {times[-1] * 1e3:.1f} ms")
+        # the sampling direction as the reference executes it (D conditioner passes per layer), one chunk of 4096 draws
+        # for one context row (pipeline.py:169-173): ~2-3 s of host work, reported beside the GPU's draws/s
+        z = torch.randn(4096, D, generator=torch.Generator().manual_seed(3))
+        t0 = time.perf_counter()
+        ref.inverse(z, ctx[:1].expand(4096, -1))
+        inv_s = time.perf_counter() - t0
+    log(f"cpu baseline inverse: 4096 draws in {inv_s:.2f} s")
     med = statistics.median(times)
     return {"value": batch / med, "unit": "samples/s", "cores": cores, "kind": "port",
             "sample": f"batch {batch}, fp32, {len(times)} iterations (~{budget_s:.0f} s of host work) after 3 warm-ups, median",
-            "ms_per_batch": med * 1e3}
+            "ms_per_batch": med * 1e3, "inverse_draws_per_s": 4096 / inv_s}
 
 
 def extras(flow, dev, batch):
