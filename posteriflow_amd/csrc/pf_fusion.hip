@@ -224,13 +224,16 @@ __global__ __launch_bounds__(512) void fusion_kernel(FusionParams p) {
         for (int i = 0; i < 3; ++i) a[0][i] = afrag(wbase, ft0 + i, ksteps, ks0);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            bf16x8 b[NT];
-#pragma unroll
-            for (int j = 0; j < NT; ++j) b[j] = bload(t0 + j, ks);
             if (ks + 1 < KS) {
 #pragma unroll
                 for (int i = 0; i < 3; ++i) a[(ks + 1) & 1][i] = afrag(wbase, ft0 + i, ksteps, ks0 + ks + 1);
             }
+            // keep the next k-step's weight loads ahead of this k-step's MFMAs: under register pressure the scheduler
+            // sinks them to ~6 MFMAs before their use and every k-step then waits out an L2 round trip
+            __builtin_amdgcn_sched_barrier(0);
+            bf16x8 b[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) b[j] = bload(t0 + j, ks);
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -321,13 +324,14 @@ __global__ __launch_bounds__(512) void fusion_kernel(FusionParams p) {
                     for (int i = 0; i < 3; ++i) a[0][i] = afrag(lw + kWqkv, tile[i], 6, 0);
 #pragma unroll
                     for (int ks = 0; ks < 6; ++ks) {
-                        bf16x8 b[3];
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) b[j] = bx(xn, 3 * tb4 + j, ks);
                         if (ks + 1 < 6) {
 #pragma unroll
                             for (int i = 0; i < 3; ++i) a[(ks + 1) & 1][i] = afrag(lw + kWqkv, tile[i], 6, ks + 1);
                         }
+                        __builtin_amdgcn_sched_barrier(0);          // (see dense)
+                        bf16x8 b[3];
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) b[j] = bx(xn, 3 * tb4 + j, ks);
 #pragma unroll
                         for (int i = 0; i < 3; ++i)
 #pragma unroll
