@@ -34,13 +34,13 @@ def log_prob_physical(model: LeanNPE, y_norm: torch.Tensor, full_ctx: torch.Tens
 @torch.no_grad()
 def sample_event(model: LeanNPE, strain: torch.Tensor, num_samples: int = 10000, rank: int = 0,
                  asd_bands: Optional[torch.Tensor] = None, seed: Optional[int] = None,
-                 batch_size: int = 32768) -> Dict[str, torch.Tensor]:
+                 batch_size: int = 98304) -> Dict[str, torch.Tensor]:
     """Posterior draws for ONE event (strain [1, n_det, 16384]), pipeline.py:161-186.
     Returns device tensors: samples [n, P] (physical units, fp64, m1 >= m2), logq [n] (fp64),
     railed [n] (bool, a non-circular parameter within 1e-3 of its bound), context [1, C].
     ``batch_size``: draws per inverse call; the reference chunks by 4096 for memory (pipeline.py:105,169), here
-    the default is 32 768 = 256 CUs x 4 full rounds of 32-row workgroups (a chunk that ends in a nearly empty
-    round of workgroups wastes that round: 25 000 draws cost as much as 32 768)."""
+    the default is 98 304 = 8 full rounds of 256 CUs x 3 sixteen-draw workgroups (a chunk that ends in a nearly
+    empty round of workgroups wastes that round: 12 289 draws cost as much as 24 576)."""
     dev = strain.device
     gen = None
     if seed is not None:
