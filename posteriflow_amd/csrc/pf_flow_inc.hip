@@ -187,7 +187,7 @@ __device__ __forceinline__ void rqs_row16_inverse(const float* par, float yin, i
 
 // kF32: the fp32 parity mode.  fp32 weights and activations, v_mfma_f32_16x16x4_f32: a fragment is 16 units x 16 k
 // (lane (r, kq) holds W[r][16 q + 4 kq .. + 3], one dwordx4; B = 4 consecutive floats of the activation row), 16
-// fragments per tile row at H = 256, activation rows of 1040 bytes (83 KB of LDS state: one workgroup per CU).
+// fragments per tile row at H = 256, activation rows of 1024 bytes (80 KB of LDS state: one workgroup per CU).
 template <int kCols, int kThreads, bool kCtx, bool kF32>
 __global__ __launch_bounds__(kThreads)
 __attribute__((amdgpu_waves_per_eu(kThreads == 256 && !kF32 ? 3 : 1, kThreads == 256 && !kF32 ? 3 : 2)))
@@ -256,13 +256,12 @@ void flow_inverse_inc_kernel(const IncParams p) {
         // used, in straight-line code with a FIXED number of loads per stage, so that the compiler can wait for exactly
         // the fragments a stage needs while the next stage's are in flight (with a load count that depends on a branch
         // it drains everything before each MFMA chain; a k-step under a branch puts an LDS round trip between
-        // consecutive MFMAs).  The reduction always runs over 8 k-steps; those beyond the units of degree <= i have
-        // masked-zero weights (never fetched, see fetch).  Two fragment
-        // buffers X / Y alternate; the head of pass i + 1 (biases, context projections, W0 and the first hidden
-        // matrix) is requested while pass i computes its spline parameters, so the buffers swap roles every pass.
-        // fragments of k-steps >= kmax are masked zeros: the buffer resource of a fetch ends after kmax fragments, the
-        // loads beyond it return zeros without touching memory (the load count stays fixed, the L1 / L2 traffic
-        // triangular); offsets are lane * 16 (+ 4096) + an instruction immediate
+        // consecutive MFMAs).  The reduction always runs over NF k-steps; those beyond the units of degree <= i have
+        // masked-zero weights: the buffer resource of a fetch ends after kmax fragments, the loads beyond it return
+        // zeros without touching memory (the load count stays fixed, the L1 / L2 traffic triangular); offsets are
+        // lane * 16 (+ 4096 j) + an instruction immediate.  Two fragment buffers X / Y alternate; the head of pass
+        // i + 1 (biases, context projections, W0 and the first hidden matrix) is requested while pass i computes its
+        // spline parameters, so the buffers swap roles every pass.
         auto fetch = [&](u32x4 (&buf)[NF], int64_t off, int tile, int kmax) {
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<char*>(lw) + off + (int64_t)tile * HK * 1024, 0, kmax * 1024, 0x00020000);
