@@ -155,6 +155,15 @@ __global__ __launch_bounds__(512) void fusion_kernel(FusionParams p) {
     // Token statistics need all 192 features = all 4 waves: per-wave partial (sum, sum of squares) through LDS.
     auto stage_tokens = [&](const float* gamma, const float* beta) {
         float mean[kHT], rstd[kHT];
+        // (the scale / shift vectors are requested before the statistics exchange: their L2 round trip runs under it)
+        f32x4 ga[3], be[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int f0 = 16 * (3 * fblk + i) + 4 * g;
+            ga[i] = f32x4{1.f, 1.f, 1.f, 1.f}; be[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (gamma) { ga[i] = *reinterpret_cast<const f32x4*>(gamma + f0); be[i] = *reinterpret_cast<const f32x4*>(beta + f0); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
         if (gamma && !(kAbl & 16)) {
 #pragma unroll
             for (int j = 0; j < kHT; ++j) {
@@ -180,14 +189,11 @@ __global__ __launch_bounds__(512) void fusion_kernel(FusionParams p) {
         }
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const int f0 = 16 * (3 * fblk + i) + 4 * g;
-            f32x4 ga = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f};
-            if (gamma) { ga = *reinterpret_cast<const f32x4*>(gamma + f0); be = *reinterpret_cast<const f32x4*>(beta + f0); }
 #pragma unroll
             for (int j = 0; j < kHT; ++j) {
                 const int tok = 16 * (kHT * th + j) + c;
                 f32x4 v = X[i][j];
-                if (gamma && !(kAbl & 16)) v = (v - mean[j]) * rstd[j] * ga + be;
+                if (gamma && !(kAbl & 16)) v = (v - mean[j]) * rstd[j] * ga[i] + be[i];
                 if (tok >= T) v = f32x4{0.f, 0.f, 0.f, 0.f};
                 *reinterpret_cast<bf16x4*>(xn + (kHT * th + j) * (16 * kXS) + wx[i]) = to_bf16(v);
             }
