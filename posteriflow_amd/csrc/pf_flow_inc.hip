@@ -11,7 +11,7 @@
 // D passes the work is ONE masked conditioner evaluation per layer ("exact incremental
 // algorithm") instead of D dense ones.  The result is the same x: no approximation is involved.
 //
-// One workgroup = 16 draws (one sixteen-row MFMA column tile), 4 waves, 49 KB of LDS, <= 168 VGPRs: three of them share
+// One workgroup = 16 draws (one sixteen-row MFMA column tile), 4 waves, 46 KB of LDS, <= 168 VGPRs: three of them share
 // a CU.  A pass is a chain of seven barrier-separated stages (six dependent GEMV-like stages + the spline) whose
 // cost is latency, so independent workgroups on the same CU are what fills it; 32 / 48-draw workgroups sharing one
 // weight fetch measured 25-30 % slower per draw.  Transposed MFMA form as everywhere:
@@ -543,7 +543,7 @@ int flow_inverse_inc(const PfFlowDesc& d, float deriv_const, const int32_t* u1, 
     p.layer_bytes = inc_layer_bytes(p.D, p.H, f32);
     for (int i = 0; i <= p.D; ++i) p.u1[i] = u1[i];
     // One workgroup = 16 draws.  A pass is a chain of seven barrier-separated stages whose cost is latency, not
-    // bandwidth, so the CU is filled with three independent 4-wave workgroups (49 KB of LDS, <= 168 VGPRs each) whose
+    // bandwidth, so the CU is filled with three independent 4-wave workgroups (46 KB of LDS, <= 168 VGPRs each) whose
     // stalls overlap; wider workgroups (32 / 48 draws sharing one weight fetch) measured 25-30 % slower per draw.
     // A wave owns one new tile per pass: at most 4 (8 with the 8-wave variant) sixteen-unit tiles may hold the
     // units of one degree.
