@@ -49,15 +49,46 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 // ---- small device helpers ------------------------------------------------------
-template <bool FAST> __device__ __forceinline__ float pf_exp(float v) { return FAST ? __expf(v) : expf(v); }
-template <bool FAST> __device__ __forceinline__ float pf_log(float v) { return FAST ? __logf(v) : logf(v); }
+// FAST = bf16 mode: bare v_exp_f32 / v_log_f32 / v_rcp_f32 (1 ulp; __expf / __logf compile to sequences with
+// denormal-range fix-ups here).  The fp32 parity mode of the forward and D-pass kernels calls the library routines
+// (the forward parity test sits at the fp32 noise floor: 1e-5 relative on the density is also what the CPU fp32
+// oracle reaches).  pf_*_acc: the bare instructions corrected to ~1 ulp -- exp and log carry the rounding error of
+// the base-2 scaling in a second term, division refines the reciprocal with two fused steps, log(1 + e) switches to
+// its series below e = 0.01 -- used by the fp32 incremental inverse, whose spline is on its critical path.
+__device__ __forceinline__ float pf_exp_acc(float v) {
+    const float t = v * 1.44269502f;                                           // float(log2 e)
+    const float r = __builtin_fmaf(v, 1.44269502f, -t) + v * 1.92596299e-8f;   // what t lost + log2 e - float(log2 e)
+    const float e = __builtin_amdgcn_exp2f(t);
+    return __builtin_fmaf(e, r * 0.693147181f, e);
+}
+__device__ __forceinline__ float pf_log_acc(float v) {
+    const float l2 = __builtin_amdgcn_logf(v);
+    return __builtin_fmaf(l2, 0.693147182f, l2 * -1.90465498e-9f);
+}
+__device__ __forceinline__ float pf_div_acc(float a, float b) {
+    float r = __builtin_amdgcn_rcpf(b);
+    r = __builtin_fmaf(__builtin_fmaf(-b, r, 1.f), r, r);
+    const float q = a * r;
+    return __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q);
+}
+template <bool FAST> __device__ __forceinline__ float pf_exp(float v) {
+    return FAST ? __builtin_amdgcn_exp2f(v * 1.44269504f) : expf(v);
+}
+template <bool FAST> __device__ __forceinline__ float pf_log(float v) {
+    return FAST ? __builtin_amdgcn_logf(v) * 0.693147181f : logf(v);
+}
 template <bool FAST> __device__ __forceinline__ float pf_div(float a, float b) {
     return FAST ? a * __builtin_amdgcn_rcpf(b) : a / b;
 }
 template <bool FAST> __device__ __forceinline__ float pf_softplus(float u) {
     // torch F.softplus: beta = 1, threshold = 20
-    if (FAST) return u > 20.f ? u : __logf(1.f + __expf(u));
+    if (FAST) return u > 20.f ? u : pf_log<true>(1.f + pf_exp<true>(u));
     return u > 20.f ? u : log1pf(expf(u));
+}
+__device__ __forceinline__ float pf_softplus_acc(float u) {
+    const float e = pf_exp_acc(u);
+    const float small = e * (1.f - e * (0.5f - e * 0.333333343f));             // log(1 + e), e < 0.01: error < e^4 / 4
+    return u > 20.f ? u : (e < 0.01f ? small : pf_log_acc(1.f + e));
 }
 template <bool FAST> __device__ __forceinline__ float pf_sigmoid(float v) {
     return pf_div<FAST>(1.f, 1.f + pf_exp<FAST>(-v));
@@ -192,7 +223,7 @@ __device__ __forceinline__ void rqs_pair_inverse(const float* par, float yin, in
     const float b = h * dl - dy * s2;
     const float c = -delta * dy;
     const float disc = b * b - 4.f * a * c;
-    const float root = pf_div<FAST>(2.f * c, -b - sqrtf(fmaxf(disc, 0.f)));
+    const float root = pf_div<FAST>(2.f * c, -b - (FAST ? __builtin_amdgcn_sqrtf(fmaxf(disc, 0.f)) : sqrtf(fmaxf(disc, 0.f))));
     const float tt = root * (1.f - root);
     const float den = delta + s2 * tt;
     const float omt = 1.f - root;

@@ -85,40 +85,16 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v) {
     for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
     return v;
 }
-// FAST = bf16 mode: bare instructions.  The fp32 parity mode corrects them to ~1 ulp instead of calling the library
-// routines (which spend most of their instructions on denormal / overflow ranges that cannot occur here): exp and
-// log carry the rounding error of the base-2 scaling in a second term, division refines v_rcp_f32 with two fused
-// steps, log(1 + e) switches to its series below e = 0.01.
-__device__ __forceinline__ float exp_acc(float v) {
-    const float t = v * 1.44269502f;                                      // float(log2 e)
-    const float r = __builtin_fmaf(v, 1.44269502f, -t) + v * 1.92596299e-8f;   // what t lost + log2 e - float(log2 e)
-    const float e = __builtin_amdgcn_exp2f(t);
-    return __builtin_fmaf(e, r * 0.693147181f, e);
-}
-__device__ __forceinline__ float log_acc(float v) {
-    const float l2 = __builtin_amdgcn_logf(v);
-    return __builtin_fmaf(l2, 0.693147182f, l2 * -1.90465498e-9f);
-}
-__device__ __forceinline__ float div_acc(float a, float b) {
-    float r = __builtin_amdgcn_rcpf(b);
-    r = __builtin_fmaf(__builtin_fmaf(-b, r, 1.f), r, r);
-    const float q = a * r;
-    return __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q);
-}
-template <bool FAST> __device__ __forceinline__ float exp_m(float v) { return FAST ? __builtin_amdgcn_exp2f(v * 1.44269504f) : exp_acc(v); }
-template <bool FAST> __device__ __forceinline__ float log_m(float v) { return FAST ? __builtin_amdgcn_logf(v) * 0.693147181f : log_acc(v); }
-template <bool FAST> __device__ __forceinline__ float div_m(float a, float b) { return FAST ? a * __builtin_amdgcn_rcpf(b) : div_acc(a, b); }
+// (math helpers: pf_flow_fwd_kernel.h -- bare instructions in bf16 mode, corrected to ~1 ulp in the fp32 parity mode)
+template <bool FAST> __device__ __forceinline__ float exp_m(float v) { return FAST ? pf_exp<true>(v) : pf_exp_acc(v); }
+template <bool FAST> __device__ __forceinline__ float log_m(float v) { return FAST ? pf_log<true>(v) : pf_log_acc(v); }
+template <bool FAST> __device__ __forceinline__ float div_m(float a, float b) { return FAST ? pf_div<true>(a, b) : pf_div_acc(a, b); }
 template <bool FAST> __device__ __forceinline__ float sqrt_m(float v) { return __builtin_amdgcn_sqrtf(v); }
-template <bool FAST> __device__ __forceinline__ float softplus_m(float u) {
-    if (FAST) return u > 20.f ? u : log_m<true>(1.f + exp_m<true>(u));
-    const float e = exp_acc(u);
-    const float small = e * (1.f - e * (0.5f - e * 0.333333343f));        // log(1 + e), e < 0.01: error < e^4 / 4
-    return u > 20.f ? u : (e < 0.01f ? small : log_acc(1.f + e));
-}
+template <bool FAST> __device__ __forceinline__ float softplus_m(float u) { return FAST ? pf_softplus<true>(u) : pf_softplus_acc(u); }
 template <bool FAST> __device__ __forceinline__ f32x4 sigmoid4(f32x4 v) {
 #pragma unroll
     for (int e = 0; e < 4; ++e)
-        v[e] = FAST ? __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(v[e] * -1.44269504f)) : div_acc(1.f, 1.f + exp_acc(-v[e]));
+        v[e] = FAST ? __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(v[e] * -1.44269504f)) : pf_div_acc(1.f, 1.f + pf_exp_acc(-v[e]));
     return v;
 }
 
