@@ -185,6 +185,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the sampling / embedding side measurements")
     ap.add_argument("--collective", action="store_true", help="run the N > 1 step (with its all-reduce) on a single rank")
+    ap.add_argument("--allreduce-every", type=int, default=16,
+                    help="N > 1: steps per all-reduce of the in-kernel (sum nll, rows) accumulator (1 = every step)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N > 1 path on fewer GPUs than ranks (collective through the host)")
     args = ap.parse_args()
@@ -221,16 +223,25 @@ def main():
     NBUF = 3
     red = [torch.zeros(2, device=dev, dtype=torch.float32) for _ in range(NBUF)]
     works = [None] * NBUF
-    state = {"k": 0}
+    state = {"k": 0, "last": 0}
+    flush_ref = [None]
 
     def drain():
+        if collective and state["k"] % max(1, args.allreduce_every):          # a partly filled window: reduce it now
+            M_ = max(1, args.allreduce_every)
+            w = state["k"] // M_
+            flush_ref[0](w % NBUF)
+            state["k"] = (w + 1) * M_
         for w in works:
             if w is not None:
                 w.wait()
 
     # One pre-bound launch per step (a few microseconds of host time: the device queue stays full, measured
-    # 113.0 us/step against 116.7 us/step for replaying a one-kernel HIP graph per step, --graph), plus, for
-    # N > 1, one asynchronous all-reduce per step.
+    # 113.0 us/step against 116.7 us/step for replaying a one-kernel HIP graph per step, --graph).  N > 1: the kernel
+    # itself accumulates (sum nll, rows); the accumulator of a window of --allreduce-every steps (default 16, the
+    # cadence at which a trainer logs its loss) is all-reduced asynchronously.  An all-reduce per step costs 11.5 us
+    # per step on one rank although it carries 8 bytes: the flow kernel needs all 256 CUs (one workgroup each, full
+    # register file), so whichever CU runs the RCCL kernel starts its workgroup that much later.
     use_graph = args.graph and not collective
     graph = None
     stream = torch.cuda.Stream(dev)
@@ -238,25 +249,40 @@ def main():
         plain = flow.bind_nll(x, ctx, nll, stream=stream)
         reduce_launch = flow.bind_nll(x, ctx, nll, sum_count=red, stream=stream) if collective else None
 
+        M = max(1, args.allreduce_every)
+
+        def flush(a):
+            """all-reduce the window accumulated in red[a]"""
+            if os.environ.get("PF_BENCH_SKIP_ALLREDUCE"):           # timing experiment only
+                pass
+            elif args.backend == "nccl":
+                works[a] = dist.all_reduce(red[a], async_op=True)
+            else:                                         # gloo rehearsal on CPU tensors
+                host = red[a].cpu()
+                dist.all_reduce(host)
+                red[a].copy_(host)
+            state["last"] = a
+
+        flush_ref[0] = flush
+
         def step():
             if not collective:
                 plain()
                 return
-            i = state["k"]
-            nxt = (i + 1) % NBUF
-            if works[nxt] is not None:
-                works[nxt].wait()                         # stream-side: its all-reduce is done before this launch zeroes it
-                works[nxt] = None
-            reduce_launch(i)
-            if os.environ.get("PF_BENCH_SKIP_ALLREDUCE"):           # timing experiment only
-                pass
-            elif args.backend == "nccl":
-                works[i % NBUF] = dist.all_reduce(red[i % NBUF], async_op=True)
-            else:                                         # gloo rehearsal on CPU tensors
-                host = red[i % NBUF].cpu()
-                dist.all_reduce(host)
-                red[i % NBUF].copy_(host)
-            state["k"] = i + 1
+            # every launch adds its (sum nll, rows) to the window's accumulator red[a] inside the kernel and zeroes
+            # the next window's; the window (M steps) is all-reduced once, asynchronously, over three rotating pairs
+            k = state["k"]
+            w, pos = divmod(k, M)
+            a = w % NBUF
+            if pos == 0:
+                nxt = (a + 1) % NBUF
+                if works[nxt] is not None:
+                    works[nxt].wait()                     # stream-side: its all-reduce is done before a launch zeroes it
+                    works[nxt] = None
+            reduce_launch(a)
+            if pos == M - 1:
+                flush(a)
+            state["k"] = k + 1
 
         step()
         drain()
@@ -314,7 +340,7 @@ def main():
 
     mean_nll = None
     if collective:
-        last = red[(state["k"] - 1) % NBUF].cpu()    # (sum nll, count) over all ranks, both all-reduced
+        last = red[state["last"]].cpu()             # (sum nll, count) of the last window over all ranks, both all-reduced
         mean_nll = (last[0] / last[1]).item()
     if rank == 0:
         fl = flops_per_sample()
@@ -334,7 +360,7 @@ def main():
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "rows_per_workgroup": int(__import__("posteriflow_amd")._lib.lib().pf_flow_rows_per_workgroup(
                            flow._desc(), args.batch)),
-                       "launch": "hipGraph" if graph is not None else ("pre-bound launch + async all-reduce" if collective else "pre-bound launch"),
+                       "launch": "hipGraph" if graph is not None else (f"pre-bound launch, in-kernel (sum nll, rows) + async all-reduce every {max(1, args.allreduce_every)} steps" if collective else "pre-bound launch"),
                        "global_mean_nll": mean_nll,
                        "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",

@@ -36,9 +36,15 @@ def test_default_step_contract():
     assert d["value"] > 1e7 and abs(d["value"] - 4096 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
 
 
-def test_collective_step_reports_the_same_loss():
-    d = _run("--collective")
-    assert d["config"]["launch"] == "pre-bound launch + async all-reduce"
+@pytest.mark.parametrize("every", [16, 1, 7])
+def test_collective_step_reports_the_same_loss(every):
+    # windows of `every` steps: 20 timed steps end in a partly filled window for 16 and 7 (flushed inside the timed region)
+    d = _run("--collective", "--allreduce-every", str(every))
+    assert d["config"]["launch"] == f"pre-bound launch, in-kernel (sum nll, rows) + async all-reduce every {every} steps"
     loss = d["config"]["global_mean_nll"]
     assert loss is not None and 50.0 < loss < 500.0          # mean NLL of the synthetic batch (134.9 for seed 1)
+    if every == 16:
+        test_collective_step_reports_the_same_loss.ref = loss
+    elif hasattr(test_collective_step_reports_the_same_loss, "ref"):
+        assert abs(loss - test_collective_step_reports_the_same_loss.ref) < 1e-3 * abs(loss)
     assert d["value"] > 5e6
