@@ -422,17 +422,23 @@ __global__ __launch_bounds__(512) void fusion_kernel(FusionParams p) {
 #pragma unroll
                 for (int j = 0; j < 3; ++j) t[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             const int tile0 = (fb2 == 0 ? 0 : 12) + 2 * h;
-#pragma unroll 3
-            for (int ks = 0; ks < 6; ++ks) {
-                bf16x8 a[2], b[3];
+            // all 12 weight fragments of the head in one batch (the residual registers are free here): one L2 round
+            // trip per head instead of one per k-step
+            bf16x8 a[6][2];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) a[i] = afrag(p.packed + kPoolW, tile0 + i, 6, ks);
+            for (int ks = 0; ks < 6; ++ks)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) a[ks][i] = afrag(p.packed + kPoolW, tile0 + i, 6, ks);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < 6; ++ks) {
+                bf16x8 b[3];
 #pragma unroll
                 for (int j = 0; j < 3; ++j) b[j] = bx(xn, 3 * tb4 + j, ks);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) t[i][j] = mfma(a[i], b[j], t[i][j]);
+                    for (int j = 0; j < 3; ++j) t[i][j] = mfma(a[ks][i], b[j], t[i][j]);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
