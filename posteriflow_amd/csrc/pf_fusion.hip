@@ -135,8 +135,11 @@ __global__ __launch_bounds__(512) void fusion_kernel(FusionParams p) {
         const int f0 = 16 * (3 * fblk + i) + 4 * g;
 #pragma unroll
         for (int j = 0; j < kHT; ++j) {
-            const int tok = 16 * (kHT * th + j) + c;
-            X[i][j] = tok < T ? *reinterpret_cast<const f32x4*>(Xg + tok * kE + f0) : f32x4{0.f, 0.f, 0.f, 0.f};
+            // (unconditional loads from a clamped row: a load under a per-lane condition is a branch of its own, and 36
+            // of them wait for one another -- 18 HBM round trips per event before the first MFMA)
+            const int tok = 16 * (kHT * th + j) + c, tokc = tok < T ? tok : T - 1;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(Xg + tokc * kE + f0);
+            X[i][j] = tok < T ? v : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
     if (p.tok_bias) {
@@ -145,8 +148,9 @@ __global__ __launch_bounds__(512) void fusion_kernel(FusionParams p) {
             const int f0 = 16 * (3 * fblk + i) + 4 * g;
 #pragma unroll
             for (int j = 0; j < kHT; ++j) {
-                const int tok = 16 * (kHT * th + j) + c;
-                if (tok < T) X[i][j] = X[i][j] + *reinterpret_cast<const f32x4*>(p.tok_bias + tok * kE + f0);
+                const int tok = 16 * (kHT * th + j) + c, tokc = tok < T ? tok : T - 1;
+                const f32x4 b = *reinterpret_cast<const f32x4*>(p.tok_bias + tokc * kE + f0);
+                X[i][j] = X[i][j] + (tok < T ? b : f32x4{0.f, 0.f, 0.f, 0.f});
             }
         }
     }
