@@ -16,6 +16,7 @@ import argparse
 import json
 import os
 import statistics
+import subprocess
 import sys
 import time
 
@@ -53,6 +54,16 @@ def flops_per_sample():
     return 2 * L * (D * H + C * H + 2 * (2 * H * H + C * H) + H * D * (3 * K - 1))
 
 
+def masked_flops_per_sample():
+    """The same count with the autoregressive masks discounted (SURVEY 8d: 7.275 MFLOP for this flow;
+    reported alongside, never instead)."""
+    deg_h = [u % max(1, D - 1) + min(1, D - 1) for u in range(H)]
+    n_in = sum(1 for u in range(H) for d in range(D) if deg_h[u] >= d + 1)
+    n_hh = sum(1 for u in range(H) for v in range(H) if deg_h[u] >= deg_h[v])
+    n_out = (3 * K - 1) * sum(1 for f in range(D) for v in range(H) if f + 1 > deg_h[v])
+    return 2 * L * (n_in + C * H + 2 * (2 * n_hh + C * H) + n_out)
+
+
 def make_inputs(batch, seed, device):
     g = torch.Generator().manual_seed(seed)
     x = torch.rand(batch, D, generator=g) * 2 - 1
@@ -75,12 +86,19 @@ def build_flow(device, precision):
     return flow
 
 
-def cpu_baseline(flow, batch, budget_s=15.0):
-    """The oracle (CPU restatement of the reference's algorithm, fp32) on the host cores."""
+def oracle_for(flow):
+    """The CPU oracle with the bench flow's weights (checker / CPU baseline only)."""
     from oracle.flow_ref import NSFPosteriorFlowRef
     ref = NSFPosteriorFlowRef(D, C, H, L, K, TB, temperature_scale=1.0)
     sd = {k: v.cpu() for k, v in flow.state_dict().items() if not k.startswith("flow.")}
     ref.load_state_dict(sd)
+    return ref
+
+
+def cpu_baseline(flow, batch, budget_s=15.0):
+    """The oracle (CPU restatement of the reference's algorithm, fp32) on the host cores.
+    Returns (baseline dict, oracle nll of the seed-1 batch)."""
+    ref = oracle_for(flow)
     cores = host_threads()
     torch.set_num_threads(cores)
     log(f"cpu baseline: {cores} threads (os.cpu_count()={os.cpu_count()})")
@@ -89,9 +107,9 @@ def cpu_baseline(flow, batch, budget_s=15.0):
     times = []
     with torch.no_grad():
         for _ in range(3):
-            ref.compute_psd_aware_nll(x, ctx, ls)
+            want = ref.compute_psd_aware_nll(x, ctx, ls)
         t_end = time.time() + budget_s                    # a bounded sample: ~15 s of host work
-        while len(times) < 200 and (time.time() < t_end or len(times) < 3):
+        while len(times) < 200 and (time.time() < t_end or len(times) < 20):
             t0 = time.perf_counter()
             ref.compute_psd_aware_nll(x, ctx, ls)
             times.append(time.perf_counter() - t0)
@@ -104,16 +122,67 @@ def cpu_baseline(flow, batch, budget_s=15.0):
         ref.inverse(z, ctx[:1].expand(4096, -1))
         inv_s = time.perf_counter() - t0
     log(f"cpu baseline inverse: 4096 draws in {inv_s:.2f} s")
-    med = statistics.median(times)
+    ts = sorted(times)
+    med = statistics.median(ts)
+    p10, p90 = ts[int(0.1 * (len(ts) - 1))], ts[int(round(0.9 * (len(ts) - 1)))]
     return {"value": batch / med, "unit": "samples/s", "cores": cores, "kind": "port",
             "sample": f"batch {batch}, fp32, {len(times)} iterations (~{budget_s:.0f} s of host work) after 3 warm-ups, median",
-            "ms_per_batch": med * 1e3, "inverse_draws_per_s": 4096 / inv_s}
+            "ms_per_batch": med * 1e3, "ms_per_batch_p10": p10 * 1e3, "ms_per_batch_p90": p90 * 1e3,
+            "inverse_draws_per_s": 4096 / inv_s}, want
+
+
+def parity_check(flow, dev, batch, want):
+    """GPU nll of the timed workload (seed-1 batch) against the oracle's, both precisions.  fp32 parity mode:
+    hard tolerance (p99 2e-5 relative between the two fp32 evaluations, each held to north_star's 1e-5 against fp64 by
+    tests/test_flow_forward_gpu.py; worst row 1e-3); bf16 throughput mode: recorded, loosely bounded."""
+    x, ctx = make_inputs(batch, 1, dev)
+    out = {}
+    prec = flow.precision
+    was_frozen = flow._frozen
+    nll = torch.empty(batch, device=dev)
+    with torch.no_grad():
+        for name in ("fp32", "bf16"):
+            flow.precision = name
+            if was_frozen:
+                flow.freeze_packed()
+            got = flow.nll_into(x, ctx, nll).cpu().double()
+            err = (got - want.double()).abs()
+            rel = err / want.double().abs().clamp_min(1.0)
+            out[name] = {"max_abs": err.max().item(), "p99_rel": rel.quantile(0.99).item(),
+                         "max_rel": rel.max().item(), "rows": batch}
+    flow.precision = prec
+    if was_frozen:
+        flow.freeze_packed()
+    log("parity vs oracle: " + json.dumps(out))
+    assert out["fp32"]["p99_rel"] < 2e-5 and out["fp32"]["max_rel"] < 1e-3, ("fp32 nll off the oracle", out)
+    assert out["bf16"]["p99_rel"] < 2e-2 and out["bf16"]["max_abs"] < 4.0, ("bf16 nll off the oracle", out)
+    return out
+
+
+def kernel_time_ms(flow, x, ctx, nll, stream, n_k):
+    """kernel-only duration: HIP events (on the launch stream) bracketing a captured chain of back-to-back launches"""
+    dev = x.device
+    with torch.cuda.stream(stream):
+        k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(5):
+            flow.nll_into(x, ctx, nll)
+        kg = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(kg, stream=stream):
+            for _ in range(n_k):
+                flow.nll_into(x, ctx, nll)
+        kg.replay()
+        stream.synchronize()
+        k0.record(stream)
+        kg.replay()
+        k1.record(stream)
+        stream.synchronize()
+        return k0.elapsed_time(k1) / n_k
 
 
 def extras(flow, dev, batch):
-    """Side measurements on the same GPU (not part of `value`): sampling through pf_flow_inverse
-    (one context row, as inference/pipeline.py:169-173) and the strain embedding of BASELINE
-    config 3 (3 detectors, batch rows) -- HIP stem alone and the whole LeanStrainEncoder."""
+    """Side measurements on the same GPU (not part of `value`): the fp32 parity mode's log_prob throughput,
+    the forward at a large batch, sampling through the inverse (one context row, as inference/pipeline.py:169-173)
+    and the strain embedding of BASELINE config 3 (3 detectors, batch rows)."""
     from posteriflow_amd import npe
     out = {}
 
@@ -126,7 +195,18 @@ def extras(flow, dev, batch):
         return (time.perf_counter() - t0) / reps
 
     with torch.no_grad():
-        # the same forward kernel on a batch large enough to amortise the per-CU weight ingest (R = 2 rows groups)
+        if flow.precision == "bf16":           # the fp32 parity mode (v_mfma_f32_16x16x4_f32) on the bench workload
+            x, ctx = make_inputs(batch, 1, dev)
+            nll = torch.empty(batch, device=dev)
+            flow.precision = "fp32"
+            flow.freeze_packed()
+            ms = kernel_time_ms(flow, x, ctx, nll, torch.cuda.current_stream(dev), 20)
+            flow.precision = "bf16"
+            flow.freeze_packed()
+            out[f"forward_samples_per_s_fp32_{batch}"] = batch / (ms * 1e-3)
+            out[f"forward_kernel_us_fp32_{batch}"] = ms * 1e3
+            out[f"forward_roofline_frac_fp32_{batch}"] = batch * flops_per_sample() / (ms * 1e-3) / 1e12 / PEAK_TFLOPS["fp32"]
+        # the forward on a batch large enough to amortise the per-CU weight ingest
         nb = 65536
         xb, cb = make_inputs(nb, 3, dev)
         ob = torch.empty(nb, device=dev)
@@ -134,6 +214,7 @@ def extras(flow, dev, batch):
         dt = timed(launch, 20)
         out["forward_samples_per_s_65536"] = nb / dt
         out["forward_tflops_65536"] = nb * flops_per_sample() / dt / 1e12
+        out["forward_roofline_frac_65536"] = out["forward_tflops_65536"] / PEAK_TFLOPS[flow.precision]
         del xb, cb, ob
         ctx1 = torch.randn(1, C, device=dev)
         for n in (4096, 131072):
@@ -164,13 +245,27 @@ def extras(flow, dev, batch):
 
 
 def pmc_traffic(args):
-    """bytes per launch at the L2's memory side from the committed PMC passes (rocprofv3 cannot run inside
-    this process): only for the configuration they were collected on, else null."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    """bytes per launch at the L2's memory side from the committed PMC passes of the build being timed (rocprofv3
+    cannot run inside this process): only for the configuration they were collected on, else null."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
     if args.batch != 4096 or args.precision != "bf16" or not os.path.exists(path):
         return None
     with open(path) as fh:
         return json.load(fh)["bytes_per_launch"]
+
+
+def spawn_ranks(args):
+    """`bench.py --gpus N` outside a launcher: start N ranks (one process per GPU, torch.distributed.run) as CHILD
+    processes before this process touches the GPU, pass their output through and exit with their code."""
+    n_dev = torch.cuda.device_count()                    # does not initialise the GPU runtime
+    if args.backend == "nccl" and n_dev < args.gpus:
+        sys.exit(f"bench.py --gpus {args.gpus}: only {n_dev} GPU(s) visible (use --backend gloo to rehearse on fewer)")
+    port = os.environ.get("MASTER_PORT", str(29500 + os.getpid() % 400))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    log("spawning: " + " ".join(cmd))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -185,15 +280,20 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the sampling / embedding side measurements")
     ap.add_argument("--collective", action="store_true", help="run the N > 1 step (with its all-reduce) on a single rank")
-    ap.add_argument("--allreduce-every", type=int, default=16,
-                    help="N > 1: steps per all-reduce of the in-kernel (sum nll, rows) accumulator (1 = every step)")
+    ap.add_argument("--allreduce-every", type=int, default=1,
+                    help="N > 1: steps per all-reduce of the in-kernel (sum nll, rows) accumulator (1 = every step, the "
+                         "contract's step; the windowed figure is reported under extras)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N > 1 path on fewer GPUs than ranks (collective through the host)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args)                                 # never returns
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch {args.gpus} ranks or drop the flag")
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     if args.backend == "gloo":
         local = local % torch.cuda.device_count()         # rehearsal: ranks may share a GPU
@@ -215,41 +315,22 @@ def main():
     log("weights packed")
     x, ctx = make_inputs(args.batch, 1 + rank, dev)
     nll = torch.empty(args.batch, device=dev)
-    # N > 1: (sum nll, count) all-reduced every step over RCCL -- the path's only exchange.  The flow
-    # kernel reduces the pair itself (wave shuffle + one pair of atomics per workgroup) and zeroes the
-    # accumulator of the NEXT step, so a step is exactly one kernel launch (a pre-bound C call: the Python
-    # wrapper's per-call work would make the loop host-bound at ~250 us) and one asynchronous 8-byte
-    # all-reduce that overlaps the next steps' kernels (three rotating accumulators).
+    # N > 1: (sum nll, count) all-reduced over RCCL -- the path's only exchange.  The flow kernel reduces the pair
+    # itself (wave shuffle + one pair of atomics per workgroup) and zeroes the accumulator of the NEXT window, so a
+    # step is exactly one kernel launch (a pre-bound C call: the Python wrapper's per-call work would make the loop
+    # host-bound at ~250 us) and one asynchronous 8-byte all-reduce that overlaps the next steps' kernels (three
+    # rotating accumulators).  --allreduce-every M > 1 reduces a window of M steps at once.
     NBUF = 3
     red = [torch.zeros(2, device=dev, dtype=torch.float32) for _ in range(NBUF)]
     works = [None] * NBUF
-    state = {"k": 0, "last": 0}
-    flush_ref = [None]
+    state = {"k": 0, "last": 0, "M": max(1, args.allreduce_every)}
 
-    def drain():
-        if collective and state["k"] % max(1, args.allreduce_every):          # a partly filled window: reduce it now
-            M_ = max(1, args.allreduce_every)
-            w = state["k"] // M_
-            flush_ref[0](w % NBUF)
-            state["k"] = (w + 1) * M_
-        for w in works:
-            if w is not None:
-                w.wait()
-
-    # One pre-bound launch per step (a few microseconds of host time: the device queue stays full, measured
-    # 113.0 us/step against 116.7 us/step for replaying a one-kernel HIP graph per step, --graph).  N > 1: the kernel
-    # itself accumulates (sum nll, rows); the accumulator of a window of --allreduce-every steps (default 16, the
-    # cadence at which a trainer logs its loss) is all-reduced asynchronously.  An all-reduce per step costs 11.5 us
-    # per step on one rank although it carries 8 bytes: the flow kernel needs all 256 CUs (one workgroup each, full
-    # register file), so whichever CU runs the RCCL kernel starts its workgroup that much later.
     use_graph = args.graph and not collective
     graph = None
     stream = torch.cuda.Stream(dev)
     with torch.cuda.stream(stream):
         plain = flow.bind_nll(x, ctx, nll, stream=stream)
         reduce_launch = flow.bind_nll(x, ctx, nll, sum_count=red, stream=stream) if collective else None
-
-        M = max(1, args.allreduce_every)
 
         def flush(a):
             """all-reduce the window accumulated in red[a]"""
@@ -263,7 +344,16 @@ def main():
                 red[a].copy_(host)
             state["last"] = a
 
-        flush_ref[0] = flush
+        def drain():
+            M = state["M"]
+            if collective and state["k"] % M:             # a partly filled window: reduce it now
+                w = state["k"] // M
+                flush(w % NBUF)
+                state["k"] = (w + 1) * M
+            for i, w in enumerate(works):
+                if w is not None:
+                    w.wait()
+                    works[i] = None
 
         def step():
             if not collective:
@@ -271,6 +361,7 @@ def main():
                 return
             # every launch adds its (sum nll, rows) to the window's accumulator red[a] inside the kernel and zeroes
             # the next window's; the window (M steps) is all-reduced once, asynchronously, over three rotating pairs
+            M = state["M"]
             k = state["k"]
             w, pos = divmod(k, M)
             a = w % NBUF
@@ -284,6 +375,31 @@ def main():
                 flush(a)
             state["k"] = k + 1
 
+        def timed_loop(run, n_steps):
+            """barrier + synchronize, n_steps steps, synchronize + barrier; max over ranks"""
+            drain()
+            stream.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            e0.record(stream)
+            for _ in range(n_steps):
+                run()
+            drain()
+            e1.record(stream)
+            stream.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([el], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = t.item()
+            return el, e0.elapsed_time(e1)
+
         step()
         drain()
         stream.synchronize()
@@ -295,57 +411,31 @@ def main():
         run = graph.replay if graph is not None else step
         for _ in range(args.warmup):
             run()
-        drain()
-        stream.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        e0.record(stream)
-        for _ in range(args.steps):
-            run()
-        drain()
-        e1.record(stream)
-        stream.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-    dev_ms = e0.elapsed_time(e1)
-    log(f"timed {args.steps} steps: {elapsed * 1e3 / args.steps:.4f} ms/step (device {dev_ms / args.steps:.4f})")
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+        elapsed, dev_ms = timed_loop(run, args.steps)
+        log(f"timed {args.steps} steps: {elapsed * 1e3 / args.steps:.4f} ms/step (device {dev_ms / args.steps:.4f})")
+        mean_nll = None
+        if collective:
+            last = red[state["last"]].cpu()         # (sum nll, count) of the last window over all ranks, both all-reduced
+            mean_nll = (last[0] / last[1]).item()
+        windowed = None
+        if collective and state["M"] == 1:               # beside the contract number: one all-reduce per 16 steps
+            state["M"], state["k"] = 16, 0
+            for i in range(NBUF):
+                red[i].zero_()
+            for _ in range(max(args.warmup, 16)):
+                run()
+            el16, _ = timed_loop(run, args.steps)
+            windowed = world * args.batch * args.steps / el16
+            state["M"] = 1
 
-    # kernel-only duration: HIP events bracketing back-to-back launches of the kernel alone
-    with torch.cuda.stream(stream):
-        k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        n_k = max(20, min(args.steps, 200))
-        for _ in range(5):
-            flow.nll_into(x, ctx, nll)
-        kg = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(kg, stream=stream):
-            for _ in range(n_k):
-                flow.nll_into(x, ctx, nll)
-        kg.replay()
-        stream.synchronize()
-        k0.record(stream)
-        kg.replay()
-        k1.record(stream)
-        stream.synchronize()
-        kernel_ms = k0.elapsed_time(k1) / n_k
+    kernel_ms = kernel_time_ms(flow, x, ctx, nll, stream, max(20, min(args.steps, 200)))
     log(f"kernel-only: {kernel_ms * 1e3:.2f} us")
 
-    mean_nll = None
-    if collective:
-        last = red[state["last"]].cpu()             # (sum nll, count) of the last window over all ranks, both all-reduced
-        mean_nll = (last[0] / last[1]).item()
     if rank == 0:
         fl = flops_per_sample()
         ach = args.batch * fl / (kernel_ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.precision]
+        lib = __import__("posteriflow_amd")._lib.lib()
         out = {
             "metric": "flow.log_prob samples/sec at batch 4096",
             "value": world * args.batch * args.steps / elapsed,
@@ -358,20 +448,23 @@ def main():
             "config": {"workload": "BASELINE config 3 flow: 8-layer MAF-RQS, D=15, C=288, H=256, K=16, "
                                    "tail_bound 5, context resident in HBM",
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
-                       "rows_per_workgroup": int(__import__("posteriflow_amd")._lib.lib().pf_flow_rows_per_workgroup(
-                           flow._desc(), args.batch)),
+                       "rows_per_workgroup": int(lib.pf_flow_rows_per_workgroup(flow._desc(), args.batch)),
                        "launch": "hipGraph" if graph is not None else (f"pre-bound launch, in-kernel (sum nll, rows) + async all-reduce every {max(1, args.allreduce_every)} steps" if collective else "pre-bound launch"),
                        "global_mean_nll": mean_nll,
                        "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                          "frac": ach / peak, "traffic": pmc_traffic(args),
-                         "kernel": "pf::flow_forward_kernel", "kernel_ms": kernel_ms,
-                         "flop_per_sample": fl, "device_ms_per_step": dev_ms / args.steps},
+                         "kernel": flow.forward_kernel_name(args.batch), "kernel_ms": kernel_ms,
+                         "flop_per_sample": fl, "flop_per_sample_mask_aware": masked_flops_per_sample(),
+                         "device_ms_per_step": dev_ms / args.steps},
         }
+        if windowed is not None:
+            out["extras"] = {"value_allreduce_every_16": windowed}
         if not args.no_extras and world == 1:
-            out["extras"] = extras(flow, dev, args.batch)
+            out.setdefault("extras", {}).update(extras(flow, dev, args.batch))
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(flow, args.batch)
+            out["cpu_baseline"], want = cpu_baseline(flow, args.batch)
+            out["parity"] = parity_check(flow, dev, args.batch, want)
         print(json.dumps(out))
     if collective:
         dist.destroy_process_group()

@@ -233,6 +233,9 @@ int pf_remix_forward(const void* noise_pool, int64_t n_noise, const void* signal
 /* ---- introspection ------------------------------------------------------------ */
 const char* pf_last_error(void);
 const char* pf_version(void);
+/* name (as rocprofv3 prints it) of the kernel pf_flow_forward dispatches for `batch` rows; thread-local
+ * storage, NULL for an unsupported desc (bench / profiling) */
+const char* pf_flow_forward_kernel_name(const PfFlowDesc* desc, int64_t batch);
 /* rows of the batch one workgroup processes for a given batch size (bench / tests) */
 int32_t pf_flow_rows_per_workgroup(const PfFlowDesc* desc, int64_t batch);
 

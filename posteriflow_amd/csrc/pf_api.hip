@@ -348,6 +348,14 @@ int pf_remix_forward(const void* noise_pool, int64_t n_noise, const void* signal
     return rc == PF_OK ? rc : fail(rc, hipGetErrorString(hipGetLastError()));
 }
 
+const char* pf_flow_forward_kernel_name(const PfFlowDesc* desc, int64_t batch) {
+    static thread_local char name[160];
+    pf::FlowPlan L;
+    if (layout_of(desc, L) != PF_OK) return nullptr;
+    pf::forward_kernel_name(L, batch, name, sizeof(name));
+    return name;
+}
+
 int32_t pf_flow_rows_per_workgroup(const PfFlowDesc* desc, int64_t batch) {
     pf::FlowPlan L;
     if (layout_of(desc, L) != PF_OK) return -1;

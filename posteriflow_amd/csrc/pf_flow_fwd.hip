@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 #include "pf_flow_params.h"
@@ -51,6 +52,13 @@ static int rows_per_workgroup_dir(const FlowPlan& L, int64_t batch, bool inverse
     return 16 * R;
 }
 int rows_per_workgroup(const FlowPlan& L, int64_t batch) { return rows_per_workgroup_dir(L, batch, false); }
+
+// the kernel launch_flow_forward picks for (plan, batch), as rocprofv3 prints it
+void forward_kernel_name(const FlowPlan& L, int64_t batch, char* out, size_t n) {
+    const int R = L.dense ? 1 : rows_per_workgroup(L, batch) / 16;
+    snprintf(out, n, "pf::flow_kernel<%s, %d, %d, %d, %s, false>", L.bf16 ? "true" : "false", L.NT, R, L.CKM,
+             L.dense ? "true" : "false");
+}
 
 int launch_flow_forward(const FwdParams& p_in, hipStream_t s) {
     if (p_in.batch == 0) return PF_OK;

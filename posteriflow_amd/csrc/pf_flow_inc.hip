@@ -32,6 +32,8 @@
 //   - LDS rows have a fixed stride, so operand addresses are one VGPR + an instruction immediate.
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
@@ -559,12 +561,19 @@ int flow_inverse_inc(const PfFlowDesc& d, float deriv_const, const int32_t* u1, 
         flow_inverse_inc_kernel<1, 512, false, false>, flow_inverse_inc_kernel<1, 512, true, false>,
         flow_inverse_inc_kernel<1, 256, false, true>,  flow_inverse_inc_kernel<1, 256, true, true>,
         flow_inverse_inc_kernel<1, 512, false, true>,  flow_inverse_inc_kernel<1, 512, true, true>};
-    static bool configured = false;
-    if (!configured) {
-        for (const Kern k : kerns)
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
-                return PF_ERR_HIP;
-        configured = true;
+    // the opt-in to > 64 KB of dynamic LDS is a per-DEVICE function attribute: remember it per device, under a lock
+    {
+        static std::mutex mu;
+        static bool configured[64] = {};
+        int devid = 0;
+        if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= 64) return PF_ERR_HIP;
+        std::lock_guard<std::mutex> lock(mu);
+        if (!configured[devid]) {
+            for (const Kern k : kerns)
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
+                    return PF_ERR_HIP;
+            configured[devid] = true;
+        }
     }
     const int variant = (f32 ? 4 : 0) + (threads == 256 ? 0 : 2) + (proj ? 1 : 0);
     const bool tracing = std::getenv("PF_INC_TRACE") != nullptr;

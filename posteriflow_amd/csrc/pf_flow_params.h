@@ -35,6 +35,7 @@ int64_t raw_param_count(const FlowPlan& L);
 int launch_pack(const FlowPlan& L, const float* raw, const int32_t* map, void* packed, hipStream_t s);
 int rows_per_workgroup(const FlowPlan& L, int64_t batch);
 int launch_flow_forward(const FwdParams& p, hipStream_t s);
+void forward_kernel_name(const FlowPlan& L, int64_t batch, char* out, size_t n);
 int launch_flow_inverse(const FwdParams& p, hipStream_t s);
 int launch_ctx_project(const FlowPlan& L, const char* packed, const float* ctx, int64_t ctx_rows,
                        void* out, hipStream_t s);

@@ -11,14 +11,13 @@
 // fragment), and the activations are the
 // B operand, read from LDS where they live as bf16 [token][feature] rows, XOR-swizzled so that every
 // ds_read_b128 lane group hits 16 distinct 4-bank groups.  The fp32 residual stream lives in REGISTERS for
-// the whole kernel, in the accumulator layout of the wave that owns the feature block (144 registers per
-// lane): the out-projection and the second FFN matmul accumulate straight into it, LayerNorm reads it from
-// there (token statistics cross the 4 waves through 6 KB of LDS), and global memory is touched only when the
-// tokens are loaded and when the result is stored (with one wave per SIMD every global round trip would be
-// fully exposed: the first version, with the residual in L2, spent 3/4 of its time waiting on it).
-//   4 waves, one per SIMD with the whole 512-register budget; dense layers: wave = (feature block of 3
-//   tiles) x all 12 token tiles: 36 MFMAs per 3 weight + 12 activation fragment loads, every weight
-//   fragment is read by exactly one wave; per-head QKV: (3 of the head's 6 Q|K|V tiles) x (6 token tiles).
+// the whole kernel, in the accumulator layout of the wave that owns the block (72 registers per lane): the
+// out-projection and the second FFN matmul accumulate straight into it, LayerNorm reads it from there (token
+// statistics cross the 4 feature-block waves through 6 KB of LDS), and global memory is touched only when the
+// tokens are loaded and when the result is stored.
+//   8 waves, two per SIMD (the 4-wave / one-per-SIMD layout of the first version overlapped nothing: DESIGN.md
+//   4.7); dense layers: wave = (feature block of 3 tiles) x (token half of 6 tiles): 18 MFMAs per 3 weight + 6
+//   activation fragment loads, a dense weight fragment is read by 2 waves, a QKV fragment by 4.
 //   attention, per (head, 16-query tile): S^T = K . Q^T is 12 MFMAs (the head dimension is one k-step),
 //   softmax over keys in registers (columns = queries: 4 rows per lane x 12 tiles, then two xor-shuffles),
 //   O^T = V^T . P^T with P taken from the S accumulators WITHOUT leaving registers: the k-step's key

@@ -51,7 +51,7 @@
 
 #include "../../include/pf_hip.h"
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define PF_HD __host__ __device__
 #else
 #define PF_HD

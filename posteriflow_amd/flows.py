@@ -208,9 +208,8 @@ class NSFPosteriorFlow(nn.Module):
             self.context_block_dim = context_features // features
         else:
             self.n_context_blocks = self.context_block_dim = None
-        if dropout and dropout > 0.0:
-            _log.warning("dropout=%s is applied by nflows in training mode only; the HIP path "
-                         "evaluates the conditioner without dropout", dropout)
+        if not 0.0 <= float(dropout) < 1.0:
+            raise ValueError(f"dropout must be in [0, 1), got {dropout}")
         # flows.py:425-435 -- per-parameter dict is kept for the API, its patching is a
         # no-op in the reference (flows.py:502), so only the global bound takes effect.
         if isinstance(tail_bound, dict):
@@ -438,9 +437,23 @@ class NSFPosteriorFlow(nn.Module):
         return dev, x, context
 
     def _needs_grad(self, *tensors) -> bool:
-        return torch.is_grad_enabled() and (
+        need = torch.is_grad_enabled() and (
             any(t is not None and t.requires_grad for t in tensors)
             or any(p.requires_grad for p in self._ordered_parameters()))
+        if need and self.training and self.dropout and self.dropout > 0.0:
+            # nflows drops relu(W0 relu(h) + b0) inside every residual block in train mode (upstream
+            # MaskedResidualBlock.forward, built at flows.py:483-496 with dropout_probability=dropout); the HIP
+            # training path has no dropout yet, and training silently without it would not be the reference's model
+            raise NotImplementedError(
+                "NSFPosteriorFlow(dropout=%g) in train() mode: conditioner dropout is not implemented on the HIP "
+                "training path; build the flow with dropout=0.0 (LeanNPE does, lean_npe.py:291-297) or call .eval()"
+                % self.dropout)
+        return need
+
+    def forward_kernel_name(self, batch: int) -> str:
+        """Name of the kernel pf_flow_forward dispatches for this flow at `batch` rows (as rocprofv3 prints it)."""
+        name = _lib.lib().pf_flow_forward_kernel_name(self._desc(), int(batch))
+        return name.decode() if name else "?"
 
     def _forward_call(self, x, context, log_sigma, want_z=True, guard=True, layer_inputs=None):
         if guard:
@@ -536,7 +549,8 @@ class NSFPosteriorFlow(nn.Module):
     def _use_incremental(self) -> bool:
         if self.incremental_inverse is False or self.use_masked_context:
             return False
-        return self.hidden_features % 32 == 0 and self.features <= min(16, self.hidden_features // 16)
+        # features == 1: every hidden unit has degree 0 (one pass, nothing incremental about it): D-pass kernel
+        return (self.hidden_features % 32 == 0 and 2 <= self.features <= min(16, self.hidden_features // 16))
 
     def _inc_state(self, dev):
         """Weights of every layer in the layout of pf_flow_inverse_inc (hidden units sorted by degree, masks

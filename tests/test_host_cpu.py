@@ -184,3 +184,24 @@ def test_data_parallel_mean_nll_gloo_world2(tmp_path):
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.count("ok") == 2
+
+
+def test_conditioner_dropout_in_train_mode_is_loud():
+    """nflows applies dropout inside every residual block in train mode (create_flow_model defaults to 0.15,
+    flows.py:980); until the HIP training path has it, a differentiable call in train() mode must raise instead of
+    silently training a different model.  eval() and dropout = 0 are unaffected."""
+    import pytest
+    from posteriflow_amd import NSFPosteriorFlow, create_flow_model
+    flow = create_flow_model("nsf", 4, 8, num_layers=1, hidden_features=64, num_bins=4)
+    assert flow.dropout == 0.15
+    x, ctx = torch.zeros(2, 4), torch.zeros(2, 8)
+    flow.train()
+    with pytest.raises(NotImplementedError, match="dropout"):
+        flow.compute_psd_aware_nll(x, ctx, None)
+    with pytest.raises(NotImplementedError, match="dropout"):
+        flow(x, ctx)
+    flow.eval()
+    with pytest.raises(RuntimeError, match="no CPU fallback|MI355X"):     # gets as far as the device check
+        flow.compute_psd_aware_nll(x, ctx, None)
+    with pytest.raises(ValueError):
+        NSFPosteriorFlow(4, 8, 64, 1, 4, dropout=1.0)
