@@ -449,7 +449,7 @@ def main():
             "config": {"workload": "BASELINE config 3 flow: 8-layer MAF-RQS, D=15, C=288, H=256, K=16, "
                                    "tail_bound 5, context resident in HBM",
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
-                       "rows_per_workgroup": int(lib.pf_flow_rows_per_workgroup(flow._desc(), args.batch)),
+                       "rows_per_workgroup": int(lib.pf_flow_rows_per_workgroup(flow._desc(wide=flow._use_wide(args.batch)), args.batch)),
                        "launch": "hipGraph" if graph is not None else (f"pre-bound launch, in-kernel (sum nll, rows) + async all-reduce every {max(1, args.allreduce_every)} steps" if collective else "pre-bound launch"),
                        "global_mean_nll": mean_nll,
                        "parallelism": f"dp{world}"},

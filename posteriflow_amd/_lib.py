@@ -17,6 +17,7 @@ PF_OK, PF_ERR_BAD_ARG, PF_ERR_UNSUPPORTED, PF_ERR_HIP = 0, -1, -2, -3
 PF_PREC_F32, PF_PREC_BF16 = 0, 1
 PF_FLAG_HOIST_CTX = 1
 PF_FLAG_MASKED_CONTEXT = 2
+PF_FLAG_WIDE = 4
 PRECISIONS = {"fp32": PF_PREC_F32, "f32": PF_PREC_F32, "bf16": PF_PREC_BF16}
 
 

@@ -17,6 +17,9 @@ PF_DECL(0, 4) PF_DECL(0, 8) PF_DECL(0, 12) PF_DECL(0, 16)
 PF_DECL(1, 4) PF_DECL(1, 8) PF_DECL(1, 12) PF_DECL(1, 16)
 #undef PF_DECL
 
+int launch_flow_wide_d15(const FwdParams&, hipStream_t);
+int launch_flow_wide_d11(const FwdParams&, hipStream_t);
+
 size_t fwd_lds_bytes_host(const FlowPlan& L, int R) {
     const size_t par = (size_t)L.D * 16 * 52 * sizeof(float);
     const size_t pb = std::max((size_t)L.HK * R * kFragBytes, par);
@@ -25,6 +28,7 @@ size_t fwd_lds_bytes_host(const FlowPlan& L, int R) {
 }
 
 static int rows_per_workgroup_dir(const FlowPlan& L, int64_t batch, bool inverse) {
+    if (L.wide) return wide::kRowsPerWG;
     // A workgroup streams the whole weight set whatever its row count, so more rows per workgroup (R groups
     // of 16) amortise the stream -- but a launch costs ceil(workgroups / 256 CUs) rounds, and a round of
     // R = 1 / 2 / 3 groups takes 108 / 142 / 195 us (forward, measured): pick the R with the cheapest launch.
@@ -55,6 +59,7 @@ int rows_per_workgroup(const FlowPlan& L, int64_t batch) { return rows_per_workg
 
 // the kernel launch_flow_forward picks for (plan, batch), as rocprofv3 prints it
 void forward_kernel_name(const FlowPlan& L, int64_t batch, char* out, size_t n) {
+    if (L.wide) { snprintf(out, n, "pf::flow_wide_kernel<%d, %d>", L.D, L.CKM); return; }
     const int R = L.dense ? 1 : rows_per_workgroup(L, batch) / 16;
     snprintf(out, n, "pf::flow_kernel<%s, %d, %d, %d, %s, false>", L.bf16 ? "true" : "false", L.NT, R, L.CKM,
              L.dense ? "true" : "false");
@@ -62,6 +67,11 @@ void forward_kernel_name(const FlowPlan& L, int64_t batch, char* out, size_t n) 
 
 int launch_flow_forward(const FwdParams& p_in, hipStream_t s) {
     if (p_in.batch == 0) return PF_OK;
+    if (p_in.plan.wide) {
+        if (p_in.plan.D == 15) return launch_flow_wide_d15(p_in, s);
+        if (p_in.plan.D == 11) return launch_flow_wide_d11(p_in, s);
+        return PF_ERR_UNSUPPORTED;
+    }
     FwdParams p = p_in;
     if (const char* a = getenv("PF_ABLATE")) p.ablate = atoi(a);   // only honoured by -DPF_ABLATE_BUILD builds
     const int R = rows_per_workgroup(p.plan, p.batch) / 16;
@@ -77,6 +87,7 @@ int launch_flow_forward(const FwdParams& p_in, hipStream_t s) {
 
 int launch_flow_inverse(const FwdParams& p, hipStream_t s) {
     if (p.batch == 0) return PF_OK;
+    if (p.plan.wide) return PF_ERR_UNSUPPORTED;             // the large-batch layout is forward-only
     const int R = rows_per_workgroup_dir(p.plan, p.batch, true) / 16;
 #define PF_CASE(P, N) case N: return launch_flow_inverse_p##P##_nt##N(p, R, s);
     if (p.plan.bf16) {

@@ -50,6 +50,7 @@
 #include <stdint.h>
 
 #include "../../include/pf_hip.h"
+#include "pf_wide_layout.h"
 
 #if defined(__HIPCC__)
 #define PF_HD __host__ __device__
@@ -90,6 +91,7 @@ struct FlowPlan {
     int hoist;                  // 1: context projections hoisted (CKM = 0 in the streams)
     int additive;               // 1: masked-context conditioner: additive context, no reverse permutation
     int dense;                  // 1: KHS = KOS = 2*HK (masks too coarse to pair up), else HK+2 / HK+1
+    int wide;                   // 1: the large-batch kernel's single common stream (pf_wide_layout.h); CKS in CKM
     int KHS, KOS, NF;
     int kH[kMaxTiles];          // active k-steps of tile t in a masked H x H GEMM
     int kO[kMaxTiles];          // active k-steps of feature f in the final layer
@@ -156,6 +158,14 @@ inline int make_plan(const PfFlowDesc& d, FlowPlan& o) {
     o.kstep = o.bf16 ? 32 : 16;
     o.CK = (o.C + o.kstep - 1) / o.kstep;
     o.additive = (d.reserved & PF_FLAG_MASKED_CONTEXT) ? 1 : 0;
+    o.wide = 0;
+    if (d.reserved & PF_FLAG_WIDE) {
+        // the large-batch kernel: bf16, H = 256, plain (GLU) conditioner, context in-layer; built for (D, C) pairs only
+        if (!o.bf16 || o.H != wide::kHidden || (d.reserved & (PF_FLAG_MASKED_CONTEXT | PF_FLAG_HOIST_CTX)) ||
+            !wide::built(o.D, o.C))
+            return PF_ERR_UNSUPPORTED;
+        o.wide = 1;
+    }
     o.hoist = (d.reserved & (PF_FLAG_HOIST_CTX | PF_FLAG_MASKED_CONTEXT)) && o.C > 0 ? 1 : 0;
     o.CKM = o.hoist ? 0 : pick_ckm(o.bf16, o.NT, o.C);
     if (o.CKM < 0 || o.CK > 64) return PF_ERR_UNSUPPORTED;
@@ -198,6 +208,16 @@ inline int make_plan(const PfFlowDesc& d, FlowPlan& o) {
     o.biasFloats = (int64_t)o.L * o.NT * kBiasFloatsPerTile;
     o.ctxFrags = o.hoist ? (int64_t)3 * o.L * o.NT * o.CK : 0;
     o.ctxBiasFloats = o.hoist ? (int64_t)3 * o.L * o.NT * 16 : 0;
+    if (o.wide) {
+        const int cks = (o.C + 15) / 16;
+        o.CKM = cks; o.hoist = 0; o.dense = 0;
+        o.NF = wide::n_frags_padded(o.D, cks);
+        o.fragsPerWave = 0;
+        o.fragsTotal = wide::stream_frags(o.D, cks, o.L);
+        o.weightBytes = o.fragsTotal * kFragBytes;
+        o.biasFloats = (int64_t)o.L * wide::kBiasFloats;
+        o.ctxFrags = 0; o.ctxBiasFloats = 0;
+    }
     const int64_t ctxp = o.C > 0 ? ((int64_t)o.H * o.C + o.H) : 0;
     o.rawPerLayer = (int64_t)o.H * o.D + o.H + ctxp
                   + (int64_t)o.NB * (ctxp + 2 * ((int64_t)o.H * o.H + o.H))

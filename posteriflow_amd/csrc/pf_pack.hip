@@ -74,7 +74,117 @@ static Entry stream_entry(const FlowPlan& L, int w, int f) {
     return x;
 }
 
+// ---- the large-batch kernel's packed layout (pf_wide_layout.h) -----------------------------------------------------
+// One common stream [layer][NFP frags] (+ one ring of zero frags), then biases [layer][kBiasFloats].
+static int build_wide_pack_map(const FlowPlan& L, int32_t* map) {
+    namespace W = wide;
+    const RawOffsets ro = raw_offsets(L);
+    const int D = L.D, C = L.C, K = L.K, H = L.H, M = L.M, CKS = L.CKM;
+    const int NF = W::n_frags(D, CKS), NFP = W::n_frags_padded(D, CKS), NB = W::n_batches(D);
+    int perm[256];
+    sorted_units(D, H, perm);
+    // spline parameter of row u of a WH tile (u < 16: width u, else height u - 16) / a DD tile (derivative u & 15)
+    auto wh_param = [&](int u) { const int i = u & 15; return i < K ? (u < 16 ? i : K + i) : -1; };
+    auto dd_param = [&](int u) { const int i = u & 15; return i < K - 1 ? 2 * K + i : -1; };
+    int64_t idx = 0;
+    for (int l = 0; l < L.L; ++l) {
+        const int64_t base = (int64_t)l * ro.total;
+        for (int E = 0; E < NFP; ++E) {
+            // decode the frag: stage 0 in, 1 ctx, 2 W0, 3 W1, 4 gate, 5 WH, 6 DD, -1 pad
+            int stage = -1, T = 0, ks = 0, blk = 0, feat = 0, m = 0;
+            if (E < W::e_blk(D, CKS, 0)) {
+                T = E / (2 + CKS);
+                const int r = E % (2 + CKS);
+                if (r < 2) { stage = 0; ks = r; } else { stage = 1; ks = r - 2; }
+            } else if (E < W::e_out(D, CKS)) {
+                int r = E - W::e_blk(D, CKS, 0);
+                blk = r / W::blk_len(D, CKS);
+                r %= W::blk_len(D, CKS);
+                if (r < W::w0_len(D)) {
+                    stage = 2;
+                    while (T + 1 < W::kTiles && W::w0_off(D, T + 1) <= r) ++T;
+                    ks = r - W::w0_off(D, T);
+                } else {
+                    r -= W::w0_len(D);
+                    while (T + 1 < W::kTiles && W::w1_off(D, CKS, T + 1) <= r) ++T;
+                    const int rr = r - W::w1_off(D, CKS, T);
+                    if (rr < W::kH16(D, T)) { stage = 3; ks = rr; } else { stage = 4; ks = rr - W::kH16(D, T); }
+                }
+            } else if (E < NF) {
+                const int r = E - W::e_out(D, CKS);
+                while (m + 1 < NB && W::out_off(D, m + 1) <= r) ++m;
+                int rr = r - W::out_off(D, m);
+                if (rr < W::kO16(D, 2 * m)) { stage = 5; feat = 2 * m; ks = rr; }
+                else {
+                    rr -= W::kO16(D, 2 * m);
+                    if (rr < W::kWHb(D, m)) { stage = 5; feat = 2 * m + 1; ks = rr; }
+                    else { stage = 6; ks = rr - W::kWHb(D, m); }
+                }
+            }
+            for (int within = 0; within < 512; ++within, ++idx) {
+                const int lane = within >> 3, j = within & 7;
+                const int r32 = lane & 31, hf = lane >> 5;
+                int64_t src = -1;
+                const int pin = 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * hf + (j & 3);   // hidden-input k
+                if (stage >= 0 && stage <= 4) {
+                    const int u = perm[32 * T + r32];
+                    if (stage == 0) {
+                        const int d = 8 * hf + j;
+                        if (d < D && hid_degree(D, u) >= d + 1) src = ro.in_w + (int64_t)u * D + d;
+                    } else if (stage == 1 || stage == 4) {
+                        const int col = 16 * ks + 8 * hf + j;
+                        if (col < C) src = (stage == 1 ? ro.c_w : ro.g_w[blk]) + (int64_t)u * C + col;
+                    } else {
+                        const int uin = perm[pin];
+                        if (hid_degree(D, u) >= hid_degree(D, uin))
+                            src = (stage == 2 ? ro.w0_w[blk] : ro.w1_w[blk]) + (int64_t)u * H + uin;
+                    }
+                } else if (stage == 5) {
+                    const int pm = wh_param(r32), uin = perm[pin];
+                    if (pm >= 0 && feat + 1 > hid_degree(D, uin)) src = ro.out_w + ((int64_t)feat * M + pm) * H + uin;
+                } else if (stage == 6) {
+                    const int f = 2 * m + (r32 >> 4), pm = dd_param(r32), uin = perm[pin];
+                    if (f < D && pm >= 0 && f + 1 > hid_degree(D, uin)) src = ro.out_w + ((int64_t)f * M + pm) * H + uin;
+                }
+                map[idx] = src < 0 ? -1 : (int32_t)(base + src);
+            }
+        }
+    }
+    for (int64_t k = 0; k < (int64_t)W::kRing * 512; ++k) map[idx++] = -1;       // the DMA's run-ahead
+    if (idx != L.fragsTotal * 512) return PF_ERR_BAD_ARG;
+    for (int l = 0; l < L.L; ++l) {
+        const int64_t base = (int64_t)l * ro.total;
+        for (int s = 0; s < W::kBiasFloats; ++s, ++idx) {
+            int64_t src = -1;
+            if (s < W::kBiasOut) {
+                const int u = perm[s & 255];
+                const int which = s >> 8;                      // 0 in, 1 ctx, 2.. : block (W0, W1, gate)
+                if (which == 0) src = ro.in_b + u;
+                else if (which == 1) { if (C > 0) src = ro.c_b + u; }
+                else {
+                    const int b = (which - 2) / 3, w = (which - 2) % 3;
+                    if (w == 0) src = ro.w0_b[b] + u;
+                    else if (w == 1) src = ro.w1_b[b] + u;
+                    else if (C > 0) src = ro.g_b[b] + u;
+                }
+            } else {
+                const int r = s - W::kBiasOut, m = r / 96, t = (r % 96) / 32, u = r % 32;
+                if (t < 2) {
+                    const int f = 2 * m + t, pm = wh_param(u);
+                    if (f < D && pm >= 0) src = ro.out_b + (int64_t)f * M + pm;
+                } else {
+                    const int f = 2 * m + (u >> 4), pm = dd_param(u);
+                    if (f < D && pm >= 0) src = ro.out_b + (int64_t)f * M + pm;
+                }
+            }
+            map[idx] = src < 0 ? -1 : (int32_t)(base + src);
+        }
+    }
+    return PF_OK;
+}
+
 int build_pack_map(const FlowPlan& L, int32_t* map) {
+    if (L.wide) return build_wide_pack_map(L, map);
     const RawOffsets ro = raw_offsets(L);
     const int fragElems = L.bf16 ? 512 : 256;
     const int per = L.bf16 ? 8 : 4;   // elements per lane

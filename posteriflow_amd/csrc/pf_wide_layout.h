@@ -90,8 +90,8 @@ constexpr int out_off(int D, int m) {
 constexpr int n_frags(int D, int CKS) { return e_out(D, CKS) + out_off(D, n_batches(D)); }
 constexpr int n_frags_padded(int D, int CKS) { return (n_frags(D, CKS) + kRing - 1) / kRing * kRing; }
 
-// total frags of the packed stream: L layers + one epoch of zero frags (the ring prefetches one epoch ahead)
-constexpr int64_t stream_frags(int D, int CKS, int L) { return (int64_t)L * n_frags_padded(D, CKS) + kEpoch; }
+// total frags of the packed stream: L layers + one ring of zero frags (the DMA runs up to two epochs ahead)
+constexpr int64_t stream_frags(int D, int CKS, int L) { return (int64_t)L * n_frags_padded(D, CKS) + kRing; }
 constexpr int64_t packed_bytes(int D, int CKS, int L) {
     return stream_frags(D, CKS, L) * kFrag + (int64_t)L * kBiasFloats * (int64_t)sizeof(float);
 }

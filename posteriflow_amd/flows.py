@@ -254,6 +254,8 @@ class NSFPosteriorFlow(nn.Module):
             self._frozen = False
             self.packed_weights()
             self.packed_weights(inverse=True)
+            if self._use_wide(1 << 30):
+                self.packed_weights(wide=True)
         self._frozen = frozen
         return self
 
@@ -272,18 +274,19 @@ class NSFPosteriorFlow(nn.Module):
             raise ValueError("nll_into: bad context")
         dev = x.device
         perm, _ = self._perms(dev)
-        desc = self._desc()
+        wide = self._use_wide(B)
+        desc = self._desc(wide=wide)
         ws, ws_bytes = self._ws(desc, B, dev)
         if sum_count is not None:
             if sum_count.dtype != torch.float32 or sum_count.numel() != 2 or not sum_count.is_contiguous():
                 raise ValueError("nll_into: sum_count must be a contiguous fp32 tensor of 2 elements")
             _lib.check(_lib.lib().pf_flow_forward_reduce(
-                desc, self.packed_weights().data_ptr(), x.data_ptr(), _dev_ptr(context),
+                desc, self.packed_weights(wide=wide).data_ptr(), x.data_ptr(), _dev_ptr(context),
                 _dev_ptr(perm), _dev_ptr(log_sigma), B, out.data_ptr(), sum_count.data_ptr(), None,
                 _dev_ptr(ws), ws_bytes, torch.cuda.current_stream(dev).cuda_stream), "pf_flow_forward_reduce")
             return out
         _lib.check(_lib.lib().pf_flow_forward(
-            desc, self.packed_weights().data_ptr(), x.data_ptr(), _dev_ptr(context),
+            desc, self.packed_weights(wide=wide).data_ptr(), x.data_ptr(), _dev_ptr(context),
             _dev_ptr(perm), _dev_ptr(log_sigma), B, None, None, out.data_ptr(),
             _dev_ptr(ws), ws_bytes, torch.cuda.current_stream(dev).cuda_stream), "pf_flow_forward")
         return out
@@ -299,9 +302,10 @@ class NSFPosteriorFlow(nn.Module):
         self.nll_into(x, context, out)                          # validates shapes once
         dev = x.device
         perm, _ = self._perms(dev)
-        desc = self._desc()
+        wide = self._use_wide(x.shape[0])
+        desc = self._desc(wide=wide)
         ws, ws_bytes = self._ws(desc, x.shape[0], dev)
-        packed = self.packed_weights()
+        packed = self.packed_weights(wide=wide)
         fn = _lib.lib().pf_flow_forward_reduce if sum_count else _lib.lib().pf_flow_forward
         st = (stream or torch.cuda.current_stream(dev)).cuda_stream
         keep = (x, context, out, perm, ws, packed, desc, sum_count)
@@ -325,8 +329,23 @@ class NSFPosteriorFlow(nn.Module):
         return launch
 
     # ---- plumbing -------------------------------------------------------------
-    def _desc(self, precision: Optional[str] = None, inverse: bool = False) -> _lib.PfFlowDesc:
+    # ---- the large-batch ("wide") forward kernel: 128 rows per workgroup, weights fetched once per workgroup ----
+    wide_min_batch: int = 12288     # rows from which pf_flow_forward is given the PF_FLAG_WIDE layout (measured crossover)
+
+    def _use_wide(self, batch: int) -> bool:
+        env = os.environ.get("PF_FLOW_WIDE", "")
+        if env == "0" or self.precision != "bf16" or self.use_masked_context or self.hoist_context:
+            return False
+        if self.hidden_features != 256 or (self.features, self.context_features) not in ((15, 288), (11, 288)):
+            return False
+        return env == "1" or batch >= self.wide_min_batch
+
+    def _desc(self, precision: Optional[str] = None, inverse: bool = False, wide: bool = False) -> _lib.PfFlowDesc:
         prec = _lib.PRECISIONS[precision or self.precision]
+        if wide:
+            return _lib.PfFlowDesc(self.features, self.context_features, self.hidden_features, self.num_bins,
+                                   self.num_layers, 2, float(self._tail_bound), _MIN_BIN, _MIN_BIN, _MIN_BIN,
+                                   _lib.PF_PREC_BF16, _lib.PF_FLAG_WIDE)
         hoist = inverse if self.hoist_context is None else self.hoist_context
         flags = _lib.PF_FLAG_HOIST_CTX if (hoist and self.context_features > 0) else 0
         if self.use_masked_context:
@@ -370,9 +389,9 @@ class NSFPosteriorFlow(nn.Module):
                 "(no CPU fallback); move the module with .to('cuda')" % dev)
         return dev
 
-    def packed_weights(self, precision: Optional[str] = None, inverse: bool = False) -> torch.Tensor:
+    def packed_weights(self, precision: Optional[str] = None, inverse: bool = False, wide: bool = False) -> torch.Tensor:
         """Packed (masked, fragment-ordered) weights, rebuilt when a parameter changed."""
-        desc = self._desc(precision, inverse)
+        desc = self._desc(precision, inverse, wide)
         ck = (desc.precision, desc.reserved)
         if self._frozen and ck in self._packed and self._packed[ck].buf is not None:
             return self._packed[ck].buf
@@ -452,7 +471,7 @@ class NSFPosteriorFlow(nn.Module):
 
     def forward_kernel_name(self, batch: int) -> str:
         """Name of the kernel pf_flow_forward dispatches for this flow at `batch` rows (as rocprofv3 prints it)."""
-        name = _lib.lib().pf_flow_forward_kernel_name(self._desc(), int(batch))
+        name = _lib.lib().pf_flow_forward_kernel_name(self._desc(wide=self._use_wide(int(batch))), int(batch))
         return name.decode() if name else "?"
 
     def _forward_call(self, x, context, log_sigma, want_z=True, guard=True, layer_inputs=None):
@@ -467,8 +486,9 @@ class NSFPosteriorFlow(nn.Module):
         logdet = torch.empty(B, dtype=torch.float32, device=dev)
         nll = torch.empty(B, dtype=torch.float32, device=dev)
         perm, _ = self._perms(dev)
-        packed = self.packed_weights()
-        desc = self._desc()
+        wide = self._use_wide(B)
+        packed = self.packed_weights(wide=wide)
+        desc = self._desc(wide=wide)
         ws, ws_bytes = self._ws(desc, B, dev)
         # layer_inputs: fp32 [L, B, D] that receives every conditioner's input (training forward)
         _lib.check(_lib.lib().pf_flow_forward_train(

@@ -1,0 +1,125 @@
+"""GPU parity of the large-batch ("wide") forward kernel (csrc/pf_flow_wide_kernel.h, PF_FLAG_WIDE): 128 rows per
+workgroup, every wave owns 32 rows through all layers, weights fetched once per workgroup through an LDS ring.
+
+It computes the same function in the same arithmetic as the bf16 mode of the 16-row kernel (bf16 operands, x as a hi + lo
+pair, fp32 accumulate / residual / spline) but sums in a different order, so it is checked
+  * against the oracle evaluated with the same operand rounding (oracle.nflows_restated.gemm_emulation("bf16")):
+    tolerances of tests/test_flow_forward_gpu.py::test_forward_bf16_tolerance (median 5e-4 on z, 5e-3 on log|det|;
+    worst row 0.1 / 0.5: one bf16 rounding-boundary flip amplified by the later layers);
+  * against the 16-row kernel on the same inputs: the two must be as close to each other as each is to the emulation;
+  * for ragged batches, a permuted autoregressive order, a PSD log-scale, the in-kernel loss reduction and the
+    training forward's layer inputs.
+"""
+import pytest
+import torch
+
+from helpers import flow_inputs, make_pair
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(D, L, scale=1.0):
+    ref, ref64, flow = make_pair(D, 288, 256, L, 16, 5.0, scale=scale)
+    flow.precision = "bf16"
+    return ref, ref64, flow
+
+
+def _both(flow, fn):
+    """fn() through the 16-row kernel and through the wide kernel"""
+    flow.wide_min_batch = 1 << 40
+    a = fn()
+    flow.wide_min_batch = 1
+    b = fn()
+    return a, b
+
+
+@pytest.mark.parametrize("D,L,B,scale", [(15, 8, 1024, 1.0), (11, 10, 300, 1.0), (15, 2, 4096 + 17, 2.0), (15, 8, 128, 2.0)])
+def test_wide_forward_matches_the_oracle_and_the_16_row_kernel(D, L, B, scale):
+    from oracle import nflows_restated as nfr
+    from posteriflow_amd import _lib
+    ref, ref64, flow = _pair(D, L, scale)
+    x, ctx = flow_inputs(B, D, 288, 5.0)
+    with torch.no_grad():
+        with nfr.gemm_emulation("bf16"):
+            zemu, ldemu = ref(x, ctx)
+        z64, ld64 = ref64(x.double(), ctx.double())
+        (za, lda), (zw, ldw) = _both(flow, lambda: flow(x.cuda(), ctx.cuda()))
+        assert flow.forward_kernel_name(B) == f"pf::flow_wide_kernel<{D}, 18>"
+        assert _lib.lib().pf_flow_rows_per_workgroup(flow._desc(wide=True), B) == 128
+    q = lambda t: "med %.1e p99 %.1e max %.1e" % tuple(t.quantile(torch.tensor([0.5, 0.99, 1.0], dtype=t.dtype)).tolist())
+    ez_w, el_w = (zw.cpu() - zemu).abs().max(dim=1).values, (ldw.cpu() - ldemu).abs()
+    ez_a, el_a = (za.cpu() - zemu).abs().max(dim=1).values, (lda.cpu() - ldemu).abs()
+    ez_p, el_p = (zw - za).abs().max(dim=1).values.cpu(), (ldw - lda).abs().cpu()
+    print(f"\n[D{D} L{L} B{B} x{scale:g}] wide vs emulation: |z| {q(ez_w)}  |ld| {q(el_w)}\n"
+          f"      16-row vs emulation: |z| {q(ez_a)}  |ld| {q(el_a)}\n      wide vs 16-row: |z| {q(ez_p)}  |ld| {q(el_p)}\n"
+          f"      wide vs fp64: |z| {(zw.cpu().double() - z64).abs().max():.2e} |ld| {(ldw.cpu().double() - ld64).abs().max():.2e}")
+    assert torch.isfinite(zw).all() and torch.isfinite(ldw).all()
+    assert ez_w.median() < 5e-4 and el_w.median() < 5e-3
+    assert ez_w.max() < 0.1 * max(1.0, scale) and el_w.max() < 0.5 * max(1.0, scale)
+    assert ez_p.median() < 5e-4 and el_p.median() < 5e-3
+    assert (zw.cpu().double() - z64).abs().max() < 1.0 and (ldw.cpu().double() - ld64).abs().max() < 4.0
+
+
+def test_wide_ragged_order_log_sigma_reduction_and_layer_inputs():
+    D, L = 15, 3
+    ref, _, flow = _pair(D, L)
+    order = [2, 0, 1, 10, 9, 3, 4, 8, 5, 7, 6, 14, 12, 13, 11]
+    ref.set_autoregressive_order(order)
+    flow.set_autoregressive_order(order)
+    for B in (1, 31, 129, 1000):
+        x, ctx = flow_inputs(B, D, 288, 5.0, tails=B > 3)
+        ls = torch.randn(B, D, generator=torch.Generator().manual_seed(B)) * 0.3
+        xg, cg, lg = x.cuda().contiguous(), ctx.cuda().contiguous(), ls.cuda()
+        with torch.no_grad():
+            a, w = _both(flow, lambda: flow.compute_psd_aware_nll(xg, cg, lg))
+            assert w.shape == (B,) and torch.isfinite(w).all()
+            err = (w - a).abs() / a.abs().clamp_min(1.0)
+            assert err.median() < 1e-4 and err.max() < 5e-2, (B, err.max())
+            # in-kernel (sum nll, rows) of the wide kernel
+            nll = torch.empty(B, device="cuda")
+            acc = torch.zeros(2, device="cuda")
+            flow.nll_into(xg, cg, nll, sum_count=acc)
+            want = flow.compute_psd_aware_nll(xg, cg, None)
+            assert torch.equal(nll, want) and acc[1].item() == B
+            assert abs(acc[0].item() - want.double().sum().item()) <= 2e-5 * want.double().abs().sum().item() + 1e-3
+            # training forward: the conditioner input of every layer (what the backward re-evaluates from)
+            ua = torch.empty(L, B, D, device="cuda"); uw = torch.empty(L, B, D, device="cuda")
+            flow.wide_min_batch = 1 << 40
+            flow._forward_call(xg, cg, None, guard=False, layer_inputs=ua)
+            flow.wide_min_batch = 1
+            flow._forward_call(xg, cg, None, guard=False, layer_inputs=uw)
+            assert torch.equal(ua[0], uw[0])                    # layer 0's input is x itself, permuted
+            assert (ua - uw).abs().median() < 1e-4 and (ua - uw).abs().max() < 5e-2
+
+
+def test_wide_is_refused_where_it_is_not_built():
+    from posteriflow_amd import _lib
+    _, _, flow = make_pair(7, 40, 128, 2, 10, 2.5)
+    flow.precision = "bf16"
+    flow.wide_min_batch = 1
+    assert not flow._use_wide(1 << 20)                          # shape not built: the 16-row kernel serves it
+    x, ctx = flow_inputs(64, 7, 40, 2.5)
+    z, _ = flow(x.cuda(), ctx.cuda())
+    assert torch.isfinite(z).all()
+    _, _, flow = _pair(15, 2)
+    flow.precision = "fp32"
+    assert not flow._use_wide(1 << 20)                          # fp32 parity mode never uses it
+    d = flow._desc(wide=True)
+    assert _lib.lib().pf_flow_inverse(d, 16, 16, 16, 1, None, 1, 16, None, None, None, 0, None) == _lib.PF_ERR_UNSUPPORTED
+
+
+def test_wide_full_size_statistics():
+    """B = 65536 (the size the kernel exists for): finite everywhere, the same mean NLL as the 16-row kernel to
+    1e-4 relative, and 64 sampled rows against the fp32 oracle like test_rows_per_workgroup_choice_and_parity."""
+    D, L, B = 15, 8, 65536
+    ref, _, flow = _pair(D, L, 2.0)
+    x, ctx = flow_inputs(B, D, 288, 5.0)
+    xg, cg = x.cuda(), ctx.cuda()
+    with torch.no_grad():
+        a, w = _both(flow, lambda: flow.compute_psd_aware_nll(xg, cg, None))
+        idx = torch.linspace(0, B - 1, 64).long()
+        want = ref.compute_psd_aware_nll(x[idx], ctx[idx], torch.zeros(64, D))
+    assert torch.isfinite(w).all()
+    assert abs(w.double().mean().item() - a.double().mean().item()) < 1e-4 * abs(a.double().mean().item())
+    err = (w.cpu()[idx] - want).abs() / want.abs().clamp_min(1.0)
+    assert err.median() < 2e-2 and err.max() < 0.3

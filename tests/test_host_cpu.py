@@ -85,6 +85,49 @@ def test_pack_map_covers_exactly_the_unmasked_weights(lib, D, C, H, K, L, prec, 
     assert sum(p.numel() for p in t.parameters()) == per_layer
 
 
+@pytest.mark.parametrize("D,K,L", [(15, 16, 2), (11, 16, 3), (15, 9, 1)])
+def test_wide_pack_map_covers_exactly_the_unmasked_weights(lib, D, K, L):
+    """The large-batch kernel's layout (PF_FLAG_WIDE, csrc/pf_wide_layout.h): one common stream of 32 x 16 fragments in
+    the accumulator-permuted k order.  Same coverage property as the per-wave streams: every unmasked weight once (the
+    x-input layer twice: hi | lo), every masked weight never, every bias once; plus the sizes the kernel assumes."""
+    from oracle import nflows_restated as nfr
+    C_, H = 288, 256
+    d = desc_of(lib, D, C_, H, K, L, "bf16", lib.PF_FLAG_WIDE)
+    h = lib.lib()
+    n = h.pf_flow_pack_map_len(C_byref(d))
+    assert n > 0
+    m = np.empty(n, dtype=np.int32)
+    assert h.pf_flow_build_pack_map(C_byref(d), m.ctypes.data) == 0
+    per_layer = h.pf_flow_raw_param_count(C_byref(d)) // L
+    counts = np.bincount(m[m >= 0], minlength=per_layer * L)
+    t = nfr.MaskedPiecewiseRationalQuadraticAutoregressiveTransform(D, H, C_, K, 5.0)
+    net = t.autoregressive_net
+    masks = {"in_w": 2 * net.initial_layer.mask.numpy(), "out_w": net.final_layer.mask.numpy()}
+    for b in range(2):
+        masks[f"w0{b}_w"] = net.blocks[b].linear_layers[0].mask.numpy()
+        masks[f"w1{b}_w"] = net.blocks[b].linear_layers[1].mask.numpy()
+    for layer in range(L):
+        off = layer * per_layer
+        for name, r, c in raw_layout(D, C_, H, K):
+            got = counts[off:off + r * c].reshape(r, c)
+            assert np.array_equal(got, masks.get(name, np.ones((r, c))).astype(np.int64)), (layer, name)
+            off += r * c
+    # stream: whole fragments, a multiple of the 72-fragment ring per layer, one ring of zero fragments behind it
+    packed = h.pf_flow_packed_bytes(C_byref(d))
+    bias_floats = 2048 + 8 * 96
+    frags = (packed - L * bias_floats * 4) // 1024
+    assert (packed - L * bias_floats * 4) % 1024 == 0 and (frags - 72) % (72 * L) == 0
+    assert n == frags * 512 + L * bias_floats
+    assert (m[(frags - 72) * 512: frags * 512] == -1).all()
+    assert h.pf_flow_rows_per_workgroup(C_byref(d), 100000) == 128
+    assert h.pf_flow_forward_kernel_name(C_byref(d), 100000) == f"pf::flow_wide_kernel<{D}, 18>".encode()
+    # shapes the wide kernel is not built for are refused, not silently served by another layout
+    for bad in (desc_of(lib, 7, 288, 256, 16, 2, "bf16", lib.PF_FLAG_WIDE), desc_of(lib, 15, 256, 256, 16, 2, "bf16", lib.PF_FLAG_WIDE),
+                desc_of(lib, 15, 288, 256, 16, 2, "fp32", lib.PF_FLAG_WIDE), desc_of(lib, 15, 288, 128, 16, 2, "bf16", lib.PF_FLAG_WIDE),
+                desc_of(lib, 15, 288, 256, 16, 2, "bf16", lib.PF_FLAG_WIDE | lib.PF_FLAG_HOIST_CTX)):
+        assert h.pf_flow_pack_map_len(C_byref(bad)) < 0
+
+
 def C_byref(x):
     return C.byref(x)
 
