@@ -96,6 +96,97 @@ template <bool FAST> __device__ __forceinline__ float pf_sigmoid(float v) {
 
 constexpr int kParStride = 52;   // floats per (row, feature) pair in the LDS transpose (48 used)
 
+// v_max_f32 / v_max3_f32 without the NaN-quieting v_max x, x that fmaxf costs under IEEE mode (rqs_pair_fast16 only;
+// a NaN operand gives the other operand, like fmaxf)
+__device__ __forceinline__ float pf_max3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float pf_max2(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// rqs_pair for K = 16 in the throughput (bf16) mode: the same spline, ~40 % fewer instructions and shallower
+// dependency chains.  Differences from the step-by-step form below (all at fp32 rounding level, none in what is
+// computed): the exponentials are one fma + v_exp each (log2 e folded in), the softmax sums are trees, the knots are a
+// fused running sum k[i+1] = k[i] + 2B min + (2B (1 - 16 min) / sum) e[i] instead of cumsum-then-affine, and the bin is
+// found by a 4-level binary search over the 17 knots (select trees on knots, heights and derivatives: 57 selects
+// instead of 6 per bin) -- knots increase strictly (min bin width), so it finds searchsorted's bin, including x = B
+// (last knot + 1e-6: never compared, the search ends in bin 15).
+__device__ __forceinline__ void rqs_pair_fast16(const float* par, float x, const FwdParams& p, float& y, float& ld) {
+    float uw[16], uh[16], kd[17];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(par + 4 * q);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(par + 16 + 4 * q);
+        const f32x4 c = *reinterpret_cast<const f32x4*>(par + 32 + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { uw[4 * q + e] = a[e]; uh[4 * q + e] = b[e]; kd[1 + 4 * q + e] = c[e]; }
+    }
+    const float tb = p.tail_bound, span = 2.f * tb;
+    kd[0] = p.deriv_const; kd[16] = p.deriv_const;
+    constexpr float kL2E = 1.44269504f;
+    auto max16 = [](const float (&v)[16]) {
+        const float a = pf_max3(v[0], v[1], v[2]), b = pf_max3(v[3], v[4], v[5]), c = pf_max3(v[6], v[7], v[8]);
+        const float d = pf_max3(v[9], v[10], v[11]), e = pf_max3(v[12], v[13], v[14]);
+        return pf_max3(pf_max3(a, b, c), pf_max3(d, e, v[15]), v[15]);
+    };
+    const float mw = -max16(uw) * kL2E, mh = -max16(uh) * kL2E;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        uw[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(uw[i], kL2E, mw));
+        uh[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(uh[i], kL2E, mh));
+    }
+    auto sum16 = [](const float (&v)[16]) {
+        return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])) +
+               (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
+    };
+    const float aw = span * (1.f - p.min_w * 16.f) * __builtin_amdgcn_rcpf(sum16(uw)), bw = span * p.min_w;
+    const float ah = span * (1.f - p.min_h * 16.f) * __builtin_amdgcn_rcpf(sum16(uh)), bh = span * p.min_h;
+    float kw[17], kh[17];
+    kw[0] = -tb; kh[0] = -tb;
+#pragma unroll
+    for (int i = 0; i < 15; ++i) {
+        kw[i + 1] = __builtin_fmaf(aw, uw[i], kw[i] + bw);
+        kh[i + 1] = __builtin_fmaf(ah, uh[i], kh[i] + bh);
+    }
+    kw[16] = tb; kh[16] = tb;
+    // binary search: after level j the candidate knots are a window of 2^(4-j) + 1 consecutive knots
+    float w9[9], h9[9], d9[9];
+    const bool c1 = x >= kw[8];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { w9[i] = c1 ? kw[8 + i] : kw[i]; h9[i] = c1 ? kh[8 + i] : kh[i]; d9[i] = c1 ? kd[8 + i] : kd[i]; }
+    float w5[5], h5[5], d5[5];
+    const bool c2 = x >= w9[4];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { w5[i] = c2 ? w9[4 + i] : w9[i]; h5[i] = c2 ? h9[4 + i] : h9[i]; d5[i] = c2 ? d9[4 + i] : d9[i]; }
+    float w3[3], h3[3], d3[3];
+    const bool c3 = x >= w5[2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { w3[i] = c3 ? w5[2 + i] : w5[i]; h3[i] = c3 ? h5[2 + i] : h5[i]; d3[i] = c3 ? d5[2 + i] : d5[i]; }
+    const bool c4 = x >= w3[1];
+    const float xl = c4 ? w3[1] : w3[0], xr = c4 ? w3[2] : w3[1];
+    const float yl = c4 ? h3[1] : h3[0], yr = c4 ? h3[2] : h3[1];
+    const float dl_raw = c4 ? d3[1] : d3[0], dr_raw = c4 ? d3[2] : d3[1];
+    const float w = xr - xl, h = yr - yl;
+    const float dl = p.min_d + pf_softplus<true>(dl_raw);
+    const float dr = p.min_d + pf_softplus<true>(dr_raw);
+    const float rw = __builtin_amdgcn_rcpf(w);
+    const float delta = h * rw;
+    const float th = (x - xl) * rw;
+    const float tt = th * (1.f - th);
+    const float numer = h * (delta * th * th + dl * tt);
+    const float den = delta + (dl + dr - 2.f * delta) * tt;
+    const float omt = 1.f - th;
+    const float dnum = delta * delta * (dr * th * th + 2.f * delta * tt + dl * omt * omt);
+    const bool inside = (x >= -tb) && (x <= tb);
+    y = inside ? yl + numer * __builtin_amdgcn_rcpf(den) : x;
+    ld = inside ? (__builtin_amdgcn_logf(dnum) - 2.f * __builtin_amdgcn_logf(den)) * 0.693147181f : 0.f;
+}
+
 // Forward RQS of one (row, feature) pair by one lane.  par: 16 raw widths | 16 raw heights |
 // 15 raw derivatives (rows >= K unused).  Follows nflows' rational_quadratic_spline /
 // unconstrained_rational_quadratic_spline (tails = 'linear') step by step: softmax,
@@ -105,6 +196,9 @@ constexpr int kParStride = 52;   // floats per (row, feature) pair in the LDS tr
 template <bool FAST>
 __device__ __forceinline__ void rqs_pair(const float* par, float x, int K, const FwdParams& p,
                                          float& y, float& ld) {
+    if constexpr (FAST) {
+        if (K == 16) { rqs_pair_fast16(par, x, p, y, ld); return; }
+    }
     float uw[16], uh[16], ud[16];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {

@@ -30,6 +30,31 @@
 #include "pf_flow_fwd_kernel.h"
 #include "pf_wide_layout.h"
 
+#ifndef PF_WIDE_ABLATE
+#define PF_WIDE_ABLATE 0   // timing experiments only: 1 no spline, 2 no weight DMA, 4 no MFMA, 8 no sigmoid, 16 no fragment reads, 32 no bias reads
+#endif
+#ifndef PF_WIDE_P
+#define PF_WIDE_P 4        // A fragments requested ahead of their MFMA
+#endif
+
+#ifndef PF_WIDE_BUFDMA
+#define PF_WIDE_BUFDMA 1   // 1: weight DMA as buffer_load_dwordx4 ... offen lds (SGPR resource + one constant lane-offset VGPR)
+#endif
+#ifndef PF_WIDE_PKRELU
+#define PF_WIDE_PKRELU 0   // 1: ReLU on the packed bf16 pairs (v_pk_max_i16 with 0) instead of on the fp32 values
+#endif
+#ifndef PF_WIDE_NOSCHED
+#define PF_WIDE_NOSCHED 0  // 1: no scheduling barriers between tiles
+#endif
+#if PF_WIDE_NOSCHED
+#define PF_WIDE_SCHED_BARRIER() ((void)0)
+#else
+#define PF_WIDE_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#endif
+#ifndef PF_WIDE_TRACE
+#define PF_WIDE_TRACE 0    // diagnostic build: wave 0 of workgroup 0 accumulates s_memtime spans per stage into p.fail_flags
+#endif
+
 namespace pf {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -55,7 +80,7 @@ __global__ __launch_bounds__(256) void flow_wide_kernel(const FwdParams p) {
     namespace W = wide;
     constexpr int NF = W::n_frags(D, CKS), NFP = W::n_frags_padded(D, CKS);
     constexpr int NB = W::n_batches(D);
-    constexpr int P = 4;                                   // A fragments requested ahead of their MFMA
+    constexpr int P = PF_WIDE_P;                           // A fragments requested ahead of their MFMA
     constexpr int XS = W::kXStride, PS = W::kParStride;
     static_assert(NFP % W::kRing == 0 && W::kEpoch % W::kWaves == 0, "ring geometry");
     static_assert(D >= 2 && D <= 16, "2 <= D <= 16");
@@ -82,10 +107,21 @@ __global__ __launch_bounds__(256) void flow_wide_kernel(const FwdParams p) {
     const char* gstream = p.packed + (int64_t)wave * W::kFrag;                   // + (layer * NFP + frag) * 1 KiB
     const uint32_t lane16 = lane * 16;
     const uint32_t ring_w = lds_addr(ring) + wave * W::kFrag;
+    __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.packed), 0, 0x7fffffff, 0x00020000);
     auto dma_epoch = [&](const char* src_u, int half) {       // src_u: uniform address of the epoch's fragment `wave`
         const char* src = src_u;
         uint32_t dst = ring_w;
         asm volatile("" : "+s"(src), "+s"(dst));
+        if (PF_WIDE_ABLATE & 2) return;
+        if (PF_WIDE_BUFDMA) {
+            const int soff = (int)(src - p.packed);
+#pragma unroll
+            for (int i = 0; i < W::kEpoch / W::kWaves; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    wrsrc, reinterpret_cast<__attribute__((address_space(3))) void*>(dst + (half * W::kEpoch + i * W::kWaves) * W::kFrag),
+                    16, lane16, soff + i * W::kWaves * W::kFrag, 0, 0);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < W::kEpoch / W::kWaves; ++i)
             __builtin_amdgcn_global_load_lds(
@@ -93,6 +129,11 @@ __global__ __launch_bounds__(256) void flow_wide_kernel(const FwdParams p) {
                 reinterpret_cast<__attribute__((address_space(3))) void*>(dst + (half * W::kEpoch + i * W::kWaves) * W::kFrag),
                 16, 0, 0);
     };
+    // diagnostic spans (PF_WIDE_TRACE): 0 stage 1, 1 W0, 2 W1 + gate, 3 final GEMMs, 4 spline, 5 pad + bias reload,
+    // 6 DMA issue, 7 barrier A, 8 barrier B, 9 whole kernel
+    unsigned long long tr[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto tick = [&]() -> unsigned long long { return PF_WIDE_TRACE ? __builtin_amdgcn_s_memtime() : 0ull; };
+    const unsigned long long t_begin = tick();
     dma_epoch(gstream, 0);
     dma_epoch(gstream + (int64_t)W::kEpoch * W::kFrag, 1);
 
@@ -155,33 +196,24 @@ __global__ __launch_bounds__(256) void flow_wide_kernel(const FwdParams p) {
     uint32_t sxn = lds_addr(s_x + 32 * XS + n * XS);
     auto rd = [&](auto e) {                                 // request fragment E (of this layer, or E - NFP of the next)
         constexpr int E = decltype(e)::value;
-        if constexpr (E % W::kEpoch == 0)                   // barrier A: the half about to be read has landed, for everyone
+        if constexpr (E % W::kEpoch == 0) {                 // barrier A: the half about to be read has landed, for everyone
+            const unsigned long long t0 = tick();
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        aq[E % P] = lds_ld_u4(rl + (E % W::kRing) * W::kFrag);
+            tr[7] += tick() - t0;
+        }
+        if (PF_WIDE_ABLATE & 16) { aq[E % P] = wu32x4{0x3f803f80u + E, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}; asm volatile("" : "+v"(aq[E % P])); }
+        else aq[E % P] = lds_ld_u4(rl + (E % W::kRing) * W::kFrag);
     };
     auto after = [&](auto e) {                              // fragment E has been consumed
         constexpr int E = decltype(e)::value;
         if constexpr ((E + 1) % W::kEpoch == 0) {           // barrier B: everyone is done with that half: refill it
+            const unsigned long long t0 = tick();
             asm volatile("s_barrier" ::: "memory");
+            const unsigned long long t1 = tick();
             dma_epoch(glayer + (int64_t)(E + 1 + W::kEpoch) * W::kFrag, ((E + 1) / W::kEpoch + 1) & 1);
+            tr[8] += t1 - t0;
+            tr[6] += tick() - t1;
         }
-    };
-    auto use = [&](auto e, const bf16x8& b, f32x16& acc) {
-        constexpr int E = decltype(e)::value;
-        const wu32x4 a = aq[E % P];
-        rd(ic<E + P>{});
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), b, acc, 0, 0, 0);
-        after(e);
-    };
-    auto bias16 = [&](int off) {                            // accumulator initialised with the tile's 32 biases
-        f32x16 r;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 v = lds_ld_f4(sb + 4 * (off + 8 * q));
-#pragma unroll
-            for (int e = 0; e < 4; ++e) r[4 * q + e] = v[e];
-        }
-        return r;
     };
     // registers 8 s .. 8 s + 7 of an accumulator tile -> the B fragment of k-step s of the next GEMM
     auto to_b = [&](const f32x16& v, int s, bool relu) {
@@ -189,7 +221,12 @@ __global__ __launch_bounds__(256) void flow_wide_kernel(const FwdParams p) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float t = v[8 * s + j];
-            o[j] = (__bf16)(relu ? fmaxf(t, 0.f) : t);
+            o[j] = (__bf16)((relu && !PF_WIDE_PKRELU) ? fmaxf(t, 0.f) : t);
+        }
+        if (relu && PF_WIDE_PKRELU) {      // a negative bf16 is a negative int16: max with 0 per 16-bit half (-0 -> +0)
+            typedef __attribute__((ext_vector_type(8))) short s16x8;
+            const s16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+            o = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, o), zero));
         }
         // B fragments live in AGPRs (the MFMA reads them there): with h, the activations and the context all in the
         // 256 architectural VGPRs the allocator spills ~2500 registers
@@ -204,8 +241,53 @@ __global__ __launch_bounds__(256) void flow_wide_kernel(const FwdParams p) {
     f32x16 h[W::kTiles];
     bf16x8 bin[W::kKSteps], bout[W::kKSteps];
 
+    // ---- software pipeline of a GEMM stage ---------------------------------------------------------------------------
+    // One wave per SIMD hides nothing by itself: the MFMA chain of a tile and its epilogue (bias, activation, bf16
+    // conversion, ...) run back to back unless they are interleaved in program order.  So the epilogue of tile T - 1
+    // is cut into 16 one-element pieces and dealt out behind the MFMAs of tile T (independent work that issues while
+    // the matrix pipe runs the chain); scheduling fences keep that order.  Chains start from C = 0 (inline constant)
+    // and the bias is added by the pieces; bias values travel through a two-deep queue of 4-float LDS reads, each
+    // requested one quad of elements ahead of its use.
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto step = [&](auto e, auto first, const bf16x8& b, f32x16& acc) {
+        constexpr int E = decltype(e)::value;
+        const wu32x4 a = aq[E % P];
+        rd(ic<E + P>{});
+        if (PF_WIDE_ABLATE & 4) asm volatile("" :: "v"(a), "a"(b));
+        else if constexpr (decltype(first)::value)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), b, zero16, 0, 0, 0);
+        else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), b, acc, 0, 0, 0);
+        after(e);
+    };
+    auto fence = [&]() { PF_WIDE_SCHED_BARRIER(); };
+    // NS MFMA steps with NP pieces dealt out behind them (all pieces first when there is no step)
+    auto interleave = [&](auto ns, auto np, auto&& do_step, auto&& do_piece) {
+        constexpr int NS = decltype(ns)::value, NP = decltype(np)::value;
+        if constexpr (NS == 0) {
+            static_for<0, NP>(do_piece);
+        } else {
+            static_for<0, NS>([&](auto kk) {
+                constexpr int k = decltype(kk)::value;
+                do_step(kk);
+                constexpr int j0 = k * NP / NS, j1 = (k + 1) * NP / NS;
+                static_for<j0, j1 - j0>(do_piece);
+                fence();
+            });
+        }
+    };
+    f32x4 bq0[2], bq1[2];                                   // bias queues (second one: the gate / context bias)
+    auto pack8 = [&](const float (&t)[8]) {                 // 8 fp32 -> one B fragment, parked in AGPRs
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (__bf16)t[j];
+        asm volatile("" : "+a"(o));
+        return o;
+    };
+
     for (int l = 0; l < NL; ++l) {
         asm volatile("" : "+v"(rl), "+v"(sb), "+v"(spw), "+v"(sxc), "+v"(sxn));
+        unsigned long long ts = tick();
+        auto span = [&](int i) { const unsigned long long t = tick(); tr[i] += t - ts; ts = t; };
         // ---- stage 1: h = W_in x + b_in + relu(W_c ctx + b_c) ----------------------------------------------------
         {
             bf16x8 xhi, xlo;
@@ -218,60 +300,114 @@ __global__ __launch_bounds__(256) void flow_wide_kernel(const FwdParams p) {
                 xhi[j] = hi;
                 xlo[j] = (__bf16)(v - (float)hi);
             }
+            f32x16 a1[2], a2[2];
+            bq0[0] = lds_ld_f4(sb + 4 * (W::kBiasIn));
+            bq1[0] = lds_ld_f4(sb + 4 * (W::kBiasCtx));
+            auto piece = [&](auto tp, auto jj) {            // element jj of tile tp: h = a1 + b_in + relu(a2 + b_c)
+                constexpr int TP = decltype(tp)::value, i = decltype(jj)::value, Q = TP * 4 + i / 4;
+                if constexpr (i % 4 == 0 && Q + 1 < 4 * W::kTiles) {
+                    bq0[(Q + 1) & 1] = lds_ld_f4(sb + 4 * (W::kBiasIn + 8 * (Q + 1)));
+                    if constexpr (CKS > 0) bq1[(Q + 1) & 1] = lds_ld_f4(sb + 4 * (W::kBiasCtx + 8 * (Q + 1)));
+                }
+                float v = a1[TP & 1][i] + bq0[Q & 1][i & 3];
+                if constexpr (CKS > 0) v += fmaxf(a2[TP & 1][i] + bq1[Q & 1][i & 3], 0.f);
+                h[TP][i] = v;
+            };
             static_for<0, W::kTiles>([&](auto tt) {
                 constexpr int T = decltype(tt)::value;
                 constexpr int E0 = W::e_in(CKS, T);
-                f32x16 a1 = bias16(W::kBiasIn + 32 * T);
-                use(ic<E0>{}, xhi, a1);
-                use(ic<E0 + 1>{}, xlo, a1);
-                if constexpr (CKS > 0) {
-                    f32x16 a2 = bias16(W::kBiasCtx + 32 * T);
-                    static_for<0, CKS>([&](auto kk) { use(ic<E0 + 2 + decltype(kk)::value>{}, cx[decltype(kk)::value], a2); });
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) a1[i] += fmaxf(a2[i], 0.f);
-                }
-                h[T] = a1;
-                __builtin_amdgcn_sched_barrier(0);
+                interleave(ic<2 + CKS>{}, ic<(T > 0 ? 16 : 0)>{},
+                           [&](auto kk) {
+                               constexpr int k = decltype(kk)::value;
+                               if constexpr (k == 0) step(ic<E0>{}, ic<1>{}, xhi, a1[T & 1]);
+                               else if constexpr (k == 1) step(ic<E0 + 1>{}, ic<0>{}, xlo, a1[T & 1]);
+                               else step(ic<E0 + k>{}, ic<(k == 2)>{}, cx[k - 2], a2[T & 1]);
+                           },
+                           [&](auto jj) { piece(ic<(T > 0 ? T - 1 : 0)>{}, jj); });
             });
+            static_for<0, 16>([&](auto jj) { piece(ic<W::kTiles - 1>{}, jj); });
+            fence();
         }
+        span(0);
         // ---- residual blocks: h += (W1 relu(W0 relu(h) + b0) + b1) * sigmoid(W_g ctx + b_g) -----------------------
         static_for<0, 2>([&](auto bb) {
             constexpr int b = decltype(bb)::value;
             constexpr int EB = W::e_blk(D, CKS, b);
             constexpr int EW1 = EB + W::w0_len(D);
+            constexpr int OB0 = W::kBiasBlk + 768 * b, OB1 = OB0 + 256, OBG = OB0 + 512;
 #pragma unroll
             for (int T = 0; T < W::kTiles; ++T) { bin[2 * T] = to_b(h[T], 0, true); bin[2 * T + 1] = to_b(h[T], 1, true); }
-            static_for<0, W::kTiles>([&](auto tt) {
-                constexpr int T = decltype(tt)::value;
-                f32x16 acc = bias16(W::kBiasBlk + 768 * b + 32 * T);
-                static_for<0, W::kH16(D, T)>([&](auto kk) {
-                    use(ic<EB + W::w0_off(D, T) + decltype(kk)::value>{}, bin[decltype(kk)::value], acc);
+            {
+                f32x16 acc[2];
+                float t8[8];
+                bq0[0] = lds_ld_f4(sb + 4 * OB0);
+                auto piece = [&](auto tp, auto jj) {        // element jj of tile tp: relu(acc + b0) -> bout
+                    constexpr int TP = decltype(tp)::value, i = decltype(jj)::value, Q = TP * 4 + i / 4;
+                    if constexpr (i % 4 == 0 && Q + 1 < 4 * W::kTiles) bq0[(Q + 1) & 1] = lds_ld_f4(sb + 4 * (OB0 + 8 * (Q + 1)));
+                    t8[i & 7] = fmaxf(acc[TP & 1][i] + bq0[Q & 1][i & 3], 0.f);
+                    if constexpr ((i & 7) == 7) bout[2 * TP + i / 8] = pack8(t8);
+                };
+                static_for<0, W::kTiles>([&](auto tt) {
+                    constexpr int T = decltype(tt)::value;
+                    interleave(ic<W::kH16(D, T)>{}, ic<(T > 0 ? 16 : 0)>{},
+                               [&](auto kk) {
+                                   constexpr int k = decltype(kk)::value;
+                                   step(ic<EB + W::w0_off(D, T) + k>{}, ic<(k == 0)>{}, bin[k], acc[T & 1]);
+                               },
+                               [&](auto jj) { piece(ic<(T > 0 ? T - 1 : 0)>{}, jj); });
                 });
-                bout[2 * T] = to_b(acc, 0, true);
-                bout[2 * T + 1] = to_b(acc, 1, true);
-                __builtin_amdgcn_sched_barrier(0);
-            });
-            static_for<0, W::kTiles>([&](auto tt) {
-                constexpr int T = decltype(tt)::value;
-                constexpr int E0 = EW1 + W::w1_off(D, CKS, T);
-                f32x16 acc = bias16(W::kBiasBlk + 768 * b + 256 + 32 * T);
-                static_for<0, W::kH16(D, T)>([&](auto kk) { use(ic<E0 + decltype(kk)::value>{}, bout[decltype(kk)::value], acc); });
-                if constexpr (CKS > 0) {
-                    f32x16 g = bias16(W::kBiasBlk + 768 * b + 512 + 32 * T);
-                    static_for<0, CKS>([&](auto kk) {
-                        use(ic<E0 + W::kH16(D, T) + decltype(kk)::value>{}, cx[decltype(kk)::value], g);
-                    });
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) h[T][i] += acc[i] * pf_sigmoid<true>(g[i]);
-                } else {
-                    h[T] += acc;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            });
+                static_for<0, 16>([&](auto jj) { piece(ic<W::kTiles - 1>{}, jj); });
+                fence();
+            }
+            span(1);
+            {
+                f32x16 accw[2], accg[2];
+                bq0[0] = lds_ld_f4(sb + 4 * OB1);
+                if constexpr (CKS > 0) bq1[0] = lds_ld_f4(sb + 4 * OBG);
+                auto piece = [&](auto tp, auto jj) {        // element jj of tile tp: h += (acc + b1) * sigmoid(g + b_g)
+                    constexpr int TP = decltype(tp)::value, i = decltype(jj)::value, Q = TP * 4 + i / 4;
+                    if constexpr (i % 4 == 0 && Q + 1 < 4 * W::kTiles) {
+                        bq0[(Q + 1) & 1] = lds_ld_f4(sb + 4 * (OB1 + 8 * (Q + 1)));
+                        if constexpr (CKS > 0) bq1[(Q + 1) & 1] = lds_ld_f4(sb + 4 * (OBG + 8 * (Q + 1)));
+                    }
+                    const float t = accw[TP & 1][i] + bq0[Q & 1][i & 3];
+                    if constexpr (CKS > 0) {
+                        const float g = accg[TP & 1][i] + bq1[Q & 1][i & 3];
+                        h[TP][i] += t * ((PF_WIDE_ABLATE & 8) ? g : pf_sigmoid<true>(g));
+                    } else {
+                        h[TP][i] += t;
+                    }
+                };
+                static_for<0, W::kTiles>([&](auto tt) {
+                    constexpr int T = decltype(tt)::value;
+                    constexpr int E0 = EW1 + W::w1_off(D, CKS, T), NW = W::kH16(D, T);
+                    interleave(ic<NW + CKS>{}, ic<(T > 0 ? 16 : 0)>{},
+                               [&](auto kk) {
+                                   constexpr int k = decltype(kk)::value;
+                                   if constexpr (k < NW) step(ic<E0 + k>{}, ic<(k == 0)>{}, bout[k], accw[T & 1]);
+                                   else step(ic<E0 + k>{}, ic<(k == NW)>{}, cx[k - NW], accg[T & 1]);
+                               },
+                               [&](auto jj) { piece(ic<(T > 0 ? T - 1 : 0)>{}, jj); });
+                });
+                static_for<0, 16>([&](auto jj) { piece(ic<W::kTiles - 1>{}, jj); });
+                fence();
+            }
+            span(2);
         });
         // ---- final masked layer + spline, two features (64 (row, feature) pairs) at a time --------------------------
 #pragma unroll
         for (int T = 0; T < W::kTiles; ++T) { bin[2 * T] = to_b(h[T], 0, false); bin[2 * T + 1] = to_b(h[T], 1, false); }
+        // the next layer's biases: requested now (h is dead, registers are free), parked in LDS behind the layer's end
+        constexpr int NBQ = (W::kBiasFloats / 4 + 255) / 256;
+        f32x4 nbias[NBQ];
+        {
+            const f32x4* gb = reinterpret_cast<const f32x4*>(gbias + (int64_t)(l + 1 < NL ? l + 1 : l) * W::kBiasFloats);
+#pragma unroll
+            for (int i = 0; i < NBQ; ++i) {
+                const int sI = tid + 256 * i;
+                nbias[i] = gb[sI < W::kBiasFloats / 4 ? sI : 0];
+            }
+        }
 #pragma nounroll
         for (int m = 0; m < NB; ++m) {
             static_for<0, NB>([&](auto mm) {
@@ -279,36 +415,67 @@ __global__ __launch_bounds__(256) void flow_wide_kernel(const FwdParams p) {
                 if (m == M) {
                     constexpr int E0 = W::e_out(D, CKS) + W::out_off(D, M);
                     constexpr int NA = W::kO16(D, 2 * M), NBf = W::kWHb(D, M), ND = W::kDD(D, M);
-                    f32x16 acc = bias16(W::kBiasOut + 96 * M);
-                    static_for<0, NA>([&](auto kk) { use(ic<E0 + decltype(kk)::value>{}, bin[decltype(kk)::value], acc); });
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        lds_st_f4(spw + 4 * (8 * q), f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]});
-                    if constexpr (2 * M + 1 < D) {
-                        acc = bias16(W::kBiasOut + 96 * M + 32);
-                        static_for<0, NBf>([&](auto kk) { use(ic<E0 + NA + decltype(kk)::value>{}, bin[decltype(kk)::value], acc); });
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            lds_st_f4(spw + 4 * (32 * PS + 8 * q), f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]});
+                    constexpr bool HASB = 2 * M + 1 < D;
+                    constexpr int OB = W::kBiasOut + 96 * M;
+                    f32x16 accA = zero16, accB = zero16, accD = zero16;
+                    float t4[4];
+                    // piece: element jj of output tile `which` (0 WH a, 1 WH b, 2 DD): + bias, to the spline transpose
+                    bq0[0] = lds_ld_f4(sb + 4 * OB);
+                    auto piece = [&](auto which, auto jj) {
+                        constexpr int WH = decltype(which)::value, i = decltype(jj)::value, Q = WH * 4 + i / 4;
+                        if constexpr (i % 4 == 0 && Q + 1 < 12) bq0[(Q + 1) & 1] = lds_ld_f4(sb + 4 * (OB + 8 * (Q + 1)));
+                        const f32x16& acc = WH == 0 ? accA : (WH == 1 ? accB : accD);
+                        t4[i & 3] = acc[i] + bq0[Q & 1][i & 3];
+                        if constexpr ((i & 3) == 3) {
+                            constexpr int q = i / 4;
+                            constexpr int off = WH == 0 ? 8 * q : (WH == 1 ? 32 * PS + 8 * q : (q >> 1) * 32 * PS + 32 + 8 * (q & 1));
+                            lds_st_f4(spw + 4 * off, f32x4{t4[0], t4[1], t4[2], t4[3]});
+                        }
+                    };
+                    interleave(ic<NA>{}, ic<0>{}, [&](auto kk) { step(ic<E0 + decltype(kk)::value>{}, ic<(decltype(kk)::value == 0)>{}, bin[decltype(kk)::value], accA); },
+                               [&](auto jj) {});
+                    if constexpr (HASB) {
+                        interleave(ic<NBf>{}, ic<16>{},
+                                   [&](auto kk) { step(ic<E0 + NA + decltype(kk)::value>{}, ic<(decltype(kk)::value == 0)>{}, bin[decltype(kk)::value], accB); },
+                                   [&](auto jj) { piece(ic<0>{}, jj); });
+                        interleave(ic<ND>{}, ic<16>{},
+                                   [&](auto kk) { step(ic<E0 + NA + NBf + decltype(kk)::value>{}, ic<(decltype(kk)::value == 0)>{}, bin[decltype(kk)::value], accD); },
+                                   [&](auto jj) { piece(ic<1>{}, jj); });
+                    } else {
+                        interleave(ic<ND>{}, ic<16>{},
+                                   [&](auto kk) { step(ic<E0 + NA + decltype(kk)::value>{}, ic<(decltype(kk)::value == 0)>{}, bin[decltype(kk)::value], accD); },
+                                   [&](auto jj) { piece(ic<0>{}, jj); });
+                        // the bias queue still walks over the absent tile's quads: skip them
+                        bq0[0] = lds_ld_f4(sb + 4 * (OB + 64));
                     }
-                    acc = bias16(W::kBiasOut + 96 * M + 64);
-                    static_for<0, ND>([&](auto kk) { use(ic<E0 + NA + NBf + decltype(kk)::value>{}, bin[decltype(kk)::value], acc); });
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)      // rows u < 16: derivatives of feature 2M; u >= 16: of feature 2M + 1
-                        lds_st_f4(spw + 4 * ((q >> 1) * 32 * PS + 32 + 8 * (q & 1)),
-                                  f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]});
+                    static_for<0, 16>([&](auto jj) {
+                        constexpr int i = decltype(jj)::value;
+                        if constexpr (HASB) piece(ic<2>{}, jj);
+                        else {                                   // DD with its own queue start (bq0[0] reloaded above)
+                            if constexpr (i % 4 == 0 && i / 4 + 1 < 4) bq0[(i / 4 + 1) & 1] = lds_ld_f4(sb + 4 * (OB + 64 + 8 * (i / 4 + 1)));
+                            t4[i & 3] = accD[i] + bq0[(i / 4) & 1][i & 3];
+                            if constexpr ((i & 3) == 3) {
+                                constexpr int q = i / 4;
+                                lds_st_f4(spw + 4 * ((q >> 1) * 32 * PS + 32 + 8 * (q & 1)), f32x4{t4[0], t4[1], t4[2], t4[3]});
+                            }
+                        }
+                    });
+                    fence();
                 }
             });
+            span(3);
             // one lane per pair: lane (n, hf) <-> (row n, feature 2 m + hf)
             const int f = 2 * m + hf;
             if (f < D) {
                 const float xv = lds_ld_f(sxc + 4 * f);
                 if (p.u_save && live) p.u_save[((int64_t)l * p.batch + row) * D + f] = xv;
                 float y, ld;
-                rqs_pair<true>(s_par + lane * PS, xv, K, p, y, ld);
+                if (PF_WIDE_ABLATE & 1) { y = xv + s_par[lane * PS]; ld = 0.f; }
+                else rqs_pair<true>(s_par + lane * PS, xv, K, p, y, ld);
                 ld_acc += ld;
                 lds_st_f(sxn + 4 * (D - 1 - f), y);            // the next layer starts with ReversePermutation
             }
+            span(4);
         }
         // ---- the pad fragments of this layer: keep the ring turning, prime the queue for the next layer ------------
         static_for<NF, NFP - NF>([&](auto e) {
@@ -318,16 +485,23 @@ __global__ __launch_bounds__(256) void flow_wide_kernel(const FwdParams p) {
         });
         glayer += (int64_t)NFP * W::kFrag;
         { const uint32_t t = sxc; sxc = sxn; sxn = t; }
-        if (l + 1 < NL) {                                      // next layer's biases
-            __syncthreads();
-            const float* gb = gbias + (int64_t)(l + 1) * W::kBiasFloats;
-            for (int s = tid; s < W::kBiasFloats / 4; s += 256)
-                reinterpret_cast<f32x4*>(s_bias)[s] = reinterpret_cast<const f32x4*>(gb)[s];
-            __syncthreads();
+        if (l + 1 < NL) {                                      // next layer's biases (loaded above)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // everyone is done with this layer's
+#pragma unroll
+            for (int i = 0; i < NBQ; ++i) {
+                const int sI = tid + 256 * i;
+                if (sI < W::kBiasFloats / 4) reinterpret_cast<f32x4*>(s_bias)[sI] = nbias[i];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
+        span(5);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the ring's last (unused) DMA pieces must land before the LDS is released
 
+    if (PF_WIDE_TRACE && p.fail_flags && blockIdx.x == 0 && tid == 0) {
+        tr[9] = tick() - t_begin;
+        for (int i = 0; i < 10; ++i) reinterpret_cast<unsigned long long*>(p.fail_flags)[i] = tr[i];
+    }
     // ---- epilogue: log-det of a row = sum over its features (two lanes), base density, stores ------------------------
     const float ld_row = ld_acc + __shfl_xor(ld_acc, 32, 64);
     float my_nll = 0.f, my_cnt = 0.f;
