@@ -51,6 +51,9 @@
 #else
 #define PF_WIDE_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #endif
+#ifndef PF_WIDE_SPREAD
+#define PF_WIDE_SPREAD 2   // 0: the 9 DMA pieces of a ring half in one burst behind barrier B; n > 0: one piece every n fragments
+#endif
 #ifndef PF_WIDE_TRACE
 #define PF_WIDE_TRACE 0    // diagnostic build: wave 0 of workgroup 0 accumulates s_memtime spans per stage into p.fail_flags
 #endif
@@ -108,26 +111,26 @@ __global__ __launch_bounds__(256) void flow_wide_kernel(const FwdParams p) {
     const uint32_t lane16 = lane * 16;
     const uint32_t ring_w = lds_addr(ring) + wave * W::kFrag;
     __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.packed), 0, 0x7fffffff, 0x00020000);
-    auto dma_epoch = [&](const char* src_u, int half) {       // src_u: uniform address of the epoch's fragment `wave`
+    // piece i (0 .. kEpoch / 4 - 1) of an epoch: this wave's fragment 4 i + wave of the ring half
+    auto dma_piece = [&](const char* src_u, int half, int i) {   // src_u: uniform address of the epoch's fragment `wave`
         const char* src = src_u;
         uint32_t dst = ring_w;
         asm volatile("" : "+s"(src), "+s"(dst));
         if (PF_WIDE_ABLATE & 2) return;
         if (PF_WIDE_BUFDMA) {
-            const int soff = (int)(src - p.packed);
-#pragma unroll
-            for (int i = 0; i < W::kEpoch / W::kWaves; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                    wrsrc, reinterpret_cast<__attribute__((address_space(3))) void*>(dst + (half * W::kEpoch + i * W::kWaves) * W::kFrag),
-                    16, lane16, soff + i * W::kWaves * W::kFrag, 0, 0);
-            return;
-        }
-#pragma unroll
-        for (int i = 0; i < W::kEpoch / W::kWaves; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                wrsrc, reinterpret_cast<__attribute__((address_space(3))) void*>(dst + (half * W::kEpoch + i * W::kWaves) * W::kFrag),
+                16, lane16, (int)(src - p.packed) + i * W::kWaves * W::kFrag, 0, 0);
+        } else {
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void*)(src + (int64_t)i * W::kWaves * W::kFrag + lane16),
                 reinterpret_cast<__attribute__((address_space(3))) void*>(dst + (half * W::kEpoch + i * W::kWaves) * W::kFrag),
                 16, 0, 0);
+        }
+    };
+    auto dma_epoch = [&](const char* src_u, int half) {
+#pragma unroll
+        for (int i = 0; i < W::kEpoch / W::kWaves; ++i) dma_piece(src_u, half, i);
     };
     // diagnostic spans (PF_WIDE_TRACE): 0 stage 1, 1 W0, 2 W1 + gate, 3 final GEMMs, 4 spline, 5 pad + bias reload,
     // 6 DMA issue, 7 barrier A, 8 barrier B, 9 whole kernel
@@ -206,12 +209,23 @@ __global__ __launch_bounds__(256) void flow_wide_kernel(const FwdParams p) {
     };
     auto after = [&](auto e) {                              // fragment E has been consumed
         constexpr int E = decltype(e)::value;
-        if constexpr ((E + 1) % W::kEpoch == 0) {           // barrier B: everyone is done with that half: refill it
+        constexpr int R = (E + 1) % W::kEpoch;               // fragments consumed of the current half
+        constexpr int EB = E + 1 - R;                        // ... which began at fragment EB
+        if constexpr (R == 0) {                              // barrier B: everyone is done with the previous half: refill it
             const unsigned long long t0 = tick();
             asm volatile("s_barrier" ::: "memory");
+            tr[8] += tick() - t0;
+        }
+        // the refill = the half after next; in one burst, or one piece every PF_WIDE_SPREAD fragments
+        if constexpr (PF_WIDE_SPREAD == 0) {
+            if constexpr (R == 0) {
+                const unsigned long long t1 = tick();
+                dma_epoch(glayer + (int64_t)(EB + W::kEpoch) * W::kFrag, (EB / W::kEpoch + 1) & 1);
+                tr[6] += tick() - t1;
+            }
+        } else if constexpr (R % PF_WIDE_SPREAD == 0 && R / PF_WIDE_SPREAD < W::kEpoch / W::kWaves) {
             const unsigned long long t1 = tick();
-            dma_epoch(glayer + (int64_t)(E + 1 + W::kEpoch) * W::kFrag, ((E + 1) / W::kEpoch + 1) & 1);
-            tr[8] += t1 - t0;
+            dma_piece(glayer + (int64_t)(EB + W::kEpoch) * W::kFrag, (EB / W::kEpoch + 1) & 1, R / PF_WIDE_SPREAD);
             tr[6] += tick() - t1;
         }
     };

@@ -330,7 +330,8 @@ class NSFPosteriorFlow(nn.Module):
 
     # ---- plumbing -------------------------------------------------------------
     # ---- the large-batch ("wide") forward kernel: 128 rows per workgroup, weights fetched once per workgroup ----
-    wide_min_batch: int = 12288     # rows from which pf_flow_forward is given the PF_FLAG_WIDE layout (measured crossover)
+    wide_min_batch: int = 20480     # rows from which pf_flow_forward is given the PF_FLAG_WIDE layout (measured crossover:
+                                    # one round of 128-row workgroups = 415 us up to 32768 rows; the 16-row kernel 320 us at 16384)
 
     def _use_wide(self, batch: int) -> bool:
         env = os.environ.get("PF_FLOW_WIDE", "")

@@ -252,6 +252,7 @@ def test_rows_per_workgroup_choice_and_parity(B, rows):
     from posteriflow_amd import _lib
     ref, _, flow = make_pair(15, 288, 256, 2, 16, 5.0)
     flow.precision = "bf16"
+    flow.wide_min_batch = 1 << 40                          # this test is about the 16-row kernel's row groups
     assert _lib.lib().pf_flow_rows_per_workgroup(flow._desc(), B) == rows
     x, ctx = flow_inputs(B, 15, 288, 5.0)
     xg, cg = x.cuda(), ctx.cuda()

