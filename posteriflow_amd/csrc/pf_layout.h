@@ -68,12 +68,18 @@ constexpr int kWindowPad = 16;            // frags of zero padding behind each w
 constexpr int kMaxWaves = 8;
 constexpr int kMaxTiles = 16;
 
+template <bool BF16> constexpr int kPadH = BF16 ? 2 : 5;
+template <bool BF16> constexpr int kPadO = BF16 ? 1 : 2;
+
 // compile-time schedule (frag offsets inside one layer of a wave's stream)
 template <bool BF16, int NT, int CKM, bool DENSE>
 struct Sched {
     static constexpr int HK = BF16 ? NT / 2 : NT;          // frags per full hidden tile row
-    static constexpr int KHS = DENSE ? 2 * HK : HK + 2;     // entries of a masked H x H GEMM (tile pair)
-    static constexpr int KOS = DENSE ? 2 * HK : HK + 1;     // entries per spline-parameter tile (feature pair)
+    // masked streams: a tile pair (w, T-1-w) needs kH[w] + kH[T-1-w] <= HK + pad entries.  32-wide bf16 k-steps pair up
+    // within HK + 2 / HK + 1; the 16-wide fp32 k-steps are finer, the sums of LeanNPE-sized flows reach HK + 5 / HK + 2
+    // (D = 11: 9 + 12 = 21 of 32 dense entries) -- still a third fewer fragments and MFMAs than the dense stream
+    static constexpr int KHS = DENSE ? 2 * HK : HK + kPadH<BF16>;   // entries of a masked H x H GEMM (tile pair)
+    static constexpr int KOS = DENSE ? 2 * HK : HK + kPadO<BF16>;   // entries per spline-parameter tile (feature pair)
     static constexpr int E_IN = 0;
     static constexpr int E_CTX = 2;
     static constexpr int E_BLK = E_CTX + 2 * CKM;
@@ -90,7 +96,7 @@ struct FlowPlan {
     int CK, CKM, HK;            // needed / scheduled context frags per tile; frags per full hidden row
     int hoist;                  // 1: context projections hoisted (CKM = 0 in the streams)
     int additive;               // 1: masked-context conditioner: additive context, no reverse permutation
-    int dense;                  // 1: KHS = KOS = 2*HK (masks too coarse to pair up), else HK+2 / HK+1
+    int dense;                  // 1: KHS = KOS = 2*HK (masks too coarse to pair up), else HK + kPadH / HK + kPadO
     int wide;                   // 1: the large-batch kernel's single common stream (pf_wide_layout.h); CKS in CKM
     int KHS, KOS, NF;
     int kH[kMaxTiles];          // active k-steps of tile t in a masked H x H GEMM
@@ -198,9 +204,10 @@ inline int make_plan(const PfFlowDesc& d, FlowPlan& o) {
         if (h > khs) khs = h;
         if (q > kos) kos = q;
     }
-    o.dense = (khs > o.HK + 2 || kos > o.HK + 1) ? 1 : 0;
-    o.KHS = o.dense ? 2 * o.HK : o.HK + 2;
-    o.KOS = o.dense ? 2 * o.HK : o.HK + 1;
+    const int padh = o.bf16 ? kPadH<true> : kPadH<false>, pado = o.bf16 ? kPadO<true> : kPadO<false>;
+    o.dense = (khs > o.HK + padh || kos > o.HK + pado || o.HK + padh > 2 * o.HK) ? 1 : 0;
+    o.KHS = o.dense ? 2 * o.HK : o.HK + padh;
+    o.KOS = o.dense ? 2 * o.HK : o.HK + pado;
     o.NF = 2 + 2 * o.CKM + o.NB * (2 * o.KHS + 2 * o.CKM) + 3 * o.KOS;
     o.fragsPerWave = (int64_t)o.L * o.NF + kWindowPad;
     o.fragsTotal = o.fragsPerWave * o.NW;

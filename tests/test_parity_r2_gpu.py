@@ -66,8 +66,15 @@ def test_bench_workload_full_size_fp32_and_bf16():
     assert rel.max() < max(1e-5, 4 * rel_ref.max().item())
     assert rel.quantile(0.999) < max(1e-5, 3 * rel_ref.quantile(0.999).item())
     assert rel_pair.quantile(0.99) < 5e-5
-    z64, ld64 = ref64(x.double(), ctx.double())
-    assert (z32.cpu().double() - z64).abs().max() < 1e-4 and (ld32.cpu().double() - ld64).abs().max() < 1e-3
+    with torch.no_grad():
+        z64, ld64 = ref64(x.double(), ctx.double())
+        zc, ldc = ref(x, ctx)
+    ez, el = (z32.cpu().double() - z64).abs(), (ld32.cpu().double() - ld64).abs()
+    ez_ref, el_ref = (zc.double() - z64).abs(), (ldc.double() - ld64).abs()
+    print(f"   |z - z64| p99 {ez.quantile(0.99):.2e} max {ez.max():.2e} (cpu fp32: {ez_ref.quantile(0.99):.2e} / {ez_ref.max():.2e})  "
+          f"|ld - ld64| p99 {el.quantile(0.99):.2e} max {el.max():.2e} (cpu fp32: {el_ref.quantile(0.99):.2e} / {el_ref.max():.2e})")
+    assert ez.quantile(0.99) < max(2e-5, 2 * ez_ref.quantile(0.99).item()) and ez.max() < max(1e-4, 4 * ez_ref.max().item())
+    assert el.quantile(0.99) < max(1e-4, 2 * el_ref.quantile(0.99).item()) and el.max() < max(1e-3, 4 * el_ref.max().item())
     e_emu, e64 = (got16 - nemu).abs(), (got16 - n64).abs()
     print(f"[bench workload bf16, 4096 rows] |nll - bf16-emulating oracle| p50 {e_emu.median():.2e} p99 "
           f"{e_emu.quantile(0.99):.2e} max {e_emu.max():.2e};  vs fp64: p50 {e64.median():.2e} p99 "
