@@ -140,6 +140,38 @@ int pf_flow_rqs_backward(const PfFlowDesc* desc, const float* u, const float* pa
                          const float* grad_y, const float* grad_logabsdet, int64_t rows,
                          float* grad_params, float* grad_u, void* stream);
 
+/* ---- backward: the data-gradient chain in one launch (fp32) -----------------------------------------
+ * Replaces the per-layer walk of the flow's backward (experiments/train_lean_npe.py:363-368 runs autograd through
+ * nflows' MADE + spline): for every layer, last first: spline backward, gh = Wf^T Gp, through the two residual blocks
+ * (GLU gates), Gh0, gu += W0^T gh, ReversePermutation.  The caller supplies the forward quantities of every layer (the
+ * layer inputs pf_flow_forward_train kept and the layer-batched re-evaluation of the conditioners) and the TRANSPOSED
+ * masked weight matrices; the kernel returns the per-layer gradients the weight-gradient GEMMs need and dL/dx.
+ * Plain (GLU) conditioner with 2 residual blocks only; context-free flows pass t2s = gates = pc = Gc = NULL.
+ * All tensors fp32, contiguous.  H in {64, 128, 192, 256}, D <= 16, K <= 16. */
+typedef struct PfFlowBwdChainArgs {
+    int64_t batch;
+    const float* WfT;    /* [L][H][PM]: (final_layer.weight * mask)^T, PM = D (3K-1) rounded up to 16, zero padded */
+    const float* W2T;    /* [2][L][H][H]: (blocks[j].linear_layers[1].weight * mask)^T  ([in][out]) */
+    const float* W1T;    /* [2][L][H][H]: (blocks[j].linear_layers[0].weight * mask)^T */
+    const float* W0T;    /* [L][16][H]: (initial_layer.weight * mask)^T, rows >= D zero */
+    const float* U;      /* [L][B][D]      layer inputs (pf_flow_forward_train) */
+    const float* params; /* [L][B][D (3K-1)] raw spline parameters */
+    const float* hs;     /* [2][L][B][H]   residual state before block j */
+    const float* t1s;    /* [2][L][B][H]   W0_j relu(h) + b (pre-activation of the block's second linear) */
+    const float* t2s;    /* [2][L][B][H]   second linear's output (before the gate), or NULL */
+    const float* gates;  /* [2][L][B][H]   sigmoid of the block's context projection, or NULL */
+    const float* pc;     /* [L][B][H]      context_layer projection (before its ReLU), or NULL */
+    const float* g_z;    /* [B][D]  dL/dz (layer order, as the forward returns z before un-permuting) */
+    const float* g_lad;  /* [B]     dL/dlogdet */
+    float* Gp;           /* [L][B][D (3K-1)]  dL/d(raw spline parameters) */
+    float* Gh0;          /* [L][B][H]  dL/d(initial layer output) */
+    float* Gt1;          /* [2][L][B][H] */
+    float* Gt2;          /* [2][L][B][H] */
+    float* Gc;           /* [L][3][B][H]  dL/d(context projections): context_layer, gate of block 0, of block 1; or NULL */
+    float* g_x;          /* [B][D]  dL/d(x[:, ar_perm]) */
+} PfFlowBwdChainArgs;
+int pf_flow_backward_chain(const PfFlowDesc* desc, const PfFlowBwdChainArgs* args, void* stream);
+
 /* ---- inverse / sampling -----------------------------------------------------
  * x = transform^-1(z, ctx)[:, ar_inv_perm], logdet of the inverse map
  * (nflows returns the log-det of the last autoregressive pass of each layer,

@@ -5,8 +5,9 @@ Plain conditioner (what LeanNPE uses): ``flow_backward`` --
   1. re-evaluates the ten conditioners from the kept inputs, *batched over layers* (they are independent
      given their inputs): one GEMM for all context projections, ``baddbmm`` over the layer dimension for
      the masked linears;
-  2. walks the layer chain backwards: the spline backward is the hand-written HIP kernel
-     ``pf_flow_rqs_backward`` (pf_flow_bwd.hip), the masked-MLP data gradients are plain GEMMs;
+  2. walks the layer chain backwards in ONE HIP launch (``pf_flow_backward_chain``, pf_flow_bwd_chain.hip): the
+     hand-derived spline backward, the transposed masked GEMMs on fp32 MFMA and the gate / ReLU algebra of every
+     layer, last first (it replaced ~25 small launches per layer);
   3. forms every weight gradient with batched GEMMs over the layer dimension and the context gradient
      with one GEMM.
 GEMMs go to the vendor library through torch (plain library GEMMs); nothing runs on the CPU and nothing
@@ -157,34 +158,37 @@ def _flow_backward_batched(flow, U, ctx, g_z, g_lad):
         hs.append(h), t1s.append(t1), t2s.append(t2)
     params = torch.baddbmm(bf[:, None, :], h, Wf.transpose(1, 2))                 # [L, B, D(3K-1)]
 
-    # 2. the chain, last layer first
-    Gp, Gh0 = torch.empty_like(params), torch.empty_like(hs[0])
-    Gt1 = [torch.empty_like(hs[0]) for _ in range(nb)]
-    Gt2 = [torch.empty_like(hs[0]) for _ in range(nb)]
-    if has_ctx:
-        Gc = torch.empty(Ln, 1 + nb, B, H, dtype=U.dtype, device=U.device)
+    # 2. the chain, last layer first: ONE launch (pf_flow_backward_chain, csrc/pf_flow_bwd_chain.hip) instead of ~25
+    #    small ones per layer -- spline backward, the transposed masked GEMMs on fp32 MFMA, the gate / ReLU algebra
     gy = g_z.contiguous()
     g_lad = g_lad.contiguous()
-    for l in range(Ln - 1, -1, -1):
-        gu = _rqs_backward(flow, U[l], params[l], gy, g_lad, Gp[l])
-        gh = Gp[l] @ Wf[l]
-        for j in range(nb - 1, -1, -1):
-            if has_ctx:
-                gate = gates[j][l]
-                gt2 = gh * gate
-                Gc[l, 1 + j] = gh * t2s[j][l] * gate * (1.0 - gate)
-            else:
-                gt2 = gh
-            Gt2[j][l] = gt2
-            gt1 = (gt2 @ W2[j][l]) * (t1s[j][l] > 0)
-            Gt1[j][l] = gt1
-            gh = gh + (gt1 @ W1[j][l]) * (hs[j][l] > 0)
-        Gh0[l] = gh
-        if has_ctx:
-            Gc[l, 0] = gh * (pc[l] > 0)
-        gu = gu + gh @ W0[l]
-        gy = gu.flip(1).contiguous()                 # through this layer's ReversePermutation
-    g_x = gy[:, flow._ar_inv_perm]                   # gy = dL/d x[:, ar_perm]
+    DM = params.shape[2]
+    PM = (DM + 15) // 16 * 16
+    WfT = F.pad(Wf.transpose(1, 2), (0, PM - DM)).contiguous()                   # [L, H, PM]
+    W2T = torch.stack([w.transpose(1, 2) for w in W2]).contiguous()              # [nb, L, H(in), H(out)]
+    W1T = torch.stack([w.transpose(1, 2) for w in W1]).contiguous()
+    W0T = F.pad(W0.transpose(1, 2), (0, 0, 0, 16 - D)).contiguous()              # [L, 16, H]
+    HSk, T1k = torch.stack(hs[:nb]), torch.stack(t1s)
+    Gp, Gh0 = torch.empty_like(params), torch.empty_like(hs[0])
+    GT1, GT2 = torch.empty_like(T1k), torch.empty_like(T1k)
+    gx_perm = torch.empty(B, D, dtype=U.dtype, device=U.device)
+    a = _lib.PfFlowBwdChainArgs()
+    a.batch = B
+    keep = [WfT, W2T, W1T, W0T, HSk, T1k, GT1, GT2, Gp, Gh0, gx_perm, gy, g_lad, params]
+    for name, t in (("WfT", WfT), ("W2T", W2T), ("W1T", W1T), ("W0T", W0T), ("U", U), ("params", params), ("hs", HSk),
+                    ("t1s", T1k), ("g_z", gy), ("g_lad", g_lad), ("Gp", Gp), ("Gh0", Gh0), ("Gt1", GT1), ("Gt2", GT2),
+                    ("g_x", gx_perm)):
+        assert t.is_contiguous() and t.dtype == torch.float32
+        setattr(a, name, t.data_ptr())
+    if has_ctx:
+        T2k, Gk, pck = torch.stack(t2s), torch.stack(gates), pc.contiguous()
+        Gc = torch.empty(Ln, 1 + nb, B, H, dtype=U.dtype, device=U.device)
+        keep += [T2k, Gk, pck, Gc]
+        a.t2s, a.gates, a.pc, a.Gc = T2k.data_ptr(), Gk.data_ptr(), pck.data_ptr(), Gc.data_ptr()
+    _lib.check(_lib.lib().pf_flow_backward_chain(flow._desc(), a, torch.cuda.current_stream(U.device).cuda_stream),
+               "pf_flow_backward_chain")
+    Gt1, Gt2 = [GT1[j] for j in range(nb)], [GT2[j] for j in range(nb)]
+    g_x = gx_perm[:, flow._ar_inv_perm]              # the kernel returns dL/d x[:, ar_perm]
 
     # 3. weight gradients, batched over layers
     gWf, gbf = torch.bmm(Gp.transpose(1, 2), hs[nb]) * mf, Gp.sum(1)

@@ -21,6 +21,13 @@ PF_FLAG_WIDE = 4
 PRECISIONS = {"fp32": PF_PREC_F32, "f32": PF_PREC_F32, "bf16": PF_PREC_BF16}
 
 
+class PfFlowBwdChainArgs(C.Structure):
+    """include/pf_hip.h PfFlowBwdChainArgs (device pointers as integers)."""
+    _fields_ = [("batch", C.c_int64)] + [(n, C.c_void_p) for n in (
+        "WfT", "W2T", "W1T", "W0T", "U", "params", "hs", "t1s", "t2s", "gates", "pc", "g_z", "g_lad",
+        "Gp", "Gh0", "Gt1", "Gt2", "Gc", "g_x")]
+
+
 class PfFlowDesc(C.Structure):
     _fields_ = [
         ("features", C.c_int32), ("context_features", C.c_int32),
@@ -52,6 +59,7 @@ SYMBOLS = {
                                          C.c_void_p]),
     "pf_flow_rqs_backward": (C.c_int, [_P, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                        C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pf_flow_backward_chain": (C.c_int, [_P, C.POINTER(PfFlowBwdChainArgs), C.c_void_p]),
     "pf_flow_inverse": (C.c_int, [_P, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                   C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_int64, C.c_void_p]),

@@ -33,6 +33,7 @@ int remix_forward(const void* noise, int64_t n_noise, const void* signals, int64
 int rqs_backward(const PfFlowDesc& d, float deriv_const, const float* u, const float* params, const float* gy,
                  const float* glad, int64_t n, float* gparams, float* gu, hipStream_t s);
 int launch_gather(bool bf16, const float* raw, const int32_t* map, void* out, int64_t n, hipStream_t s);
+int flow_backward_chain(const PfFlowDesc& d, float deriv_const, const PfFlowBwdChainArgs& a, hipStream_t s);
 }  // namespace pf
 
 namespace {
@@ -175,6 +176,29 @@ int pf_flow_rqs_backward(const PfFlowDesc* desc, const float* u, const float* pa
     const int rc = pf::rqs_backward(*desc, dc, u, params, grad_y, grad_logabsdet, rows, grad_params, grad_u,
                                     static_cast<hipStream_t>(stream));
     return rc == PF_OK ? rc : fail(rc, hipGetErrorString(hipGetLastError()));
+}
+
+int pf_flow_backward_chain(const PfFlowDesc* desc, const PfFlowBwdChainArgs* a, void* stream) {
+    if (!desc || !a) return fail(PF_ERR_BAD_ARG, "null pointer");
+    const int D = desc->features, H = desc->hidden_features, K = desc->num_bins;
+    if (H % 64 || H < 64 || H > 256 || D < 1 || D > 16 || K < 2 || K > 16 || desc->num_blocks != 2 || desc->num_layers < 1 ||
+        (desc->reserved & PF_FLAG_MASKED_CONTEXT))
+        return fail(PF_ERR_UNSUPPORTED, "backward chain: plain conditioner, H in {64,128,192,256}, D <= 16, K <= 16, 2 blocks");
+    if (!(desc->tail_bound > 0.f)) return fail(PF_ERR_BAD_ARG, "tail_bound must be positive");
+    if (a->batch < 0) return fail(PF_ERR_BAD_ARG, "negative batch");
+    if (a->batch == 0) return PF_OK;
+    if (!a->WfT || !a->W2T || !a->W1T || !a->W0T || !a->U || !a->params || !a->hs || !a->t1s || !a->g_z || !a->g_lad ||
+        !a->Gp || !a->Gh0 || !a->Gt1 || !a->Gt2 || !a->g_x)
+        return fail(PF_ERR_BAD_ARG, "null pointer");
+    const bool ctx = a->gates != nullptr;
+    if (ctx != (a->t2s != nullptr) || ctx != (a->pc != nullptr) || ctx != (a->Gc != nullptr))
+        return fail(PF_ERR_BAD_ARG, "t2s, gates, pc and Gc go together (all NULL for a context-free flow)");
+    const void* al[] = {a->WfT, a->W2T, a->W1T, a->W0T, a->hs, a->t1s, a->t2s, a->gates, a->pc, a->Gh0, a->Gt1, a->Gt2, a->Gc};
+    for (const void* q : al)
+        if (misaligned(q, 16)) return fail(PF_ERR_BAD_ARG, "weight / activation tensors must be 16-byte aligned");
+    const float dc = (float)std::log(std::exp(1.0 - (double)desc->min_derivative) - 1.0);
+    const int rc = pf::flow_backward_chain(*desc, dc, *a, static_cast<hipStream_t>(stream));
+    return rc == PF_OK ? rc : fail(rc, rc == PF_ERR_HIP ? hipGetErrorString(hipGetLastError()) : "unsupported shape");
 }
 
 int pf_flow_inverse(const PfFlowDesc* desc, const void* packed, const float* z, const float* ctx,

@@ -1,0 +1,249 @@
+// pf_flow_bwd_chain.hip -- the data-gradient chain of the flow's backward pass in ONE kernel (fp32).
+//
+// What it replaces: step 2 of posteriflow_amd/_flow_autograd.py::_flow_backward_batched, ~25 small launches per layer
+// (one pf_flow_rqs_backward + 6 matmuls + ~16 element-wise ops, ~250-300 per backward of a 10-layer flow), i.e. the
+// part of autograd's walk through nflows' MADE that the reference executes under experiments/train_lean_npe.py:363-368
+// (loss.backward()).  The layer-batched conditioner re-evaluation (step 1) and the weight-gradient GEMMs (step 3) are
+// plain batched library GEMMs and stay where they are.
+//
+// Per layer l, last layer first, for a workgroup's 16 batch rows (rows are independent, layers sequential):
+//   spline:  (gy, glad) -> Gp = dL/d(raw spline parameters) [D (3K-1)],  gu = direct dL/du          (pf_rqs_bwd.h)
+//   gh  = Wf^T Gp
+//   for block j = 1, 0:   gt2 = gh * gate_j            Gc[1+j] = gh * t2_j * gate_j (1 - gate_j)
+//                         gt1 = (W2_j^T gt2) * [t1_j > 0]
+//                         gh += (W1_j^T gt1) * [h_j > 0]
+//   Gh0 = gh              Gc[0] = gh * [pc > 0]         gu += W0^T gh        gy <- flip(gu)   (ReversePermutation)
+// Gp, Gh0, Gt1, Gt2, Gc go to HBM for the weight-gradient GEMMs; h_j, t1_j, t2_j, gate_j, pc and the raw parameters
+// come from the re-evaluation.
+//
+// Work split: workgroup = 16 rows = one MFMA column tile, 4 waves; everything TRANSPOSED as in the forward kernels,
+// out^T[unit, row] = W^T[unit, k] . in^T[k, row] on v_mfma_f32_16x16x4_f32 (exact fp32: gradients keep the 3e-4 agreement
+// with autograd through the oracle).  Wave w owns unit tiles w, w + 4, ...; the B operand (the incoming gradient vector
+// of all units) is exchanged through LDS as fp32 [row][k] rows, the A operand is read straight from the dense
+// TRANSPOSED masked weight matrices the caller prepares each step ((W * mask)^T, row-major, k padded to 16): lane
+// (r, g) of k-group q takes the 4 consecutive floats W^T[16 t + r][16 q + 4 g ..] as the A values of 4 MFMAs whose
+// k order is (16 q + 4 g + e) -- the B rows in LDS are read the same way, so neither side needs packing.
+// Masked zeros are multiplied (the dense count): at 16 rows per CU this kernel is bound by the 1.8 MB of weights a
+// layer streams per workgroup, ~0.3 ms per launch whatever the batch up to 4096 rows.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/pf_hip.h"
+#include "pf_rqs_bwd.h"
+
+namespace pf {
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+struct ChainArgs {
+    PfFlowBwdChainArgs a;
+    RqsConsts c;
+    int D, H, L, M, PM;       // M = 3K-1, PM = D*M padded to 16
+    int64_t B;
+};
+
+template <int TPW>   // unit tiles per wave = H / 64
+__global__ __launch_bounds__(256) void flow_bwd_chain_kernel(const ChainArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, c = lane & 15;
+    const int D = p.D, H = p.H, M = p.M, PM = p.PM, L = p.L;
+    const int64_t B = p.B, row0 = (int64_t)blockIdx.x * 16;
+    const int PMS = PM + 4, HS = H + 4;
+    float* s_gp = reinterpret_cast<float*>(smem);            // [16][PMS]: raw parameters, then their gradients
+    float* s_v0 = s_gp + 16 * PMS;                            // [16][HS]: gradient vectors exchanged between GEMMs
+    float* s_v1 = s_v0 + 16 * HS;
+    float* s_gy = s_v1 + 16 * HS;                             // [16][16] dL/dy of the current layer
+    float* s_gu = s_gy + 256;                                 // [16][16] direct dL/du
+    float* s_part = s_gu + 256;                               // [4][16][16] partial sums of the W0^T product
+    const int64_t my_row = row0 + c < B ? row0 + c : B - 1;   // clamped (stores are guarded)
+    const bool live = row0 + c < B;
+    const PfFlowBwdChainArgs& A = p.a;
+    const bool has_ctx = A.gates != nullptr;
+
+    for (int s = tid; s < 256; s += 256) {
+        const int r = s >> 4, d = s & 15;
+        const int64_t row = row0 + r < B ? row0 + r : B - 1;
+        s_gy[s] = d < D ? A.g_z[row * D + d] : 0.f;
+    }
+    __syncthreads();
+
+    // out^T tile(s) of this wave = W^T[16 t + r][k] . s_in[col][k], k = 0 .. K-1 (K a multiple of 16)
+    auto gemm = [&](const float* WT, int ldk, int K, const float* s_in, int lds_stride, f32x4 (&acc)[TPW]) {
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* wrow[TPW];
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) wrow[i] = WT + (size_t)(16 * (wave + 4 * i) + c) * ldk + 4 * g;
+        const float* brow = s_in + c * lds_stride + 4 * g;
+        const int nq = K >> 4;
+        // the A values of k-group q are requested two groups ahead (an L2 round trip is longer than the 16 MFMAs of a group)
+        f32x4 a0[TPW], a1[TPW], a2[TPW];
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            a0[i] = *reinterpret_cast<const f32x4*>(wrow[i]);
+            a1[i] = *reinterpret_cast<const f32x4*>(wrow[i] + 16 * (nq > 1 ? 1 : 0));
+        }
+        for (int q = 0; q < nq; ++q) {
+            const int qn = q + 2 < nq ? q + 2 : nq - 1;
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) a2[i] = *reinterpret_cast<const f32x4*>(wrow[i] + 16 * qn);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(brow + 16 * q);
+#pragma unroll
+            for (int i = 0; i < TPW; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i][e], b[e], acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) { a0[i] = a1[i]; a1[i] = a2[i]; }
+        }
+    };
+    // C-layout access of slab `idx` of a [slabs][B][H] tensor: units 16 t + 4 g .. + 3 of row my_row
+    // ([L][B][H]: idx = l; [2][L][B][H]: idx = j L + l; Gc [L][3][B][H]: idx = 3 l + k)
+    auto at = [&](const float* base, int idx, int t) { return base + ((size_t)idx * B + my_row) * H + 16 * t + 4 * g; };
+    auto ld4 = [&](const float* base, int idx, int t) { return *reinterpret_cast<const f32x4*>(at(base, idx, t)); };
+    auto st4 = [&](float* base, int idx, int t, const f32x4& v) {
+        if (live) *reinterpret_cast<f32x4*>(const_cast<float*>(at(base, idx, t))) = v;
+    };
+    auto to_lds = [&](float* s_out, int t, const f32x4& v) { *reinterpret_cast<f32x4*>(s_out + c * HS + 16 * t + 4 * g) = v; };
+
+    for (int l = L - 1; l >= 0; --l) {
+        // ---- spline backward: raw parameters of the 16 rows -> LDS (coalesced), one lane per (row, feature) pair ----
+        for (int s = tid; s < 16 * PM; s += 256) {
+            const int r = s / PM, k = s - r * PM;
+            const int64_t row = row0 + r < B ? row0 + r : B - 1;
+            s_gp[r * PMS + k] = k < D * M ? A.params[((size_t)l * B + row) * (D * M) + k] : 0.f;
+        }
+        __syncthreads();
+        if (tid < 16 * D) {
+            const int r = tid & 15, f = tid >> 4;
+            const int64_t row = row0 + r < B ? row0 + r : B - 1;
+            float* par = s_gp + r * PMS + f * M;
+            s_gu[r * 16 + f] = rqs_backward_pair(par, par, A.U[((size_t)l * B + row) * D + f], s_gy[r * 16 + f],
+                                                 A.g_lad[row], p.c);
+        }
+        __syncthreads();
+        for (int s = tid; s < 16 * D * M; s += 256) {          // Gp -> HBM (weight gradient of the final layer)
+            const int r = s / (D * M), k = s - r * (D * M);
+            if (row0 + r < B) A.Gp[((size_t)l * B + row0 + r) * (D * M) + k] = s_gp[r * PMS + k];
+        }
+        // ---- gh = Wf^T Gp ----------------------------------------------------------------------------------------
+        f32x4 gh[TPW], acc[TPW];
+        gemm(A.WfT + (size_t)l * H * PM, PM, PM, s_gp, PMS, gh);
+        // ---- residual blocks, last first -------------------------------------------------------------------------
+        for (int j = 1; j >= 0; --j) {
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                const int t = wave + 4 * i;
+                f32x4 gt2 = gh[i];
+                if (has_ctx) {
+                    const f32x4 gate = ld4(A.gates, j * L + l, t), t2 = ld4(A.t2s, j * L + l, t);
+                    f32x4 gc;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        gt2[e] = gh[i][e] * gate[e];
+                        gc[e] = gh[i][e] * t2[e] * gate[e] * (1.f - gate[e]);
+                    }
+                    st4(A.Gc, 3 * l + 1 + j, t, gc);
+                }
+                st4(A.Gt2, j * L + l, t, gt2);
+                to_lds(s_v0, t, gt2);
+            }
+            __syncthreads();
+            f32x4 t1[TPW], hj[TPW];                          // requested ahead of the GEMMs whose epilogues use them
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) { t1[i] = ld4(A.t1s, j * L + l, wave + 4 * i); hj[i] = ld4(A.hs, j * L + l, wave + 4 * i); }
+            gemm(A.W2T + ((size_t)j * L + l) * H * H, H, H, s_v0, HS, acc);
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                const int t = wave + 4 * i;
+                f32x4 gt1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) gt1[e] = t1[i][e] > 0.f ? acc[i][e] : 0.f;
+                st4(A.Gt1, j * L + l, t, gt1);
+                to_lds(s_v1, t, gt1);
+            }
+            __syncthreads();
+            gemm(A.W1T + ((size_t)j * L + l) * H * H, H, H, s_v1, HS, acc);
+#pragma unroll
+            for (int i = 0; i < TPW; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) gh[i][e] += hj[i][e] > 0.f ? acc[i][e] : 0.f;
+        }
+        // ---- initial layer: Gh0, Gc[0], gu += W0^T gh -------------------------------------------------------------
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int t = wave + 4 * i;
+            st4(A.Gh0, l, t, gh[i]);
+            if (has_ctx) {
+                const f32x4 pc = ld4(A.pc, l, t);
+                f32x4 gc;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) gc[e] = pc[e] > 0.f ? gh[i][e] : 0.f;
+                st4(A.Gc, 3 * l, t, gc);
+            }
+            to_lds(s_v0, t, gh[i]);
+        }
+        __syncthreads();
+        {   // one output tile (the D <= 16 features), the k range split over the four waves, reduced through LDS
+            f32x4 part = {0.f, 0.f, 0.f, 0.f};
+            const float* wrow = A.W0T + ((size_t)l * 16 + c) * H + 4 * g;
+            const int kq = H / 64;                           // k-groups of 16 per wave
+            for (int q = wave * kq; q < (wave + 1) * kq; ++q) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(wrow + 16 * q);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(s_v0 + c * HS + 16 * q + 4 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) part = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], part, 0, 0, 0);
+            }
+            // lane (g, c): features 4 g .. 4 g + 3 of row c
+            *reinterpret_cast<f32x4*>(s_part + (wave * 16 + c) * 16 + 4 * g) = part;
+        }
+        __syncthreads();
+        {
+            const int r = tid >> 4, d = tid & 15;            // 256 threads = 16 rows x 16 feature slots
+            float v = 0.f;
+            if (d < D) {
+                v = s_gu[r * 16 + d];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) v += s_part[(w * 16 + r) * 16 + d];
+            }
+            if (d < D) s_gy[r * 16 + (D - 1 - d)] = v;      // through this layer's ReversePermutation
+        }
+        __syncthreads();
+    }
+    if (tid < 256) {
+        const int r = tid >> 4, d = tid & 15;
+        if (d < D && row0 + r < B) A.g_x[(row0 + r) * D + d] = s_gy[r * 16 + d];
+    }
+}
+
+}  // namespace
+
+int flow_backward_chain(const PfFlowDesc& d, float deriv_const, const PfFlowBwdChainArgs& a, hipStream_t s) {
+    ChainArgs p{};
+    p.a = a;
+    p.c = RqsConsts{d.num_bins, d.tail_bound, d.min_bin_width, d.min_bin_height, d.min_derivative, deriv_const};
+    p.D = d.features; p.H = d.hidden_features; p.L = d.num_layers; p.M = 3 * d.num_bins - 1;
+    p.PM = (p.D * p.M + 15) / 16 * 16;
+    p.B = a.batch;
+    const size_t lds = ((size_t)16 * (p.PM + 4) + 2 * 16 * (p.H + 4) + 256 + 256 + 4 * 256) * sizeof(float);
+    const unsigned grid = (unsigned)((a.batch + 15) / 16);
+    auto launch = [&](auto kern) {
+        if (lds > 64 * 1024 &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return PF_ERR_HIP;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, p);
+        return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
+    };
+    switch (p.H / 64) {
+    case 1: return launch(flow_bwd_chain_kernel<1>);
+    case 2: return launch(flow_bwd_chain_kernel<2>);
+    case 3: return launch(flow_bwd_chain_kernel<3>);
+    case 4: return launch(flow_bwd_chain_kernel<4>);
+    }
+    return PF_ERR_UNSUPPORTED;
+}
+
+}  // namespace pf

@@ -30,6 +30,8 @@ n_rows = 2 * B
 ctx = torch.randn(n_rows, flow.context_features, device=dev, requires_grad=True)
 x = (torch.rand(n_rows, flow.features, device=dev) * 2 - 1)
 def flow_fb():
+    for q in flow.parameters(): q.grad = None          # as optimizer.zero_grad(set_to_none=True): no accumulation kernels
+    ctx.grad = None
     flow.compute_psd_aware_nll(x, ctx, torch.zeros_like(x)).mean().backward()
 def flow_f():
     with torch.no_grad(): flow.compute_psd_aware_nll(x, ctx, torch.zeros_like(x))
