@@ -21,7 +21,7 @@ def test_lr_schedule_matches_reference_formula():
 GRAD_WORKER = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
-from posteriflow_amd.train import allreduce_gradients
+from posteriflow_amd.train import OverlappedGradReducer, allreduce_gradients
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 torch.manual_seed(0)
@@ -34,6 +34,28 @@ torch.nn.functional.mse_loss(net(x[lo:hi]), y[lo:hi]).backward()
 allreduce_gradients(net.parameters(), bucket_bytes=20000)          # several buckets
 for p, w in zip(net.parameters(), want):
     assert torch.allclose(p.grad, w, atol=1e-6), (p.grad - w).abs().max()
+# the overlapped reducer: gradients are views into 3 flat buckets, all-reduced from hooks during backward
+red = OverlappedGradReducer(net.parameters(), n_buckets=3)
+assert 1 <= len(red.buckets) <= 3 and sum(b["flat"].numel() for b in red.buckets) == sum(p.numel() for p in net.parameters())
+for step in range(2):                                               # twice: the buckets re-arm
+    red.zero()
+    torch.nn.functional.mse_loss(net(x[lo:hi]), y[lo:hi]).backward()
+    assert all(b["launched"] for b in red.buckets)                  # every bucket went out before backward() returned
+    red.finish()
+    for p, w in zip(net.parameters(), want):
+        assert torch.allclose(p.grad, w, atol=1e-6), (step, (p.grad - w).abs().max())
+        assert any(p.grad.data_ptr() >= b["flat"].data_ptr() and p.grad.data_ptr() < b["flat"].data_ptr() + 4 * b["flat"].numel() for b in red.buckets)
+red.close()
+# a parameter without a gradient this step: finish() still reduces its bucket
+extra = torch.nn.Parameter(torch.zeros(5))
+red2 = OverlappedGradReducer(list(net.parameters()) + [extra], n_buckets=2)
+red2.zero()
+torch.nn.functional.mse_loss(net(x[lo:hi]), y[lo:hi]).backward()
+red2.finish()
+for p, w in zip(net.parameters(), want):
+    assert torch.allclose(p.grad, w, atol=1e-6)
+assert torch.equal(extra.grad, torch.zeros(5))
+red2.close()
 dist.destroy_process_group()
 print("ok", rank)
 """
