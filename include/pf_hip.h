@@ -52,7 +52,7 @@ extern "C" {
 
 #define PF_FLAG_WIDE 4        /* forward only: the large-batch kernel (128 rows per workgroup, every wave owns 32 rows
                               * through all layers, weights fetched once per workgroup through an LDS ring).  bf16,
-                              * H = 256, plain conditioner, (D, C) in {(15, 288), (11, 288)}; other shapes:
+                              * H = 256, K = 16, plain conditioner, (D, C) in {(15, 288), (11, 288)}; other shapes:
                               * PF_ERR_UNSUPPORTED from every entry point.  The packed buffer of a PF_FLAG_WIDE desc
                               * has its own layout (pf_flow_packed_bytes / pack_map / pack with the same desc). */
 

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void flow_wide_kernel(const FwdParams p) {
     float* const s_x = reinterpret_cast<float*>(smem + W::kRing * W::kFrag + W::kWaves * 64 * PS * 4) + wave * (2 * 32 * XS);
     float* const s_bias = reinterpret_cast<float*>(smem + W::kRing * W::kFrag + W::kWaves * 64 * PS * 4 + W::kWaves * 2 * 32 * XS * 4);
     const char* const ring_lane = ring + lane * 16;
-    const int K = p.plan.K, C = p.plan.C, NL = p.plan.L;
+    const int C = p.plan.C, NL = p.plan.L;
     const int64_t row_w = (int64_t)blockIdx.x * W::kRowsPerWG + wave * W::kRowsPerWave;   // first row of this wave
     int64_t row = row_w + n;
     const bool live = row < p.batch;
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(256) void flow_wide_kernel(const FwdParams p) {
                 if (p.u_save && live) p.u_save[((int64_t)l * p.batch + row) * D + f] = xv;
                 float y, ld;
                 if (PF_WIDE_ABLATE & 1) { y = xv + s_par[lane * PS]; ld = 0.f; }
-                else rqs_pair<true>(s_par + lane * PS, xv, K, p, y, ld);
+                else rqs_pair_fast16(s_par + lane * PS, xv, p, y, ld);       // the wide plans are K = 16 only
                 ld_acc += ld;
                 lds_st_f(sxn + 4 * (D - 1 - f), y);            // the next layer starts with ReversePermutation
             }

@@ -167,7 +167,7 @@ inline int make_plan(const PfFlowDesc& d, FlowPlan& o) {
     o.wide = 0;
     if (d.reserved & PF_FLAG_WIDE) {
         // the large-batch kernel: bf16, H = 256, plain (GLU) conditioner, context in-layer; built for (D, C) pairs only
-        if (!o.bf16 || o.H != wide::kHidden || (d.reserved & (PF_FLAG_MASKED_CONTEXT | PF_FLAG_HOIST_CTX)) ||
+        if (!o.bf16 || o.H != wide::kHidden || o.K != 16 || (d.reserved & (PF_FLAG_MASKED_CONTEXT | PF_FLAG_HOIST_CTX)) ||
             !wide::built(o.D, o.C))
             return PF_ERR_UNSUPPORTED;
         o.wide = 1;

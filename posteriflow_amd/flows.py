@@ -337,7 +337,7 @@ class NSFPosteriorFlow(nn.Module):
         env = os.environ.get("PF_FLOW_WIDE", "")
         if env == "0" or self.precision != "bf16" or self.use_masked_context or self.hoist_context:
             return False
-        if self.hidden_features != 256 or (self.features, self.context_features) not in ((15, 288), (11, 288)):
+        if self.hidden_features != 256 or self.num_bins != 16 or (self.features, self.context_features) not in ((15, 288), (11, 288)):
             return False
         return env == "1" or batch >= self.wide_min_batch
 
