@@ -196,9 +196,11 @@ __device__ __forceinline__ void rqs_pair_fast16(const float* par, float x, const
 template <bool FAST>
 __device__ __forceinline__ void rqs_pair(const float* par, float x, int K, const FwdParams& p,
                                          float& y, float& ld) {
+#ifndef PF_NO_FAST16
     if constexpr (FAST) {
         if (K == 16) { rqs_pair_fast16(par, x, p, y, ld); return; }
     }
+#endif
     float uw[16], uh[16], ud[16];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {

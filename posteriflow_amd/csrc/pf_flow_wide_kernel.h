@@ -34,7 +34,7 @@
 #define PF_WIDE_ABLATE 0   // timing experiments only: 1 no spline, 2 no weight DMA, 4 no MFMA, 8 no sigmoid, 16 no fragment reads, 32 no bias reads
 #endif
 #ifndef PF_WIDE_P
-#define PF_WIDE_P 4        // A fragments requested ahead of their MFMA
+#define PF_WIDE_P 3        // A fragments requested ahead of their MFMA
 #endif
 
 #ifndef PF_WIDE_BUFDMA
