@@ -10,7 +10,7 @@ for spec in "$@"; do
   name=${spec%%:*}; flags=${spec#*:}
   (
   for d in 15 11; do
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $flags -DPF_WIDE_D=$d -c pf_flow_wide_inst.hip -o ../lib/abl/wide_${name}_d$d.o
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form=1 $flags -DPF_WIDE_D=$d -c pf_flow_wide_inst.hip -o ../lib/abl/wide_${name}_d$d.o
   done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS ../lib/abl/wide_${name}_d15.o ../lib/abl/wide_${name}_d11.o -o ../lib/abl/libpfhip_${name}.so
   echo built $name
