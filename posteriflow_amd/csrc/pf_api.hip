@@ -6,6 +6,7 @@
 #include <cstring>
 
 #include "pf_flow_params.h"
+#include "pf_status.h"
 
 namespace pf {
 int64_t stem_pack_map_len(bool bf16);
@@ -35,6 +36,10 @@ int rqs_backward(const PfFlowDesc& d, float deriv_const, const float* u, const f
 int launch_gather(bool bf16, const float* raw, const int32_t* map, void* out, int64_t n, hipStream_t s);
 int flow_backward_chain(const PfFlowDesc& d, float deriv_const, const PfFlowBwdChainArgs& a, hipStream_t s);
 }  // namespace pf
+
+namespace pf {
+thread_local int g_hip_error = 0;
+}
 
 namespace {
 thread_local char g_err[256] = "";
@@ -90,7 +95,7 @@ int pf_flow_pack(const PfFlowDesc* desc, const float* raw, const int32_t* map, v
     if (!raw || !map || !packed) return fail(PF_ERR_BAD_ARG, "null pointer");
     if (misaligned(map, 16) || misaligned(packed, 16)) return fail(PF_ERR_BAD_ARG, "map/packed must be 16-byte aligned");
     rc = pf::launch_pack(L, raw, map, packed, static_cast<hipStream_t>(stream));
-    return rc == PF_OK ? rc : fail(rc, hipGetErrorString(hipGetLastError()));
+    return rc == PF_OK ? rc : fail(rc, hipGetErrorString(static_cast<hipError_t>(pf::g_hip_error)));
 }
 
 int64_t pf_flow_workspace_bytes(const PfFlowDesc* desc, int64_t ctx_rows) {
@@ -108,7 +113,7 @@ static int project_context(const pf::FlowPlan& L, pf::FwdParams& p, void* worksp
     if (!workspace || workspace_bytes < need) return fail(PF_ERR_BAD_ARG, "workspace too small (pf_flow_workspace_bytes)");
     if (misaligned(workspace, 16)) return fail(PF_ERR_BAD_ARG, "workspace must be 16-byte aligned");
     const int rc = pf::launch_ctx_project(L, p.packed, p.ctx, p.ctx_rows, workspace, s);
-    if (rc != PF_OK) return fail(rc, hipGetErrorString(hipGetLastError()));
+    if (rc != PF_OK) return fail(rc, hipGetErrorString(static_cast<hipError_t>(pf::g_hip_error)));
     p.cproj = workspace;
     return PF_OK;
 }
@@ -135,7 +140,7 @@ static int flow_forward_impl(const PfFlowDesc* desc, const void* packed, const f
     rc = project_context(L, p, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
     if (rc != PF_OK) return rc;
     rc = pf::launch_flow_forward(p, static_cast<hipStream_t>(stream));
-    return rc == PF_OK ? rc : fail(rc, rc == PF_ERR_HIP ? hipGetErrorString(hipGetLastError()) : "unsupported launch shape");
+    return rc == PF_OK ? rc : fail(rc, rc == PF_ERR_HIP ? hipGetErrorString(static_cast<hipError_t>(pf::g_hip_error)) : "unsupported launch shape");
 }
 
 int pf_flow_forward_train(const PfFlowDesc* desc, const void* packed, const float* x, const float* ctx,
@@ -175,7 +180,7 @@ int pf_flow_rqs_backward(const PfFlowDesc* desc, const float* u, const float* pa
     const float dc = (float)std::log(std::exp(1.0 - (double)desc->min_derivative) - 1.0);
     const int rc = pf::rqs_backward(*desc, dc, u, params, grad_y, grad_logabsdet, rows, grad_params, grad_u,
                                     static_cast<hipStream_t>(stream));
-    return rc == PF_OK ? rc : fail(rc, hipGetErrorString(hipGetLastError()));
+    return rc == PF_OK ? rc : fail(rc, hipGetErrorString(static_cast<hipError_t>(pf::g_hip_error)));
 }
 
 int pf_flow_backward_chain(const PfFlowDesc* desc, const PfFlowBwdChainArgs* a, void* stream) {
@@ -198,7 +203,7 @@ int pf_flow_backward_chain(const PfFlowDesc* desc, const PfFlowBwdChainArgs* a, 
         if (misaligned(q, 16)) return fail(PF_ERR_BAD_ARG, "weight / activation tensors must be 16-byte aligned");
     const float dc = (float)std::log(std::exp(1.0 - (double)desc->min_derivative) - 1.0);
     const int rc = pf::flow_backward_chain(*desc, dc, *a, static_cast<hipStream_t>(stream));
-    return rc == PF_OK ? rc : fail(rc, rc == PF_ERR_HIP ? hipGetErrorString(hipGetLastError()) : "unsupported shape");
+    return rc == PF_OK ? rc : fail(rc, rc == PF_ERR_HIP ? hipGetErrorString(static_cast<hipError_t>(pf::g_hip_error)) : "unsupported shape");
 }
 
 int pf_flow_inverse(const PfFlowDesc* desc, const void* packed, const float* z, const float* ctx,
@@ -229,7 +234,7 @@ int pf_flow_inverse(const PfFlowDesc* desc, const void* packed, const float* z, 
     rc = project_context(L, p, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
     if (rc != PF_OK) return rc;
     rc = pf::launch_flow_inverse(p, static_cast<hipStream_t>(stream));
-    return rc == PF_OK ? rc : fail(rc, rc == PF_ERR_HIP ? hipGetErrorString(hipGetLastError()) : "unsupported launch shape");
+    return rc == PF_OK ? rc : fail(rc, rc == PF_ERR_HIP ? hipGetErrorString(static_cast<hipError_t>(pf::g_hip_error)) : "unsupported launch shape");
 }
 
 // ---- strain-embedding stem -----------------------------------------------------------------
@@ -263,7 +268,7 @@ int pf_embed_stem_pack(int32_t precision, const float* raw, const int32_t* map, 
     int rc = pf::launch_gather(bf, raw, map, packed, nw, static_cast<hipStream_t>(stream));
     if (rc == PF_OK)
         rc = pf::launch_gather(false, raw, map + nw, static_cast<char*>(packed) + wbytes, nbias, static_cast<hipStream_t>(stream));
-    return rc == PF_OK ? rc : fail(rc, hipGetErrorString(hipGetLastError()));
+    return rc == PF_OK ? rc : fail(rc, hipGetErrorString(static_cast<hipError_t>(pf::g_hip_error)));
 }
 int64_t pf_embed_stem_workspace_bytes(int32_t precision, int64_t n_sequences) {
     if (prec_ok(precision) != PF_OK || n_sequences < 0) return -1;
@@ -284,7 +289,7 @@ int pf_embed_stem_forward(int32_t precision, const void* packed, const float* st
         return fail(PF_ERR_BAD_ARG, "packed/strain/tokens must be 16-byte, workspace 256-byte aligned");
     const int rc = pf::stem_forward(bf, static_cast<const char*>(packed), strain, n_sequences, tokens, log_energy,
                                     static_cast<char*>(workspace), static_cast<hipStream_t>(stream));
-    return rc == PF_OK ? rc : fail(rc, hipGetErrorString(hipGetLastError()));
+    return rc == PF_OK ? rc : fail(rc, hipGetErrorString(static_cast<hipError_t>(pf::g_hip_error)));
 }
 
 // ---- incremental inverse ------------------------------------------------------------------------
@@ -293,7 +298,7 @@ int pf_pack_bf16_frags(const float* src, int32_t n_rows, int32_t k, void* out, v
     if (n_rows <= 0 || k <= 0 || n_rows % 16 || k % 32) return fail(PF_ERR_BAD_ARG, "rows must be a multiple of 16, k of 32");
     if (misaligned(out, 16)) return fail(PF_ERR_BAD_ARG, "out must be 16-byte aligned");
     const int rc = pf::inc_pack_frags(src, n_rows, k, out, static_cast<hipStream_t>(stream));
-    return rc == PF_OK ? rc : fail(rc, hipGetErrorString(hipGetLastError()));
+    return rc == PF_OK ? rc : fail(rc, hipGetErrorString(static_cast<hipError_t>(pf::g_hip_error)));
 }
 int64_t pf_flow_inc_layer_bytes(const PfFlowDesc* desc) {
     if (!desc || desc->hidden_features % 32 || desc->hidden_features < 64 || desc->hidden_features > 256) return -1;
@@ -320,7 +325,7 @@ int pf_flow_inverse_inc(const PfFlowDesc* desc, const int32_t* units_upto_degree
     const int rc = pf::flow_inverse_inc(*desc, dc, units_upto_degree, packed, ctx_proj, ctx_proj ? ctx_rows : batch, z,
                                         ar_inv_perm, batch, x, logdet, fail_flags, static_cast<hipStream_t>(stream));
     if (rc == PF_ERR_UNSUPPORTED) return fail(rc, "incremental inverse: more than 8 sixteen-unit tiles hold the units of one degree");
-    return rc == PF_OK ? rc : fail(rc, hipGetErrorString(hipGetLastError()));
+    return rc == PF_OK ? rc : fail(rc, hipGetErrorString(static_cast<hipError_t>(pf::g_hip_error)));
 }
 
 // ---- strain-embedding token mixer (fusion transformer + attention pool) ------------------------
@@ -330,7 +335,7 @@ int pf_embed_fusion_pack(const float* raw, void* packed, void* stream) {
     if (!raw || !packed) return fail(PF_ERR_BAD_ARG, "null pointer");
     if (misaligned(packed, 16) || misaligned(raw, 4)) return fail(PF_ERR_BAD_ARG, "packed must be 16-byte aligned");
     const int rc = pf::fusion_pack(raw, static_cast<char*>(packed), static_cast<hipStream_t>(stream));
-    return rc == PF_OK ? rc : fail(rc, hipGetErrorString(hipGetLastError()));
+    return rc == PF_OK ? rc : fail(rc, hipGetErrorString(static_cast<hipError_t>(pf::g_hip_error)));
 }
 int pf_embed_fusion_forward(const void* packed, float* tokens, int32_t n_tokens, const float* token_bias,
                             const float* pool_queries, int64_t n_events, float* pooled, void* stream) {
@@ -344,7 +349,7 @@ int pf_embed_fusion_forward(const void* packed, float* tokens, int32_t n_tokens,
         return fail(PF_ERR_BAD_ARG, "packed/tokens/token_bias/pooled must be 16-byte aligned");
     const int rc = pf::fusion_forward(static_cast<const char*>(packed), tokens, n_tokens, token_bias, pool_queries, n_events, pooled,
                                       static_cast<hipStream_t>(stream));
-    return rc == PF_OK ? rc : fail(rc, hipGetErrorString(hipGetLastError()));
+    return rc == PF_OK ? rc : fail(rc, hipGetErrorString(static_cast<hipError_t>(pf::g_hip_error)));
 }
 
 // ---- training-example remix --------------------------------------------------------------------
@@ -369,7 +374,7 @@ int pf_remix_forward(const void* noise_pool, int64_t n_noise, const void* signal
     const int rc = pf::remix_forward(noise_pool, n_noise, signal_pool, n_signals, noise_row, sig_start, nsig, scale,
                                      shift, fill_row, fill, n_fill, batch, strain, sig_sum, net_snr, workspace,
                                      static_cast<hipStream_t>(stream));
-    return rc == PF_OK ? rc : fail(rc, hipGetErrorString(hipGetLastError()));
+    return rc == PF_OK ? rc : fail(rc, hipGetErrorString(static_cast<hipError_t>(pf::g_hip_error)));
 }
 
 const char* pf_flow_forward_kernel_name(const PfFlowDesc* desc, int64_t batch) {

@@ -23,6 +23,8 @@
 //   f32  mode: v_mfma_f32_16x16x4_f32,   activations fp32 throughout (parity mode)
 #include <hip/hip_runtime.h>
 
+#include "pf_status.h"
+
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -475,7 +477,7 @@ static int launch_layer(const ConvParams& p, hipStream_t s) {
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PF_ERR_HIP;
     const unsigned gx = (L.lout + G.cg * 16 - 1) / (G.cg * 16);
     hipLaunchKernelGGL(k, dim3(gx, (unsigned)p.n_seq), dim3(G.nwaves * 64), lds, s, p);
-    return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
+    return launch_status();
 }
 
 template <bool BF16>
@@ -487,7 +489,7 @@ static int launch_fused12(const ConvParams& p, hipStream_t s) {
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PF_ERR_HIP;
     const unsigned gx = (L.lout + kFuseCG * 16 - 1) / (kFuseCG * 16);
     hipLaunchKernelGGL(k, dim3(gx, (unsigned)p.n_seq), dim3(4 * 64), lds, s, p);
-    return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
+    return launch_status();
 }
 
 template <bool BF16>

@@ -18,6 +18,8 @@
 // the transform is the identity: dL/du = gy and no parameter gradient.
 #include <hip/hip_runtime.h>
 
+#include "pf_status.h"
+
 #include <cstdint>
 
 #include "../../include/pf_hip.h"
@@ -53,6 +55,6 @@ int rqs_backward(const PfFlowDesc& d, float deriv_const, const float* u, const f
                  RqsConsts{d.num_bins, d.tail_bound, d.min_bin_width, d.min_bin_height, d.min_derivative, deriv_const}};
     const int64_t pairs = n * d.features;
     rqs_backward_kernel<<<dim3(static_cast<unsigned>((pairs + 255) / 256)), dim3(256), 0, s>>>(a);
-    return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
+    return launch_status();
 }
 }  // namespace pf

@@ -27,6 +27,8 @@
 // layer streams per workgroup, ~0.3 ms per launch whatever the batch up to 4096 rows.
 #include <hip/hip_runtime.h>
 
+#include "pf_status.h"
+
 #include <cstdint>
 
 #include "../../include/pf_hip.h"
@@ -235,7 +237,7 @@ int flow_backward_chain(const PfFlowDesc& d, float deriv_const, const PfFlowBwdC
             hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return PF_ERR_HIP;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, p);
-        return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
+        return launch_status();
     };
     switch (p.H / 64) {
     case 1: return launch(flow_bwd_chain_kernel<1>);

@@ -13,6 +13,8 @@
 // columns of 4 MFMA column groups, the context tile is staged once in LDS in B-fragment order.
 #include <hip/hip_runtime.h>
 
+#include "pf_status.h"
+
 #include "pf_flow_params.h"
 
 namespace pf {
@@ -195,7 +197,7 @@ int launch_ctx_project(const FlowPlan& L, const char* packed, const float* ctx, 
                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PF_ERR_HIP;
         hipLaunchKernelGGL(k, dim3(row_blocks, chunks), dim3(256), lds, s, p);
     }
-    return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
+    return launch_status();
 }
 
 }  // namespace pf

@@ -40,7 +40,7 @@ static int rows_per_workgroup_dir(const FlowPlan& L, int64_t batch, bool inverse
     } else if (inverse) {
         if (batch > 256 * 16) R = 2;
     } else {
-        const bool r3 = L.bf16 && L.NT == 16 && !L.hoist;
+        const bool r3 = L.bf16 && L.NT == 16 && !L.hoist && L.dense == 0;
         const double t[4] = {0.0, 1.0, 1.32, 1.81};
         double best = 1e300;
         for (int r = 1; r <= (r3 ? 3 : 2); ++r) {
@@ -49,9 +49,9 @@ static int rows_per_workgroup_dir(const FlowPlan& L, int64_t batch, bool inverse
             if (cost < best - 1e-9) { best = cost; R = r; }
         }
     }
-    const bool r3_built = !inverse && L.bf16 && L.NT == 16 && !L.hoist;
+    const bool r3_built = !inverse && L.bf16 && L.NT == 16 && !L.hoist && L.dense == 0;
     if (R == 3 && !r3_built) R = 2;
-    if (L.dense) R = 1;
+    if (L.dense == 1) R = 1;
     while (R > 1 && fwd_lds_bytes_host(L, R) > 160 * 1024) --R;
     return 16 * R;
 }
@@ -60,9 +60,8 @@ int rows_per_workgroup(const FlowPlan& L, int64_t batch) { return rows_per_workg
 // the kernel launch_flow_forward picks for (plan, batch), as rocprofv3 prints it
 void forward_kernel_name(const FlowPlan& L, int64_t batch, char* out, size_t n) {
     if (L.wide) { snprintf(out, n, "pf::flow_wide_kernel<%d, %d>", L.D, L.CKM); return; }
-    const int R = L.dense ? 1 : rows_per_workgroup(L, batch) / 16;
-    snprintf(out, n, "pf::flow_kernel<%s, %d, %d, %d, %s, false>", L.bf16 ? "true" : "false", L.NT, R, L.CKM,
-             L.dense ? "true" : "false");
+    const int R = L.dense == 1 ? 1 : rows_per_workgroup(L, batch) / 16;
+    snprintf(out, n, "pf::flow_kernel<%s, %d, %d, %d, %d, false>", L.bf16 ? "true" : "false", L.NT, R, L.CKM, L.dense);
 }
 
 int launch_flow_forward(const FwdParams& p_in, hipStream_t s) {

@@ -37,6 +37,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "pf_status.h"
+
 #include <cstdlib>
 #include <type_traits>
 
@@ -353,7 +355,7 @@ template <int V> using ic = std::integral_constant<int, V>;
 #define PF_ABL(mask) false
 #endif
 
-template <bool BF16, int NT, int R, int CKM, bool DENSE, bool INV>
+template <bool BF16, int NT, int R, int CKM, int DENSE, bool INV>
 __global__ __launch_bounds__(NT * 32) void flow_kernel(const FwdParams p) {
     using S = Sched<BF16, NT, CKM, DENSE>;
     constexpr bool FAST = BF16;
@@ -867,7 +869,7 @@ inline size_t fwd_lds_bytes(const FlowPlan& L, int R) {
          + (size_t)(3 * 16 * 16 * R + 2 * L.NT * kBiasFloatsPerTile + L.D * 16 * R) * sizeof(float);
 }
 
-template <bool BF16, int NT, int R, int CKM, bool DENSE, bool INV>
+template <bool BF16, int NT, int R, int CKM, int DENSE, bool INV>
 inline int launch_variant(const FwdParams& p, hipStream_t s) {
     const unsigned grid = (unsigned)((p.batch + 16 * R - 1) / (16 * R));
     const size_t lds = fwd_lds_bytes(p.plan, R);
@@ -877,18 +879,25 @@ inline int launch_variant(const FwdParams& p, hipStream_t s) {
                             (int)lds) != hipSuccess)
         return PF_ERR_HIP;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT * 32), lds, s, p);
-    return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
+    return launch_status();
 }
 
 // all built variants of one (precision, NT): R in {1,2} x {masked}, R = 1 x {dense}
 template <bool BF16, int NT, int CKM, bool INV>
 inline int launch_ckm(const FwdParams& p, int R, hipStream_t s) {
-    if (p.plan.dense) return launch_variant<BF16, NT, 1, CKM, true, INV>(p, s);
-    if constexpr (BF16 && NT == 16 && !INV) {            // large batches, LeanNPE-sized hidden width: 48 rows per workgroup
-        if (R == 3) return launch_variant<BF16, NT, 3, CKM, false, INV>(p, s);
+    if (p.plan.dense == 1) return launch_variant<BF16, NT, 1, CKM, 1, INV>(p, s);
+    if constexpr (BF16 && NT == 16) {
+        if (p.plan.dense == 2) {
+            if (R >= 2) return launch_variant<BF16, NT, 2, CKM, 2, INV>(p, s);
+            return launch_variant<BF16, NT, 1, CKM, 2, INV>(p, s);
+        }
     }
-    if (R >= 2) return launch_variant<BF16, NT, 2, CKM, false, INV>(p, s);
-    return launch_variant<BF16, NT, 1, CKM, false, INV>(p, s);
+    if (p.plan.dense != 0) return PF_ERR_UNSUPPORTED;
+    if constexpr (BF16 && NT == 16 && !INV) {            // large batches, LeanNPE-sized hidden width: 48 rows per workgroup
+        if (R == 3) return launch_variant<BF16, NT, 3, CKM, 0, INV>(p, s);
+    }
+    if (R >= 2) return launch_variant<BF16, NT, 2, CKM, 0, INV>(p, s);
+    return launch_variant<BF16, NT, 1, CKM, 0, INV>(p, s);
 }
 
 }  // namespace pf

@@ -32,6 +32,8 @@
 //   - LDS rows have a fixed stride, so operand addresses are one VGPR + an instruction immediate.
 #include <hip/hip_runtime.h>
 
+#include "pf_status.h"
+
 #include <mutex>
 
 #include <algorithm>
@@ -515,7 +517,7 @@ int inc_pack_frags(const float* src, int n_rows, int k, void* out, hipStream_t s
     const int64_t tot = static_cast<int64_t>(n_rows) * k;
     inc_pack_frags_kernel<<<dim3(static_cast<unsigned>((tot + 255) / 256)), dim3(256), 0, s>>>(
         src, n_rows, k, static_cast<__bf16*>(out));
-    return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
+    return launch_status();
 }
 
 int64_t inc_layer_bytes(int D, int H, bool f32) {
@@ -593,6 +595,6 @@ int flow_inverse_inc(const PfFlowDesc& d, float deriv_const, const int32_t* u1, 
                 std::fprintf(stderr, "  | pass %lld\n", (long long)(r[7] - r[0]));
             }
     }
-    return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
+    return launch_status();
 }
 }  // namespace pf

@@ -33,7 +33,7 @@ int PF_CAT(launch_flow_wide_d, PF_WIDE_D)(const FwdParams& p, hipStream_t s) {
 #else
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, p);
 #endif
-    return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
+    return launch_status();
 }
 
 }  // namespace pf

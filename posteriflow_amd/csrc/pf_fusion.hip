@@ -28,6 +28,8 @@
 // bf16 operands, fp32 accumulation, fp32 LayerNorm / softmax / GELU (erf) / residual.
 #include <hip/hip_runtime.h>
 
+#include "pf_status.h"
+
 #include <cstdint>
 
 #include "../../include/pf_hip.h"
@@ -515,7 +517,7 @@ int fusion_pack(const float* raw, char* packed, hipStream_t s) {
     }
     frags(r, 384, 192, kPoolW); r += 384 * 192;
     vec(r, 384, kPoolB);
-    return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
+    return launch_status();
 }
 
 int fusion_forward(const char* packed, float* tokens, int n_tokens, const float* tok_bias, const float* pool_q,
@@ -529,6 +531,6 @@ int fusion_forward(const char* packed, float* tokens, int n_tokens, const float*
     }
     FusionParams p{packed, tokens, tok_bias, pool_q, pooled, n_tokens};
     fusion_kernel<<<dim3(static_cast<unsigned>(n_events)), dim3(512), kLds, s>>>(p);
-    return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
+    return launch_status();
 }
 }  // namespace pf

@@ -72,14 +72,14 @@ template <bool BF16> constexpr int kPadH = BF16 ? 2 : 5;
 template <bool BF16> constexpr int kPadO = BF16 ? 1 : 2;
 
 // compile-time schedule (frag offsets inside one layer of a wave's stream)
-template <bool BF16, int NT, int CKM, bool DENSE>
+template <bool BF16, int NT, int CKM, int DENSE>   // DENSE: 0 masked stream, 1 dense stream, 2 masked with one more H x H entry
 struct Sched {
     static constexpr int HK = BF16 ? NT / 2 : NT;          // frags per full hidden tile row
     // masked streams: a tile pair (w, T-1-w) needs kH[w] + kH[T-1-w] <= HK + pad entries.  32-wide bf16 k-steps pair up
     // within HK + 2 / HK + 1; the 16-wide fp32 k-steps are finer, the sums of LeanNPE-sized flows reach HK + 5 / HK + 2
     // (D = 11: 9 + 12 = 21 of 32 dense entries) -- still a third fewer fragments and MFMAs than the dense stream
-    static constexpr int KHS = DENSE ? 2 * HK : HK + kPadH<BF16>;   // entries of a masked H x H GEMM (tile pair)
-    static constexpr int KOS = DENSE ? 2 * HK : HK + kPadO<BF16>;   // entries per spline-parameter tile (feature pair)
+    static constexpr int KHS = DENSE == 1 ? 2 * HK : HK + kPadH<BF16> + (DENSE == 2 ? 1 : 0);   // entries of a masked H x H GEMM (tile pair)
+    static constexpr int KOS = DENSE == 1 ? 2 * HK : HK + kPadO<BF16>;   // entries per spline-parameter tile (feature pair)
     static constexpr int E_IN = 0;
     static constexpr int E_CTX = 2;
     static constexpr int E_BLK = E_CTX + 2 * CKM;
@@ -96,7 +96,8 @@ struct FlowPlan {
     int CK, CKM, HK;            // needed / scheduled context frags per tile; frags per full hidden row
     int hoist;                  // 1: context projections hoisted (CKM = 0 in the streams)
     int additive;               // 1: masked-context conditioner: additive context, no reverse permutation
-    int dense;                  // 1: KHS = KOS = 2*HK (masks too coarse to pair up), else HK + kPadH / HK + kPadO
+    int dense;                  // 0: masked stream, KHS / KOS = HK + kPadH / HK + kPadO; 1: KHS = KOS = 2*HK (masks too coarse to
+                                // pair up); 2: masked, KHS = HK + kPadH + 1 (bf16, NT = 16)
     int wide;                   // 1: the large-batch kernel's single common stream (pf_wide_layout.h); CKS in CKM
     int KHS, KOS, NF;
     int kH[kMaxTiles];          // active k-steps of tile t in a masked H x H GEMM
@@ -206,8 +207,11 @@ inline int make_plan(const PfFlowDesc& d, FlowPlan& o) {
     }
     const int padh = o.bf16 ? kPadH<true> : kPadH<false>, pado = o.bf16 ? kPadO<true> : kPadO<false>;
     o.dense = (khs > o.HK + padh || kos > o.HK + pado || o.HK + padh > 2 * o.HK) ? 1 : 0;
-    o.KHS = o.dense ? 2 * o.HK : o.HK + padh;
-    o.KOS = o.dense ? 2 * o.HK : o.HK + pado;
+    // LeanNPE's own shape (D = 11, H = 256) in bf16: tile-pair sums reach HK + 3 -- a variant with one more entry per
+    // H x H GEMM (11 of 16 dense entries) instead of the dense stream
+    if (o.dense && o.bf16 && o.NT == 16 && khs <= o.HK + padh + 1 && kos <= o.HK + pado) o.dense = 2;
+    o.KHS = o.dense == 1 ? 2 * o.HK : o.HK + padh + (o.dense == 2 ? 1 : 0);
+    o.KOS = o.dense == 1 ? 2 * o.HK : o.HK + pado;
     o.NF = 2 + 2 * o.CKM + o.NB * (2 * o.KHS + 2 * o.CKM) + 3 * o.KOS;
     o.fragsPerWave = (int64_t)o.L * o.NF + kWindowPad;
     o.fragsTotal = o.fragsPerWave * o.NW;

@@ -9,6 +9,8 @@
 //   hidden mask: deg_out >= deg_in;  output mask: deg_out > deg_in.
 #include <hip/hip_runtime.h>
 
+#include "pf_status.h"
+
 #include <algorithm>
 
 #include "pf_flow_params.h"
@@ -344,7 +346,7 @@ int launch_gather(bool bf16, const float* raw, const int32_t* map, void* out, in
         hipLaunchKernelGGL(pack_f32_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, raw, map,
                            reinterpret_cast<float*>(out), n);
     }
-    return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
+    return launch_status();
 }
 
 int launch_pack(const FlowPlan& L, const float* raw, const int32_t* map, void* packed,
@@ -371,7 +373,7 @@ int launch_pack(const FlowPlan& L, const float* raw, const int32_t* map, void* p
     gather_f(map + nW, out + L.weightBytes, nB);
     gather_w(map + nW + nB, out + L.ctx_frag_offset(), nCW);
     gather_f(map + nW + nB + nCW, out + L.ctx_bias_offset(), nCB);
-    return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
+    return launch_status();
 }
 
 }  // namespace pf

@@ -12,6 +12,8 @@
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 
+#include "pf_status.h"
+
 #include <cstdint>
 
 #include "../../include/pf_hip.h"
@@ -164,6 +166,6 @@ int remix_forward(const void* noise, int64_t n_noise, const void* signals, int64
     if (net_snr)
         remix_snr_kernel<<<dim3(static_cast<unsigned>((batch + 255) / 256)), dim3(256), 0, s>>>(
             static_cast<const double*>(ws), net_snr, batch);
-    return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
+    return launch_status();
 }
 }  // namespace pf

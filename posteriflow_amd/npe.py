@@ -429,12 +429,18 @@ class LeanNPE(nn.Module):
         return out
 
 
-def batch_nll(model: LeanNPE, strain, params, nsig, asd_bands=None):
+def batch_nll(model: LeanNPE, strain, params, nsig, asd_bands=None, row_cap: Optional[int] = None):
     """Mean per-signal NLL of a batch of events with up to ``max_signals`` signals each
     (experiments/train_lean_npe.py:108-127), as ONE flow call over all (event, rank) pairs with a
     0/1 weight for rank < nsig, instead of looping over ranks with a boolean-index host sync per rank
     (SURVEY H6): sum / count is identical, shapes are static (every step launches the same kernels) and nothing
-    waits on the host."""
+    waits on the host.
+
+    ``row_cap``: a STATIC upper bound on the number of (event, rank) pairs that exist in a batch (e.g. 2 x batch for
+    the reference's mix of 1-5 signals, mean ~1.8).  The existing pairs are moved to the front by a stable sort (no
+    host sync) and only the first ``row_cap`` rows go through the flow, forward and backward -- instead of
+    ``max_signals`` = 5 rows per event whatever ``nsig`` is.  Pairs beyond the cap would be dropped from the mean:
+    ``batch_nll.last_overflow`` (a device scalar, read it when convenient) counts them."""
     context = model.encode(strain, asd_bands)
     b, r_max = params.shape[0], params.shape[1]
     ranks = torch.arange(r_max, device=nsig.device)[None, :].expand(b, r_max)
@@ -442,5 +448,13 @@ def batch_nll(model: LeanNPE, strain, params, nsig, asd_bands=None):
     # rows of absent ranks are all-zero labels (remix_data.py:229): give them a valid stand-in (rank 0 of
     # the same event) so that the unused rows stay finite; their weight is 0
     rows = torch.where(keep[:, None], params.reshape(b * r_max, -1), params[:, :1].expand(-1, r_max, -1).reshape(b * r_max, -1))
-    nll = model.nll(None, rows, ranks.reshape(-1), context=context.repeat_interleave(r_max, dim=0))
+    rank_flat = ranks.reshape(-1)
+    if row_cap is not None and row_cap < b * r_max:
+        order = torch.argsort((~keep).to(torch.int8), stable=True)[:row_cap]       # existing pairs first, static length
+        batch_nll.last_overflow = (keep.sum() - keep[order].sum()).detach()
+        event = order // r_max
+        nll = model.nll(None, rows[order], rank_flat[order], context=context[event])
+        kept = keep[order]
+        return torch.where(kept, nll, torch.zeros_like(nll)).sum() / kept.sum().clamp_min(1)
+    nll = model.nll(None, rows, rank_flat, context=context.repeat_interleave(r_max, dim=0))
     return torch.where(keep, nll, torch.zeros_like(nll)).sum() / keep.sum().clamp_min(1)

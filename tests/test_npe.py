@@ -143,6 +143,12 @@ def test_lean_npe_nll_and_sampling_gpu(golden_encoder):
             torch.zeros_like(p))
         want_b = lean_ref.batch_nll_ref(ref_nll, ctx_cpu, params, nsig).item()
         assert abs(got - want_b) / abs(want_b) < 1e-3
+        # static row cap (11 existing pairs of 20): the same mean from 12 flow rows instead of 20; a cap that is too
+        # small is reported, not silently absorbed
+        got_c = npe.batch_nll(model, strain.cuda(), params.cuda(), nsig.cuda(), row_cap=12).item()
+        assert abs(got_c - want_b) / abs(want_b) < 1e-3 and int(npe.batch_nll.last_overflow) == 0
+        npe.batch_nll(model, strain.cuda(), params.cuda(), nsig.cuda(), row_cap=8)
+        assert int(npe.batch_nll.last_overflow) == 3
 
 
 @pytest.mark.gpu
