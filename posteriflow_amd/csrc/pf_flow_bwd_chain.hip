@@ -95,9 +95,9 @@ __global__ __launch_bounds__(256) void flow_bwd_chain_kernel(const ChainArgs p) 
             for (int i = 0; i < TPW; ++i) a2[i] = *reinterpret_cast<const f32x4*>(wrow[i] + 16 * qn);
             const f32x4 b = *reinterpret_cast<const f32x4*>(brow + 16 * q);
 #pragma unroll
-            for (int i = 0; i < TPW; ++i)
+            for (int e = 0; e < 4; ++e)                      // tiles innermost: consecutive MFMAs are independent
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i][e], b[e], acc[i], 0, 0, 0);
+                for (int i = 0; i < TPW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i][e], b[e], acc[i], 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < TPW; ++i) { a0[i] = a1[i]; a1[i] = a2[i]; }
         }
@@ -133,6 +133,11 @@ __global__ __launch_bounds__(256) void flow_bwd_chain_kernel(const ChainArgs p) 
         }
         // ---- gh = Wf^T Gp ----------------------------------------------------------------------------------------
         f32x4 gh[TPW], acc[TPW];
+        f32x4 gate_n[TPW], t2_n[TPW];                        // block operands, requested one GEMM ahead of their use
+        if (has_ctx) {
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) { gate_n[i] = ld4(A.gates, 1 * L + l, wave + 4 * i); t2_n[i] = ld4(A.t2s, 1 * L + l, wave + 4 * i); }
+        }
         gemm(A.WfT + (size_t)l * H * PM, PM, PM, s_gp, PMS, gh);
         // ---- residual blocks, last first -------------------------------------------------------------------------
         for (int j = 1; j >= 0; --j) {
@@ -141,7 +146,7 @@ __global__ __launch_bounds__(256) void flow_bwd_chain_kernel(const ChainArgs p) 
                 const int t = wave + 4 * i;
                 f32x4 gt2 = gh[i];
                 if (has_ctx) {
-                    const f32x4 gate = ld4(A.gates, j * L + l, t), t2 = ld4(A.t2s, j * L + l, t);
+                    const f32x4 gate = gate_n[i], t2 = t2_n[i];
                     f32x4 gc;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -157,6 +162,13 @@ __global__ __launch_bounds__(256) void flow_bwd_chain_kernel(const ChainArgs p) 
             f32x4 t1[TPW], hj[TPW];                          // requested ahead of the GEMMs whose epilogues use them
 #pragma unroll
             for (int i = 0; i < TPW; ++i) { t1[i] = ld4(A.t1s, j * L + l, wave + 4 * i); hj[i] = ld4(A.hs, j * L + l, wave + 4 * i); }
+            if (has_ctx) {                                   // the next block's gate / t2 (block 0 after block 1), or the context layer's pc
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) {
+                    if (j == 1) { gate_n[i] = ld4(A.gates, l, wave + 4 * i); t2_n[i] = ld4(A.t2s, l, wave + 4 * i); }
+                    else gate_n[i] = ld4(A.pc, l, wave + 4 * i);
+                }
+            }
             gemm(A.W2T + ((size_t)j * L + l) * H * H, H, H, s_v0, HS, acc);
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
@@ -180,7 +192,7 @@ __global__ __launch_bounds__(256) void flow_bwd_chain_kernel(const ChainArgs p) 
             const int t = wave + 4 * i;
             st4(A.Gh0, l, t, gh[i]);
             if (has_ctx) {
-                const f32x4 pc = ld4(A.pc, l, t);
+                const f32x4 pc = gate_n[i];
                 f32x4 gc;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) gc[e] = pc[e] > 0.f ? gh[i][e] : 0.f;
