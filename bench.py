@@ -297,6 +297,9 @@ def main():
     ap.add_argument("--allreduce-every", type=int, default=1,
                     help="N > 1: steps per all-reduce of the in-kernel (sum nll, rows) accumulator (1 = every step, the "
                          "contract's step; the windowed figure is reported under extras)")
+    ap.add_argument("--settle", type=int, default=300,
+                    help="untimed launches BEFORE the W warm-up steps (part of set-up, like packing the weights): an idle GPU "
+                         "takes tens of milliseconds to reach the clock it holds under load, and K = 20 steps are 2 ms")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N > 1 path on fewer GPUs than ranks (collective through the host)")
     args = ap.parse_args()
@@ -423,6 +426,9 @@ def main():
                 step()
         log("step captured" if use_graph else "one pre-bound launch per step" + (" + async all-reduce" if collective else ""))
         run = graph.replay if graph is not None else step
+        for _ in range(max(0, args.settle)):              # clock settling (set-up), then the contract's W warm-up steps
+            plain()
+        stream.synchronize()
         for _ in range(args.warmup):
             run()
         elapsed, dev_ms = timed_loop(run, args.steps)
