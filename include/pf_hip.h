@@ -125,6 +125,20 @@ int pf_flow_forward_train(const PfFlowDesc* desc, const void* packed,
                           const float* log_sigma, int64_t batch,
                           float* z, float* logdet, float* nll, float* layer_inputs,
                           void* workspace, int64_t workspace_bytes, void* stream);
+/* pf_flow_forward_train_dropout = pf_flow_forward_train in TRAIN mode of a flow built with dropout_probability > 0
+ * (src/ahsd/models/flows.py:522 passes it to nflows; create_flow_model defaults to 0.15, flows.py:1008): nflows'
+ * MaskedResidualBlock applies dropout after the second activation of every residual block.  The keep decision of
+ * (row, layer, block, hidden unit) is a counter hash of dropout_seed -- kept values are scaled by 1 / (1 - p) -- so the
+ * backward regenerates the factors with pf_flow_dropout_mask: mask[2][L][batch][H] (block, layer, row, unit in nflows
+ * order), each 0 or 1 / (1 - p).  dropout_p = 0 is pf_flow_forward_train.  Not available with PF_FLAG_WIDE. */
+int pf_flow_forward_train_dropout(const PfFlowDesc* desc, const void* packed,
+                                  const float* x, const float* ctx, const int32_t* ar_perm,
+                                  const float* log_sigma, int64_t batch,
+                                  float* z, float* logdet, float* nll, float* layer_inputs,
+                                  float dropout_p, uint64_t dropout_seed,
+                                  void* workspace, int64_t workspace_bytes, void* stream);
+int pf_flow_dropout_mask(const PfFlowDesc* desc, float dropout_p, uint64_t dropout_seed, int64_t batch,
+                         float* mask, void* stream);
 /* pf_flow_forward_reduce: pf_flow_forward for a loss -- nll (may be NULL) as there, and
  * nll_sum_count[0] += sum of nll over the batch, nll_sum_count[1] += batch (float atomics, one pair per
  * workgroup after a wave shuffle reduction): the 8-byte vector a data-parallel rank all-reduces

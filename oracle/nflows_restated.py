@@ -205,10 +205,11 @@ class MaskedContextLinear(nn.Module):
 
 
 class MaskedContextResidualBlock(nn.Module):
-    """flows.py:186-234: relu, W0, + ctx, relu, W1, residual add (no gate)."""
+    """flows.py:186-234: relu, W0, + ctx, relu, dropout, W1, residual add (no gate)."""
 
-    def __init__(self, in_degrees, autoregressive_features, n_blocks, block_dim):
+    def __init__(self, in_degrees, autoregressive_features, n_blocks, block_dim, dropout_probability=0.0):
         super().__init__()
+        self.dropout = nn.Dropout(p=dropout_probability)               # flows.py:219
         features = len(in_degrees)
         self.context_layer = MaskedContextLinear(n_blocks, block_dim, in_degrees)
         l0 = MaskedLinear(in_degrees, features, autoregressive_features, False)
@@ -222,20 +223,21 @@ class MaskedContextResidualBlock(nn.Module):
         t = self.linear_layers[0](F.relu(inputs))
         if context is not None:
             t = t + self.context_layer(context)
-        t = self.linear_layers[1](F.relu(t))
+        t = self.linear_layers[1](self.dropout(F.relu(t)))             # flows.py:231-233
         return inputs + t
 
 
 class MADEWithMaskedContext(nn.Module):
     """flows.py:237-303"""
 
-    def __init__(self, features, hidden_features, n_blocks, block_dim, num_blocks=2, output_multiplier=1):
+    def __init__(self, features, hidden_features, n_blocks, block_dim, num_blocks=2, output_multiplier=1,
+                 dropout_probability=0.0):
         super().__init__()
         self.initial_layer = MaskedLinear(input_degrees(features), hidden_features, features, False)
         self.initial_layer.split_input = True
         deg = self.initial_layer.degrees
         self.context_layer = MaskedContextLinear(n_blocks, block_dim, deg)
-        self.blocks = nn.ModuleList([MaskedContextResidualBlock(deg, features, n_blocks, block_dim)
+        self.blocks = nn.ModuleList([MaskedContextResidualBlock(deg, features, n_blocks, block_dim, dropout_probability)
                                      for _ in range(num_blocks)])
         self.final_layer = MaskedLinear(deg, features * output_multiplier, features, True)
 
@@ -407,7 +409,7 @@ class MaskedPiecewiseRationalQuadraticAutoregressiveTransform(nn.Module):
         self.scale_by_sqrt_hidden = scale_by_sqrt_hidden
         if masked_context_blocks:     # (n_blocks, block_dim): flows.py:306-360
             self.autoregressive_net = MADEWithMaskedContext(features, hidden_features, *masked_context_blocks,
-                                                            num_blocks, self.output_multiplier())
+                                                            num_blocks, self.output_multiplier(), dropout_probability)
         else:
             self.autoregressive_net = MADE(features, hidden_features, context_features,
                                            num_blocks, self.output_multiplier(),

@@ -69,36 +69,50 @@ def rqs_forward(x, uw, uh, ud, tail_bound):
     return torch.where(inside, y, x), torch.where(inside, lad, torch.zeros_like(lad))
 
 
-def made_forward(net, x, ctx, additive=False):
+def made_forward(net, x, ctx, additive=False, drop=None):
     """nflows MADE over the parameter container ``flows._MADE`` (weights * masks); context enters
     through GLU gates (nflows) or, for the reference's masked-context variant, additively between the
-    two masked linears of a block (flows.py:225-234)."""
+    two masked linears of a block (flows.py:225-234).  ``drop``: per-block dropout factors [nb][B, H]
+    (0 or 1 / (1 - p), ``dropout_mask``) applied where both put their nn.Dropout, or None."""
     lin = lambda m, v: F.linear(v, m.weight * m.mask, m.bias)
     cl = lambda m, v: F.linear(v, m.weight * m.mask, m.bias) if hasattr(m, "mask") else m(v)
     h = lin(net.initial_layer, x)
     if ctx is not None:
         h = h + F.relu(cl(net.context_layer, ctx))
-    for blk in net.blocks:
+    for j, blk in enumerate(net.blocks):
         t = lin(blk.linear_layers[0], F.relu(h))
         if additive and ctx is not None:
             t = t + cl(blk.context_layer, ctx)
-        t = lin(blk.linear_layers[1], F.relu(t))
+        t = F.relu(t)
+        if drop is not None:
+            t = t * drop[j]
+        t = lin(blk.linear_layers[1], t)
         if ctx is not None and not additive:
             t = t * torch.sigmoid(blk.context_layer(ctx))
         h = h + t
     return lin(net.final_layer, h)
 
 
-def flow_forward(flow, x, ctx):
-    """(z, logdet) of ``NSFPosteriorFlow`` with tensor ops (autograd-differentiable)."""
+def dropout_mask(flow, batch, seed, device):
+    """the factors flow_train_kernel applied with this seed: fp32 [2, L, batch, H], 0 or 1 / (1 - p)
+    (block, layer, row, hidden unit in nflows order); pf_flow_dropout_mask evaluates the kernel's counter hash."""
+    m = torch.empty(2, flow.num_layers, batch, flow.hidden_features, dtype=torch.float32, device=device)
+    _lib.check(_lib.lib().pf_flow_dropout_mask(flow._desc(), float(flow.dropout), int(seed), batch, m.data_ptr(),
+                                               torch.cuda.current_stream(device).cuda_stream), "pf_flow_dropout_mask")
+    return m
+
+
+def flow_forward(flow, x, ctx, drop=None):
+    """(z, logdet) of ``NSFPosteriorFlow`` with tensor ops (autograd-differentiable); ``drop``: ``dropout_mask``."""
     x = x[:, flow._ar_perm]
     k, d = flow.num_bins, flow.features
     logdet = x.new_zeros(x.shape[0])
     additive = bool(getattr(flow, "use_masked_context", False))
-    for layer in flow._ar_transforms:
+    for l, layer in enumerate(flow._ar_transforms):
         if not additive:
             x = x.flip(1)                                               # ReversePermutation
-        p = made_forward(layer.autoregressive_net, x, ctx, additive).view(-1, d, 3 * k - 1)
+        dl = None if drop is None else drop[:, l]
+        p = made_forward(layer.autoregressive_net, x, ctx, additive, dl).view(-1, d, 3 * k - 1)
         x, lad = rqs_forward(x, p[..., :k], p[..., k:2 * k], p[..., 2 * k:], float(flow._tail_bound))
         logdet = logdet + lad.sum(dim=1)
     return x, logdet
@@ -116,9 +130,10 @@ def _rqs_backward(flow, u, params, gy, glad, gparams):
 
 
 @torch.no_grad()
-def _flow_backward_batched(flow, U, ctx, g_z, g_lad):
+def _flow_backward_batched(flow, U, ctx, g_z, g_lad, drop=None):
     """U [L, B, D] conditioner inputs kept by the forward kernel; g_z [B, D] = dL/dz, g_lad [B] =
-    dL/dlogdet.  Returns dL/dx [B, D], dL/dctx (or None) and the parameter gradients batched over layers."""
+    dL/dlogdet; drop: the forward's dropout factors (``dropout_mask``) or None.  Returns dL/dx [B, D], dL/dctx (or
+    None) and the parameter gradients batched over layers."""
     nets = [t.autoregressive_net for t in flow._ar_transforms]
     Ln, B, D = U.shape
     nb = len(nets[0].blocks)
@@ -150,12 +165,13 @@ def _flow_backward_batched(flow, U, ctx, g_z, g_lad):
     h = torch.baddbmm(b0[:, None, :], U, W0.transpose(1, 2))
     if has_ctx:
         h = h + F.relu(pc)
-    hs, t1s, t2s = [h], [], []
+    hs, t1s, t2s, a1s = [h], [], [], []
     for j in range(nb):
         t1 = torch.baddbmm(b1[j][:, None, :], F.relu(h), W1[j].transpose(1, 2))
-        t2 = torch.baddbmm(b2[j][:, None, :], F.relu(t1), W2[j].transpose(1, 2))
+        a1 = F.relu(t1) if drop is None else F.relu(t1) * drop[j]                 # the second linear's input
+        t2 = torch.baddbmm(b2[j][:, None, :], a1, W2[j].transpose(1, 2))
         h = h + (t2 * gates[j] if has_ctx else t2)
-        hs.append(h), t1s.append(t1), t2s.append(t2)
+        hs.append(h), t1s.append(t1), t2s.append(t2), a1s.append(a1)
     params = torch.baddbmm(bf[:, None, :], h, Wf.transpose(1, 2))                 # [L, B, D(3K-1)]
 
     # 2. the chain, last layer first: ONE launch (pf_flow_backward_chain, csrc/pf_flow_bwd_chain.hip) instead of ~25
@@ -169,6 +185,11 @@ def _flow_backward_batched(flow, U, ctx, g_z, g_lad):
     W1T = torch.stack([w.transpose(1, 2) for w in W1]).contiguous()
     W0T = F.pad(W0.transpose(1, 2), (0, 0, 0, 16 - D)).contiguous()              # [L, 16, H]
     HSk, T1k = torch.stack(hs[:nb]), torch.stack(t1s)
+    if drop is not None:
+        # gt1 = (W2^T gt2) . factor . [t1 > 0], factor in {0, s}: the kernel computes (W2T gt2) . [t1s > 0], so a dropped
+        # unit is handed a negative pre-activation and the kept ones' factor s = 1 / (1 - p) rides on W2T
+        T1k = torch.where(drop > 0, T1k, torch.full_like(T1k, -1.0))
+        W2T = W2T * (1.0 / (1.0 - float(flow.dropout)))
     Gp, Gh0 = torch.empty_like(params), torch.empty_like(hs[0])
     GT1, GT2 = torch.empty_like(T1k), torch.empty_like(T1k)
     gx_perm = torch.empty(B, D, dtype=U.dtype, device=U.device)
@@ -194,7 +215,7 @@ def _flow_backward_batched(flow, U, ctx, g_z, g_lad):
     gWf, gbf = torch.bmm(Gp.transpose(1, 2), hs[nb]) * mf, Gp.sum(1)
     gW0, gb0 = torch.bmm(Gh0.transpose(1, 2), U) * m0, Gh0.sum(1)
     gW1 = [torch.bmm(Gt1[j].transpose(1, 2), F.relu(hs[j])) * m1[j] for j in range(nb)]
-    gW2 = [torch.bmm(Gt2[j].transpose(1, 2), F.relu(t1s[j])) * m2[j] for j in range(nb)]
+    gW2 = [torch.bmm(Gt2[j].transpose(1, 2), a1s[j]) * m2[j] for j in range(nb)]
     gb1, gb2 = [g.sum(1) for g in Gt1], [g.sum(1) for g in Gt2]
     g_ctx = gWcat = gbcat = None
     if has_ctx:
@@ -222,11 +243,13 @@ def _per_parameter(flow, g):
     return grads
 
 
-def flow_backward(flow, U, ctx, g_z, g_lad):
-    """(dL/dx, dL/dctx or None, per-parameter gradients in ``flow._ordered_parameters()`` order).
+def flow_backward(flow, U, ctx, g_z, g_lad, drop_seed=None):
+    """(dL/dx, dL/dctx or None, per-parameter gradients in ``flow._ordered_parameters()`` order); drop_seed: the seed
+    the training forward applied dropout with, or None.
     (Replaying the chain from a captured hipGraph was tried: inside a training step the launches are
     already hidden behind queued encoder work, so it bought nothing and was dropped.)"""
-    g = _flow_backward_batched(flow, U, ctx, g_z.contiguous().float(), g_lad.contiguous().float())
+    drop = None if drop_seed is None else dropout_mask(flow, U.shape[1], drop_seed, U.device)
+    g = _flow_backward_batched(flow, U, ctx, g_z.contiguous().float(), g_lad.contiguous().float(), drop)
     return g["g_x"], g["g_ctx"], _per_parameter(flow, g)
 
 
@@ -244,9 +267,11 @@ class FlowNLL(torch.autograd.Function):
     @staticmethod
     def forward(ctx_, flow, x, context, log_sigma, *params):
         U = _layer_inputs(flow, x) if _fast(flow) else None
+        seed = flow._draw_dropout_seed() if flow._drop_active() else None
         with torch.no_grad():
-            z, logdet, nll = flow._forward_call(x, context, log_sigma, want_z=True, guard=False, layer_inputs=U)
-        ctx_.flow = flow
+            z, logdet, nll = flow._forward_call(x, context, log_sigma, want_z=True, guard=False, layer_inputs=U,
+                                                dropout_seed=seed)
+        ctx_.flow, ctx_.drop_seed = flow, seed
         ctx_.save_for_backward(x, context, log_sigma, U, z)
         ctx_.mark_non_differentiable(z, logdet)
         return nll, z, logdet
@@ -264,7 +289,7 @@ class FlowNLL(torch.autograd.Function):
                 zs2 = (z * torch.exp(-log_sigma)).square()
                 g_z = g_nll[:, None] * z * torch.exp(-2.0 * log_sigma)
                 gl = g_nll[:, None] * (1.0 - zs2) if ctx_.needs_input_grad[3] else None
-            gx, gc, gp = flow_backward(flow, U, context, g_z, -g_nll)
+            gx, gc, gp = flow_backward(flow, U, context, g_z, -g_nll, ctx_.drop_seed)
             return (None, gx if ctx_.needs_input_grad[1] else None,
                     gc if (context is not None and ctx_.needs_input_grad[2]) else None, gl,
                     *[g if p.requires_grad else None for g, p in zip(gp, params)])
@@ -272,7 +297,8 @@ class FlowNLL(torch.autograd.Function):
             xs = x.detach().requires_grad_(x.requires_grad)
             cs = None if context is None else context.detach().requires_grad_(context.requires_grad)
             ls = None if log_sigma is None else log_sigma.detach().requires_grad_(log_sigma.requires_grad)
-            z, logdet = flow_forward(flow, xs, cs)
+            drop = None if ctx_.drop_seed is None else dropout_mask(flow, x.shape[0], ctx_.drop_seed, x.device)
+            z, logdet = flow_forward(flow, xs, cs, drop)
             if ls is None:
                 logp = -0.5 * (z.square().sum(dim=1) + flow.features * math.log(2.0 * math.pi))
             else:
@@ -296,9 +322,11 @@ class FlowForward(torch.autograd.Function):
     @staticmethod
     def forward(ctx_, flow, x, context, *params):
         U = _layer_inputs(flow, x) if _fast(flow) else None
+        seed = flow._draw_dropout_seed() if flow._drop_active() else None
         with torch.no_grad():
-            z, logdet, _ = flow._forward_call(x, context, None, want_z=True, guard=False, layer_inputs=U)
-        ctx_.flow = flow
+            z, logdet, _ = flow._forward_call(x, context, None, want_z=True, guard=False, layer_inputs=U,
+                                              dropout_seed=seed)
+        ctx_.flow, ctx_.drop_seed = flow, seed
         ctx_.save_for_backward(x, context, U)
         return z, logdet
 
@@ -310,14 +338,15 @@ class FlowForward(torch.autograd.Function):
         if U is not None:
             gz = torch.zeros_like(x) if gz is None else gz
             gld = torch.zeros(x.shape[0], device=x.device) if gld is None else gld
-            gx, gc, gp = flow_backward(flow, U, context, gz, gld)
+            gx, gc, gp = flow_backward(flow, U, context, gz, gld, ctx_.drop_seed)
             return (None, gx if ctx_.needs_input_grad[1] else None,
                     gc if (context is not None and ctx_.needs_input_grad[2]) else None,
                     *[g if p.requires_grad else None for g, p in zip(gp, params)])
         with torch.enable_grad():
             xs = x.detach().requires_grad_(x.requires_grad)
             cs = None if context is None else context.detach().requires_grad_(context.requires_grad)
-            z, logdet = flow_forward(flow, xs, cs)
+            drop = None if ctx_.drop_seed is None else dropout_mask(flow, x.shape[0], ctx_.drop_seed, x.device)
+            z, logdet = flow_forward(flow, xs, cs, drop)
             wanted = [t for t in (xs, cs) if t is not None and t.requires_grad]
             wanted += [p for p in params if p.requires_grad]
             grads = torch.autograd.grad([z, logdet], wanted, grad_outputs=[gz, gld], allow_unused=True)

@@ -54,6 +54,10 @@ SYMBOLS = {
     "pf_flow_forward_train": (C.c_int, [_P, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_int64, C.c_void_p]),
+    "pf_flow_forward_train_dropout": (C.c_int, [_P, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.c_float, C.c_uint64, C.c_void_p, C.c_int64, C.c_void_p]),
+    "pf_flow_dropout_mask": (C.c_int, [_P, C.c_float, C.c_uint64, C.c_int64, C.c_void_p, C.c_void_p]),
     "pf_flow_forward_reduce": (C.c_int, [_P, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                          C.c_void_p]),

@@ -104,6 +104,9 @@ int64_t pf_flow_workspace_bytes(const PfFlowDesc* desc, int64_t ctx_rows) {
     return pf::ctx_project_bytes(L, ctx_rows);
 }
 
+// keep <=> (hash >> 8) >= threshold: P(drop) = round(p 2^24) / 2^24
+static uint32_t drop_threshold(float p) { return static_cast<uint32_t>(std::lround((double)p * 16777216.0)); }
+
 // hoisted plans: run the context projection into the workspace, hand it to the chain kernel
 static int project_context(const pf::FlowPlan& L, pf::FwdParams& p, void* workspace, int64_t workspace_bytes,
                            hipStream_t s) {
@@ -121,7 +124,8 @@ static int project_context(const pf::FlowPlan& L, pf::FwdParams& p, void* worksp
 static int flow_forward_impl(const PfFlowDesc* desc, const void* packed, const float* x, const float* ctx,
                              const int32_t* ar_perm, const float* log_sigma, int64_t batch, float* z,
                              float* logdet, float* nll, float* layer_inputs, float* nll_sum, float* zero_pair,
-                             void* workspace, int64_t workspace_bytes, void* stream) {
+                             void* workspace, int64_t workspace_bytes, void* stream, float dropout_p = 0.f,
+                             uint64_t dropout_seed = 0) {
     pf::FlowPlan L;
     int rc = layout_of(desc, L);
     if (rc != PF_OK) return rc;
@@ -137,6 +141,11 @@ static int flow_forward_impl(const PfFlowDesc* desc, const void* packed, const f
     p.tail_bound = desc->tail_bound; p.min_w = desc->min_bin_width; p.min_h = desc->min_bin_height;
     p.min_d = desc->min_derivative;
     p.deriv_const = (float)std::log(std::exp(1.0 - (double)desc->min_derivative) - 1.0);
+    if (!(dropout_p >= 0.f && dropout_p < 1.f)) return fail(PF_ERR_BAD_ARG, "dropout_p must be in [0, 1)");
+    p.drop_thresh = drop_threshold(dropout_p);
+    p.drop_seed = static_cast<uint32_t>(dropout_seed ^ (dropout_seed >> 32));
+    p.drop_scale = 1.f / (1.f - dropout_p);
+    if (p.drop_thresh && L.wide) return fail(PF_ERR_UNSUPPORTED, "PF_FLAG_WIDE is an evaluation layout: no dropout");
     rc = project_context(L, p, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
     if (rc != PF_OK) return rc;
     rc = pf::launch_flow_forward(p, static_cast<hipStream_t>(stream));
@@ -149,6 +158,25 @@ int pf_flow_forward_train(const PfFlowDesc* desc, const void* packed, const floa
                           int64_t workspace_bytes, void* stream) {
     return flow_forward_impl(desc, packed, x, ctx, ar_perm, log_sigma, batch, z, logdet, nll, layer_inputs, nullptr,
                              nullptr, workspace, workspace_bytes, stream);
+}
+int pf_flow_forward_train_dropout(const PfFlowDesc* desc, const void* packed, const float* x, const float* ctx,
+                                  const int32_t* ar_perm, const float* log_sigma, int64_t batch, float* z,
+                                  float* logdet, float* nll, float* layer_inputs, float dropout_p,
+                                  uint64_t dropout_seed, void* workspace, int64_t workspace_bytes, void* stream) {
+    return flow_forward_impl(desc, packed, x, ctx, ar_perm, log_sigma, batch, z, logdet, nll, layer_inputs, nullptr,
+                             nullptr, workspace, workspace_bytes, stream, dropout_p, dropout_seed);
+}
+int pf_flow_dropout_mask(const PfFlowDesc* desc, float dropout_p, uint64_t dropout_seed, int64_t batch, float* mask,
+                         void* stream) {
+    pf::FlowPlan L;
+    int rc = layout_of(desc, L);
+    if (rc != PF_OK) return rc;
+    if (batch < 0 || !(dropout_p >= 0.f && dropout_p < 1.f)) return fail(PF_ERR_BAD_ARG, "need batch >= 0 and dropout_p in [0, 1)");
+    if (batch == 0) return PF_OK;
+    if (!mask) return fail(PF_ERR_BAD_ARG, "mask is null");
+    rc = pf::launch_dropout_mask(L, drop_threshold(dropout_p), static_cast<uint32_t>(dropout_seed ^ (dropout_seed >> 32)),
+                                 1.f / (1.f - dropout_p), batch, mask, static_cast<hipStream_t>(stream));
+    return rc == PF_OK ? rc : fail(rc, rc == PF_ERR_HIP ? hipGetErrorString(static_cast<hipError_t>(pf::g_hip_error)) : "hidden_features > 256");
 }
 int pf_flow_forward_reduce(const PfFlowDesc* desc, const void* packed, const float* x, const float* ctx,
                            const int32_t* ar_perm, const float* log_sigma, int64_t batch, float* nll,

@@ -7,12 +7,14 @@
 #include <cstdlib>
 
 #include "pf_flow_params.h"
+#include "pf_status.h"
 
 namespace pf {
 
 #define PF_DECL(P, N)                                                           \
     int launch_flow_forward_p##P##_nt##N(const FwdParams&, int, hipStream_t); \
-    int launch_flow_inverse_p##P##_nt##N(const FwdParams&, int, hipStream_t);
+    int launch_flow_inverse_p##P##_nt##N(const FwdParams&, int, hipStream_t); \
+    int launch_flow_train_p##P##_nt##N(const FwdParams&, int, hipStream_t);
 PF_DECL(0, 4) PF_DECL(0, 8) PF_DECL(0, 12) PF_DECL(0, 16)
 PF_DECL(1, 4) PF_DECL(1, 8) PF_DECL(1, 12) PF_DECL(1, 16)
 #undef PF_DECL
@@ -67,6 +69,7 @@ void forward_kernel_name(const FlowPlan& L, int64_t batch, char* out, size_t n) 
 int launch_flow_forward(const FwdParams& p_in, hipStream_t s) {
     if (p_in.batch == 0) return PF_OK;
     if (p_in.plan.wide) {
+        if (p_in.drop_thresh) return PF_ERR_UNSUPPORTED;   // the large-batch kernel is an evaluation kernel
         if (p_in.plan.D == 15) return launch_flow_wide_d15(p_in, s);
         if (p_in.plan.D == 11) return launch_flow_wide_d11(p_in, s);
         return PF_ERR_UNSUPPORTED;
@@ -74,7 +77,7 @@ int launch_flow_forward(const FwdParams& p_in, hipStream_t s) {
     FwdParams p = p_in;
     if (const char* a = getenv("PF_ABLATE")) p.ablate = atoi(a);   // only honoured by -DPF_ABLATE_BUILD builds
     const int R = rows_per_workgroup(p.plan, p.batch) / 16;
-#define PF_CASE(P, N) case N: return launch_flow_forward_p##P##_nt##N(p, R, s);
+#define PF_CASE(P, N) case N: return p.drop_thresh ? launch_flow_train_p##P##_nt##N(p, R, s) : launch_flow_forward_p##P##_nt##N(p, R, s);
     if (p.plan.bf16) {
         switch (p.plan.NT) { PF_CASE(1, 4) PF_CASE(1, 8) PF_CASE(1, 12) PF_CASE(1, 16) }
     } else {
@@ -82,6 +85,39 @@ int launch_flow_forward(const FwdParams& p_in, hipStream_t s) {
     }
 #undef PF_CASE
     return PF_ERR_UNSUPPORTED;
+}
+
+// The dropout factors flow_train_kernel applied, for the backward: mask[j][l][row][unit] in {0, 1 / (1 - p)}, units in
+// nflows order (the kernel hashes the degree-sorted position; sorted_units maps it back).
+namespace {
+struct DropMaskArgs {
+    float* mask;
+    int64_t batch;
+    int L, H;
+    uint32_t thresh, seed;
+    float scale;
+    uint8_t pos_of_unit[256];
+};
+__global__ __launch_bounds__(256) void dropout_mask_kernel(const DropMaskArgs a) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x, n = 2 * (int64_t)a.L * a.batch * a.H;
+    if (idx >= n) return;
+    const int u = (int)(idx % a.H);
+    const int64_t t = idx / a.H, row = t % a.batch, jl = t / a.batch;
+    const int l = (int)(jl % a.L), j = (int)(jl / a.L);
+    a.mask[idx] = drop_factor(drop_row_hash(a.seed, (uint32_t)row), 2 * l + j, a.pos_of_unit[u], a.thresh, a.scale);
+}
+}  // namespace
+
+int launch_dropout_mask(const FlowPlan& L, uint32_t thresh, uint32_t seed, float scale, int64_t batch, float* mask, hipStream_t s) {
+    if (L.H > 256) return PF_ERR_UNSUPPORTED;
+    DropMaskArgs a{mask, batch, L.L, L.H, thresh, seed, scale, {}};
+    int perm[256];
+    sorted_units(L.D, L.H, perm);
+    for (int p = 0; p < L.H; ++p) a.pos_of_unit[perm[p]] = (uint8_t)p;
+    const int64_t n = 2 * (int64_t)L.L * batch * L.H;
+    if (n == 0) return PF_OK;
+    dropout_mask_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(a);
+    return launch_status();
 }
 
 int launch_flow_inverse(const FwdParams& p, hipStream_t s) {

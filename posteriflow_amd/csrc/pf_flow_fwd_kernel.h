@@ -355,8 +355,9 @@ template <int V> using ic = std::integral_constant<int, V>;
 #define PF_ABL(mask) false
 #endif
 
-template <bool BF16, int NT, int R, int CKM, int DENSE, bool INV>
-__global__ __launch_bounds__(NT * 32) void flow_kernel(const FwdParams p) {
+// DROP: training forward with dropout in the residual blocks (flow_train_kernel below); never set for the inverse
+template <bool BF16, int NT, int R, int CKM, int DENSE, bool INV, bool DROP>
+__device__ __forceinline__ void flow_body(const FwdParams& p) {
     using S = Sched<BF16, NT, CKM, DENSE>;
     constexpr bool FAST = BF16;
     constexpr int NW = NT / 2, HK = S::HK, KHS = S::KHS, KOS = S::KOS, NF = S::NF;
@@ -693,6 +694,19 @@ __global__ __launch_bounds__(NT * 32) void flow_kernel(const FwdParams p) {
                         tAv[r][e] = fmaxf(tAv[r][e] + b0A[e], 0.f);
                         tBv[r][e] = fmaxf(tBv[r][e] + b0B[e], 0.f);
                     }
+                if constexpr (DROP) {
+                    // nflows MaskedResidualBlock.forward: dropout after the second activation.  C fragment: element e
+                    // of lane (g, c) is sorted position 16 tile + 4 g + e of row row0 + 16 r + c
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const uint32_t hr = drop_row_hash(p.drop_seed, (uint32_t)(row0 + 16 * r + c));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            tAv[r][e] *= drop_factor(hr, 2 * l + b, 16 * tA + 4 * g + e, p.drop_thresh, p.drop_scale);
+                            tBv[r][e] *= drop_factor(hr, 2 * l + b, 16 * tB + 4 * g + e, p.drop_thresh, p.drop_scale);
+                        }
+                    }
+                }
             }
             store_act(s_act1, tA, tAv);
             store_act(s_act1, tB, tBv);
@@ -862,6 +876,16 @@ __global__ __launch_bounds__(NT * 32) void flow_kernel(const FwdParams p) {
     }
 }
 
+template <bool BF16, int NT, int R, int CKM, int DENSE, bool INV>
+__global__ __launch_bounds__(NT * 32) void flow_kernel(const FwdParams p) {
+    flow_body<BF16, NT, R, CKM, DENSE, INV, false>(p);
+}
+// training forward of a flow with dropout > 0 (nflows applies it inside every residual block in train mode)
+template <bool BF16, int NT, int R, int CKM, int DENSE>
+__global__ __launch_bounds__(NT * 32) void flow_train_kernel(const FwdParams p) {
+    flow_body<BF16, NT, R, CKM, DENSE, false, true>(p);
+}
+
 // ---- host side ---------------------------------------------------------------------------
 inline size_t fwd_lds_bytes(const FlowPlan& L, int R) {
     const size_t pb = std::max((size_t)L.HK * R * kFragBytes, (size_t)L.D * 16 * kParStride * sizeof(float));
@@ -869,11 +893,14 @@ inline size_t fwd_lds_bytes(const FlowPlan& L, int R) {
          + (size_t)(3 * 16 * 16 * R + 2 * L.NT * kBiasFloatsPerTile + L.D * 16 * R) * sizeof(float);
 }
 
-template <bool BF16, int NT, int R, int CKM, int DENSE, bool INV>
+template <bool BF16, int NT, int R, int CKM, int DENSE, bool INV, bool DROP>
 inline int launch_variant(const FwdParams& p, hipStream_t s) {
     const unsigned grid = (unsigned)((p.batch + 16 * R - 1) / (16 * R));
     const size_t lds = fwd_lds_bytes(p.plan, R);
-    auto kern = flow_kernel<BF16, NT, R, CKM, DENSE, INV>;
+    auto kern = [] {
+        if constexpr (DROP) return flow_train_kernel<BF16, NT, R, CKM, DENSE>;
+        else return flow_kernel<BF16, NT, R, CKM, DENSE, INV>;
+    }();
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
@@ -883,21 +910,21 @@ inline int launch_variant(const FwdParams& p, hipStream_t s) {
 }
 
 // all built variants of one (precision, NT): R in {1,2} x {masked}, R = 1 x {dense}
-template <bool BF16, int NT, int CKM, bool INV>
+template <bool BF16, int NT, int CKM, bool INV, bool DROP = false>
 inline int launch_ckm(const FwdParams& p, int R, hipStream_t s) {
-    if (p.plan.dense == 1) return launch_variant<BF16, NT, 1, CKM, 1, INV>(p, s);
+    if (p.plan.dense == 1) return launch_variant<BF16, NT, 1, CKM, 1, INV, DROP>(p, s);
     if constexpr (BF16 && NT == 16) {
         if (p.plan.dense == 2) {
-            if (R >= 2) return launch_variant<BF16, NT, 2, CKM, 2, INV>(p, s);
-            return launch_variant<BF16, NT, 1, CKM, 2, INV>(p, s);
+            if (R >= 2) return launch_variant<BF16, NT, 2, CKM, 2, INV, DROP>(p, s);
+            return launch_variant<BF16, NT, 1, CKM, 2, INV, DROP>(p, s);
         }
     }
     if (p.plan.dense != 0) return PF_ERR_UNSUPPORTED;
-    if constexpr (BF16 && NT == 16 && !INV) {            // large batches, LeanNPE-sized hidden width: 48 rows per workgroup
-        if (R == 3) return launch_variant<BF16, NT, 3, CKM, 0, INV>(p, s);
+    if constexpr (BF16 && NT == 16 && !INV && !DROP) {   // large batches, LeanNPE-sized hidden width: 48 rows per workgroup
+        if (R == 3) return launch_variant<BF16, NT, 3, CKM, 0, INV, DROP>(p, s);
     }
-    if (R >= 2) return launch_variant<BF16, NT, 2, CKM, 0, INV>(p, s);
-    return launch_variant<BF16, NT, 1, CKM, 0, INV>(p, s);
+    if (R >= 2) return launch_variant<BF16, NT, 2, CKM, 0, INV, DROP>(p, s);
+    return launch_variant<BF16, NT, 1, CKM, 0, INV, DROP>(p, s);
 }
 
 }  // namespace pf

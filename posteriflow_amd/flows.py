@@ -267,6 +267,7 @@ class NSFPosteriorFlow(nn.Module):
         ``sum_count`` (fp32 [2], zeroed by the caller): the kernel also adds (sum of nll, B) to it --
         the 8-byte vector a data-parallel rank all-reduces."""
         B = x.shape[0]
+        self._eval_only("nll_into")
         if x.shape[1] != self.features or out.shape[0] != B or not x.is_contiguous():
             raise ValueError("nll_into: bad shapes / non-contiguous input")
         if self.context_features > 0 and (context is None or context.shape != (B, self.context_features)
@@ -460,22 +461,35 @@ class NSFPosteriorFlow(nn.Module):
         need = torch.is_grad_enabled() and (
             any(t is not None and t.requires_grad for t in tensors)
             or any(p.requires_grad for p in self._ordered_parameters()))
-        if need and self.training and self.dropout and self.dropout > 0.0:
-            # nflows drops relu(W0 relu(h) + b0) inside every residual block in train mode (upstream
-            # MaskedResidualBlock.forward, built at flows.py:483-496 with dropout_probability=dropout); the HIP
-            # training path has no dropout yet, and training silently without it would not be the reference's model
-            raise NotImplementedError(
-                "NSFPosteriorFlow(dropout=%g) in train() mode: conditioner dropout is not implemented on the HIP "
-                "training path; build the flow with dropout=0.0 (LeanNPE does, lean_npe.py:291-297) or call .eval()"
-                % self.dropout)
         return need
+
+    # ---- conditioner dropout (train mode) ---------------------------------------------
+    # nflows drops relu(W0 relu(h) + b0) inside every residual block while the module is in train mode (upstream
+    # MaskedResidualBlock.forward, built at flows.py:510-524 with dropout_probability=dropout; the reference's own
+    # masked-context block does the same, flows.py:225-234).  The training forward kernel (flow_train_kernel) applies
+    # it from a counter hash of a per-call seed; the backward regenerates the factors (pf_flow_dropout_mask).
+    def _drop_active(self) -> bool:
+        return bool(self.training and self.dropout and self.dropout > 0.0)
+
+    def _eval_only(self, what: str) -> None:
+        """the serving entry points and the inverse have no dropout: in train() mode of a flow with dropout > 0 nflows
+        would apply a fresh mask in every MADE call (every autoregressive pass of the inverse) -- fail loudly instead
+        of silently evaluating a different model"""
+        if self._drop_active():
+            raise RuntimeError(f"NSFPosteriorFlow.{what}: the flow is in train() mode with dropout={self.dropout:g}; "
+                               "call .eval() first (dropout is applied by the differentiable forward only)")
+
+    @staticmethod
+    def _draw_dropout_seed() -> int:
+        """a fresh 62-bit seed from torch's CPU generator (follows torch.manual_seed; no device sync)"""
+        return int(torch.randint(0, 1 << 62, (1,), dtype=torch.int64).item())
 
     def forward_kernel_name(self, batch: int) -> str:
         """Name of the kernel pf_flow_forward dispatches for this flow at `batch` rows (as rocprofv3 prints it)."""
         name = _lib.lib().pf_flow_forward_kernel_name(self._desc(wide=self._use_wide(int(batch))), int(batch))
         return name.decode() if name else "?"
 
-    def _forward_call(self, x, context, log_sigma, want_z=True, guard=True, layer_inputs=None):
+    def _forward_call(self, x, context, log_sigma, want_z=True, guard=True, layer_inputs=None, dropout_seed=None):
         if guard:
             dev, x, context = self._check_inputs(x, context, "NSFPosteriorFlow.forward")
         else:                       # already validated (and context blocks permuted) by the caller
@@ -487,15 +501,21 @@ class NSFPosteriorFlow(nn.Module):
         logdet = torch.empty(B, dtype=torch.float32, device=dev)
         nll = torch.empty(B, dtype=torch.float32, device=dev)
         perm, _ = self._perms(dev)
-        wide = self._use_wide(B)
+        drop = self._drop_active()
+        wide = self._use_wide(B) and not drop
         packed = self.packed_weights(wide=wide)
         desc = self._desc(wide=wide)
         ws, ws_bytes = self._ws(desc, B, dev)
         # layer_inputs: fp32 [L, B, D] that receives every conditioner's input (training forward)
-        _lib.check(_lib.lib().pf_flow_forward_train(
-            desc, packed.data_ptr(), x.data_ptr(), _dev_ptr(context), _dev_ptr(perm),
-            _dev_ptr(log_sigma), B, _dev_ptr(z), logdet.data_ptr(), nll.data_ptr(), _dev_ptr(layer_inputs),
-            _dev_ptr(ws), ws_bytes, torch.cuda.current_stream(dev).cuda_stream), "pf_flow_forward")
+        head = (desc, packed.data_ptr(), x.data_ptr(), _dev_ptr(context), _dev_ptr(perm), _dev_ptr(log_sigma), B,
+                _dev_ptr(z), logdet.data_ptr(), nll.data_ptr(), _dev_ptr(layer_inputs))
+        tail = (_dev_ptr(ws), ws_bytes, torch.cuda.current_stream(dev).cuda_stream)
+        if drop:                    # train mode: a no-grad call draws its own seed, like nn.Dropout would
+            seed = self._draw_dropout_seed() if dropout_seed is None else int(dropout_seed)
+            _lib.check(_lib.lib().pf_flow_forward_train_dropout(*head, float(self.dropout), seed, *tail),
+                       "pf_flow_forward_train_dropout")
+        else:
+            _lib.check(_lib.lib().pf_flow_forward_train(*head, *tail), "pf_flow_forward")
         return z, logdet, nll
 
     def _nll(self, x, context, log_sigma):
@@ -648,6 +668,7 @@ class NSFPosteriorFlow(nn.Module):
         return st
 
     def _inverse_call(self, z, context, ctx_rows):
+        self._eval_only("inverse / sample")
         dev = self._device()
         B = z.shape[0]
         x = torch.empty_like(z)

@@ -230,21 +230,28 @@ def test_data_parallel_mean_nll_gloo_world2(tmp_path):
     assert out.stdout.count("ok") == 2
 
 
-def test_conditioner_dropout_in_train_mode_is_loud():
+def test_conditioner_dropout_host_rules():
     """nflows applies dropout inside every residual block in train mode (create_flow_model defaults to 0.15,
-    flows.py:980); until the HIP training path has it, a differentiable call in train() mode must raise instead of
-    silently training a different model.  eval() and dropout = 0 are unaffected."""
+    flows.py:1008).  The HIP training forward applies it (tests/test_flow_dropout_gpu.py); on the host: the probability
+    is validated, the serving entry points and the inverse refuse a train()-mode flow with dropout > 0 instead of
+    silently evaluating a different model, eval() and dropout = 0 are unaffected, and the seed follows torch's generator."""
     import pytest
     from posteriflow_amd import NSFPosteriorFlow, create_flow_model
     flow = create_flow_model("nsf", 4, 8, num_layers=1, hidden_features=64, num_bins=4)
     assert flow.dropout == 0.15
     x, ctx = torch.zeros(2, 4), torch.zeros(2, 8)
     flow.train()
-    with pytest.raises(NotImplementedError, match="dropout"):
-        flow.compute_psd_aware_nll(x, ctx, None)
-    with pytest.raises(NotImplementedError, match="dropout"):
-        flow(x, ctx)
+    assert flow._drop_active()
+    with pytest.raises(RuntimeError, match="eval"):
+        flow.nll_into(x, ctx, torch.empty(2))
+    with pytest.raises(RuntimeError, match="eval"):
+        flow._inverse_call(x, ctx, 2)
+    torch.manual_seed(5)
+    a = [flow._draw_dropout_seed() for _ in range(3)]
+    torch.manual_seed(5)
+    assert a == [flow._draw_dropout_seed() for _ in range(3)] and len(set(a)) == 3 and all(0 <= v < 1 << 62 for v in a)
     flow.eval()
+    assert not flow._drop_active()
     with pytest.raises(RuntimeError, match="no CPU fallback|MI355X"):     # gets as far as the device check
         flow.compute_psd_aware_nll(x, ctx, None)
     with pytest.raises(ValueError):
