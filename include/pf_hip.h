@@ -56,6 +56,13 @@ extern "C" {
                               * PF_ERR_UNSUPPORTED from every entry point.  The packed buffer of a PF_FLAG_WIDE desc
                               * has its own layout (pf_flow_packed_bytes / pack_map / pack with the same desc). */
 
+#define PF_FLAG_BWD 8         /* packing only: the TRANSPOSED masked weight matrices of the backward's data-gradient chain
+                              * as bf16 MFMA A-fragments (pf_flow_backward_chain with a bf16 desc), nflows unit order:
+                              * per layer  WfT [H/16 tiles][ceil(D(3K-1)/32) k-steps] | for block j: W2T_j, W1T_j
+                              * [H/16][H/32] | W0T [H/32], 1 KiB per (tile, k-step).  bf16, plain conditioner.
+                              * pf_flow_packed_bytes / pack_map_len / build_pack_map / pack take the flag; the forward,
+                              * inverse and workspace entry points refuse it. */
+
 /* Plain-old-data description of one NSFPosteriorFlow (flows.py:379-548).
  * conditioner: nflows MADE, num_blocks residual blocks with GLU context gate,
  * ReversePermutation in front of every layer, tails='linear'. */
@@ -183,6 +190,9 @@ typedef struct PfFlowBwdChainArgs {
     float* Gt2;          /* [2][L][B][H] */
     float* Gc;           /* [L][3][B][H]  dL/d(context projections): context_layer, gate of block 0, of block 1; or NULL */
     float* g_x;          /* [B][D]  dL/d(x[:, ar_perm]) */
+    const void* packed;  /* bf16 descs: the PF_FLAG_BWD stream (W*T above are ignored): the transposed GEMMs run on bf16
+                          * MFMA with bf16-rounded gradient vectors as their second operand; the spline, the accumulators,
+                          * the gate / ReLU algebra and every output stay fp32.  fp32 descs: ignored. */
 } PfFlowBwdChainArgs;
 int pf_flow_backward_chain(const PfFlowDesc* desc, const PfFlowBwdChainArgs* args, void* stream);
 

@@ -42,7 +42,8 @@ class PSDScaledNormalRef(nn.Module):
 class NSFPosteriorFlowRef(nn.Module):
     def __init__(self, features, context_features=0, hidden_features=256,
                  num_layers=12, num_bins=16, tail_bound=FLOW_NORM_BOUND,
-                 dropout=0.0, temperature_scale=1.5, scale_by_sqrt_hidden=False, use_masked_context=False):
+                 dropout=0.0, temperature_scale=1.5, scale_by_sqrt_hidden=False, use_masked_context=False,
+                 full_context=True):
         super().__init__()
         self.features = features
         self.context_features = context_features
@@ -65,7 +66,7 @@ class NSFPosteriorFlowRef(nn.Module):
                 num_bins=num_bins, tail_bound=tb, num_blocks=2,
                 dropout_probability=dropout,
                 scale_by_sqrt_hidden=scale_by_sqrt_hidden,
-                masked_context_blocks=(features, context_features // features) if use_masked_context else None))
+                masked_context_blocks=(features, context_features // features, full_context) if use_masked_context else None))
         self.transform = nfr.CompositeTransform(ts)
         self.register_buffer("_ar_perm", torch.arange(features))
         self.register_buffer("_ar_inv_perm", torch.arange(features))

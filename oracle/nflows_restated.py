@@ -207,11 +207,12 @@ class MaskedContextLinear(nn.Module):
 class MaskedContextResidualBlock(nn.Module):
     """flows.py:186-234: relu, W0, + ctx, relu, dropout, W1, residual add (no gate)."""
 
-    def __init__(self, in_degrees, autoregressive_features, n_blocks, block_dim, dropout_probability=0.0):
+    def __init__(self, in_degrees, autoregressive_features, n_blocks, block_dim, dropout_probability=0.0,
+                 full_context=True):
         super().__init__()
         self.dropout = nn.Dropout(p=dropout_probability)               # flows.py:219
         features = len(in_degrees)
-        self.context_layer = MaskedContextLinear(n_blocks, block_dim, in_degrees)
+        self.context_layer = MaskedContextLinear(n_blocks, block_dim, in_degrees, full_context)
         l0 = MaskedLinear(in_degrees, features, autoregressive_features, False)
         l1 = MaskedLinear(l0.degrees, features, autoregressive_features, False)
         self.linear_layers = nn.ModuleList([l0, l1])
@@ -231,14 +232,16 @@ class MADEWithMaskedContext(nn.Module):
     """flows.py:237-303"""
 
     def __init__(self, features, hidden_features, n_blocks, block_dim, num_blocks=2, output_multiplier=1,
-                 dropout_probability=0.0):
+                 dropout_probability=0.0, full_context=True):
         super().__init__()
         self.initial_layer = MaskedLinear(input_degrees(features), hidden_features, features, False)
         self.initial_layer.split_input = True
         deg = self.initial_layer.degrees
-        self.context_layer = MaskedContextLinear(n_blocks, block_dim, deg)
-        self.blocks = nn.ModuleList([MaskedContextResidualBlock(deg, features, n_blocks, block_dim, dropout_probability)
-                                     for _ in range(num_blocks)])
+        # the reference never passes full_context (flows.py:268, 275-283): True everywhere; False kept reachable for the
+        # product's keyword of the same name
+        self.context_layer = MaskedContextLinear(n_blocks, block_dim, deg, full_context)
+        self.blocks = nn.ModuleList([MaskedContextResidualBlock(deg, features, n_blocks, block_dim, dropout_probability,
+                                                                full_context) for _ in range(num_blocks)])
         self.final_layer = MaskedLinear(deg, features * output_multiplier, features, True)
 
     def forward(self, inputs, context=None):
@@ -408,8 +411,9 @@ class MaskedPiecewiseRationalQuadraticAutoregressiveTransform(nn.Module):
         #  -> inactive by default, switchable for audit.
         self.scale_by_sqrt_hidden = scale_by_sqrt_hidden
         if masked_context_blocks:     # (n_blocks, block_dim): flows.py:306-360
-            self.autoregressive_net = MADEWithMaskedContext(features, hidden_features, *masked_context_blocks,
-                                                            num_blocks, self.output_multiplier(), dropout_probability)
+            self.autoregressive_net = MADEWithMaskedContext(features, hidden_features, *masked_context_blocks[:2],
+                                                            num_blocks, self.output_multiplier(), dropout_probability,
+                                                            *masked_context_blocks[2:])
         else:
             self.autoregressive_net = MADE(features, hidden_features, context_features,
                                            num_blocks, self.output_multiplier(),

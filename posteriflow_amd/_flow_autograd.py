@@ -180,11 +180,15 @@ def _flow_backward_batched(flow, U, ctx, g_z, g_lad, drop=None):
     g_lad = g_lad.contiguous()
     DM = params.shape[2]
     PM = (DM + 15) // 16 * 16
-    WfT = F.pad(Wf.transpose(1, 2), (0, PM - DM)).contiguous()                   # [L, H, PM]
-    W2T = torch.stack([w.transpose(1, 2) for w in W2]).contiguous()              # [nb, L, H(in), H(out)]
-    W1T = torch.stack([w.transpose(1, 2) for w in W1]).contiguous()
-    W0T = F.pad(W0.transpose(1, 2), (0, 0, 0, 16 - D)).contiguous()              # [L, 16, H]
+    # bf16 mode: the chain runs on bf16 MFMA from the packed PF_FLAG_BWD stream (dropout: the kept units' factor cannot
+    # ride on W2T there, so that case keeps the fp32 chain)
+    bf = flow.precision == "bf16" and H % 32 == 0 and drop is None
     HSk, T1k = torch.stack(hs[:nb]), torch.stack(t1s)
+    if not bf:
+        WfT = F.pad(Wf.transpose(1, 2), (0, PM - DM)).contiguous()                   # [L, H, PM]
+        W2T = torch.stack([w.transpose(1, 2) for w in W2]).contiguous()              # [nb, L, H(in), H(out)]
+        W1T = torch.stack([w.transpose(1, 2) for w in W1]).contiguous()
+        W0T = F.pad(W0.transpose(1, 2), (0, 0, 0, 16 - D)).contiguous()              # [L, 16, H]
     if drop is not None:
         # gt1 = (W2^T gt2) . factor . [t1 > 0], factor in {0, s}: the kernel computes (W2T gt2) . [t1s > 0], so a dropped
         # unit is handed a negative pre-activation and the kept ones' factor s = 1 / (1 - p) rides on W2T
@@ -195,10 +199,17 @@ def _flow_backward_batched(flow, U, ctx, g_z, g_lad, drop=None):
     gx_perm = torch.empty(B, D, dtype=U.dtype, device=U.device)
     a = _lib.PfFlowBwdChainArgs()
     a.batch = B
-    keep = [WfT, W2T, W1T, W0T, HSk, T1k, GT1, GT2, Gp, Gh0, gx_perm, gy, g_lad, params]
-    for name, t in (("WfT", WfT), ("W2T", W2T), ("W1T", W1T), ("W0T", W0T), ("U", U), ("params", params), ("hs", HSk),
-                    ("t1s", T1k), ("g_z", gy), ("g_lad", g_lad), ("Gp", Gp), ("Gh0", Gh0), ("Gt1", GT1), ("Gt2", GT2),
-                    ("g_x", gx_perm)):
+    keep = [HSk, T1k, GT1, GT2, Gp, Gh0, gx_perm, gy, g_lad, params]
+    ops = [("U", U), ("params", params), ("hs", HSk), ("t1s", T1k), ("g_z", gy), ("g_lad", g_lad), ("Gp", Gp), ("Gh0", Gh0),
+           ("Gt1", GT1), ("Gt2", GT2), ("g_x", gx_perm)]
+    if bf:      # the transposed matrices come from the PF_FLAG_BWD stream (one gather per weight update)
+        packed = flow.packed_weights(bwd=True)
+        a.packed = packed.data_ptr()
+        keep.append(packed)
+    else:
+        ops += [("WfT", WfT), ("W2T", W2T), ("W1T", W1T), ("W0T", W0T)]
+        keep += [WfT, W2T, W1T, W0T]
+    for name, t in ops:
         assert t.is_contiguous() and t.dtype == torch.float32
         setattr(a, name, t.data_ptr())
     if has_ctx:
@@ -206,8 +217,8 @@ def _flow_backward_batched(flow, U, ctx, g_z, g_lad, drop=None):
         Gc = torch.empty(Ln, 1 + nb, B, H, dtype=U.dtype, device=U.device)
         keep += [T2k, Gk, pck, Gc]
         a.t2s, a.gates, a.pc, a.Gc = T2k.data_ptr(), Gk.data_ptr(), pck.data_ptr(), Gc.data_ptr()
-    _lib.check(_lib.lib().pf_flow_backward_chain(flow._desc(), a, torch.cuda.current_stream(U.device).cuda_stream),
-               "pf_flow_backward_chain")
+    _lib.check(_lib.lib().pf_flow_backward_chain(flow._desc("bf16" if bf else "fp32"), a,
+                                                 torch.cuda.current_stream(U.device).cuda_stream), "pf_flow_backward_chain")
     Gt1, Gt2 = [GT1[j] for j in range(nb)], [GT2[j] for j in range(nb)]
     g_x = gx_perm[:, flow._ar_inv_perm]              # the kernel returns dL/d x[:, ar_perm]
 

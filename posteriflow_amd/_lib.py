@@ -18,6 +18,7 @@ PF_PREC_F32, PF_PREC_BF16 = 0, 1
 PF_FLAG_HOIST_CTX = 1
 PF_FLAG_MASKED_CONTEXT = 2
 PF_FLAG_WIDE = 4
+PF_FLAG_BWD = 8
 PRECISIONS = {"fp32": PF_PREC_F32, "f32": PF_PREC_F32, "bf16": PF_PREC_BF16}
 
 
@@ -25,7 +26,7 @@ class PfFlowBwdChainArgs(C.Structure):
     """include/pf_hip.h PfFlowBwdChainArgs (device pointers as integers)."""
     _fields_ = [("batch", C.c_int64)] + [(n, C.c_void_p) for n in (
         "WfT", "W2T", "W1T", "W0T", "U", "params", "hs", "t1s", "t2s", "gates", "pc", "g_z", "g_lad",
-        "Gp", "Gh0", "Gt1", "Gt2", "Gc", "g_x")]
+        "Gp", "Gh0", "Gt1", "Gt2", "Gc", "g_x", "packed")]
 
 
 class PfFlowDesc(C.Structure):

@@ -58,6 +58,12 @@ int layout_of(const PfFlowDesc* d, pf::FlowPlan& L) {
         return fail(PF_ERR_BAD_ARG, "minimal bin size too large for the number of bins");
     return PF_OK;
 }
+// entry points that compute with the packed weights: a PF_FLAG_BWD desc only describes a packing
+int compute_layout_of(const PfFlowDesc* d, pf::FlowPlan& L) {
+    const int rc = layout_of(d, L);
+    if (rc != PF_OK) return rc;
+    return L.bwd ? fail(PF_ERR_UNSUPPORTED, "PF_FLAG_BWD describes the backward chain's weight stream only") : PF_OK;
+}
 bool misaligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) != 0; }
 }  // namespace
 
@@ -100,7 +106,7 @@ int pf_flow_pack(const PfFlowDesc* desc, const float* raw, const int32_t* map, v
 
 int64_t pf_flow_workspace_bytes(const PfFlowDesc* desc, int64_t ctx_rows) {
     pf::FlowPlan L;
-    if (layout_of(desc, L) != PF_OK || ctx_rows < 0) return -1;
+    if (compute_layout_of(desc, L) != PF_OK || ctx_rows < 0) return -1;
     return pf::ctx_project_bytes(L, ctx_rows);
 }
 
@@ -127,7 +133,7 @@ static int flow_forward_impl(const PfFlowDesc* desc, const void* packed, const f
                              void* workspace, int64_t workspace_bytes, void* stream, float dropout_p = 0.f,
                              uint64_t dropout_seed = 0) {
     pf::FlowPlan L;
-    int rc = layout_of(desc, L);
+    int rc = compute_layout_of(desc, L);
     if (rc != PF_OK) return rc;
     if (batch < 0) return fail(PF_ERR_BAD_ARG, "negative batch");
     if (batch == 0) return PF_OK;
@@ -220,13 +226,20 @@ int pf_flow_backward_chain(const PfFlowDesc* desc, const PfFlowBwdChainArgs* a, 
     if (!(desc->tail_bound > 0.f)) return fail(PF_ERR_BAD_ARG, "tail_bound must be positive");
     if (a->batch < 0) return fail(PF_ERR_BAD_ARG, "negative batch");
     if (a->batch == 0) return PF_OK;
-    if (!a->WfT || !a->W2T || !a->W1T || !a->W0T || !a->U || !a->params || !a->hs || !a->t1s || !a->g_z || !a->g_lad ||
-        !a->Gp || !a->Gh0 || !a->Gt1 || !a->Gt2 || !a->g_x)
+    const bool bf = desc->precision == PF_PREC_BF16;
+    if (desc->precision != PF_PREC_F32 && !bf) return fail(PF_ERR_BAD_ARG, "bad precision");
+    if (desc->reserved & ~PF_FLAG_MASKED_CONTEXT & ~PF_FLAG_HOIST_CTX & ~PF_FLAG_WIDE)
+        return fail(PF_ERR_BAD_ARG, "pass the flow's own desc (PF_FLAG_BWD belongs to the packing calls)");
+    if (bf ? !a->packed : (!a->WfT || !a->W2T || !a->W1T || !a->W0T))
+        return fail(PF_ERR_BAD_ARG, bf ? "bf16 desc: args.packed (the PF_FLAG_BWD stream) is null" : "null weight pointer");
+    if (bf && H % 32) return fail(PF_ERR_UNSUPPORTED, "bf16 backward chain needs H % 32 == 0");
+    if (!a->U || !a->params || !a->hs || !a->t1s || !a->g_z || !a->g_lad || !a->Gp || !a->Gh0 || !a->Gt1 || !a->Gt2 || !a->g_x)
         return fail(PF_ERR_BAD_ARG, "null pointer");
     const bool ctx = a->gates != nullptr;
     if (ctx != (a->t2s != nullptr) || ctx != (a->pc != nullptr) || ctx != (a->Gc != nullptr))
         return fail(PF_ERR_BAD_ARG, "t2s, gates, pc and Gc go together (all NULL for a context-free flow)");
-    const void* al[] = {a->WfT, a->W2T, a->W1T, a->W0T, a->hs, a->t1s, a->t2s, a->gates, a->pc, a->Gh0, a->Gt1, a->Gt2, a->Gc};
+    const void* al[] = {bf ? nullptr : a->WfT, bf ? nullptr : a->W2T, bf ? nullptr : a->W1T, bf ? nullptr : a->W0T, bf ? a->packed : nullptr,
+                        a->hs, a->t1s, a->t2s, a->gates, a->pc, a->Gh0, a->Gt1, a->Gt2, a->Gc};
     for (const void* q : al)
         if (misaligned(q, 16)) return fail(PF_ERR_BAD_ARG, "weight / activation tensors must be 16-byte aligned");
     const float dc = (float)std::log(std::exp(1.0 - (double)desc->min_derivative) - 1.0);
@@ -239,7 +252,7 @@ int pf_flow_inverse(const PfFlowDesc* desc, const void* packed, const float* z, 
                     float* logdet, uint32_t* fail_flags, void* workspace, int64_t workspace_bytes,
                     void* stream) {
     pf::FlowPlan L;
-    int rc = layout_of(desc, L);
+    int rc = compute_layout_of(desc, L);
     if (rc != PF_OK) return rc;
     if (batch < 0) return fail(PF_ERR_BAD_ARG, "negative batch");
     if (batch == 0) return PF_OK;
@@ -408,14 +421,14 @@ int pf_remix_forward(const void* noise_pool, int64_t n_noise, const void* signal
 const char* pf_flow_forward_kernel_name(const PfFlowDesc* desc, int64_t batch) {
     static thread_local char name[160];
     pf::FlowPlan L;
-    if (layout_of(desc, L) != PF_OK) return nullptr;
+    if (compute_layout_of(desc, L) != PF_OK) return nullptr;
     pf::forward_kernel_name(L, batch, name, sizeof(name));
     return name;
 }
 
 int32_t pf_flow_rows_per_workgroup(const PfFlowDesc* desc, int64_t batch) {
     pf::FlowPlan L;
-    if (layout_of(desc, L) != PF_OK) return -1;
+    if (compute_layout_of(desc, L) != PF_OK) return -1;
     return pf::rows_per_workgroup(L, batch);
 }
 

@@ -25,6 +25,14 @@
 // k order is (16 q + 4 g + e) -- the B rows in LDS are read the same way, so neither side needs packing.
 // Masked zeros are multiplied (the dense count): at 16 rows per CU this kernel is bound by the 1.8 MB of weights a
 // layer streams per workgroup, ~0.3 ms per launch whatever the batch up to 4096 rows.
+//
+// bf16 descs (BF = true; the throughput mode a trainer runs in): the same walk on v_mfma_f32_16x16x32_bf16.  The A operand
+// is the PF_FLAG_BWD stream (pf_pack.hip: the transposed masked matrices as bf16 A-fragments, one contiguous 1-KiB load per
+// wave and (tile, k-step) instead of sixteen 64-B row segments of the fp32 matrices -- those touched every 128-B line
+// twice, half of it each time, with an L1 too small to keep the line in between); the gradient vectors cross LDS as bf16
+// rows; accumulators, spline, gate / ReLU algebra and every output stay fp32 (the library's bf16 GEMMs are only 1.5x faster
+// than its fp32 ones at these sizes, less than the casts of their operands cost, so the weight-gradient GEMMs stay fp32).
+// 8x fewer MFMA instructions, half the weight bytes.
 #include <hip/hip_runtime.h>
 
 #include "pf_status.h"
@@ -38,6 +46,9 @@ namespace pf {
 namespace {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 struct ChainArgs {
     PfFlowBwdChainArgs a;
@@ -46,7 +57,7 @@ struct ChainArgs {
     int64_t B;
 };
 
-template <int TPW>   // unit tiles per wave = H / 64
+template <int TPW, bool BF>   // unit tiles per wave = H / 64; BF: bf16 operands from the PF_FLAG_BWD stream
 __global__ __launch_bounds__(256) void flow_bwd_chain_kernel(const ChainArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -61,6 +72,14 @@ __global__ __launch_bounds__(256) void flow_bwd_chain_kernel(const ChainArgs p) 
     float* s_gy = s_v1 + 16 * HS;                             // [16][16] dL/dy of the current layer
     float* s_gu = s_gy + 256;                                 // [16][16] direct dL/du
     float* s_part = s_gu + 256;                               // [4][16][16] partial sums of the W0^T product
+    // BF: the B operands as bf16 rows (k contiguous): the two exchange vectors alias s_v0 / s_v1, Gp gets its own image
+    const int KSF = (D * M + 31) / 32, HK = H / 32, NT = H / 16;
+    const int HSB = H + 8, GSB = 32 * KSF + 8;                // row strides in bf16 elements
+    __bf16* s_b0 = reinterpret_cast<__bf16*>(s_v0);
+    __bf16* s_b1 = reinterpret_cast<__bf16*>(s_v1);
+    __bf16* s_gpb = reinterpret_cast<__bf16*>(s_part + 1024); // [16][GSB]
+    const u32x4* frags = reinterpret_cast<const u32x4*>(p.a.packed);
+    const int layer_frags = NT * KSF + 4 * NT * HK + HK;
     const int64_t my_row = row0 + c < B ? row0 + c : B - 1;   // clamped (stores are guarded)
     const bool live = row0 + c < B;
     const PfFlowBwdChainArgs& A = p.a;
@@ -102,14 +121,41 @@ __global__ __launch_bounds__(256) void flow_bwd_chain_kernel(const ChainArgs p) 
             for (int i = 0; i < TPW; ++i) { a0[i] = a1[i]; a1[i] = a2[i]; }
         }
     };
+    // bf16: A = fragments [tile][ks][lane] of the packed stream, B = bf16 row c of s_in, k = 32 ks + 8 g ..
+    auto gemm_bf = [&](const u32x4* fr, int nks, const __bf16* s_in, int stride, f32x4 (&acc)[TPW]) {
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const u32x4* fa[TPW];
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) fa[i] = fr + (size_t)(wave + 4 * i) * nks * 64 + lane;
+        const __bf16* brow = s_in + c * stride + 8 * g;
+        u32x4 a0[TPW], a1[TPW], a2[TPW];
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) { a0[i] = fa[i][0]; a1[i] = fa[i][64 * (nks > 1 ? 1 : 0)]; }
+        for (int ks = 0; ks < nks; ++ks) {
+            const int kn = ks + 2 < nks ? ks + 2 : nks - 1;
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) a2[i] = fa[i][64 * kn];
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(brow + 32 * ks);
+#pragma unroll
+            for (int i = 0; i < TPW; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a0[i]), b, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) { a0[i] = a1[i]; a1[i] = a2[i]; }
+        }
+    };
     // C-layout access of slab `idx` of a [slabs][B][H] tensor: units 16 t + 4 g .. + 3 of row my_row
     // ([L][B][H]: idx = l; [2][L][B][H]: idx = j L + l; Gc [L][3][B][H]: idx = 3 l + k)
     auto at = [&](const float* base, int idx, int t) { return base + ((size_t)idx * B + my_row) * H + 16 * t + 4 * g; };
     auto ld4 = [&](const float* base, int idx, int t) { return *reinterpret_cast<const f32x4*>(at(base, idx, t)); };
+    auto cvt4 = [](const f32x4& v) { bf16x4 o; for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e]; return o; };
     auto st4 = [&](float* base, int idx, int t, const f32x4& v) {
         if (live) *reinterpret_cast<f32x4*>(const_cast<float*>(at(base, idx, t))) = v;
     };
-    auto to_lds = [&](float* s_out, int t, const f32x4& v) { *reinterpret_cast<f32x4*>(s_out + c * HS + 16 * t + 4 * g) = v; };
+    auto to_lds = [&](int which, int t, const f32x4& v) {               // exchange vector 0 / 1
+        if constexpr (BF) *reinterpret_cast<bf16x4*>((which ? s_b1 : s_b0) + c * HSB + 16 * t + 4 * g) = cvt4(v);
+        else *reinterpret_cast<f32x4*>((which ? s_v1 : s_v0) + c * HS + 16 * t + 4 * g) = v;
+    };
 
     for (int l = L - 1; l >= 0; --l) {
         // ---- spline backward: raw parameters of the 16 rows -> LDS (coalesced), one lane per (row, feature) pair ----
@@ -131,6 +177,15 @@ __global__ __launch_bounds__(256) void flow_bwd_chain_kernel(const ChainArgs p) 
             const int r = s / (D * M), k = s - r * (D * M);
             if (row0 + r < B) A.Gp[((size_t)l * B + row0 + r) * (D * M) + k] = s_gp[r * PMS + k];
         }
+        if constexpr (BF) {                                     // and its bf16 image, the B operand of the next GEMM
+            const int kw = 32 * KSF;
+            for (int s = tid; s < 16 * kw; s += 256) {
+                const int r = s / kw, k = s - r * kw;
+                s_gpb[r * GSB + k] = (__bf16)(k < D * M ? s_gp[r * PMS + k] : 0.f);
+            }
+            __syncthreads();
+        }
+        const u32x4* lf = frags + (size_t)l * layer_frags * 64;   // BF: this layer's fragments (64 lanes x 16 B each)
         // ---- gh = Wf^T Gp ----------------------------------------------------------------------------------------
         f32x4 gh[TPW], acc[TPW];
         f32x4 gate_n[TPW], t2_n[TPW];                        // block operands, requested one GEMM ahead of their use
@@ -138,7 +193,8 @@ __global__ __launch_bounds__(256) void flow_bwd_chain_kernel(const ChainArgs p) 
 #pragma unroll
             for (int i = 0; i < TPW; ++i) { gate_n[i] = ld4(A.gates, 1 * L + l, wave + 4 * i); t2_n[i] = ld4(A.t2s, 1 * L + l, wave + 4 * i); }
         }
-        gemm(A.WfT + (size_t)l * H * PM, PM, PM, s_gp, PMS, gh);
+        if constexpr (BF) gemm_bf(lf, KSF, s_gpb, GSB, gh);
+        else gemm(A.WfT + (size_t)l * H * PM, PM, PM, s_gp, PMS, gh);
         // ---- residual blocks, last first -------------------------------------------------------------------------
         for (int j = 1; j >= 0; --j) {
 #pragma unroll
@@ -156,7 +212,7 @@ __global__ __launch_bounds__(256) void flow_bwd_chain_kernel(const ChainArgs p) 
                     st4(A.Gc, 3 * l + 1 + j, t, gc);
                 }
                 st4(A.Gt2, j * L + l, t, gt2);
-                to_lds(s_v0, t, gt2);
+                to_lds(0, t, gt2);
             }
             __syncthreads();
             f32x4 t1[TPW], hj[TPW];                          // requested ahead of the GEMMs whose epilogues use them
@@ -169,7 +225,8 @@ __global__ __launch_bounds__(256) void flow_bwd_chain_kernel(const ChainArgs p) 
                     else gate_n[i] = ld4(A.pc, l, wave + 4 * i);
                 }
             }
-            gemm(A.W2T + ((size_t)j * L + l) * H * H, H, H, s_v0, HS, acc);
+            if constexpr (BF) gemm_bf(lf + ((size_t)NT * KSF + (size_t)(2 * j) * NT * HK) * 64, HK, s_b0, HSB, acc);
+            else gemm(A.W2T + ((size_t)j * L + l) * H * H, H, H, s_v0, HS, acc);
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
                 const int t = wave + 4 * i;
@@ -177,10 +234,11 @@ __global__ __launch_bounds__(256) void flow_bwd_chain_kernel(const ChainArgs p) 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) gt1[e] = t1[i][e] > 0.f ? acc[i][e] : 0.f;
                 st4(A.Gt1, j * L + l, t, gt1);
-                to_lds(s_v1, t, gt1);
+                to_lds(1, t, gt1);
             }
             __syncthreads();
-            gemm(A.W1T + ((size_t)j * L + l) * H * H, H, H, s_v1, HS, acc);
+            if constexpr (BF) gemm_bf(lf + ((size_t)NT * KSF + (size_t)(2 * j + 1) * NT * HK) * 64, HK, s_b1, HSB, acc);
+            else gemm(A.W1T + ((size_t)j * L + l) * H * H, H, H, s_v1, HS, acc);
 #pragma unroll
             for (int i = 0; i < TPW; ++i)
 #pragma unroll
@@ -198,11 +256,18 @@ __global__ __launch_bounds__(256) void flow_bwd_chain_kernel(const ChainArgs p) 
                 for (int e = 0; e < 4; ++e) gc[e] = pc[e] > 0.f ? gh[i][e] : 0.f;
                 st4(A.Gc, 3 * l, t, gc);
             }
-            to_lds(s_v0, t, gh[i]);
+            to_lds(0, t, gh[i]);
         }
         __syncthreads();
         {   // one output tile (the D <= 16 features), the k range split over the four waves, reduced through LDS
             f32x4 part = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (BF) {
+                const u32x4* fr = lf + ((size_t)NT * KSF + (size_t)4 * NT * HK) * 64 + lane;
+                for (int ks = wave; ks < HK; ks += 4) {
+                    const bf16x8 b = *reinterpret_cast<const bf16x8*>(s_b0 + c * HSB + 32 * ks + 8 * g);
+                    part = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fr[64 * ks]), b, part, 0, 0, 0);
+                }
+            } else {
             const float* wrow = A.W0T + ((size_t)l * 16 + c) * H + 4 * g;
             const int kq = H / 64;                           // k-groups of 16 per wave
             for (int q = wave * kq; q < (wave + 1) * kq; ++q) {
@@ -210,6 +275,7 @@ __global__ __launch_bounds__(256) void flow_bwd_chain_kernel(const ChainArgs p) 
                 const f32x4 b = *reinterpret_cast<const f32x4*>(s_v0 + c * HS + 16 * q + 4 * g);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) part = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], part, 0, 0, 0);
+            }
             }
             // lane (g, c): features 4 g .. 4 g + 3 of row c
             *reinterpret_cast<f32x4*>(s_part + (wave * 16 + c) * 16 + 4 * g) = part;
@@ -242,7 +308,9 @@ int flow_backward_chain(const PfFlowDesc& d, float deriv_const, const PfFlowBwdC
     p.D = d.features; p.H = d.hidden_features; p.L = d.num_layers; p.M = 3 * d.num_bins - 1;
     p.PM = (p.D * p.M + 15) / 16 * 16;
     p.B = a.batch;
-    const size_t lds = ((size_t)16 * (p.PM + 4) + 2 * 16 * (p.H + 4) + 256 + 256 + 4 * 256) * sizeof(float);
+    const bool bf = d.precision == PF_PREC_BF16;
+    const size_t lds = ((size_t)16 * (p.PM + 4) + 2 * 16 * (p.H + 4) + 256 + 256 + 4 * 256) * sizeof(float)
+                     + (bf ? (size_t)16 * (32 * ((p.D * p.M + 31) / 32) + 8) * 2 : 0);
     const unsigned grid = (unsigned)((a.batch + 15) / 16);
     auto launch = [&](auto kern) {
         if (lds > 64 * 1024 &&
@@ -252,10 +320,10 @@ int flow_backward_chain(const PfFlowDesc& d, float deriv_const, const PfFlowBwdC
         return launch_status();
     };
     switch (p.H / 64) {
-    case 1: return launch(flow_bwd_chain_kernel<1>);
-    case 2: return launch(flow_bwd_chain_kernel<2>);
-    case 3: return launch(flow_bwd_chain_kernel<3>);
-    case 4: return launch(flow_bwd_chain_kernel<4>);
+    case 1: return bf ? launch(flow_bwd_chain_kernel<1, true>) : launch(flow_bwd_chain_kernel<1, false>);
+    case 2: return bf ? launch(flow_bwd_chain_kernel<2, true>) : launch(flow_bwd_chain_kernel<2, false>);
+    case 3: return bf ? launch(flow_bwd_chain_kernel<3, true>) : launch(flow_bwd_chain_kernel<3, false>);
+    case 4: return bf ? launch(flow_bwd_chain_kernel<4, true>) : launch(flow_bwd_chain_kernel<4, false>);
     }
     return PF_ERR_UNSUPPORTED;
 }

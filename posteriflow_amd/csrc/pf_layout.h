@@ -99,6 +99,7 @@ struct FlowPlan {
     int dense;                  // 0: masked stream, KHS / KOS = HK + kPadH / HK + kPadO; 1: KHS = KOS = 2*HK (masks too coarse to
                                 // pair up); 2: masked, KHS = HK + kPadH + 1 (bf16, NT = 16)
     int wide;                   // 1: the large-batch kernel's single common stream (pf_wide_layout.h); CKS in CKM
+    int bwd;                    // 1: PF_FLAG_BWD -- transposed bf16 A-fragments of the backward chain (bwd_* below), no biases
     int KHS, KOS, NF;
     int kH[kMaxTiles];          // active k-steps of tile t in a masked H x H GEMM
     int kO[kMaxTiles];          // active k-steps of feature f in the final layer
@@ -117,6 +118,15 @@ struct FlowPlan {
     // byte offsets of the regions inside the packed buffer
     PF_HD int64_t ctx_frag_offset() const { return weightBytes + biasFloats * (int64_t)sizeof(float); }
     PF_HD int64_t ctx_bias_offset() const { return ctx_frag_offset() + ctxFrags * kFragBytes; }
+
+    // PF_FLAG_BWD stream, in 1-KiB fragments: per layer [WfT][W2T_0][W1T_0][W2T_1][W1T_1][W0T]
+    PF_HD int bwd_ksf() const { return (D * M + 31) / 32; }                   // k-steps of the final layer's transpose
+    PF_HD int bwd_wf_frags() const { return NT * bwd_ksf(); }
+    PF_HD int bwd_hh_frags() const { return NT * (H / 32); }
+    PF_HD int bwd_layer_frags() const { return bwd_wf_frags() + 4 * bwd_hh_frags() + H / 32; }
+    PF_HD int64_t bwd_w2t(int layer, int j) const { return (int64_t)layer * bwd_layer_frags() + bwd_wf_frags() + (2 * j) * bwd_hh_frags(); }
+    PF_HD int64_t bwd_w1t(int layer, int j) const { return bwd_w2t(layer, j) + bwd_hh_frags(); }
+    PF_HD int64_t bwd_w0t(int layer) const { return (int64_t)layer * bwd_layer_frags() + bwd_wf_frags() + 4 * bwd_hh_frags(); }
 
     PF_HD int64_t bias_index(int layer, int tile) const {
         return ((int64_t)layer * NT + tile) * kBiasFloatsPerTile;
@@ -173,6 +183,11 @@ inline int make_plan(const PfFlowDesc& d, FlowPlan& o) {
             return PF_ERR_UNSUPPORTED;
         o.wide = 1;
     }
+    o.bwd = 0;
+    if (d.reserved & PF_FLAG_BWD) {
+        if (!o.bf16 || (d.reserved & ~PF_FLAG_BWD) || o.H % 32) return PF_ERR_UNSUPPORTED;
+        o.bwd = 1;
+    }
     o.hoist = (d.reserved & (PF_FLAG_HOIST_CTX | PF_FLAG_MASKED_CONTEXT)) && o.C > 0 ? 1 : 0;
     o.CKM = o.hoist ? 0 : pick_ckm(o.bf16, o.NT, o.C);
     if (o.CKM < 0 || o.CK > 64) return PF_ERR_UNSUPPORTED;
@@ -228,6 +243,12 @@ inline int make_plan(const PfFlowDesc& d, FlowPlan& o) {
         o.weightBytes = o.fragsTotal * kFragBytes;
         o.biasFloats = (int64_t)o.L * wide::kBiasFloats;
         o.ctxFrags = 0; o.ctxBiasFloats = 0;
+    }
+    if (o.bwd) {
+        o.fragsPerWave = 0;
+        o.fragsTotal = (int64_t)o.L * o.bwd_layer_frags();
+        o.weightBytes = o.fragsTotal * kFragBytes;
+        o.biasFloats = 0; o.ctxFrags = 0; o.ctxBiasFloats = 0;
     }
     const int64_t ctxp = o.C > 0 ? ((int64_t)o.H * o.C + o.H) : 0;
     o.rawPerLayer = (int64_t)o.H * o.D + o.H + ctxp

@@ -185,7 +185,54 @@ static int build_wide_pack_map(const FlowPlan& L, int32_t* map) {
     return PF_OK;
 }
 
+// ---- PF_FLAG_BWD: transposed masked matrices of the backward chain as bf16 A-fragments (pf_flow_bwd_chain.hip) -------
+// out^T[unit, row] = sum_k A[unit][k] in^T[k, row]; lane (i = lane & 15, g = lane >> 4) of fragment (tile t, k-step ks)
+// holds A[16 t + i][32 ks + 8 g + j], j = 0..7.  Units in nflows order (the re-evaluated activations are).
+static int build_bwd_pack_map(const FlowPlan& L, int32_t* map) {
+    const RawOffsets ro = raw_offsets(L);
+    const int D = L.D, H = L.H, M = L.M, NT = L.NT, HK = H / 32, KSF = L.bwd_ksf();
+    int64_t idx = 0;
+    auto frag = [&](auto&& src_of) {       // src_of(i, k) -> raw offset inside the layer or -1
+        for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j) map[idx++] = (int32_t)src_of(lane & 15, 8 * (lane >> 4) + j);
+    };
+    for (int l = 0; l < L.L; ++l) {
+        const int64_t base = (int64_t)l * ro.total;
+        auto at = [&](int64_t off) { return off < 0 ? (int64_t)-1 : base + off; };
+        // gh[u] = sum_p Wf[p][u] Gp[p]            (output mask: deg_out(feature) > deg(u))
+        for (int t = 0; t < NT; ++t)
+            for (int ks = 0; ks < KSF; ++ks)
+                frag([&](int i, int kk) {
+                    const int u = 16 * t + i, p = 32 * ks + kk;
+                    if (p >= D * M || !(p / M + 1 > hid_degree(D, u))) return (int64_t)-1;
+                    return at(ro.out_w + (int64_t)p * H + u);
+                });
+        for (int j = 0; j < 2; ++j) {
+            // gt1[u] = sum_k W2_j[k][u] gt2[k], then gr[u] = sum_k W1_j[k][u] gt1[k]   (hidden mask: deg(k) >= deg(u))
+            for (int which = 0; which < 2; ++which) {
+                const int64_t w = which == 0 ? ro.w1_w[j] : ro.w0_w[j];   // linear_layers[1] first (the chain walks backwards)
+                for (int t = 0; t < NT; ++t)
+                    for (int ks = 0; ks < HK; ++ks)
+                        frag([&](int i, int kk) {
+                            const int u = 16 * t + i, k = 32 * ks + kk;
+                            if (hid_degree(D, k) < hid_degree(D, u)) return (int64_t)-1;
+                            return at(w + (int64_t)k * H + u);
+                        });
+            }
+        }
+        // gu[f] = sum_k W0[k][f] gh[k]              (input mask: deg(k) >= f + 1)
+        for (int ks = 0; ks < HK; ++ks)
+            frag([&](int f, int kk) {
+                const int k = 32 * ks + kk;
+                if (f >= D || hid_degree(D, k) < f + 1) return (int64_t)-1;
+                return at(ro.in_w + (int64_t)k * D + f);
+            });
+    }
+    return idx == L.fragsTotal * 512 ? PF_OK : PF_ERR_BAD_ARG;
+}
+
 int build_pack_map(const FlowPlan& L, int32_t* map) {
+    if (L.bwd) return build_bwd_pack_map(L, map);
     if (L.wide) return build_wide_pack_map(L, map);
     const RawOffsets ro = raw_offsets(L);
     const int fragElems = L.bf16 ? 512 : 256;

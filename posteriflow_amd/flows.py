@@ -51,15 +51,26 @@ class _MaskedLinear(nn.Linear):
 
 
 class _MaskedContextLinear(nn.Module):
-    """Parameters of the reference's MaskedContextLinear (flows.py:112-183, full_context=True:
-    the mask buffer is all ones)."""
+    """Parameters of the reference's MaskedContextLinear (flows.py:112-183).  full_context=True (what
+    MADEWithMaskedContext builds, flows.py:268): the mask buffer is all ones; full_context=False (flows.py:171-174):
+    context block i is visible to hidden units of degree >= i.  The mask is folded into the weights when they are
+    packed (``masked_weight``)."""
 
-    def __init__(self, n_blocks: int, block_dim: int, hidden: int):
+    def __init__(self, n_blocks: int, block_dim: int, hidden_degrees: torch.Tensor, full_context: bool = True):
         super().__init__()
+        hidden = hidden_degrees.shape[0]
         self.weight = nn.Parameter(torch.empty(hidden, n_blocks * block_dim))
         self.bias = nn.Parameter(torch.zeros(hidden))
         nn.init.kaiming_uniform_(self.weight, a=5 ** 0.5)
-        self.register_buffer("mask", torch.ones(hidden, n_blocks * block_dim))
+        if full_context:
+            in_deg = torch.full((n_blocks * block_dim,), -1, dtype=torch.long)
+        else:
+            in_deg = torch.arange(n_blocks).repeat_interleave(block_dim)
+        self.full_context = bool(full_context)
+        self.register_buffer("mask", (hidden_degrees[:, None] >= in_deg[None, :]).float())
+
+    def masked_weight(self) -> torch.Tensor:
+        return self.weight if self.full_context else self.weight * self.mask
 
 
 class _ResidualBlock(nn.Module):
@@ -67,7 +78,7 @@ class _ResidualBlock(nn.Module):
         super().__init__()
         h = len(in_degrees)
         if masked_blocks:
-            self.context_layer = _MaskedContextLinear(masked_blocks[0], masked_blocks[1], h)
+            self.context_layer = _MaskedContextLinear(masked_blocks[0], masked_blocks[1], in_degrees, *masked_blocks[2:])
         elif context_features:
             self.context_layer = nn.Linear(context_features, h)
         l0 = _MaskedLinear(in_degrees, h, features, False)
@@ -82,7 +93,8 @@ class _MADE(nn.Module):
         super().__init__()
         self.initial_layer = _MaskedLinear(torch.arange(1, features + 1), hidden, features, False)
         if masked_blocks:
-            self.context_layer = _MaskedContextLinear(masked_blocks[0], masked_blocks[1], hidden)
+            self.context_layer = _MaskedContextLinear(masked_blocks[0], masked_blocks[1], self.initial_layer.degrees,
+                                                      *masked_blocks[2:])
         elif context_features:
             self.context_layer = nn.Linear(context_features, hidden)
         self.blocks = nn.ModuleList(
@@ -91,14 +103,17 @@ class _MADE(nn.Module):
         self.final_layer = _MaskedLinear(self.initial_layer.degrees, features * multiplier,
                                          features, True)
 
-    def ordered_parameters(self) -> List[torch.Tensor]:
-        """Raw layout of include/pf_hip.h ("raw parameter layout")."""
+    def ordered_parameters(self, for_packing: bool = False) -> List[torch.Tensor]:
+        """Raw layout of include/pf_hip.h ("raw parameter layout").  for_packing: the tensors pf_flow_pack reads --
+        a masked-context linear built with full_context=False contributes weight * mask (the x-side masks are
+        rebuilt by the pack map from the degree rule; the context mask of that variant is not)."""
+        cw = lambda m: m.masked_weight() if for_packing and isinstance(m, _MaskedContextLinear) else m.weight
         out = [self.initial_layer.weight, self.initial_layer.bias]
         if hasattr(self, "context_layer"):
-            out += [self.context_layer.weight, self.context_layer.bias]
+            out += [cw(self.context_layer), self.context_layer.bias]
         for b in self.blocks:
             if hasattr(b, "context_layer"):
-                out += [b.context_layer.weight, b.context_layer.bias]
+                out += [cw(b.context_layer), b.context_layer.bias]
             for lin in b.linear_layers:
                 out += [lin.weight, lin.bias]
         return out + [self.final_layer.weight, self.final_layer.bias]
@@ -227,7 +242,10 @@ class NSFPosteriorFlow(nn.Module):
 
         ctx = context_features if context_features > 0 else None
         transforms, self._ar_transforms = [], []
-        mblocks = (self.n_context_blocks, self.context_block_dim) if self.use_masked_context else None
+        # MaskedContextLinear's full_context (flows.py:145): MADEWithMaskedContext never passes it (flows.py:268), so every
+        # flow the reference builds has the all-ones context mask; the per-position mask is reachable here as a keyword
+        full_context = bool(kwargs.pop("full_context", True))
+        mblocks = (self.n_context_blocks, self.context_block_dim, full_context) if self.use_masked_context else None
         for _ in range(num_layers):
             if not self.use_masked_context:                              # flows.py:459-460
                 transforms.append(_Reverse(features))
@@ -342,8 +360,13 @@ class NSFPosteriorFlow(nn.Module):
             return False
         return env == "1" or batch >= self.wide_min_batch
 
-    def _desc(self, precision: Optional[str] = None, inverse: bool = False, wide: bool = False) -> _lib.PfFlowDesc:
+    def _desc(self, precision: Optional[str] = None, inverse: bool = False, wide: bool = False,
+              bwd: bool = False) -> _lib.PfFlowDesc:
         prec = _lib.PRECISIONS[precision or self.precision]
+        if bwd:     # packing only: the backward chain's transposed bf16 fragments (PF_FLAG_BWD)
+            return _lib.PfFlowDesc(self.features, self.context_features, self.hidden_features, self.num_bins,
+                                   self.num_layers, 2, float(self._tail_bound), _MIN_BIN, _MIN_BIN, _MIN_BIN,
+                                   _lib.PF_PREC_BF16, _lib.PF_FLAG_BWD)
         if wide:
             return _lib.PfFlowDesc(self.features, self.context_features, self.hidden_features, self.num_bins,
                                    self.num_layers, 2, float(self._tail_bound), _MIN_BIN, _MIN_BIN, _MIN_BIN,
@@ -391,9 +414,10 @@ class NSFPosteriorFlow(nn.Module):
                 "(no CPU fallback); move the module with .to('cuda')" % dev)
         return dev
 
-    def packed_weights(self, precision: Optional[str] = None, inverse: bool = False, wide: bool = False) -> torch.Tensor:
+    def packed_weights(self, precision: Optional[str] = None, inverse: bool = False, wide: bool = False,
+                       bwd: bool = False) -> torch.Tensor:
         """Packed (masked, fragment-ordered) weights, rebuilt when a parameter changed."""
-        desc = self._desc(precision, inverse, wide)
+        desc = self._desc(precision, inverse, wide, bwd)
         ck = (desc.precision, desc.reserved)
         if self._frozen and ck in self._packed and self._packed[ck].buf is not None:
             return self._packed[ck].buf
@@ -412,7 +436,9 @@ class NSFPosteriorFlow(nn.Module):
             _lib.check(L.pf_flow_build_pack_map(desc, host.data_ptr()), "pf_flow_build_pack_map")
             pk.map = host.to(dev)
             pk.buf = torch.empty(L.pf_flow_packed_bytes(desc), dtype=torch.uint8, device=dev)
-        raw = torch.cat([p.detach().reshape(-1).float() for p in params])
+        with torch.no_grad():
+            packing = [t for layer in self._ar_transforms for t in layer.autoregressive_net.ordered_parameters(True)]
+            raw = torch.cat([p.detach().reshape(-1).float() for p in packing])
         assert raw.numel() == L.pf_flow_raw_param_count(desc)
         _lib.check(L.pf_flow_pack(desc, raw.data_ptr(), pk.map.data_ptr(), pk.buf.data_ptr(),
                                   torch.cuda.current_stream(dev).cuda_stream), "pf_flow_pack")

@@ -10,6 +10,7 @@ n_rows = 2048
 ctx = torch.randn(n_rows, flow.context_features, device=dev, requires_grad=True)
 x = (torch.rand(n_rows, flow.features, device=dev) * 2 - 1)
 def flow_fb():
+    flow.zero_grad(set_to_none=True); ctx.grad = None          # as a training loop does (optimizer.zero_grad())
     flow.compute_psd_aware_nll(x, ctx, torch.zeros_like(x)).mean().backward()
 for _ in range(3): flow_fb()
 torch.cuda.synchronize(); t0 = time.perf_counter()

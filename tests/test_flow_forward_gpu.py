@@ -222,6 +222,58 @@ def test_masked_context_conditioner_a14():
 
 
 @pytest.mark.gpu
+def test_masked_context_per_position_mask_full_context_false():
+    """MaskedContextLinear(full_context=False) (flows.py:171-174): context block i reaches hidden units of degree >= i
+    only.  No flow the reference builds uses it (MADEWithMaskedContext passes the default, flows.py:268); the product
+    exposes it as the keyword of the same name and folds the mask into the packed weights.  Forward / inverse / gradients
+    against the oracle, and the structural property: z_g does not depend on context blocks after position g."""
+    from helpers import oracle_state_for_product
+    from oracle.flow_ref import NSFPosteriorFlowRef
+    from posteriflow_amd import NSFPosteriorFlow
+    D, C, H, L, K, tb, B = 6, 48, 128, 3, 8, 4.0, 128                 # 6 blocks x 8
+    torch.manual_seed(0)
+    ref = NSFPosteriorFlowRef(D, C, H, L, K, tb, temperature_scale=1.0, use_masked_context=True, full_context=False)
+    ref64 = NSFPosteriorFlowRef(D, C, H, L, K, tb, temperature_scale=1.0, use_masked_context=True, full_context=False).double()
+    ref64.load_state_dict(ref.state_dict())
+    flow = NSFPosteriorFlow(D, C, H, L, K, tb, temperature_scale=1.0, full_context=False)
+    net = flow._ar_transforms[0].autoregressive_net
+    assert flow.use_masked_context and not net.context_layer.full_context
+    assert 0.0 < net.context_layer.mask.mean() < 1.0 and 0.0 < net.blocks[1].context_layer.mask.mean() < 1.0
+    flow.load_state_dict(oracle_state_for_product(ref))
+    assert torch.equal(net.context_layer.mask, ref.transform._transforms[0].autoregressive_net.context_layer.mask)
+    flow = flow.cuda()
+    x, ctx = flow_inputs(B, D, C, tb)
+    with torch.no_grad():
+        z64, ld64 = ref64(x.double(), ctx.double())
+        flow.precision = "fp32"
+        z, ld = flow(x.cuda(), ctx.cuda())
+        assert (z.cpu().double() - z64).abs().max() < 2e-5 and (ld.cpu().double() - ld64).abs().max() < 1e-4
+        # changing the LAST context block moves only the last position of z (layer order = autoregressive order here)
+        ctx2 = ctx.clone()
+        ctx2[:, -8:] += 1.0
+        z2, _ = flow(x.cuda(), ctx2.cuda())
+        moved = (z2 - z).abs().max(dim=0).values.cpu()
+        assert (moved[:-1] == 0).all() and moved[-1] > 1e-3, moved
+        flow.precision = "bf16"
+        zb, ldb = flow(x.cuda(), ctx.cuda())
+        assert (zb.cpu().double() - z64).abs().max() < 0.5 and (ldb.cpu().double() - ld64).abs().max() < 4.0
+        flow.precision = "fp32"
+        zz = torch.randn(64, D)
+        xi, _, flags = flow._inverse_call(zz.cuda(), flow._permute_context_blocks(ctx[:64].cuda()).contiguous(), 64)
+        xr, _ = ref64.inverse_raw(zz.double(), ctx[:64].double())
+        assert int(flags.sum()) == 0 and (xi.cpu().double() - xr).abs().max() < 2e-4
+    xg, cg = x[:32].cuda().requires_grad_(True), ctx[:32].cuda().requires_grad_(True)
+    flow.compute_psd_aware_nll(xg, cg, None).sum().backward()
+    xr_, cr_ = x[:32].clone().requires_grad_(True), ctx[:32].clone().requires_grad_(True)
+    ref.compute_psd_aware_nll(xr_, cr_, torch.zeros(32, D)).sum().backward()
+    relg = lambda a, b: ((a - b).abs().max() / b.abs().max()).item()
+    assert relg(xg.grad.cpu(), xr_.grad) < 1e-3 and relg(cg.grad.cpu(), cr_.grad) < 1e-3
+    g_ref = dict(ref.named_parameters())["transform._transforms.0.autoregressive_net.context_layer.weight"].grad
+    g_got = flow._ar_transforms[0].autoregressive_net.context_layer.weight.grad.cpu()
+    assert relg(g_got, g_ref) < 1e-3 and (g_got[net.context_layer.mask.cpu() == 0] == 0).all()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B", [1, 37, 4096, 5000])
 def test_in_kernel_loss_reduction(B):
     """pf_flow_forward_reduce: (sum nll, rows) accumulated by the kernel (wave shuffle + atomics) equals the

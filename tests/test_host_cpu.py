@@ -85,6 +85,58 @@ def test_pack_map_covers_exactly_the_unmasked_weights(lib, D, C, H, K, L, prec, 
     assert sum(p.numel() for p in t.parameters()) == per_layer
 
 
+@pytest.mark.parametrize("D,C,H,K,L", [(11, 288, 256, 16, 2), (15, 288, 256, 16, 1), (4, 0, 64, 8, 2), (7, 40, 128, 10, 2)])
+def test_backward_pack_map_is_the_transposed_masked_matrices(lib, D, C, H, K, L):
+    """PF_FLAG_BWD (the bf16 backward chain's weight stream): gathering a raw parameter vector through the map and decoding
+    the A-fragments (lane (i, g), element j of fragment (tile t, k-step ks) = A[16 t + i][32 ks + 8 g + j]) must give
+    exactly (W * mask)^T of the final layer, of both linears of both blocks and of the initial layer, zero padded; the
+    context weights and all biases never appear; the compute entry points refuse the flag."""
+    from oracle import nflows_restated as nfr
+    d = desc_of(lib, D, C, H, K, L, "bf16", lib.PF_FLAG_BWD)
+    h = lib.lib()
+    n = h.pf_flow_pack_map_len(C_byref(d))
+    M = 3 * K - 1
+    NT, HK, KSF = H // 16, H // 32, (D * M + 31) // 32
+    layer_frags = NT * KSF + 4 * NT * HK + HK
+    assert n == L * layer_frags * 512 and h.pf_flow_packed_bytes(C_byref(d)) == 2 * n
+    m = np.empty(n, dtype=np.int32)
+    assert h.pf_flow_build_pack_map(C_byref(d), m.ctypes.data) == 0
+    per_layer = h.pf_flow_raw_param_count(C_byref(d)) // L
+    raw = np.random.default_rng(0).standard_normal(per_layer * L).astype(np.float32)
+    packed = np.where(m >= 0, raw[np.maximum(m, 0)], 0.0).reshape(L, layer_frags, 64, 8)
+    t = nfr.MaskedPiecewiseRationalQuadraticAutoregressiveTransform(D, H, C or None, K, 5.0)
+    net = t.autoregressive_net
+
+    def decode(frags, tiles, nks):          # [tiles * nks, 64, 8] -> A [16 tiles, 32 nks]
+        f = frags.reshape(tiles, nks, 4, 16, 8)                         # lane = 16 g + i
+        return f.transpose(0, 3, 1, 2, 4).reshape(16 * tiles, 32 * nks)  # [t, i, ks, g, j]
+
+    for layer in range(L):
+        off, mats = layer * per_layer, {}
+        for name, r, c in raw_layout(D, C, H, K):
+            mats[name] = raw[off:off + r * c].reshape(r, c)
+            off += r * c
+        fr = packed[layer]
+        pos = 0
+        A = decode(fr[pos:pos + NT * KSF], NT, KSF); pos += NT * KSF
+        want = np.zeros((H, 32 * KSF), np.float32)
+        want[:, :D * M] = (mats["out_w"] * net.final_layer.mask.numpy()).T
+        assert np.array_equal(A, want), (layer, "WfT")
+        for j in range(2):
+            for name, lin in ((f"w1{j}_w", net.blocks[j].linear_layers[1]), (f"w0{j}_w", net.blocks[j].linear_layers[0])):
+                A = decode(fr[pos:pos + NT * HK], NT, HK); pos += NT * HK
+                assert np.array_equal(A, (mats[name] * lin.mask.numpy()).T), (layer, name)
+        A = decode(fr[pos:pos + HK], 1, HK); pos += HK
+        want = np.zeros((16, H), np.float32)
+        want[:D] = (mats["in_w"] * net.initial_layer.mask.numpy()).T
+        assert np.array_equal(A, want), (layer, "W0T")
+        assert pos == layer_frags
+    # the flag is a packing layout only
+    assert h.pf_flow_workspace_bytes(C_byref(d), 16) == -1 and h.pf_flow_rows_per_workgroup(C_byref(d), 16) == -1
+    assert h.pf_flow_forward(C_byref(d), 16, 16, 16, None, None, 16, None, None, 16, None, 0, None) == lib.PF_ERR_UNSUPPORTED
+    assert h.pf_flow_pack_map_len(C_byref(desc_of(lib, D, C, H, K, L, "fp32", lib.PF_FLAG_BWD))) == -1
+
+
 @pytest.mark.parametrize("D,K,L", [(15, 16, 2), (11, 16, 3)])
 def test_wide_pack_map_covers_exactly_the_unmasked_weights(lib, D, K, L):
     """The large-batch kernel's layout (PF_FLAG_WIDE, csrc/pf_wide_layout.h): one common stream of 32 x 16 fragments in
