@@ -196,6 +196,27 @@ typedef struct PfFlowBwdChainArgs {
 } PfFlowBwdChainArgs;
 int pf_flow_backward_chain(const PfFlowDesc* desc, const PfFlowBwdChainArgs* args, void* stream);
 
+/* ---- backward: the conditioner re-evaluation in one launch (bf16 descs) -------------------------------------------
+ * Recomputes, from the layer inputs pf_flow_forward_train kept, the activations of every layer's MADE that the chain and the
+ * weight-gradient GEMMs read -- what autograd keeps alive for the reference under flows.py:615-617.  Grid = 16-row blocks x
+ * layers (the layers are independent given their inputs); bf16 operands, x as hi + lo, fp32 accumulate: the arithmetic of the
+ * bf16 forward kernel.  `packed` is the PF_FLAG_BWD stream (its forward region).  Plain conditioner, bf16 desc, H % 32 == 0.
+ * Outputs fp32, nflows unit order; context-free flows pass ctx = t2s = gates = pc = NULL. */
+typedef struct PfFlowReevalArgs {
+    int64_t batch;
+    const void* packed;  /* PF_FLAG_BWD stream */
+    const float* U;      /* [L][B][D] layer inputs */
+    const float* ctx;    /* [B][C] or NULL */
+    float* hs;           /* [2][L][B][H] residual state before block j */
+    float* t1s;          /* [2][L][B][H] */
+    float* t2s;          /* [2][L][B][H] or NULL */
+    float* gates;        /* [2][L][B][H] or NULL */
+    float* pc;           /* [L][B][H] or NULL */
+    float* h2;           /* [L][B][H] residual state after the last block (input of the final layer) */
+    float* params;       /* [L][B][D (3K-1)] raw spline parameters */
+} PfFlowReevalArgs;
+int pf_flow_reevaluate(const PfFlowDesc* desc, const PfFlowReevalArgs* args, void* stream);
+
 /* ---- inverse / sampling -----------------------------------------------------
  * x = transform^-1(z, ctx)[:, ar_inv_perm], logdet of the inverse map
  * (nflows returns the log-det of the last autoregressive pass of each layer,

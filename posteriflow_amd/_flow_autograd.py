@@ -129,6 +129,31 @@ def _rqs_backward(flow, u, params, gy, glad, gparams):
     return gu
 
 
+REEVAL_HIP = True      # tests: False keeps the tensor-op re-evaluation in bf16 mode (isolates the bf16 chain kernel)
+
+
+def _reevaluate_hip(flow, U, ctx):
+    """bf16 mode: every layer's conditioner from its kept input in ONE launch (pf_flow_reevaluate, csrc/pf_flow_reeval.hip),
+    in the arithmetic of the bf16 forward kernel.  Returns (hs [h_0, h_1, h_2], t1s, t2s, gates, pc, params)."""
+    Ln, B, D = U.shape
+    H, dev = flow.hidden_features, U.device
+    has_ctx = ctx is not None
+    new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+    HS, T1, H2 = new(2, Ln, B, H), new(2, Ln, B, H), new(Ln, B, H)
+    params = new(Ln, B, D * (3 * flow.num_bins - 1))
+    T2 = G = PC = None
+    packed = flow.packed_weights(bwd=True)
+    a = _lib.PfFlowReevalArgs()
+    a.batch, a.packed, a.U = B, packed.data_ptr(), U.data_ptr()
+    a.hs, a.t1s, a.h2, a.params = HS.data_ptr(), T1.data_ptr(), H2.data_ptr(), params.data_ptr()
+    if has_ctx:
+        T2, G, PC = new(2, Ln, B, H), new(2, Ln, B, H), new(Ln, B, H)
+        a.ctx, a.t2s, a.gates, a.pc = ctx.data_ptr(), T2.data_ptr(), G.data_ptr(), PC.data_ptr()
+    _lib.check(_lib.lib().pf_flow_reevaluate(flow._desc("bf16"), a, torch.cuda.current_stream(dev).cuda_stream),
+               "pf_flow_reevaluate")
+    return HS, T1, T2, G, PC, H2, params
+
+
 @torch.no_grad()
 def _flow_backward_batched(flow, U, ctx, g_z, g_lad, drop=None):
     """U [L, B, D] conditioner inputs kept by the forward kernel; g_z [B, D] = dL/dz, g_lad [B] =
@@ -138,63 +163,62 @@ def _flow_backward_batched(flow, U, ctx, g_z, g_lad, drop=None):
     Ln, B, D = U.shape
     nb = len(nets[0].blocks)
     has_ctx = ctx is not None
+    H = flow.hidden_features
     st = lambda f: torch.stack([f(n) for n in nets])
     net0 = nets[0]                                   # every layer has the same degrees, hence masks
     m0, mf = net0.initial_layer.mask, net0.final_layer.mask
     m1 = [net0.blocks[j].linear_layers[0].mask for j in range(nb)]
     m2 = [net0.blocks[j].linear_layers[1].mask for j in range(nb)]
-    W0, b0 = st(lambda n: n.initial_layer.weight) * m0, st(lambda n: n.initial_layer.bias)
-    Wf, bf = st(lambda n: n.final_layer.weight) * mf, st(lambda n: n.final_layer.bias)
-    W1 = [st(lambda n: n.blocks[j].linear_layers[0].weight) * m1[j] for j in range(nb)]
-    W2 = [st(lambda n: n.blocks[j].linear_layers[1].weight) * m2[j] for j in range(nb)]
-    b1 = [st(lambda n: n.blocks[j].linear_layers[0].bias) for j in range(nb)]
-    b2 = [st(lambda n: n.blocks[j].linear_layers[1].bias) for j in range(nb)]
-    H = W0.shape[1]
-
-    # 1. conditioners, batched over layers
     if has_ctx:
         C = ctx.shape[1]
         Wcat = torch.cat([st(lambda n: n.context_layer.weight)]
                          + [st(lambda n: n.blocks[j].context_layer.weight) for j in range(nb)], dim=1)
-        bcat = torch.cat([st(lambda n: n.context_layer.bias)]
-                         + [st(lambda n: n.blocks[j].context_layer.bias) for j in range(nb)], dim=1)
-        proj = torch.addmm(bcat.reshape(-1), ctx, Wcat.reshape(-1, C).t())
-        proj = proj.view(B, Ln, 1 + nb, H).permute(1, 2, 0, 3)                   # [L, 1+nb, B, H]
-        pc = proj[:, 0]
-        gates = [torch.sigmoid(proj[:, 1 + j]) for j in range(nb)]
-    h = torch.baddbmm(b0[:, None, :], U, W0.transpose(1, 2))
-    if has_ctx:
-        h = h + F.relu(pc)
-    hs, t1s, t2s, a1s = [h], [], [], []
-    for j in range(nb):
-        t1 = torch.baddbmm(b1[j][:, None, :], F.relu(h), W1[j].transpose(1, 2))
-        a1 = F.relu(t1) if drop is None else F.relu(t1) * drop[j]                 # the second linear's input
-        t2 = torch.baddbmm(b2[j][:, None, :], a1, W2[j].transpose(1, 2))
-        h = h + (t2 * gates[j] if has_ctx else t2)
-        hs.append(h), t1s.append(t1), t2s.append(t2), a1s.append(a1)
-    params = torch.baddbmm(bf[:, None, :], h, Wf.transpose(1, 2))                 # [L, B, D(3K-1)]
+    # bf16 mode: re-evaluation and chain are HIP kernels reading the packed PF_FLAG_BWD stream (one gather per weight
+    # update).  Dropout keeps the fp32 path: the kept units' factor rides on the transposed W2 there.
+    bf = flow.precision == "bf16" and H % 32 == 0 and drop is None and nb == 2 and U.is_contiguous() and \
+        (ctx is None or ctx.is_contiguous())
+
+    # 1. conditioners
+    if bf and REEVAL_HIP:
+        HSk, T1k, T2k, Gk, pck, h_last, params = _reevaluate_hip(flow, U, ctx)
+        relu_h = [F.relu(HSk[j]) for j in range(nb)]
+        a1s = [F.relu(T1k[j]) for j in range(nb)]
+    else:
+        W0, b0 = st(lambda n: n.initial_layer.weight) * m0, st(lambda n: n.initial_layer.bias)
+        Wf, bf_ = st(lambda n: n.final_layer.weight) * mf, st(lambda n: n.final_layer.bias)
+        W1 = [st(lambda n: n.blocks[j].linear_layers[0].weight) * m1[j] for j in range(nb)]
+        W2 = [st(lambda n: n.blocks[j].linear_layers[1].weight) * m2[j] for j in range(nb)]
+        b1 = [st(lambda n: n.blocks[j].linear_layers[0].bias) for j in range(nb)]
+        b2 = [st(lambda n: n.blocks[j].linear_layers[1].bias) for j in range(nb)]
+        if has_ctx:       # batched over layers: one GEMM for all context projections
+            bcat = torch.cat([st(lambda n: n.context_layer.bias)]
+                             + [st(lambda n: n.blocks[j].context_layer.bias) for j in range(nb)], dim=1)
+            proj = torch.addmm(bcat.reshape(-1), ctx, Wcat.reshape(-1, C).t())
+            proj = proj.view(B, Ln, 1 + nb, H).permute(1, 2, 0, 3)                   # [L, 1+nb, B, H]
+            pc = proj[:, 0]
+            gates = [torch.sigmoid(proj[:, 1 + j]) for j in range(nb)]
+        h = torch.baddbmm(b0[:, None, :], U, W0.transpose(1, 2))
+        if has_ctx:
+            h = h + F.relu(pc)
+        hs, t1s, t2s, a1s = [h], [], [], []
+        for j in range(nb):
+            t1 = torch.baddbmm(b1[j][:, None, :], F.relu(h), W1[j].transpose(1, 2))
+            a1 = F.relu(t1) if drop is None else F.relu(t1) * drop[j]                 # the second linear's input
+            t2 = torch.baddbmm(b2[j][:, None, :], a1, W2[j].transpose(1, 2))
+            h = h + (t2 * gates[j] if has_ctx else t2)
+            hs.append(h), t1s.append(t1), t2s.append(t2), a1s.append(a1)
+        params = torch.baddbmm(bf_[:, None, :], h, Wf.transpose(1, 2))                # [L, B, D(3K-1)]
+        h_last, relu_h = hs[nb], [F.relu(hs[j]) for j in range(nb)]
+        HSk, T1k = torch.stack(hs[:nb]), torch.stack(t1s)
+        if has_ctx:
+            T2k, Gk, pck = torch.stack(t2s), torch.stack(gates), pc.contiguous()
 
     # 2. the chain, last layer first: ONE launch (pf_flow_backward_chain, csrc/pf_flow_bwd_chain.hip) instead of ~25
-    #    small ones per layer -- spline backward, the transposed masked GEMMs on fp32 MFMA, the gate / ReLU algebra
+    #    small ones per layer -- spline backward, the transposed masked GEMMs on MFMA, the gate / ReLU algebra
     gy = g_z.contiguous()
     g_lad = g_lad.contiguous()
     DM = params.shape[2]
-    PM = (DM + 15) // 16 * 16
-    # bf16 mode: the chain runs on bf16 MFMA from the packed PF_FLAG_BWD stream (dropout: the kept units' factor cannot
-    # ride on W2T there, so that case keeps the fp32 chain)
-    bf = flow.precision == "bf16" and H % 32 == 0 and drop is None
-    HSk, T1k = torch.stack(hs[:nb]), torch.stack(t1s)
-    if not bf:
-        WfT = F.pad(Wf.transpose(1, 2), (0, PM - DM)).contiguous()                   # [L, H, PM]
-        W2T = torch.stack([w.transpose(1, 2) for w in W2]).contiguous()              # [nb, L, H(in), H(out)]
-        W1T = torch.stack([w.transpose(1, 2) for w in W1]).contiguous()
-        W0T = F.pad(W0.transpose(1, 2), (0, 0, 0, 16 - D)).contiguous()              # [L, 16, H]
-    if drop is not None:
-        # gt1 = (W2^T gt2) . factor . [t1 > 0], factor in {0, s}: the kernel computes (W2T gt2) . [t1s > 0], so a dropped
-        # unit is handed a negative pre-activation and the kept ones' factor s = 1 / (1 - p) rides on W2T
-        T1k = torch.where(drop > 0, T1k, torch.full_like(T1k, -1.0))
-        W2T = W2T * (1.0 / (1.0 - float(flow.dropout)))
-    Gp, Gh0 = torch.empty_like(params), torch.empty_like(hs[0])
+    Gp, Gh0 = torch.empty_like(params), torch.empty_like(h_last)
     GT1, GT2 = torch.empty_like(T1k), torch.empty_like(T1k)
     gx_perm = torch.empty(B, D, dtype=U.dtype, device=U.device)
     a = _lib.PfFlowBwdChainArgs()
@@ -202,32 +226,41 @@ def _flow_backward_batched(flow, U, ctx, g_z, g_lad, drop=None):
     keep = [HSk, T1k, GT1, GT2, Gp, Gh0, gx_perm, gy, g_lad, params]
     ops = [("U", U), ("params", params), ("hs", HSk), ("t1s", T1k), ("g_z", gy), ("g_lad", g_lad), ("Gp", Gp), ("Gh0", Gh0),
            ("Gt1", GT1), ("Gt2", GT2), ("g_x", gx_perm)]
-    if bf:      # the transposed matrices come from the PF_FLAG_BWD stream (one gather per weight update)
+    if bf:      # the transposed matrices come from the PF_FLAG_BWD stream
         packed = flow.packed_weights(bwd=True)
         a.packed = packed.data_ptr()
         keep.append(packed)
     else:
+        PM = (DM + 15) // 16 * 16
+        WfT = F.pad(Wf.transpose(1, 2), (0, PM - DM)).contiguous()                   # [L, H, PM]
+        W2T = torch.stack([w.transpose(1, 2) for w in W2]).contiguous()              # [nb, L, H(in), H(out)]
+        W1T = torch.stack([w.transpose(1, 2) for w in W1]).contiguous()
+        W0T = F.pad(W0.transpose(1, 2), (0, 0, 0, 16 - D)).contiguous()              # [L, 16, H]
+        if drop is not None:
+            # gt1 = (W2^T gt2) . factor . [t1 > 0], factor in {0, s}: the kernel computes (W2T gt2) . [t1s > 0], so a
+            # dropped unit is handed a negative pre-activation and the kept ones' factor s = 1 / (1 - p) rides on W2T
+            T1k = torch.where(drop > 0, T1k, torch.full_like(T1k, -1.0))
+            W2T = W2T * (1.0 / (1.0 - float(flow.dropout)))
+            ops[3] = ("t1s", T1k)
         ops += [("WfT", WfT), ("W2T", W2T), ("W1T", W1T), ("W0T", W0T)]
-        keep += [WfT, W2T, W1T, W0T]
+        keep += [WfT, W2T, W1T, W0T, T1k]
     for name, t in ops:
         assert t.is_contiguous() and t.dtype == torch.float32
         setattr(a, name, t.data_ptr())
     if has_ctx:
-        T2k, Gk, pck = torch.stack(t2s), torch.stack(gates), pc.contiguous()
         Gc = torch.empty(Ln, 1 + nb, B, H, dtype=U.dtype, device=U.device)
         keep += [T2k, Gk, pck, Gc]
         a.t2s, a.gates, a.pc, a.Gc = T2k.data_ptr(), Gk.data_ptr(), pck.data_ptr(), Gc.data_ptr()
     _lib.check(_lib.lib().pf_flow_backward_chain(flow._desc("bf16" if bf else "fp32"), a,
                                                  torch.cuda.current_stream(U.device).cuda_stream), "pf_flow_backward_chain")
-    Gt1, Gt2 = [GT1[j] for j in range(nb)], [GT2[j] for j in range(nb)]
     g_x = gx_perm[:, flow._ar_inv_perm]              # the kernel returns dL/d x[:, ar_perm]
 
     # 3. weight gradients, batched over layers
-    gWf, gbf = torch.bmm(Gp.transpose(1, 2), hs[nb]) * mf, Gp.sum(1)
+    gWf, gbf = torch.bmm(Gp.transpose(1, 2), h_last) * mf, Gp.sum(1)
     gW0, gb0 = torch.bmm(Gh0.transpose(1, 2), U) * m0, Gh0.sum(1)
-    gW1 = [torch.bmm(Gt1[j].transpose(1, 2), F.relu(hs[j])) * m1[j] for j in range(nb)]
-    gW2 = [torch.bmm(Gt2[j].transpose(1, 2), a1s[j]) * m2[j] for j in range(nb)]
-    gb1, gb2 = [g.sum(1) for g in Gt1], [g.sum(1) for g in Gt2]
+    gW1 = [torch.bmm(GT1[j].transpose(1, 2), relu_h[j]) * m1[j] for j in range(nb)]
+    gW2 = [torch.bmm(GT2[j].transpose(1, 2), a1s[j]) * m2[j] for j in range(nb)]
+    gb1, gb2 = [GT1[j].sum(1) for j in range(nb)], [GT2[j].sum(1) for j in range(nb)]
     g_ctx = gWcat = gbcat = None
     if has_ctx:
         flat = Gc.permute(2, 0, 1, 3).reshape(B, -1)                            # [B, L (1+nb) H]
@@ -241,17 +274,18 @@ def _flow_backward_batched(flow, U, ctx, g_z, g_lad, drop=None):
 def _per_parameter(flow, g):
     """the layer-batched gradients as one tensor per parameter, in ``flow._ordered_parameters()`` order."""
     has_ctx, nb = g["Wcat"] is not None, len(g["W1"])
-    grads = []
-    for l in range(g["W0"].shape[0]):
-        grads += [g["W0"][l], g["b0"][l]]
+    # one unbind per batched tensor (a view per layer) instead of one indexing call per parameter
+    ub = lambda t: t.unbind(0)
+    cols = [ub(g["W0"]), ub(g["b0"])]
+    if has_ctx:
+        wc, bc = [ub(t) for t in g["Wcat"].unbind(1)], [ub(t) for t in g["bcat"].unbind(1)]
+        cols += [wc[0], bc[0]]
+    for j in range(nb):
         if has_ctx:
-            grads += [g["Wcat"][l, 0], g["bcat"][l, 0]]
-        for j in range(nb):
-            if has_ctx:
-                grads += [g["Wcat"][l, 1 + j], g["bcat"][l, 1 + j]]
-            grads += [g["W1"][j][l], g["b1"][j][l], g["W2"][j][l], g["b2"][j][l]]
-        grads += [g["Wf"][l], g["bf"][l]]
-    return grads
+            cols += [wc[1 + j], bc[1 + j]]
+        cols += [ub(g["W1"][j]), ub(g["b1"][j]), ub(g["W2"][j]), ub(g["b2"][j])]
+    cols += [ub(g["Wf"]), ub(g["bf"])]
+    return [c[l] for l in range(g["W0"].shape[0]) for c in cols]
 
 
 def flow_backward(flow, U, ctx, g_z, g_lad, drop_seed=None):

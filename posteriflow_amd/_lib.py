@@ -29,6 +29,12 @@ class PfFlowBwdChainArgs(C.Structure):
         "Gp", "Gh0", "Gt1", "Gt2", "Gc", "g_x", "packed")]
 
 
+class PfFlowReevalArgs(C.Structure):
+    """include/pf_hip.h PfFlowReevalArgs"""
+    _fields_ = [("batch", C.c_int64)] + [(n, C.c_void_p) for n in (
+        "packed", "U", "ctx", "hs", "t1s", "t2s", "gates", "pc", "h2", "params")]
+
+
 class PfFlowDesc(C.Structure):
     _fields_ = [
         ("features", C.c_int32), ("context_features", C.c_int32),
@@ -65,6 +71,7 @@ SYMBOLS = {
     "pf_flow_rqs_backward": (C.c_int, [_P, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                        C.c_void_p, C.c_void_p, C.c_void_p]),
     "pf_flow_backward_chain": (C.c_int, [_P, C.POINTER(PfFlowBwdChainArgs), C.c_void_p]),
+    "pf_flow_reevaluate": (C.c_int, [_P, C.POINTER(PfFlowReevalArgs), C.c_void_p]),
     "pf_flow_inverse": (C.c_int, [_P, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                   C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_int64, C.c_void_p]),

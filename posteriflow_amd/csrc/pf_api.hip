@@ -35,6 +35,7 @@ int rqs_backward(const PfFlowDesc& d, float deriv_const, const float* u, const f
                  const float* glad, int64_t n, float* gparams, float* gu, hipStream_t s);
 int launch_gather(bool bf16, const float* raw, const int32_t* map, void* out, int64_t n, hipStream_t s);
 int flow_backward_chain(const PfFlowDesc& d, float deriv_const, const PfFlowBwdChainArgs& a, hipStream_t s);
+int flow_reevaluate(const FlowPlan& P, const PfFlowReevalArgs& a, hipStream_t s);
 }  // namespace pf
 
 namespace pf {
@@ -244,6 +245,28 @@ int pf_flow_backward_chain(const PfFlowDesc* desc, const PfFlowBwdChainArgs* a, 
         if (misaligned(q, 16)) return fail(PF_ERR_BAD_ARG, "weight / activation tensors must be 16-byte aligned");
     const float dc = (float)std::log(std::exp(1.0 - (double)desc->min_derivative) - 1.0);
     const int rc = pf::flow_backward_chain(*desc, dc, *a, static_cast<hipStream_t>(stream));
+    return rc == PF_OK ? rc : fail(rc, rc == PF_ERR_HIP ? hipGetErrorString(static_cast<hipError_t>(pf::g_hip_error)) : "unsupported shape");
+}
+
+int pf_flow_reevaluate(const PfFlowDesc* desc, const PfFlowReevalArgs* a, void* stream) {
+    if (!desc || !a) return fail(PF_ERR_BAD_ARG, "null pointer");
+    if (desc->precision != PF_PREC_BF16 || (desc->reserved & (PF_FLAG_MASKED_CONTEXT | PF_FLAG_BWD)))
+        return fail(PF_ERR_UNSUPPORTED, "re-evaluation kernel: bf16 desc of a plain-conditioner flow (the flow's own desc)");
+    PfFlowDesc d = *desc;
+    d.reserved = PF_FLAG_BWD;                       // the layout of the stream it reads
+    pf::FlowPlan P;
+    const int rc0 = layout_of(&d, P);
+    if (rc0 != PF_OK) return rc0;
+    if (a->batch < 0) return fail(PF_ERR_BAD_ARG, "negative batch");
+    if (a->batch == 0) return PF_OK;
+    if (!a->packed || !a->U || !a->hs || !a->t1s || !a->h2 || !a->params) return fail(PF_ERR_BAD_ARG, "null pointer");
+    const bool ctx = P.C > 0;
+    if (ctx != (a->ctx != nullptr) || ctx != (a->t2s != nullptr) || ctx != (a->gates != nullptr) || ctx != (a->pc != nullptr))
+        return fail(PF_ERR_BAD_ARG, "ctx, t2s, gates and pc go together with context_features > 0");
+    const void* al[] = {a->packed, a->hs, a->t1s, a->t2s, a->gates, a->pc, a->h2};
+    for (const void* q : al)
+        if (misaligned(q, 16)) return fail(PF_ERR_BAD_ARG, "stream / activation tensors must be 16-byte aligned");
+    const int rc = pf::flow_reevaluate(P, *a, static_cast<hipStream_t>(stream));
     return rc == PF_OK ? rc : fail(rc, rc == PF_ERR_HIP ? hipGetErrorString(static_cast<hipError_t>(pf::g_hip_error)) : "unsupported shape");
 }
 

@@ -122,27 +122,49 @@ __global__ __launch_bounds__(256) void flow_bwd_chain_kernel(const ChainArgs p) 
         }
     };
     // bf16: A = fragments [tile][ks][lane] of the packed stream, B = bf16 row c of s_in, k = 32 ks + 8 g ..
+    // The fragments are requested a chunk of 4 k-steps ahead (two register chunks): a k-step of TPW MFMAs is 64 cycles,
+    // an L2 round trip ~800, so a two-k-step lookahead stalled every k-step.
     auto gemm_bf = [&](const u32x4* fr, int nks, const __bf16* s_in, int stride, f32x4 (&acc)[TPW]) {
+        constexpr int P = 4;
 #pragma unroll
         for (int i = 0; i < TPW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         const u32x4* fa[TPW];
 #pragma unroll
         for (int i = 0; i < TPW; ++i) fa[i] = fr + (size_t)(wave + 4 * i) * nks * 64 + lane;
         const __bf16* brow = s_in + c * stride + 8 * g;
-        u32x4 a0[TPW], a1[TPW], a2[TPW];
+        u32x4 A0[P][TPW], A1[P][TPW];
+        auto fetch = [&](u32x4 (&A)[P][TPW], int k0) {
 #pragma unroll
-        for (int i = 0; i < TPW; ++i) { a0[i] = fa[i][0]; a1[i] = fa[i][64 * (nks > 1 ? 1 : 0)]; }
-        for (int ks = 0; ks < nks; ++ks) {
-            const int kn = ks + 2 < nks ? ks + 2 : nks - 1;
+            for (int q = 0; q < P; ++q) {
+                const int k = k0 + q < nks ? k0 + q : nks - 1;           // clamped: loads stay unconditional
 #pragma unroll
-            for (int i = 0; i < TPW; ++i) a2[i] = fa[i][64 * kn];
-            const bf16x8 b = *reinterpret_cast<const bf16x8*>(brow + 32 * ks);
+                for (int i = 0; i < TPW; ++i) A[q][i] = fa[i][64 * k];
+            }
+        };
+        auto compute = [&](const u32x4 (&A)[P][TPW], int k0) {
 #pragma unroll
-            for (int i = 0; i < TPW; ++i)
-                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a0[i]), b, acc[i], 0, 0, 0);
+            for (int q = 0; q < P; ++q) {
+                if (k0 + q < nks) {
+                    const bf16x8 b = *reinterpret_cast<const bf16x8*>(brow + 32 * (k0 + q));
 #pragma unroll
-            for (int i = 0; i < TPW; ++i) { a0[i] = a1[i]; a1[i] = a2[i]; }
+                    for (int i = 0; i < TPW; ++i)
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[q][i]), b, acc[i], 0, 0, 0);
+                }
+            }
+        };
+        fetch(A0, 0);
+        for (int k0 = 0; k0 < nks; k0 += 2 * P) {
+            fetch(A1, k0 + P);
+            compute(A0, k0);
+            fetch(A0, k0 + 2 * P);
+            compute(A1, k0 + P);
         }
+        // let the matrix pipe drain before the epilogue reads the accumulators: behind a loop exit hipcc (ROCm 7.2) placed
+        // v_accvgpr_read right after the last MFMA with too few wait states and three of four values came back stale
+        // (pf_flow_reeval.hip's final layer, found on the hardware)
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) asm volatile("s_nop 7" : "+a"(acc[i]));
+        asm volatile("s_nop 15");
     };
     // C-layout access of slab `idx` of a [slabs][B][H] tensor: units 16 t + 4 g .. + 3 of row my_row
     // ([L][B][H]: idx = l; [2][L][B][H]: idx = j L + l; Gc [L][3][B][H]: idx = 3 l + k)

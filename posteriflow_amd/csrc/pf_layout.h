@@ -99,7 +99,7 @@ struct FlowPlan {
     int dense;                  // 0: masked stream, KHS / KOS = HK + kPadH / HK + kPadO; 1: KHS = KOS = 2*HK (masks too coarse to
                                 // pair up); 2: masked, KHS = HK + kPadH + 1 (bf16, NT = 16)
     int wide;                   // 1: the large-batch kernel's single common stream (pf_wide_layout.h); CKS in CKM
-    int bwd;                    // 1: PF_FLAG_BWD -- transposed bf16 A-fragments of the backward chain (bwd_* below), no biases
+    int bwd;                    // 1: PF_FLAG_BWD -- bf16 A-fragments for the backward: transposed matrices (chain), forward matrices + biases (re-evaluation)
     int KHS, KOS, NF;
     int kH[kMaxTiles];          // active k-steps of tile t in a masked H x H GEMM
     int kO[kMaxTiles];          // active k-steps of feature f in the final layer
@@ -127,6 +127,15 @@ struct FlowPlan {
     PF_HD int64_t bwd_w2t(int layer, int j) const { return (int64_t)layer * bwd_layer_frags() + bwd_wf_frags() + (2 * j) * bwd_hh_frags(); }
     PF_HD int64_t bwd_w1t(int layer, int j) const { return bwd_w2t(layer, j) + bwd_hh_frags(); }
     PF_HD int64_t bwd_w0t(int layer) const { return (int64_t)layer * bwd_layer_frags() + bwd_wf_frags() + 4 * bwd_hh_frags(); }
+    // ... followed by the FORWARD matrices in the same fragment form (nflows unit order, for the conditioner re-evaluation
+    // kernel, pf_flow_reeval.hip): per layer [Win: NT x 1 (x as hi | lo)][Wc, Wg0, Wg1: NT x CKB each, if C > 0]
+    // [W1_0, W2_0, W1_1, W2_1: NT x H/32][Wf: NTF x H/32], then fp32 biases per layer
+    // [b_in H][bc, bg0, bg1: H each, if C > 0][b1_0, b2_0, b1_1, b2_1: H each][bf: 16 NTF]
+    PF_HD int bwd_ckb() const { return (C + 31) / 32; }
+    PF_HD int bwd_ntf() const { return (D * M + 15) / 16; }
+    PF_HD int fwd_layer_frags() const { return NT + (C > 0 ? 3 * NT * bwd_ckb() : 0) + 4 * bwd_hh_frags() + bwd_ntf() * (H / 32); }
+    PF_HD int fwd_layer_bias() const { return H + (C > 0 ? 3 * H : 0) + 4 * H + 16 * bwd_ntf(); }
+    PF_HD int64_t fwd_region() const { return (int64_t)L * bwd_layer_frags(); }          // first forward fragment
 
     PF_HD int64_t bias_index(int layer, int tile) const {
         return ((int64_t)layer * NT + tile) * kBiasFloatsPerTile;
@@ -246,9 +255,9 @@ inline int make_plan(const PfFlowDesc& d, FlowPlan& o) {
     }
     if (o.bwd) {
         o.fragsPerWave = 0;
-        o.fragsTotal = (int64_t)o.L * o.bwd_layer_frags();
+        o.fragsTotal = (int64_t)o.L * (o.bwd_layer_frags() + o.fwd_layer_frags());
         o.weightBytes = o.fragsTotal * kFragBytes;
-        o.biasFloats = 0; o.ctxFrags = 0; o.ctxBiasFloats = 0;
+        o.biasFloats = (int64_t)o.L * o.fwd_layer_bias(); o.ctxFrags = 0; o.ctxBiasFloats = 0;
     }
     const int64_t ctxp = o.C > 0 ? ((int64_t)o.H * o.C + o.H) : 0;
     o.rawPerLayer = (int64_t)o.H * o.D + o.H + ctxp

@@ -228,7 +228,58 @@ static int build_bwd_pack_map(const FlowPlan& L, int32_t* map) {
                 return at(ro.in_w + (int64_t)k * D + f);
             });
     }
-    return idx == L.fragsTotal * 512 ? PF_OK : PF_ERR_BAD_ARG;
+    // forward matrices, same fragment form: A[16 t + i][32 ks + 8 g + j] = W[out unit 16 t + i][in k]
+    const int C = L.C, CKB = L.bwd_ckb(), NTF = L.bwd_ntf();
+    for (int l = 0; l < L.L; ++l) {
+        const int64_t base = (int64_t)l * ro.total;
+        auto at = [&](int64_t off) { return off < 0 ? (int64_t)-1 : base + off; };
+        for (int t = 0; t < NT; ++t)         // x enters as hi | lo halves of one k-step: the input weights twice
+            frag([&](int i, int kk) {
+                const int u = 16 * t + i, d = kk & 15;
+                if (d >= D || hid_degree(D, u) < d + 1) return (int64_t)-1;
+                return at(ro.in_w + (int64_t)u * D + d);
+            });
+        if (C > 0)
+            for (int m = 0; m < 3; ++m) {
+                const int64_t w = m == 0 ? ro.c_w : ro.g_w[m - 1];
+                for (int t = 0; t < NT; ++t)
+                    for (int ks = 0; ks < CKB; ++ks)
+                        frag([&](int i, int kk) {
+                            const int col = 32 * ks + kk;
+                            return col < C ? at(w + (int64_t)(16 * t + i) * C + col) : (int64_t)-1;
+                        });
+            }
+        for (int j = 0; j < 2; ++j)
+            for (int which = 0; which < 2; ++which) {
+                const int64_t w = which == 0 ? ro.w0_w[j] : ro.w1_w[j];
+                for (int t = 0; t < NT; ++t)
+                    for (int ks = 0; ks < HK; ++ks)
+                        frag([&](int i, int kk) {
+                            const int u = 16 * t + i, k = 32 * ks + kk;
+                            if (hid_degree(D, u) < hid_degree(D, k)) return (int64_t)-1;
+                            return at(w + (int64_t)u * H + k);
+                        });
+            }
+        for (int t = 0; t < NTF; ++t)
+            for (int ks = 0; ks < HK; ++ks)
+                frag([&](int i, int kk) {
+                    const int p = 16 * t + i, k = 32 * ks + kk;
+                    if (p >= D * M || !(p / M + 1 > hid_degree(D, k))) return (int64_t)-1;
+                    return at(ro.out_w + (int64_t)p * H + k);
+                });
+    }
+    if (idx != L.fragsTotal * 512) return PF_ERR_BAD_ARG;
+    for (int l = 0; l < L.L; ++l) {          // biases
+        const int64_t base = (int64_t)l * ro.total;
+        auto run = [&](int64_t off, int n, int padded) {
+            for (int i = 0; i < padded; ++i) map[idx++] = i < n ? (int32_t)(base + off + i) : -1;
+        };
+        run(ro.in_b, H, H);
+        if (C > 0) { run(ro.c_b, H, H); run(ro.g_b[0], H, H); run(ro.g_b[1], H, H); }
+        for (int j = 0; j < 2; ++j) { run(ro.w0_b[j], H, H); run(ro.w1_b[j], H, H); }
+        run(ro.out_b, D * M, 16 * NTF);
+    }
+    return idx == L.fragsTotal * 512 + L.biasFloats ? PF_OK : PF_ERR_BAD_ARG;
 }
 
 int build_pack_map(const FlowPlan& L, int32_t* map) {

@@ -401,9 +401,12 @@ class NSFPosteriorFlow(nn.Module):
         return self._workspace, need
 
     def _ordered_parameters(self) -> List[torch.Tensor]:
-        out = []
-        for layer in self._ar_transforms:
-            out += layer.autoregressive_net.ordered_parameters()
+        out = self.__dict__.get("_ordered_cache")        # the module tree is fixed after __init__ (a list of the same
+        if out is None:                                  # Parameter objects .to() / load_state_dict keep)
+            out = []
+            for layer in self._ar_transforms:
+                out += layer.autoregressive_net.ordered_parameters()
+            self.__dict__["_ordered_cache"] = out
         return out
 
     def _device(self) -> torch.device:
@@ -457,8 +460,13 @@ class NSFPosteriorFlow(nn.Module):
                                   self._ar_inv_perm.to(dev, torch.int32).contiguous())
         return self._perm_i32[1], self._perm_i32[2]
 
+    def _apply(self, fn, *args, **kwargs):
+        self.__dict__.pop("_ordered_cache", None)     # .to() / .cuda() may swap Parameter objects
+        return super()._apply(fn, *args, **kwargs)
+
     def _load_from_state_dict(self, *args, **kwargs):
         super()._load_from_state_dict(*args, **kwargs)
+        self.__dict__.pop("_ordered_cache", None)
         self._perm_i32 = None          # _ar_perm may have come from the checkpoint
         self._frozen = False
 

@@ -10,9 +10,16 @@ n_rows = 2048
 ctx = torch.randn(n_rows, flow.context_features, device=dev, requires_grad=True)
 x = (torch.rand(n_rows, flow.features, device=dev) * 2 - 1)
 def flow_fb():
-    flow.zero_grad(set_to_none=True); ctx.grad = None          # as a training loop does (optimizer.zero_grad())
+    for p_ in flow._ordered_parameters(): p_.grad = None        # what optimizer.zero_grad() does (set_to_none)
+    ctx.grad = None
     flow.compute_psd_aware_nll(x, ctx, torch.zeros_like(x)).mean().backward()
 for _ in range(3): flow_fb()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(10): flow_fb()
 torch.cuda.synchronize(); print(f"flow fwd+bwd {n_rows} rows {prec}: {(time.perf_counter() - t0) / 10 * 1e3:.2f} ms")
+if len(sys.argv) > 2 and sys.argv[2] == "cprofile":      # where the host time of one iteration goes
+    import cProfile, pstats
+    pr = cProfile.Profile(); pr.enable()
+    for _ in range(50): flow_fb()
+    torch.cuda.synchronize(); pr.disable()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(45)

@@ -86,24 +86,35 @@ def test_pack_map_covers_exactly_the_unmasked_weights(lib, D, C, H, K, L, prec, 
 
 
 @pytest.mark.parametrize("D,C,H,K,L", [(11, 288, 256, 16, 2), (15, 288, 256, 16, 1), (4, 0, 64, 8, 2), (7, 40, 128, 10, 2)])
-def test_backward_pack_map_is_the_transposed_masked_matrices(lib, D, C, H, K, L):
-    """PF_FLAG_BWD (the bf16 backward chain's weight stream): gathering a raw parameter vector through the map and decoding
-    the A-fragments (lane (i, g), element j of fragment (tile t, k-step ks) = A[16 t + i][32 ks + 8 g + j]) must give
-    exactly (W * mask)^T of the final layer, of both linears of both blocks and of the initial layer, zero padded; the
-    context weights and all biases never appear; the compute entry points refuse the flag."""
+def test_backward_pack_map_is_the_masked_matrices_and_their_transposes(lib, D, C, H, K, L):
+    """PF_FLAG_BWD (the weight stream of the bf16 backward: chain + conditioner re-evaluation): gathering a raw parameter
+    vector through the map and decoding the A-fragments (lane (i, g), element j of fragment (tile t, k-step ks) =
+    A[16 t + i][32 ks + 8 g + j]) must give exactly
+      * the transposed region: (W * mask)^T of the final layer, of both linears of both blocks, of the initial layer;
+      * the forward region: W * mask of the initial layer (twice: x enters as hi | lo), the three context projections,
+        the four block linears, the final layer -- zero padded;
+      * the fp32 bias region in the kernel's order;
+    and the compute entry points refuse the flag."""
     from oracle import nflows_restated as nfr
     d = desc_of(lib, D, C, H, K, L, "bf16", lib.PF_FLAG_BWD)
     h = lib.lib()
     n = h.pf_flow_pack_map_len(C_byref(d))
     M = 3 * K - 1
-    NT, HK, KSF = H // 16, H // 32, (D * M + 31) // 32
-    layer_frags = NT * KSF + 4 * NT * HK + HK
-    assert n == L * layer_frags * 512 and h.pf_flow_packed_bytes(C_byref(d)) == 2 * n
+    NT, HK, KSF, CKB, NTF = H // 16, H // 32, (D * M + 31) // 32, (C + 31) // 32, (D * M + 15) // 16
+    bwd_frags = NT * KSF + 4 * NT * HK + HK
+    fwd_frags = NT + (3 * NT * CKB if C else 0) + 4 * NT * HK + NTF * HK
+    nbias = H + (3 * H if C else 0) + 4 * H + 16 * NTF
+    assert n == L * (bwd_frags + fwd_frags) * 512 + L * nbias
+    assert h.pf_flow_packed_bytes(C_byref(d)) == 2 * L * (bwd_frags + fwd_frags) * 512 + 4 * L * nbias
     m = np.empty(n, dtype=np.int32)
     assert h.pf_flow_build_pack_map(C_byref(d), m.ctypes.data) == 0
     per_layer = h.pf_flow_raw_param_count(C_byref(d)) // L
     raw = np.random.default_rng(0).standard_normal(per_layer * L).astype(np.float32)
-    packed = np.where(m >= 0, raw[np.maximum(m, 0)], 0.0).reshape(L, layer_frags, 64, 8)
+    gathered = np.where(m >= 0, raw[np.maximum(m, 0)], 0.0)
+    nw = L * (bwd_frags + fwd_frags) * 512
+    bwd = gathered[:L * bwd_frags * 512].reshape(L, bwd_frags, 64, 8)
+    fwd = gathered[L * bwd_frags * 512:nw].reshape(L, fwd_frags, 64, 8)
+    bias = gathered[nw:].reshape(L, nbias)
     t = nfr.MaskedPiecewiseRationalQuadraticAutoregressiveTransform(D, H, C or None, K, 5.0)
     net = t.autoregressive_net
 
@@ -111,26 +122,46 @@ def test_backward_pack_map_is_the_transposed_masked_matrices(lib, D, C, H, K, L)
         f = frags.reshape(tiles, nks, 4, 16, 8)                         # lane = 16 g + i
         return f.transpose(0, 3, 1, 2, 4).reshape(16 * tiles, 32 * nks)  # [t, i, ks, g, j]
 
+    def padded(a, rows, cols):
+        out = np.zeros((rows, cols), np.float32)
+        out[:a.shape[0], :a.shape[1]] = a
+        return out
+
     for layer in range(L):
         off, mats = layer * per_layer, {}
         for name, r, c in raw_layout(D, C, H, K):
             mats[name] = raw[off:off + r * c].reshape(r, c)
             off += r * c
-        fr = packed[layer]
-        pos = 0
-        A = decode(fr[pos:pos + NT * KSF], NT, KSF); pos += NT * KSF
-        want = np.zeros((H, 32 * KSF), np.float32)
-        want[:, :D * M] = (mats["out_w"] * net.final_layer.mask.numpy()).T
-        assert np.array_equal(A, want), (layer, "WfT")
+        Win, Wf = mats["in_w"] * net.initial_layer.mask.numpy(), mats["out_w"] * net.final_layer.mask.numpy()
+        blk = [(mats[f"w0{j}_w"] * net.blocks[j].linear_layers[0].mask.numpy(),
+                mats[f"w1{j}_w"] * net.blocks[j].linear_layers[1].mask.numpy()) for j in range(2)]
+        # transposed region (the chain walks backwards: second linear first)
+        fr, pos = bwd[layer], 0
+        assert np.array_equal(decode(fr[pos:pos + NT * KSF], NT, KSF), padded(Wf.T, H, 32 * KSF)); pos += NT * KSF
         for j in range(2):
-            for name, lin in ((f"w1{j}_w", net.blocks[j].linear_layers[1]), (f"w0{j}_w", net.blocks[j].linear_layers[0])):
-                A = decode(fr[pos:pos + NT * HK], NT, HK); pos += NT * HK
-                assert np.array_equal(A, (mats[name] * lin.mask.numpy()).T), (layer, name)
-        A = decode(fr[pos:pos + HK], 1, HK); pos += HK
-        want = np.zeros((16, H), np.float32)
-        want[:D] = (mats["in_w"] * net.initial_layer.mask.numpy()).T
-        assert np.array_equal(A, want), (layer, "W0T")
-        assert pos == layer_frags
+            for w in (blk[j][1], blk[j][0]):
+                assert np.array_equal(decode(fr[pos:pos + NT * HK], NT, HK), w.T), (layer, j); pos += NT * HK
+        assert np.array_equal(decode(fr[pos:pos + HK], 1, HK), padded(Win.T, 16, H)); pos += HK
+        assert pos == bwd_frags
+        # forward region
+        fr, pos = fwd[layer], 0
+        want = np.zeros((H, 32), np.float32)
+        want[:, :D] = Win
+        want[:, 16:16 + D] = Win
+        assert np.array_equal(decode(fr[pos:pos + NT], NT, 1), want); pos += NT
+        if C:
+            for name in ("c_w", "g0_w", "g1_w"):
+                assert np.array_equal(decode(fr[pos:pos + NT * CKB], NT, CKB), padded(mats[name], H, 32 * CKB)), name
+                pos += NT * CKB
+        for j in range(2):
+            for w in blk[j]:
+                assert np.array_equal(decode(fr[pos:pos + NT * HK], NT, HK), w), (layer, j); pos += NT * HK
+        assert np.array_equal(decode(fr[pos:pos + NTF * HK], NTF, HK), padded(Wf, 16 * NTF, H)); pos += NTF * HK
+        assert pos == fwd_frags
+        # biases
+        names = ["in_b"] + (["c_b", "g0_b", "g1_b"] if C else []) + ["w00_b", "w10_b", "w01_b", "w11_b"]
+        want = np.concatenate([mats[k].ravel() for k in names] + [padded(mats["out_b"].reshape(1, -1), 1, 16 * NTF).ravel()])
+        assert np.array_equal(bias[layer], want)
     # the flag is a packing layout only
     assert h.pf_flow_workspace_bytes(C_byref(d), 16) == -1 and h.pf_flow_rows_per_workgroup(C_byref(d), 16) == -1
     assert h.pf_flow_forward(C_byref(d), 16, 16, 16, None, None, 16, None, None, 16, None, 0, None) == lib.PF_ERR_UNSUPPORTED
