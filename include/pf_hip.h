@@ -190,6 +190,8 @@ typedef struct PfFlowBwdChainArgs {
     float* Gt2;          /* [2][L][B][H] */
     float* Gc;           /* [L][3][B][H]  dL/d(context projections): context_layer, gate of block 0, of block 1; or NULL */
     float* g_x;          /* [B][D]  dL/d(x[:, ar_perm]) */
+    const float* drop;   /* [2][L][B][H] dropout factors of the forward (pf_flow_dropout_mask), or NULL:
+                          * gt1 = (W2^T gt2) . drop . [t1 > 0] */
     const void* packed;  /* bf16 descs: the PF_FLAG_BWD stream (W*T above are ignored): the transposed GEMMs run on bf16
                           * MFMA with bf16-rounded gradient vectors as their second operand; the spline, the accumulators,
                           * the gate / ReLU algebra and every output stay fp32.  fp32 descs: ignored. */
@@ -214,6 +216,8 @@ typedef struct PfFlowReevalArgs {
     float* pc;           /* [L][B][H] or NULL */
     float* h2;           /* [L][B][H] residual state after the last block (input of the final layer) */
     float* params;       /* [L][B][D (3K-1)] raw spline parameters */
+    const float* drop;   /* [2][L][B][H] dropout factors the training forward applied (pf_flow_dropout_mask), or NULL:
+                          * the second linear of block j sees relu(t1_j) . drop[j] */
 } PfFlowReevalArgs;
 int pf_flow_reevaluate(const PfFlowDesc* desc, const PfFlowReevalArgs* args, void* stream);
 

@@ -132,7 +132,7 @@ def _rqs_backward(flow, u, params, gy, glad, gparams):
 REEVAL_HIP = True      # tests: False keeps the tensor-op re-evaluation in bf16 mode (isolates the bf16 chain kernel)
 
 
-def _reevaluate_hip(flow, U, ctx):
+def _reevaluate_hip(flow, U, ctx, drop=None):
     """bf16 mode: every layer's conditioner from its kept input in ONE launch (pf_flow_reevaluate, csrc/pf_flow_reeval.hip),
     in the arithmetic of the bf16 forward kernel.  Returns (hs [h_0, h_1, h_2], t1s, t2s, gates, pc, params)."""
     Ln, B, D = U.shape
@@ -149,6 +149,8 @@ def _reevaluate_hip(flow, U, ctx):
     if has_ctx:
         T2, G, PC = new(2, Ln, B, H), new(2, Ln, B, H), new(Ln, B, H)
         a.ctx, a.t2s, a.gates, a.pc = ctx.data_ptr(), T2.data_ptr(), G.data_ptr(), PC.data_ptr()
+    if drop is not None:
+        a.drop = drop.data_ptr()
     _lib.check(_lib.lib().pf_flow_reevaluate(flow._desc("bf16"), a, torch.cuda.current_stream(dev).cuda_stream),
                "pf_flow_reevaluate")
     return HS, T1, T2, G, PC, H2, params
@@ -173,16 +175,14 @@ def _flow_backward_batched(flow, U, ctx, g_z, g_lad, drop=None):
         C = ctx.shape[1]
         Wcat = torch.cat([st(lambda n: n.context_layer.weight)]
                          + [st(lambda n: n.blocks[j].context_layer.weight) for j in range(nb)], dim=1)
-    # bf16 mode: re-evaluation and chain are HIP kernels reading the packed PF_FLAG_BWD stream (one gather per weight
-    # update).  Dropout keeps the fp32 path: the kept units' factor rides on the transposed W2 there.
-    bf = flow.precision == "bf16" and H % 32 == 0 and drop is None and nb == 2 and U.is_contiguous() and \
-        (ctx is None or ctx.is_contiguous())
+    # bf16 mode: re-evaluation and chain are HIP kernels reading the packed PF_FLAG_BWD stream (one gather per weight update)
+    bf = flow.precision == "bf16" and H % 32 == 0 and nb == 2 and U.is_contiguous() and (ctx is None or ctx.is_contiguous())
 
     # 1. conditioners
     if bf and REEVAL_HIP:
-        HSk, T1k, T2k, Gk, pck, h_last, params = _reevaluate_hip(flow, U, ctx)
+        HSk, T1k, T2k, Gk, pck, h_last, params = _reevaluate_hip(flow, U, ctx, drop)
         relu_h = [F.relu(HSk[j]) for j in range(nb)]
-        a1s = [F.relu(T1k[j]) for j in range(nb)]
+        a1s = [F.relu(T1k[j]) if drop is None else F.relu(T1k[j]) * drop[j] for j in range(nb)]
     else:
         W0, b0 = st(lambda n: n.initial_layer.weight) * m0, st(lambda n: n.initial_layer.bias)
         Wf, bf_ = st(lambda n: n.final_layer.weight) * mf, st(lambda n: n.final_layer.bias)
@@ -236,14 +236,10 @@ def _flow_backward_batched(flow, U, ctx, g_z, g_lad, drop=None):
         W2T = torch.stack([w.transpose(1, 2) for w in W2]).contiguous()              # [nb, L, H(in), H(out)]
         W1T = torch.stack([w.transpose(1, 2) for w in W1]).contiguous()
         W0T = F.pad(W0.transpose(1, 2), (0, 0, 0, 16 - D)).contiguous()              # [L, 16, H]
-        if drop is not None:
-            # gt1 = (W2^T gt2) . factor . [t1 > 0], factor in {0, s}: the kernel computes (W2T gt2) . [t1s > 0], so a
-            # dropped unit is handed a negative pre-activation and the kept ones' factor s = 1 / (1 - p) rides on W2T
-            T1k = torch.where(drop > 0, T1k, torch.full_like(T1k, -1.0))
-            W2T = W2T * (1.0 / (1.0 - float(flow.dropout)))
-            ops[3] = ("t1s", T1k)
         ops += [("WfT", WfT), ("W2T", W2T), ("W1T", W1T), ("W0T", W0T)]
-        keep += [WfT, W2T, W1T, W0T, T1k]
+        keep += [WfT, W2T, W1T, W0T]
+    if drop is not None:        # gt1 = (W2^T gt2) . factor . [t1 > 0]: the chain reads the forward's factors
+        ops.append(("drop", drop))
     for name, t in ops:
         assert t.is_contiguous() and t.dtype == torch.float32
         setattr(a, name, t.data_ptr())

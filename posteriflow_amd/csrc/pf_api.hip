@@ -240,7 +240,7 @@ int pf_flow_backward_chain(const PfFlowDesc* desc, const PfFlowBwdChainArgs* a, 
     if (ctx != (a->t2s != nullptr) || ctx != (a->pc != nullptr) || ctx != (a->Gc != nullptr))
         return fail(PF_ERR_BAD_ARG, "t2s, gates, pc and Gc go together (all NULL for a context-free flow)");
     const void* al[] = {bf ? nullptr : a->WfT, bf ? nullptr : a->W2T, bf ? nullptr : a->W1T, bf ? nullptr : a->W0T, bf ? a->packed : nullptr,
-                        a->hs, a->t1s, a->t2s, a->gates, a->pc, a->Gh0, a->Gt1, a->Gt2, a->Gc};
+                        a->hs, a->t1s, a->t2s, a->gates, a->pc, a->Gh0, a->Gt1, a->Gt2, a->Gc, a->drop};
     for (const void* q : al)
         if (misaligned(q, 16)) return fail(PF_ERR_BAD_ARG, "weight / activation tensors must be 16-byte aligned");
     const float dc = (float)std::log(std::exp(1.0 - (double)desc->min_derivative) - 1.0);
@@ -263,7 +263,7 @@ int pf_flow_reevaluate(const PfFlowDesc* desc, const PfFlowReevalArgs* a, void* 
     const bool ctx = P.C > 0;
     if (ctx != (a->ctx != nullptr) || ctx != (a->t2s != nullptr) || ctx != (a->gates != nullptr) || ctx != (a->pc != nullptr))
         return fail(PF_ERR_BAD_ARG, "ctx, t2s, gates and pc go together with context_features > 0");
-    const void* al[] = {a->packed, a->hs, a->t1s, a->t2s, a->gates, a->pc, a->h2};
+    const void* al[] = {a->packed, a->hs, a->t1s, a->t2s, a->gates, a->pc, a->h2, a->drop};
     for (const void* q : al)
         if (misaligned(q, 16)) return fail(PF_ERR_BAD_ARG, "stream / activation tensors must be 16-byte aligned");
     const int rc = pf::flow_reevaluate(P, *a, static_cast<hipStream_t>(stream));

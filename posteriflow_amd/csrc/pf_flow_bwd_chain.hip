@@ -10,7 +10,7 @@
 //   spline:  (gy, glad) -> Gp = dL/d(raw spline parameters) [D (3K-1)],  gu = direct dL/du          (pf_rqs_bwd.h)
 //   gh  = Wf^T Gp
 //   for block j = 1, 0:   gt2 = gh * gate_j            Gc[1+j] = gh * t2_j * gate_j (1 - gate_j)
-//                         gt1 = (W2_j^T gt2) * [t1_j > 0]
+//                         gt1 = (W2_j^T gt2) * [t1_j > 0]     (* the forward's dropout factor, if any)
 //                         gh += (W1_j^T gt1) * [h_j > 0]
 //   Gh0 = gh              Gc[0] = gh * [pc > 0]         gu += W0^T gh        gy <- flip(gu)   (ReversePermutation)
 // Gp, Gh0, Gt1, Gt2, Gc go to HBM for the weight-gradient GEMMs; h_j, t1_j, t2_j, gate_j, pc and the raw parameters
@@ -240,6 +240,19 @@ __global__ __launch_bounds__(256) void flow_bwd_chain_kernel(const ChainArgs p) 
             f32x4 t1[TPW], hj[TPW];                          // requested ahead of the GEMMs whose epilogues use them
 #pragma unroll
             for (int i = 0; i < TPW; ++i) { t1[i] = ld4(A.t1s, j * L + l, wave + 4 * i); hj[i] = ld4(A.hs, j * L + l, wave + 4 * i); }
+            if (A.drop) {                                    // training dropout: fold the forward's factor into the ReLU mask
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) {
+                    const f32x4 dr = ld4(A.drop, j * L + l, wave + 4 * i);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t1[i][e] = t1[i][e] > 0.f ? dr[e] : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < TPW; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t1[i][e] = t1[i][e] > 0.f ? 1.f : 0.f;
+            }
             if (has_ctx) {                                   // the next block's gate / t2 (block 0 after block 1), or the context layer's pc
 #pragma unroll
                 for (int i = 0; i < TPW; ++i) {
@@ -254,7 +267,7 @@ __global__ __launch_bounds__(256) void flow_bwd_chain_kernel(const ChainArgs p) 
                 const int t = wave + 4 * i;
                 f32x4 gt1;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) gt1[e] = t1[i][e] > 0.f ? acc[i][e] : 0.f;
+                for (int e = 0; e < 4; ++e) gt1[e] = acc[i][e] * t1[i][e];        // t1 holds [t1 > 0] (. dropout factor)
                 st4(A.Gt1, j * L + l, t, gt1);
                 to_lds(1, t, gt1);
             }

@@ -188,7 +188,15 @@ __global__ __launch_bounds__(256) void flow_reeval_kernel(const ReevalArgs p) {
             const int t = wave + 4 * i;
             const f32x4 t1 = acc[i] + bias4(b_blk + (2 * j) * H, t);
             st4(A.t1s, j * L + l, t, t1);
-            to_lds_relu(t, t1);
+            if (A.drop) {                                      // training dropout, as flow_train_kernel applied it
+                const f32x4 dr = *reinterpret_cast<const f32x4*>(A.drop + ((size_t)(j * L + l) * B + my_row) * H + 16 * t + 4 * g);
+                f32x4 a1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a1[e] = fmaxf(t1[e], 0.f) * dr[e];
+                to_lds_relu(t, a1);
+            } else {
+                to_lds_relu(t, t1);
+            }
         }
         __syncthreads();
         gemm(f_blk + (size_t)(2 * j + 1) * NT * HK * 64, HK, 0, NT - 1, s_a, HSB, acc);

@@ -246,6 +246,67 @@ def test_dropout_modes_seeds_and_precisions():
             assert prm.grad is not None and torch.isfinite(prm.grad).all(), name
 
 
+def test_dropout_backward_in_bf16_mode_follows_the_fp32_mode():
+    """precision = "bf16": the training forward (bf16 flow_train_kernel), the HIP re-evaluation and the bf16 chain all take
+    the same factors.  On the same seed the bf16-mode gradients must be close to the fp32-mode ones: cosine > 0.98 over all
+    parameters and for x / context (the bf16 forward's own distance from fp32, tests/test_flow_backward_gpu.py), and the
+    chain alone, on identical layer inputs / activations / factors, within 5e-2 / cosine 0.995 of the fp32 chain; the
+    re-evaluation kernel's second linears against same-rounding tensor ops with the factors applied (2e-3)."""
+    from posteriflow_amd import _flow_autograd as fa
+    D, C, H, L, K, tb, B, p = 11, 288, 256, 3, 16, 5.0, 160, 0.15
+    _, _, flow = _pair(D, C, H, L, K, tb, p)
+    x, ctx = flow_inputs(B, D, C, tb)
+    flow.train()
+    cos = lambda a, b: torch.nn.functional.cosine_similarity(a.flatten().double(), b.flatten().double(), dim=0).item()
+    grads = {}
+    for prec in ("fp32", "bf16"):
+        flow.precision = prec
+        flow.zero_grad(set_to_none=True)
+        xg, cg = x.cuda().requires_grad_(True), ctx.cuda().requires_grad_(True)
+        torch.manual_seed(77)
+        flow.compute_psd_aware_nll(xg, cg, None).mean().backward()
+        grads[prec] = (xg.grad.clone(), cg.grad.clone(),
+                       torch.cat([q.grad.flatten() for n, q in flow.named_parameters() if n.startswith("transform.")]))
+        assert all(torch.isfinite(t).all() for t in grads[prec])
+    cs = [cos(a, b) for a, b in zip(grads["fp32"], grads["bf16"])]
+    print(f"\n[dropout, bf16 vs fp32 mode] cosine x {cs[0]:.5f} context {cs[1]:.5f} parameters {cs[2]:.5f}")
+    assert min(cs) > 0.98
+    # the backward alone: same layer inputs, same factors, same incoming gradients
+    flow.precision = "fp32"
+    U = torch.empty(L, B, D, device="cuda")
+    with torch.no_grad():
+        flow._forward_call(x.cuda(), ctx.cuda(), None, layer_inputs=U, dropout_seed=5)
+        drop = fa.dropout_mask(flow, B, 5, torch.device("cuda"))
+        g = torch.Generator().manual_seed(3)
+        gz, gl = torch.randn(B, D, generator=g).cuda(), torch.randn(B, generator=g).cuda()
+        out = {}
+        fa.REEVAL_HIP = False                  # the chain's handling of the factors, on identical activations
+        try:
+            for prec in ("fp32", "bf16"):
+                flow.precision = prec
+                out[prec] = fa._flow_backward_batched(flow, U, ctx.cuda(), gz, gl, drop)
+        finally:
+            fa.REEVAL_HIP = True
+        # the re-evaluation kernel's handling: the second linear of each block sees relu(t1) . factor (same-rounding tensor ops)
+        import torch.nn.functional as F
+        rb = lambda t: t.bfloat16().float()
+        HS, T1, T2, G, PC, H2, params = fa._reevaluate_hip(flow, U, ctx.cuda(), drop)
+        for l, layer in enumerate(flow._ar_transforms):
+            for j, blk in enumerate(layer.autoregressive_net.blocks):
+                lin2 = blk.linear_layers[1]
+                want = F.linear(rb(F.relu(T1[j, l]) * drop[j, l]), rb(lin2.weight * lin2.mask), lin2.bias)
+                err = (T2[j, l] - want).abs().max() / want.abs().max()
+                assert err < 2e-3, (l, j, err.item())
+                without = F.linear(rb(F.relu(T1[j, l])), rb(lin2.weight * lin2.mask), lin2.bias)
+                assert (T2[j, l] - without).abs().max() / want.abs().max() > 0.05      # the factors matter
+    for k, v in out["fp32"].items():
+        if v is None:
+            continue
+        for a, b in zip(v if isinstance(v, list) else [v], out["bf16"][k] if isinstance(v, list) else [out["bf16"][k]]):
+            r_ = ((a - b).abs().max() / a.abs().max().clamp_min(1e-12)).item()
+            assert r_ < 5e-2 and cos(a, b) > 0.995, (k, r_, cos(a, b))
+
+
 def test_masked_context_flow_trains_with_dropout():
     """the reference's own masked-context block drops at the same place (flows.py:232); its backward here is autograd over
     device tensor ops (_flow_autograd.flow_forward) with the forward's factors"""
