@@ -218,8 +218,10 @@ def _flow_backward_batched(flow, U, ctx, g_z, g_lad, drop=None):
     gy = g_z.contiguous()
     g_lad = g_lad.contiguous()
     DM = params.shape[2]
-    Gp, Gh0 = torch.empty_like(params), torch.empty_like(h_last)
-    GT1, GT2 = torch.empty_like(T1k), torch.empty_like(T1k)
+    Gp = torch.empty_like(params)
+    # Gt1 | Gt2 | Gh0 in one buffer: their bias gradients are ONE column reduction instead of five
+    G5 = torch.empty(2 * nb + 1, Ln, B, H, dtype=U.dtype, device=U.device)
+    GT1, GT2, Gh0 = G5[:nb], G5[nb:2 * nb], G5[2 * nb]
     gx_perm = torch.empty(B, D, dtype=U.dtype, device=U.device)
     a = _lib.PfFlowBwdChainArgs()
     a.batch = B
@@ -252,11 +254,12 @@ def _flow_backward_batched(flow, U, ctx, g_z, g_lad, drop=None):
     g_x = gx_perm[:, flow._ar_inv_perm]              # the kernel returns dL/d x[:, ar_perm]
 
     # 3. weight gradients, batched over layers
+    gb5 = G5.sum(2)                                                             # [2 nb + 1, L, H]
     gWf, gbf = torch.bmm(Gp.transpose(1, 2), h_last) * mf, Gp.sum(1)
-    gW0, gb0 = torch.bmm(Gh0.transpose(1, 2), U) * m0, Gh0.sum(1)
+    gW0, gb0 = torch.bmm(Gh0.transpose(1, 2), U) * m0, gb5[2 * nb]
     gW1 = [torch.bmm(GT1[j].transpose(1, 2), relu_h[j]) * m1[j] for j in range(nb)]
     gW2 = [torch.bmm(GT2[j].transpose(1, 2), a1s[j]) * m2[j] for j in range(nb)]
-    gb1, gb2 = [GT1[j].sum(1) for j in range(nb)], [GT2[j].sum(1) for j in range(nb)]
+    gb1, gb2 = [gb5[j] for j in range(nb)], [gb5[nb + j] for j in range(nb)]
     g_ctx = gWcat = gbcat = None
     if has_ctx:
         flat = Gc.permute(2, 0, 1, 3).reshape(B, -1)                            # [B, L (1+nb) H]
