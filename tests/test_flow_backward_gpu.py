@@ -87,7 +87,8 @@ def test_training_forward_keeps_every_conditioner_input():
     assert torch.equal(z, z2) and torch.equal(ld, ld2)
 
 
-@pytest.mark.parametrize("D,C,H,L,order", [(11, 288, 256, 3, None), (15, 288, 256, 2, "perm"), (4, 0, 64, 3, None)])
+@pytest.mark.parametrize("D,C,H,L,order", [(11, 288, 256, 3, None), (15, 288, 256, 2, "perm"), (4, 0, 64, 3, None),
+                                           (11, 288, 192, 2, None)])
 def test_flow_gradients_match_oracle_autograd(D, C, H, L, order):
     from helpers import flow_inputs, make_pair
     ref, _, flow = make_pair(D, C, H, L, 16, 5.0)
@@ -132,7 +133,7 @@ def test_flow_gradients_match_oracle_autograd(D, C, H, L, order):
             assert rel(p.grad.cpu(), ref_params[name].grad) < 3e-4, name
 
 
-@pytest.mark.parametrize("D,C,H,L", [(11, 288, 256, 3), (15, 288, 256, 2), (4, 0, 64, 3), (7, 40, 128, 2)])
+@pytest.mark.parametrize("D,C,H,L", [(11, 288, 256, 3), (15, 288, 256, 2), (4, 0, 64, 3), (7, 40, 128, 2), (11, 288, 192, 2)])
 def test_flow_gradients_in_bf16_mode(D, C, H, L):
     """precision = "bf16" (the throughput mode): the backward's data-gradient chain runs on bf16 MFMA from the PF_FLAG_BWD
     stream (bf16-rounded gradient vectors and weights, fp32 accumulate, fp32 spline and outputs), the conditioners are
@@ -216,7 +217,8 @@ def test_flow_gradients_in_bf16_mode(D, C, H, L):
         assert c_emu > 0.95 and c_32 > c_inh - 0.05, (what, c_emu, c_32, c_inh)
 
 
-@pytest.mark.parametrize("D,C,H,L,K", [(11, 288, 256, 3, 16), (15, 288, 256, 2, 16), (4, 0, 64, 3, 8), (7, 40, 128, 2, 10)])
+@pytest.mark.parametrize("D,C,H,L,K", [(11, 288, 256, 3, 16), (15, 288, 256, 2, 16), (4, 0, 64, 3, 8), (7, 40, 128, 2, 10),
+                                       (11, 288, 192, 2, 16), (2, 5, 64, 1, 4)])
 def test_hip_reevaluation_matches_tensor_ops(D, C, H, L, K):
     """pf_flow_reevaluate (one launch, grid = row blocks x layers, bf16 operands / fp32 accumulate like the bf16 forward
     kernel) against the same conditioners evaluated with tensor ops from the same layer inputs, every matrix-product operand

@@ -72,12 +72,16 @@ def test_gradient_allreduce_gloo_world2(tmp_path):
 
 
 @pytest.mark.gpu
-def test_train_step_reduces_loss_gpu():
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_train_step_reduces_loss_gpu(precision):
+    """eight optimiser steps on one small batch; bf16: the throughput mode (bf16 training forward, HIP re-evaluation,
+    bf16 chain, weights re-packed into all three streams after every optimiser step)"""
     import recipe
     from posteriflow_amd import LeanNPE
     from posteriflow_amd.train import checkpoint_dict, make_optimizer, make_scheduler, train_step
     torch.manual_seed(0)
     model = LeanNPE(flow_layers=2).cuda()
+    model.flow.precision = model.encoder.precision = precision
     opt = make_optimizer(model, lr=1e-3)
     sched = make_scheduler(opt, total_steps=100, warmup_steps=2)
     strain = recipe.strain_batch(8, 3, seed=1).cuda()
