@@ -16,9 +16,10 @@
 // Gp, Gh0, Gt1, Gt2, Gc go to HBM for the weight-gradient GEMMs; h_j, t1_j, t2_j, gate_j, pc and the raw parameters
 // come from the re-evaluation.
 //
-// Work split: workgroup = 16 rows = one MFMA column tile, 4 waves; everything TRANSPOSED as in the forward kernels,
+// Work split: workgroup = 16 rows = one MFMA column tile, NW waves (8 at H = 128 / 256, else 4); everything TRANSPOSED as in
+// the forward kernels,
 // out^T[unit, row] = W^T[unit, k] . in^T[k, row] on v_mfma_f32_16x16x4_f32 (exact fp32: gradients keep the 3e-4 agreement
-// with autograd through the oracle).  Wave w owns unit tiles w, w + 4, ...; the B operand (the incoming gradient vector
+// with autograd through the oracle).  Wave w owns unit tiles w, w + NW, ...; the B operand (the incoming gradient vector
 // of all units) is exchanged through LDS as fp32 [row][k] rows, the A operand is read straight from the dense
 // TRANSPOSED masked weight matrices the caller prepares each step ((W * mask)^T, row-major, k padded to 16): lane
 // (r, g) of k-group q takes the 4 consecutive floats W^T[16 t + r][16 q + 4 g ..] as the A values of 4 MFMAs whose
@@ -57,8 +58,11 @@ struct ChainArgs {
     int64_t B;
 };
 
-template <int TPW, bool BF>   // unit tiles per wave = H / 64; BF: bf16 operands from the PF_FLAG_BWD stream
-__global__ __launch_bounds__(256) void flow_bwd_chain_kernel(const ChainArgs p) {
+// NW waves per workgroup, TPW = H / (16 NW) unit tiles per wave; BF: bf16 operands from the PF_FLAG_BWD stream.
+// 8 waves (two per SIMD) where the tile count allows it (H = 128, 256): 569 -> 459 us per launch against 4 waves --
+// a second wave per SIMD runs its MFMAs / LDS reads under the first one's loads (pitfall 9).
+template <int TPW, bool BF, int NW>
+__global__ __launch_bounds__(NW * 64) void flow_bwd_chain_kernel(const ChainArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -71,13 +75,13 @@ __global__ __launch_bounds__(256) void flow_bwd_chain_kernel(const ChainArgs p) 
     float* s_v1 = s_v0 + 16 * HS;
     float* s_gy = s_v1 + 16 * HS;                             // [16][16] dL/dy of the current layer
     float* s_gu = s_gy + 256;                                 // [16][16] direct dL/du
-    float* s_part = s_gu + 256;                               // [4][16][16] partial sums of the W0^T product
+    float* s_part = s_gu + 256;                               // [NW][16][16] partial sums of the W0^T product
     // BF: the B operands as bf16 rows (k contiguous): the two exchange vectors alias s_v0 / s_v1, Gp gets its own image
     const int KSF = (D * M + 31) / 32, HK = H / 32, NT = H / 16;
     const int HSB = H + 8, GSB = 32 * KSF + 8;                // row strides in bf16 elements
     __bf16* s_b0 = reinterpret_cast<__bf16*>(s_v0);
     __bf16* s_b1 = reinterpret_cast<__bf16*>(s_v1);
-    __bf16* s_gpb = reinterpret_cast<__bf16*>(s_part + 1024); // [16][GSB]
+    __bf16* s_gpb = reinterpret_cast<__bf16*>(s_part + NW * 256); // [16][GSB]
     const u32x4* frags = reinterpret_cast<const u32x4*>(p.a.packed);
     const int layer_frags = NT * KSF + 4 * NT * HK + HK;
     const int64_t my_row = row0 + c < B ? row0 + c : B - 1;   // clamped (stores are guarded)
@@ -85,7 +89,7 @@ __global__ __launch_bounds__(256) void flow_bwd_chain_kernel(const ChainArgs p) 
     const PfFlowBwdChainArgs& A = p.a;
     const bool has_ctx = A.gates != nullptr;
 
-    for (int s = tid; s < 256; s += 256) {
+    for (int s = tid; s < 256; s += NW * 64) {
         const int r = s >> 4, d = s & 15;
         const int64_t row = row0 + r < B ? row0 + r : B - 1;
         s_gy[s] = d < D ? A.g_z[row * D + d] : 0.f;
@@ -98,7 +102,7 @@ __global__ __launch_bounds__(256) void flow_bwd_chain_kernel(const ChainArgs p) 
         for (int i = 0; i < TPW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         const float* wrow[TPW];
 #pragma unroll
-        for (int i = 0; i < TPW; ++i) wrow[i] = WT + (size_t)(16 * (wave + 4 * i) + c) * ldk + 4 * g;
+        for (int i = 0; i < TPW; ++i) wrow[i] = WT + (size_t)(16 * (wave + NW * i) + c) * ldk + 4 * g;
         const float* brow = s_in + c * lds_stride + 4 * g;
         const int nq = K >> 4;
         // the A values of k-group q are requested two groups ahead (an L2 round trip is longer than the 16 MFMAs of a group)
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(256) void flow_bwd_chain_kernel(const ChainArgs p) 
         for (int i = 0; i < TPW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         const u32x4* fa[TPW];
 #pragma unroll
-        for (int i = 0; i < TPW; ++i) fa[i] = fr + (size_t)(wave + 4 * i) * nks * 64 + lane;
+        for (int i = 0; i < TPW; ++i) fa[i] = fr + (size_t)(wave + NW * i) * nks * 64 + lane;
         const __bf16* brow = s_in + c * stride + 8 * g;
         u32x4 A0[P][TPW], A1[P][TPW];
         auto fetch = [&](u32x4 (&A)[P][TPW], int k0) {
@@ -181,7 +185,7 @@ __global__ __launch_bounds__(256) void flow_bwd_chain_kernel(const ChainArgs p) 
 
     for (int l = L - 1; l >= 0; --l) {
         // ---- spline backward: raw parameters of the 16 rows -> LDS (coalesced), one lane per (row, feature) pair ----
-        for (int s = tid; s < 16 * PM; s += 256) {
+        for (int s = tid; s < 16 * PM; s += NW * 64) {
             const int r = s / PM, k = s - r * PM;
             const int64_t row = row0 + r < B ? row0 + r : B - 1;
             s_gp[r * PMS + k] = k < D * M ? A.params[((size_t)l * B + row) * (D * M) + k] : 0.f;
@@ -195,13 +199,13 @@ __global__ __launch_bounds__(256) void flow_bwd_chain_kernel(const ChainArgs p) 
                                                  A.g_lad[row], p.c);
         }
         __syncthreads();
-        for (int s = tid; s < 16 * D * M; s += 256) {          // Gp -> HBM (weight gradient of the final layer)
+        for (int s = tid; s < 16 * D * M; s += NW * 64) {          // Gp -> HBM (weight gradient of the final layer)
             const int r = s / (D * M), k = s - r * (D * M);
             if (row0 + r < B) A.Gp[((size_t)l * B + row0 + r) * (D * M) + k] = s_gp[r * PMS + k];
         }
         if constexpr (BF) {                                     // and its bf16 image, the B operand of the next GEMM
             const int kw = 32 * KSF;
-            for (int s = tid; s < 16 * kw; s += 256) {
+            for (int s = tid; s < 16 * kw; s += NW * 64) {
                 const int r = s / kw, k = s - r * kw;
                 s_gpb[r * GSB + k] = (__bf16)(k < D * M ? s_gp[r * PMS + k] : 0.f);
             }
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(256) void flow_bwd_chain_kernel(const ChainArgs p) 
         f32x4 gate_n[TPW], t2_n[TPW];                        // block operands, requested one GEMM ahead of their use
         if (has_ctx) {
 #pragma unroll
-            for (int i = 0; i < TPW; ++i) { gate_n[i] = ld4(A.gates, 1 * L + l, wave + 4 * i); t2_n[i] = ld4(A.t2s, 1 * L + l, wave + 4 * i); }
+            for (int i = 0; i < TPW; ++i) { gate_n[i] = ld4(A.gates, 1 * L + l, wave + NW * i); t2_n[i] = ld4(A.t2s, 1 * L + l, wave + NW * i); }
         }
         if constexpr (BF) gemm_bf(lf, KSF, s_gpb, GSB, gh);
         else gemm(A.WfT + (size_t)l * H * PM, PM, PM, s_gp, PMS, gh);
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(256) void flow_bwd_chain_kernel(const ChainArgs p) 
         for (int j = 1; j >= 0; --j) {
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
-                const int t = wave + 4 * i;
+                const int t = wave + NW * i;
                 f32x4 gt2 = gh[i];
                 if (has_ctx) {
                     const f32x4 gate = gate_n[i], t2 = t2_n[i];
@@ -239,11 +243,11 @@ __global__ __launch_bounds__(256) void flow_bwd_chain_kernel(const ChainArgs p) 
             __syncthreads();
             f32x4 t1[TPW], hj[TPW];                          // requested ahead of the GEMMs whose epilogues use them
 #pragma unroll
-            for (int i = 0; i < TPW; ++i) { t1[i] = ld4(A.t1s, j * L + l, wave + 4 * i); hj[i] = ld4(A.hs, j * L + l, wave + 4 * i); }
+            for (int i = 0; i < TPW; ++i) { t1[i] = ld4(A.t1s, j * L + l, wave + NW * i); hj[i] = ld4(A.hs, j * L + l, wave + NW * i); }
             if (A.drop) {                                    // training dropout: fold the forward's factor into the ReLU mask
 #pragma unroll
                 for (int i = 0; i < TPW; ++i) {
-                    const f32x4 dr = ld4(A.drop, j * L + l, wave + 4 * i);
+                    const f32x4 dr = ld4(A.drop, j * L + l, wave + NW * i);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) t1[i][e] = t1[i][e] > 0.f ? dr[e] : 0.f;
                 }
@@ -256,15 +260,15 @@ __global__ __launch_bounds__(256) void flow_bwd_chain_kernel(const ChainArgs p) 
             if (has_ctx) {                                   // the next block's gate / t2 (block 0 after block 1), or the context layer's pc
 #pragma unroll
                 for (int i = 0; i < TPW; ++i) {
-                    if (j == 1) { gate_n[i] = ld4(A.gates, l, wave + 4 * i); t2_n[i] = ld4(A.t2s, l, wave + 4 * i); }
-                    else gate_n[i] = ld4(A.pc, l, wave + 4 * i);
+                    if (j == 1) { gate_n[i] = ld4(A.gates, l, wave + NW * i); t2_n[i] = ld4(A.t2s, l, wave + NW * i); }
+                    else gate_n[i] = ld4(A.pc, l, wave + NW * i);
                 }
             }
             if constexpr (BF) gemm_bf(lf + ((size_t)NT * KSF + (size_t)(2 * j) * NT * HK) * 64, HK, s_b0, HSB, acc);
             else gemm(A.W2T + ((size_t)j * L + l) * H * H, H, H, s_v0, HS, acc);
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
-                const int t = wave + 4 * i;
+                const int t = wave + NW * i;
                 f32x4 gt1;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) gt1[e] = acc[i][e] * t1[i][e];        // t1 holds [t1 > 0] (. dropout factor)
@@ -282,7 +286,7 @@ __global__ __launch_bounds__(256) void flow_bwd_chain_kernel(const ChainArgs p) 
         // ---- initial layer: Gh0, Gc[0], gu += W0^T gh -------------------------------------------------------------
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
-            const int t = wave + 4 * i;
+            const int t = wave + NW * i;
             st4(A.Gh0, l, t, gh[i]);
             if (has_ctx) {
                 const f32x4 pc = gate_n[i];
@@ -298,13 +302,13 @@ __global__ __launch_bounds__(256) void flow_bwd_chain_kernel(const ChainArgs p) 
             f32x4 part = {0.f, 0.f, 0.f, 0.f};
             if constexpr (BF) {
                 const u32x4* fr = lf + ((size_t)NT * KSF + (size_t)4 * NT * HK) * 64 + lane;
-                for (int ks = wave; ks < HK; ks += 4) {
+                for (int ks = wave; ks < HK; ks += NW) {
                     const bf16x8 b = *reinterpret_cast<const bf16x8*>(s_b0 + c * HSB + 32 * ks + 8 * g);
                     part = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fr[64 * ks]), b, part, 0, 0, 0);
                 }
             } else {
             const float* wrow = A.W0T + ((size_t)l * 16 + c) * H + 4 * g;
-            const int kq = H / 64;                           // k-groups of 16 per wave
+            const int kq = H / (16 * NW);                    // k-groups of 16 per wave
             for (int q = wave * kq; q < (wave + 1) * kq; ++q) {
                 const f32x4 a = *reinterpret_cast<const f32x4*>(wrow + 16 * q);
                 const f32x4 b = *reinterpret_cast<const f32x4*>(s_v0 + c * HS + 16 * q + 4 * g);
@@ -319,12 +323,12 @@ __global__ __launch_bounds__(256) void flow_bwd_chain_kernel(const ChainArgs p) 
         {
             const int r = tid >> 4, d = tid & 15;            // 256 threads = 16 rows x 16 feature slots
             float v = 0.f;
-            if (d < D) {
+            if (d < D && tid < 256) {
                 v = s_gu[r * 16 + d];
 #pragma unroll
-                for (int w = 0; w < 4; ++w) v += s_part[(w * 16 + r) * 16 + d];
+                for (int w = 0; w < NW; ++w) v += s_part[(w * 16 + r) * 16 + d];
+                s_gy[r * 16 + (D - 1 - d)] = v;              // through this layer's ReversePermutation
             }
-            if (d < D) s_gy[r * 16 + (D - 1 - d)] = v;      // through this layer's ReversePermutation
         }
         __syncthreads();
     }
@@ -344,21 +348,22 @@ int flow_backward_chain(const PfFlowDesc& d, float deriv_const, const PfFlowBwdC
     p.PM = (p.D * p.M + 15) / 16 * 16;
     p.B = a.batch;
     const bool bf = d.precision == PF_PREC_BF16;
-    const size_t lds = ((size_t)16 * (p.PM + 4) + 2 * 16 * (p.H + 4) + 256 + 256 + 4 * 256) * sizeof(float)
+    const int nw = p.H % 128 == 0 ? 8 : 4;
+    const size_t lds = ((size_t)16 * (p.PM + 4) + 2 * 16 * (p.H + 4) + 256 + 256 + nw * 256) * sizeof(float)
                      + (bf ? (size_t)16 * (32 * ((p.D * p.M + 31) / 32) + 8) * 2 : 0);
     const unsigned grid = (unsigned)((a.batch + 15) / 16);
     auto launch = [&](auto kern) {
         if (lds > 64 * 1024 &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return PF_ERR_HIP;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, p);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(nw * 64), lds, s, p);
         return launch_status();
     };
-    switch (p.H / 64) {
-    case 1: return bf ? launch(flow_bwd_chain_kernel<1, true>) : launch(flow_bwd_chain_kernel<1, false>);
-    case 2: return bf ? launch(flow_bwd_chain_kernel<2, true>) : launch(flow_bwd_chain_kernel<2, false>);
-    case 3: return bf ? launch(flow_bwd_chain_kernel<3, true>) : launch(flow_bwd_chain_kernel<3, false>);
-    case 4: return bf ? launch(flow_bwd_chain_kernel<4, true>) : launch(flow_bwd_chain_kernel<4, false>);
+    switch (p.H) {
+    case 64: return bf ? launch(flow_bwd_chain_kernel<1, true, 4>) : launch(flow_bwd_chain_kernel<1, false, 4>);
+    case 128: return bf ? launch(flow_bwd_chain_kernel<1, true, 8>) : launch(flow_bwd_chain_kernel<1, false, 8>);
+    case 192: return bf ? launch(flow_bwd_chain_kernel<3, true, 4>) : launch(flow_bwd_chain_kernel<3, false, 4>);
+    case 256: return bf ? launch(flow_bwd_chain_kernel<2, true, 8>) : launch(flow_bwd_chain_kernel<2, false, 8>);
     }
     return PF_ERR_UNSUPPORTED;
 }

@@ -9,8 +9,8 @@
 // The layers are independent given their inputs, so the grid is (16-row blocks) x (layers): 1280 workgroups for 2048 rows
 // of a 10-layer flow, each streaming ONE layer's forward matrices (1.2 MB of bf16 A-fragments, the forward region of the
 // PF_FLAG_BWD stream, pf_pack.hip) -- unlike the chain, which has to walk the layers in sequence on 128 workgroups.
-// Same transposed MFMA form as everywhere (out^T[unit, row] = W . act^T on v_mfma_f32_16x16x32_bf16, 4 waves, wave w owns
-// unit tiles w, w + 4, ...; activations cross LDS as bf16 rows), same arithmetic as the bf16 forward kernel: bf16 operands,
+// Same transposed MFMA form as everywhere (out^T[unit, row] = W . act^T on v_mfma_f32_16x16x32_bf16, NW = 8 waves where the
+// tile count allows it (else 4), wave w owns unit tiles w, w + NW, ...; activations cross LDS as bf16 rows), same arithmetic as the bf16 forward kernel: bf16 operands,
 // x as a hi + lo pair, fp32 accumulate / bias / residual / gate -- the re-evaluated activations are those of the forward
 // that produced z, not those of an fp32 model evaluated on the bf16 trajectory.
 //
@@ -43,8 +43,8 @@ struct ReevalArgs {
     int64_t bias_offset;       // bytes from the start of the stream to the fp32 biases
 };
 
-template <int TPW>   // unit tiles per wave = H / 64
-__global__ __launch_bounds__(256) void flow_reeval_kernel(const ReevalArgs p) {
+template <int TPW, int NW>   // NW waves, TPW = H / (16 NW) unit tiles per wave (8 waves where the tile count allows it)
+__global__ __launch_bounds__(NW * 64) void flow_reeval_kernel(const ReevalArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -63,12 +63,12 @@ __global__ __launch_bounds__(256) void flow_reeval_kernel(const ReevalArgs p) {
     const bool live = row0 + c < B;
 
     // ---- stage the operands of the first GEMMs: context rows (bf16) and the layer input as hi | lo ----
-    for (int s = tid; s < 16 * 32 * CKB; s += 256) {
+    for (int s = tid; s < 16 * 32 * CKB; s += NW * 64) {
         const int r = s / (32 * CKB), k = s - r * (32 * CKB);
         const int64_t row = row0 + r < B ? row0 + r : B - 1;
         s_ctx[r * CSB + k] = (__bf16)(k < C ? A.ctx[row * C + k] : 0.f);
     }
-    for (int s = tid; s < 16 * 16; s += 256) {
+    for (int s = tid; s < 16 * 16; s += NW * 64) {
         const int r = s >> 4, d = s & 15;
         const int64_t row = row0 + r < B ? row0 + r : B - 1;
         const float v = d < D ? A.U[((int64_t)l * B + row) * D + d] : 0.f;
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void flow_reeval_kernel(const ReevalArgs p) {
     }
     __syncthreads();
 
-    // acc[i] = W[tile t0 + wave + 4 i][k-steps] . s_in  (fragments [tile][ks][lane]; tiles beyond tmax re-read tile tmax and
+    // acc[i] = W[tile t0 + wave + NW i][k-steps] . s_in  (fragments [tile][ks][lane]; tiles beyond tmax re-read tile tmax and
     // are not stored).  The fragments are requested a chunk of 4 k-steps ahead (two register chunks): a k-step of TPW MFMAs
     // is 64 cycles, an L2 round trip ~800.
     auto gemm = [&](const u32x4* fr, int nks, int t0, int tmax, const __bf16* s_in, int stride, f32x4 (&acc)[TPW]) {
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void flow_reeval_kernel(const ReevalArgs p) {
         const u32x4* fa[TPW];
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
-            const int t = t0 + wave + 4 * i;
+            const int t = t0 + wave + NW * i;
             fa[i] = fr + (size_t)(t < tmax ? t : tmax) * nks * 64 + lane;
         }
         const __bf16* brow = s_in + c * stride + 8 * g;
@@ -151,12 +151,12 @@ __global__ __launch_bounds__(256) void flow_reeval_kernel(const ReevalArgs p) {
     f32x4 h[TPW], gate[2][TPW], acc[TPW];
     gemm(f_in, 1, 0, NT - 1, s_x, 40, h);
 #pragma unroll
-    for (int i = 0; i < TPW; ++i) h[i] += bias4(b_in, wave + 4 * i);
+    for (int i = 0; i < TPW; ++i) h[i] += bias4(b_in, wave + NW * i);
     if (C > 0) {
         gemm(f_ctx, CKB, 0, NT - 1, s_ctx, CSB, acc);
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
-            const int t = wave + 4 * i;
+            const int t = wave + NW * i;
             const f32x4 pc = acc[i] + bias4(b_ctx, t);
             st4(A.pc, l, t, pc);
 #pragma unroll
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void flow_reeval_kernel(const ReevalArgs p) {
             gemm(f_ctx + (size_t)(1 + j) * NT * CKB * 64, CKB, 0, NT - 1, s_ctx, CSB, acc);
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
-                const int t = wave + 4 * i;
+                const int t = wave + NW * i;
                 const f32x4 z = acc[i] + bias4(b_ctx + (1 + j) * H, t);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) gate[j][i][e] = 1.f / (1.f + __expf(-z[e]));
@@ -179,13 +179,13 @@ __global__ __launch_bounds__(256) void flow_reeval_kernel(const ReevalArgs p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
 #pragma unroll
-        for (int i = 0; i < TPW; ++i) { st4(A.hs, j * L + l, wave + 4 * i, h[i]); to_lds_relu(wave + 4 * i, h[i]); }
+        for (int i = 0; i < TPW; ++i) { st4(A.hs, j * L + l, wave + NW * i, h[i]); to_lds_relu(wave + NW * i, h[i]); }
         __syncthreads();
         gemm(f_blk + (size_t)(2 * j) * NT * HK * 64, HK, 0, NT - 1, s_a, HSB, acc);
         __syncthreads();                                       // every wave has read relu(h) before it is overwritten
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
-            const int t = wave + 4 * i;
+            const int t = wave + NW * i;
             const f32x4 t1 = acc[i] + bias4(b_blk + (2 * j) * H, t);
             st4(A.t1s, j * L + l, t, t1);
             if (A.drop) {                                      // training dropout, as flow_train_kernel applied it
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void flow_reeval_kernel(const ReevalArgs p) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
-            const int t = wave + 4 * i;
+            const int t = wave + NW * i;
             const f32x4 t2 = acc[i] + bias4(b_blk + (2 * j + 1) * H, t);
             if (C > 0) {
                 st4(A.t2s, j * L + l, t, t2);
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void flow_reeval_kernel(const ReevalArgs p) {
     // ---- final layer: the raw spline parameters ----
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
-        const int t = wave + 4 * i;
+        const int t = wave + NW * i;
         st4(A.h2, l, t, h[i]);
         bf16x4 o;
 #pragma unroll
@@ -225,11 +225,11 @@ __global__ __launch_bounds__(256) void flow_reeval_kernel(const ReevalArgs p) {
     }
     __syncthreads();
     const int DM = D * M;
-    for (int t0 = 0; t0 < NTF; t0 += 4 * TPW) {                // 4 TPW output tiles per pass, TPW per wave
+    for (int t0 = 0; t0 < NTF; t0 += NW * TPW) {               // NW TPW output tiles per pass, TPW per wave
         gemm(f_out, HK, t0, NTF - 1, s_a, HSB, acc);
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
-            const int t = t0 + wave + 4 * i;
+            const int t = t0 + wave + NW * i;
             if (t < NTF && live) {
                 const f32x4 o = acc[i] + bias4(b_out, t);
                 float* dst = A.params + ((size_t)l * B + my_row) * DM + 16 * t + 4 * g;
@@ -254,15 +254,16 @@ int flow_reevaluate(const FlowPlan& P, const PfFlowReevalArgs& a, hipStream_t s)
     const int CKB = P.bwd_ckb();
     const size_t lds = ((size_t)16 * (32 * CKB + 8) + 16 * 40 + 16 * (P.H + 8)) * 2;
     const dim3 grid((unsigned)((a.batch + 15) / 16), (unsigned)P.L);
+    const int nw = P.H % 128 == 0 ? 8 : 4;
     auto launch = [&](auto kern) {
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+        hipLaunchKernelGGL(kern, grid, dim3(nw * 64), lds, s, p);
         return launch_status();
     };
-    switch (P.H / 64) {
-    case 1: return launch(flow_reeval_kernel<1>);
-    case 2: return launch(flow_reeval_kernel<2>);
-    case 3: return launch(flow_reeval_kernel<3>);
-    case 4: return launch(flow_reeval_kernel<4>);
+    switch (P.H) {
+    case 64: return launch(flow_reeval_kernel<1, 4>);
+    case 128: return launch(flow_reeval_kernel<1, 8>);
+    case 192: return launch(flow_reeval_kernel<3, 4>);
+    case 256: return launch(flow_reeval_kernel<2, 8>);
     }
     return PF_ERR_UNSUPPORTED;
 }
