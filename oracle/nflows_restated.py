@@ -17,6 +17,16 @@ reference call site that fixes how it is used:
 
 Module and parameter names follow upstream so that a ``state_dict`` is
 interchangeable (SURVEY.md section 8a "state_dict layout").
+
+PARITY UNPINNED for this file: the reference holds no golden vector, checkpoint or
+fixture of the flow transform and nflows itself is not installed here, so nothing
+reference-held pins this restatement.  What stands in: the known-answer tests of
+tests/test_oracle_kat.py (round trip, fp64 slogdet of the Jacobian, autoregressive
+structure, normalisation), and scripts/compare_with_nflows.py, which builds the
+reference's exact transform from a real nflows where one is importable and compares
+forward / inverse to 1e-6 (exit 77 here).  The own-code parts of the reference
+(PSDScaledNormal, masks of the masked-context variant, ParamScaler, encoders) ARE
+pinned by reference-generated fixtures under tests/golden/.
 """
 from __future__ import annotations
 
