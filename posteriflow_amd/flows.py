@@ -439,9 +439,14 @@ class NSFPosteriorFlow(nn.Module):
             _lib.check(L.pf_flow_build_pack_map(desc, host.data_ptr()), "pf_flow_build_pack_map")
             pk.map = host.to(dev)
             pk.buf = torch.empty(L.pf_flow_packed_bytes(desc), dtype=torch.uint8, device=dev)
-        with torch.no_grad():
-            packing = [t for layer in self._ar_transforms for t in layer.autoregressive_net.ordered_parameters(True)]
-            raw = torch.cat([p.detach().reshape(-1).float() for p in packing])
+        rk = self.__dict__.get("_raw_cache")          # one flat copy of the parameters serves every stream of a weight update
+        if rk is not None and rk[0] == key:
+            raw = rk[1]
+        else:
+            with torch.no_grad():
+                packing = [t for layer in self._ar_transforms for t in layer.autoregressive_net.ordered_parameters(True)]
+                raw = torch.cat([p.detach().reshape(-1).float() for p in packing])
+            self.__dict__["_raw_cache"] = (key, raw)
         assert raw.numel() == L.pf_flow_raw_param_count(desc)
         _lib.check(L.pf_flow_pack(desc, raw.data_ptr(), pk.map.data_ptr(), pk.buf.data_ptr(),
                                   torch.cuda.current_stream(dev).cuda_stream), "pf_flow_pack")
