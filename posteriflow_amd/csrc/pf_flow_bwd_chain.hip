@@ -61,6 +61,9 @@ struct ChainArgs {
 // NW waves per workgroup, TPW = H / (16 NW) unit tiles per wave; BF: bf16 operands from the PF_FLAG_BWD stream.
 // 8 waves (two per SIMD) where the tile count allows it (H = 128, 256): 569 -> 459 us per launch against 4 waves --
 // a second wave per SIMD runs its MFMAs / LDS reads under the first one's loads (pitfall 9).
+#ifndef PF_CHAIN_ABLATE
+#define PF_CHAIN_ABLATE 0      // timing experiments (side builds): 1 no spline backward, 2 no MFMA, 4 no gradient stores, 8 no activation loads
+#endif
 template <int TPW, bool BF, int NW>
 __global__ __launch_bounds__(NW * 64) void flow_bwd_chain_kernel(const ChainArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -151,8 +154,11 @@ __global__ __launch_bounds__(NW * 64) void flow_bwd_chain_kernel(const ChainArgs
                 if (k0 + q < nks) {
                     const bf16x8 b = *reinterpret_cast<const bf16x8*>(brow + 32 * (k0 + q));
 #pragma unroll
-                    for (int i = 0; i < TPW; ++i)
+                    for (int i = 0; i < TPW; ++i) {
+                        if constexpr (PF_CHAIN_ABLATE & 2) { acc[i][0] += __builtin_bit_cast(f32x4, A[q][i])[0] + (float)b[0]; }
+                        else
                         acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[q][i]), b, acc[i], 0, 0, 0);
+                    }
                 }
             }
         };
@@ -173,9 +179,13 @@ __global__ __launch_bounds__(NW * 64) void flow_bwd_chain_kernel(const ChainArgs
     // C-layout access of slab `idx` of a [slabs][B][H] tensor: units 16 t + 4 g .. + 3 of row my_row
     // ([L][B][H]: idx = l; [2][L][B][H]: idx = j L + l; Gc [L][3][B][H]: idx = 3 l + k)
     auto at = [&](const float* base, int idx, int t) { return base + ((size_t)idx * B + my_row) * H + 16 * t + 4 * g; };
-    auto ld4 = [&](const float* base, int idx, int t) { return *reinterpret_cast<const f32x4*>(at(base, idx, t)); };
+    auto ld4 = [&](const float* base, int idx, int t) {
+        if constexpr (PF_CHAIN_ABLATE & 8) return f32x4{0.5f, 0.25f, 0.125f, 1.f};
+        else return *reinterpret_cast<const f32x4*>(at(base, idx, t));
+    };
     auto cvt4 = [](const f32x4& v) { bf16x4 o; for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e]; return o; };
     auto st4 = [&](float* base, int idx, int t, const f32x4& v) {
+        if constexpr (PF_CHAIN_ABLATE & 4) { if (v[0] == 1.2345e30f) *const_cast<float*>(at(base, idx, t)) = v[1]; return; }
         if (live) *reinterpret_cast<f32x4*>(const_cast<float*>(at(base, idx, t))) = v;
     };
     auto to_lds = [&](int which, int t, const f32x4& v) {               // exchange vector 0 / 1
@@ -195,6 +205,8 @@ __global__ __launch_bounds__(NW * 64) void flow_bwd_chain_kernel(const ChainArgs
             const int r = tid & 15, f = tid >> 4;
             const int64_t row = row0 + r < B ? row0 + r : B - 1;
             float* par = s_gp + r * PMS + f * M;
+            if constexpr (PF_CHAIN_ABLATE & 1) s_gu[r * 16 + f] = s_gy[r * 16 + f] + par[0];
+            else
             s_gu[r * 16 + f] = rqs_backward_pair(par, par, A.U[((size_t)l * B + row) * D + f], s_gy[r * 16 + f],
                                                  A.g_lad[row], p.c);
         }
