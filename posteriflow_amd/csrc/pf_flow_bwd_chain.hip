@@ -129,53 +129,76 @@ __global__ __launch_bounds__(NW * 64) void flow_bwd_chain_kernel(const ChainArgs
         }
     };
     // bf16: A = fragments [tile][ks][lane] of the packed stream, B = bf16 row c of s_in, k = 32 ks + 8 g ..
-    // The fragments are requested a chunk of 4 k-steps ahead (two register chunks): a k-step of TPW MFMAs is 64 cycles,
-    // an L2 round trip ~800, so a two-k-step lookahead stalled every k-step.
-    auto gemm_bf = [&](const u32x4* fr, int nks, const __bf16* s_in, int stride, f32x4 (&acc)[TPW]) {
-        constexpr int P = 4;
-#pragma unroll
-        for (int i = 0; i < TPW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const u32x4* fa[TPW];
-#pragma unroll
-        for (int i = 0; i < TPW; ++i) fa[i] = fr + (size_t)(wave + NW * i) * nks * 64 + lane;
-        const __bf16* brow = s_in + c * stride + 8 * g;
-        u32x4 A0[P][TPW], A1[P][TPW];
-        auto fetch = [&](u32x4 (&A)[P][TPW], int k0) {
-#pragma unroll
-            for (int q = 0; q < P; ++q) {
-                const int k = k0 + q < nks ? k0 + q : nks - 1;           // clamped: loads stay unconditional
-#pragma unroll
-                for (int i = 0; i < TPW; ++i) A[q][i] = fa[i][64 * k];
-            }
-        };
-        auto compute = [&](const u32x4 (&A)[P][TPW], int k0) {
-#pragma unroll
-            for (int q = 0; q < P; ++q) {
-                if (k0 + q < nks) {
-                    const bf16x8 b = *reinterpret_cast<const bf16x8*>(brow + 32 * (k0 + q));
-#pragma unroll
-                    for (int i = 0; i < TPW; ++i) {
-                        if constexpr (PF_CHAIN_ABLATE & 2) { acc[i][0] += __builtin_bit_cast(f32x4, A[q][i])[0] + (float)b[0]; }
-                        else
-                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[q][i]), b, acc[i], 0, 0, 0);
-                    }
-                }
-            }
-        };
-        fetch(A0, 0);
-        for (int k0 = 0; k0 < nks; k0 += 2 * P) {
-            fetch(A1, k0 + P);
-            compute(A0, k0);
-            fetch(A0, k0 + 2 * P);
-            compute(A1, k0 + P);
-        }
-        // let the matrix pipe drain before the epilogue reads the accumulators: behind a loop exit hipcc (ROCm 7.2) placed
-        // v_accvgpr_read right after the last MFMA with too few wait states and three of four values came back stale
-        // (pf_flow_reeval.hip's final layer, found on the hardware)
+    // ---- BF: the fragment stream of a wave is static, so it is requested ACROSS phase and layer boundaries ----------
+    // (ablations: ~300 of the 458 us were fifty dependent GEMM phases each starting with a cold round trip to the MALL)
+    //   ring[ks][i]: the H x H phase in flight -- slot ks is refilled with the NEXT phase's k-step ks as soon as it is
+    //   consumed, so every phase finds its fragments requested one whole phase earlier;
+    //   FA[q][i]: the final layer's transpose (KSF k-steps, run-time count), PF k-steps ahead; its first PF k-steps and the
+    //   first H x H phase are requested right behind the spline backward, under the Gp store and the bf16 image.
+    constexpr int HKc = NW * TPW / 2;                         // H / 32
+    constexpr int PF = 8;
+    u32x4 ring[BF ? HKc : 1][TPW], FA[BF ? PF : 1][TPW];
+    auto tile_ptr = [&](const u32x4* base, int nks, int i) { return base + (size_t)(wave + NW * i) * nks * 64 + lane; };
+    auto drain = [&](f32x4 (&acc)[TPW]) {
 #pragma unroll
         for (int i = 0; i < TPW; ++i) asm volatile("s_nop 7" : "+a"(acc[i]));
         asm volatile("s_nop 15");
     };
+    auto issue_phase = [&](const u32x4* base) {
+#pragma unroll
+        for (int ks = 0; ks < HKc; ++ks)
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) ring[ks][i] = tile_ptr(base, HKc, i)[64 * ks];
+    };
+    auto run_phase = [&](const __bf16* s_in, const u32x4* next, f32x4 (&acc)[TPW]) {
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const __bf16* brow = s_in + c * HSB + 8 * g;
+#pragma unroll
+        for (int ks = 0; ks < HKc; ++ks) {
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(brow + 32 * ks);
+#pragma unroll
+            for (int i = 0; i < TPW; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ring[ks][i]), b, acc[i], 0, 0, 0);
+            if (next) {
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) ring[ks][i] = tile_ptr(next, HKc, i)[64 * ks];
+            }
+        }
+        drain(acc);
+    };
+    auto f_prefill = [&](const u32x4* fbase) {
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+            const int k = q < KSF ? q : KSF - 1;
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) FA[q][i] = tile_ptr(fbase, KSF, i)[64 * k];
+        }
+    };
+    auto f_run = [&](const u32x4* fbase, f32x4 (&acc)[TPW]) {
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const __bf16* brow = s_gpb + c * GSB + 8 * g;
+        for (int k0 = 0; k0 < KSF; k0 += PF) {
+#pragma unroll
+            for (int q = 0; q < PF; ++q) {
+                const int k = k0 + q;
+                if (k < KSF) {
+                    const bf16x8 b = *reinterpret_cast<const bf16x8*>(brow + 32 * k);
+#pragma unroll
+                    for (int i = 0; i < TPW; ++i)
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, FA[q][i]), b, acc[i], 0, 0, 0);
+                    if (k + PF < KSF) {
+#pragma unroll
+                        for (int i = 0; i < TPW; ++i) FA[q][i] = tile_ptr(fbase, KSF, i)[64 * (k + PF)];
+                    }
+                }
+            }
+        }
+        drain(acc);
+    };
+    auto hh_phase = [&](const u32x4* lfp, int idx) { return lfp + ((size_t)NT * KSF + (size_t)idx * NT * HK) * 64; };
+
     // C-layout access of slab `idx` of a [slabs][B][H] tensor: units 16 t + 4 g .. + 3 of row my_row
     // ([L][B][H]: idx = l; [2][L][B][H]: idx = j L + l; Gc [L][3][B][H]: idx = 3 l + k)
     auto at = [&](const float* base, int idx, int t) { return base + ((size_t)idx * B + my_row) * H + 16 * t + 4 * g; };
@@ -195,10 +218,14 @@ __global__ __launch_bounds__(NW * 64) void flow_bwd_chain_kernel(const ChainArgs
 
     for (int l = L - 1; l >= 0; --l) {
         // ---- spline backward: raw parameters of the 16 rows -> LDS (coalesced), one lane per (row, feature) pair ----
-        for (int s = tid; s < 16 * PM; s += NW * 64) {
-            const int r = s / PM, k = s - r * PM;
-            const int64_t row = row0 + r < B ? row0 + r : B - 1;
-            s_gp[r * PMS + k] = k < D * M ? A.params[((size_t)l * B + row) * (D * M) + k] : 0.f;
+        // (row = tid / TPR, columns strided by TPR: no integer division per element -- these three staging loops were
+        // ~2000 instructions per thread and layer with it)
+        constexpr int TPR = NW * 4;                              // threads per row
+        const int sr = tid / TPR, sk = tid - sr * TPR;
+        const int64_t srow = row0 + sr < B ? row0 + sr : B - 1;
+        {
+            const float* src = A.params + ((size_t)l * B + srow) * (D * M);
+            for (int k = sk; k < PM; k += TPR) s_gp[sr * PMS + k] = k < D * M ? src[k] : 0.f;
         }
         __syncthreads();
         if (tid < 16 * D) {
@@ -211,19 +238,19 @@ __global__ __launch_bounds__(NW * 64) void flow_bwd_chain_kernel(const ChainArgs
                                                  A.g_lad[row], p.c);
         }
         __syncthreads();
-        for (int s = tid; s < 16 * D * M; s += NW * 64) {          // Gp -> HBM (weight gradient of the final layer)
-            const int r = s / (D * M), k = s - r * (D * M);
-            if (row0 + r < B) A.Gp[((size_t)l * B + row0 + r) * (D * M) + k] = s_gp[r * PMS + k];
+        const u32x4* lf = frags + (size_t)l * layer_frags * 64;   // BF: this layer's fragments (64 lanes x 16 B each)
+        if constexpr (BF) {       // the layer's stream starts here, under the Gp store and the bf16 image (not before the spline:
+            f_prefill(lf);        // 128 fragment registers live across rqs_backward_pair spilled 47 VGPRs)
+            issue_phase(hh_phase(lf, 2));                     // block 1's W2^T, consumed after the final layer's transpose
+        }
+        if (row0 + sr < B) {                                    // Gp -> HBM (weight gradient of the final layer)
+            float* dst = A.Gp + ((size_t)l * B + row0 + sr) * (D * M);
+            for (int k = sk; k < D * M; k += TPR) dst[k] = s_gp[sr * PMS + k];
         }
         if constexpr (BF) {                                     // and its bf16 image, the B operand of the next GEMM
-            const int kw = 32 * KSF;
-            for (int s = tid; s < 16 * kw; s += NW * 64) {
-                const int r = s / kw, k = s - r * kw;
-                s_gpb[r * GSB + k] = (__bf16)(k < D * M ? s_gp[r * PMS + k] : 0.f);
-            }
+            for (int k = sk; k < 32 * KSF; k += TPR) s_gpb[sr * GSB + k] = (__bf16)(k < D * M ? s_gp[sr * PMS + k] : 0.f);
             __syncthreads();
         }
-        const u32x4* lf = frags + (size_t)l * layer_frags * 64;   // BF: this layer's fragments (64 lanes x 16 B each)
         // ---- gh = Wf^T Gp ----------------------------------------------------------------------------------------
         f32x4 gh[TPW], acc[TPW];
         f32x4 gate_n[TPW], t2_n[TPW];                        // block operands, requested one GEMM ahead of their use
@@ -231,7 +258,7 @@ __global__ __launch_bounds__(NW * 64) void flow_bwd_chain_kernel(const ChainArgs
 #pragma unroll
             for (int i = 0; i < TPW; ++i) { gate_n[i] = ld4(A.gates, 1 * L + l, wave + NW * i); t2_n[i] = ld4(A.t2s, 1 * L + l, wave + NW * i); }
         }
-        if constexpr (BF) gemm_bf(lf, KSF, s_gpb, GSB, gh);
+        if constexpr (BF) f_run(lf, gh);
         else gemm(A.WfT + (size_t)l * H * PM, PM, PM, s_gp, PMS, gh);
         // ---- residual blocks, last first -------------------------------------------------------------------------
         for (int j = 1; j >= 0; --j) {
@@ -276,7 +303,7 @@ __global__ __launch_bounds__(NW * 64) void flow_bwd_chain_kernel(const ChainArgs
                     else gate_n[i] = ld4(A.pc, l, wave + NW * i);
                 }
             }
-            if constexpr (BF) gemm_bf(lf + ((size_t)NT * KSF + (size_t)(2 * j) * NT * HK) * 64, HK, s_b0, HSB, acc);
+            if constexpr (BF) run_phase(s_b0, hh_phase(lf, 2 * j + 1), acc);
             else gemm(A.W2T + ((size_t)j * L + l) * H * H, H, H, s_v0, HS, acc);
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
@@ -288,8 +315,10 @@ __global__ __launch_bounds__(NW * 64) void flow_bwd_chain_kernel(const ChainArgs
                 to_lds(1, t, gt1);
             }
             __syncthreads();
-            if constexpr (BF) gemm_bf(lf + ((size_t)NT * KSF + (size_t)(2 * j + 1) * NT * HK) * 64, HK, s_b1, HSB, acc);
-            else gemm(A.W1T + ((size_t)j * L + l) * H * H, H, H, s_v1, HS, acc);
+            if constexpr (BF) {
+                if (j == 1) run_phase(s_b1, hh_phase(lf, 0), acc);
+                else run_phase(s_b1, nullptr, acc);
+            } else gemm(A.W1T + ((size_t)j * L + l) * H * H, H, H, s_v1, HS, acc);
 #pragma unroll
             for (int i = 0; i < TPW; ++i)
 #pragma unroll
