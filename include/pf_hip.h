@@ -56,12 +56,16 @@ extern "C" {
                               * PF_ERR_UNSUPPORTED from every entry point.  The packed buffer of a PF_FLAG_WIDE desc
                               * has its own layout (pf_flow_packed_bytes / pack_map / pack with the same desc). */
 
-#define PF_FLAG_BWD 8         /* packing only: the TRANSPOSED masked weight matrices of the backward's data-gradient chain
-                              * as bf16 MFMA A-fragments (pf_flow_backward_chain with a bf16 desc), nflows unit order:
-                              * per layer  WfT [H/16 tiles][ceil(D(3K-1)/32) k-steps] | for block j: W2T_j, W1T_j
-                              * [H/16][H/32] | W0T [H/32], 1 KiB per (tile, k-step).  bf16, plain conditioner.
-                              * pf_flow_packed_bytes / pack_map_len / build_pack_map / pack take the flag; the forward,
-                              * inverse and workspace entry points refuse it. */
+#define PF_FLAG_BWD 8         /* packing only: the weight stream of the bf16 backward, bf16 MFMA A-fragments of 1 KiB per
+                              * (16-unit tile, 32-wide k-step), nflows unit order, masks folded in:
+                              *  transposed region (pf_flow_backward_chain), per layer: WfT [H/16][ceil(D(3K-1)/32)] |
+                              *    for block j: W2T_j, W1T_j [H/16][H/32] | W0T [H/32];
+                              *  forward region (pf_flow_reevaluate), per layer: Win [H/16][1] (x as hi | lo) | Wc, Wg0,
+                              *    Wg1 [H/16][ceil(C/32)] (if C > 0) | W1_0, W2_0, W1_1, W2_1 [H/16][H/32] |
+                              *    Wf [ceil(D(3K-1)/16)][H/32];
+                              *  then fp32 biases per layer: b_in | bc, bg0, bg1 | b1_0, b2_0, b1_1, b2_1 | bf (padded to 16).
+                              * bf16 precision, plain conditioner.  pf_flow_packed_bytes / pack_map_len / build_pack_map /
+                              * pack take the flag; the forward, inverse and workspace entry points refuse it. */
 
 /* Plain-old-data description of one NSFPosteriorFlow (flows.py:379-548).
  * conditioner: nflows MADE, num_blocks residual blocks with GLU context gate,
