@@ -362,7 +362,10 @@ __device__ __forceinline__ void flow_body(const FwdParams& p) {
     constexpr bool FAST = BF16;
     constexpr int NW = NT / 2, HK = S::HK, KHS = S::KHS, KOS = S::KOS, NF = S::NF;
     constexpr int COLS = 16 * R;
-    constexpr int W = 16;                               // frags in flight per wave
+#ifndef PF_FWD_W
+#define PF_FWD_W 16
+#endif
+    constexpr int W = PF_FWD_W;                         // frags in flight per wave
     constexpr int NE = (NF + W - 1) / W * W;            // schedule length rounded to the window
     constexpr bool CTX_REGS = (R == 1) && CKM > 0 && CKM <= 9;   // context B fragments live in registers
     static_assert(W <= kWindowPad, "stream pad too small");
