@@ -188,6 +188,11 @@ typedef struct PfFlowBwdChainArgs {
     const float* pc;     /* [L][B][H]      context_layer projection (before its ReLU), or NULL */
     const float* g_z;    /* [B][D]  dL/dz (layer order, as the forward returns z before un-permuting) */
     const float* g_lad;  /* [B]     dL/dlogdet */
+    /* ... or, for the loss of compute_psd_aware_nll (flows.py:727-779), g_z = g_lad = NULL and the three below: the kernel
+     * forms dL/dz = g_nll z exp(-2 log_sigma) and dL/dlogdet = -g_nll itself (log_sigma NULL: the N(0, I) base) */
+    const float* g_nll;      /* [B] dL/dnll, or NULL */
+    const float* nll_z;      /* [B][D] z as the forward returned it */
+    const float* log_sigma;  /* [B][D] or NULL */
     float* Gp;           /* [L][B][D (3K-1)]  dL/d(raw spline parameters) */
     float* Gh0;          /* [L][B][H]  dL/d(initial layer output) */
     float* Gt1;          /* [2][L][B][H] */

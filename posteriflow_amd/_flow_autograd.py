@@ -157,10 +157,11 @@ def _reevaluate_hip(flow, U, ctx, drop=None):
 
 
 @torch.no_grad()
-def _flow_backward_batched(flow, U, ctx, g_z, g_lad, drop=None):
+def _flow_backward_batched(flow, U, ctx, g_z, g_lad, drop=None, nll=None):
     """U [L, B, D] conditioner inputs kept by the forward kernel; g_z [B, D] = dL/dz, g_lad [B] =
-    dL/dlogdet; drop: the forward's dropout factors (``dropout_mask``) or None.  Returns dL/dx [B, D], dL/dctx (or
-    None) and the parameter gradients batched over layers."""
+    dL/dlogdet -- or both None and nll = (g_nll [B], z [B, D], log_sigma [B, D] or None): the chain kernel then forms
+    dL/dz = g_nll z e^{-2 ls} and dL/dlogdet = -g_nll itself; drop: the forward's dropout factors (``dropout_mask``) or
+    None.  Returns dL/dx [B, D], dL/dctx (or None) and the parameter gradients batched over layers."""
     nets = [t.autoregressive_net for t in flow._ar_transforms]
     Ln, B, D = U.shape
     nb = len(nets[0].blocks)
@@ -215,8 +216,6 @@ def _flow_backward_batched(flow, U, ctx, g_z, g_lad, drop=None):
 
     # 2. the chain, last layer first: ONE launch (pf_flow_backward_chain, csrc/pf_flow_bwd_chain.hip) instead of ~25
     #    small ones per layer -- spline backward, the transposed masked GEMMs on MFMA, the gate / ReLU algebra
-    gy = g_z.contiguous()
-    g_lad = g_lad.contiguous()
     DM = params.shape[2]
     Gp = torch.empty_like(params)
     # Gt1 | Gt2 | Gh0 in one buffer: their bias gradients are ONE column reduction instead of five
@@ -225,9 +224,16 @@ def _flow_backward_batched(flow, U, ctx, g_z, g_lad, drop=None):
     gx_perm = torch.empty(B, D, dtype=U.dtype, device=U.device)
     a = _lib.PfFlowBwdChainArgs()
     a.batch = B
-    keep = [HSk, T1k, GT1, GT2, Gp, Gh0, gx_perm, gy, g_lad, params]
-    ops = [("U", U), ("params", params), ("hs", HSk), ("t1s", T1k), ("g_z", gy), ("g_lad", g_lad), ("Gp", Gp), ("Gh0", Gh0),
+    keep = [HSk, T1k, GT1, GT2, Gp, Gh0, gx_perm, params]
+    ops = [("U", U), ("params", params), ("hs", HSk), ("t1s", T1k), ("Gp", Gp), ("Gh0", Gh0),
            ("Gt1", GT1), ("Gt2", GT2), ("g_x", gx_perm)]
+    if nll is not None:
+        ops += [("g_nll", nll[0].contiguous()), ("nll_z", nll[1].contiguous())]
+        if nll[2] is not None:
+            ops.append(("log_sigma", nll[2].contiguous()))
+    else:
+        ops += [("g_z", g_z.contiguous()), ("g_lad", g_lad.contiguous())]
+    keep += [t for _, t in ops[-3:]]
     if bf:      # the transposed matrices come from the PF_FLAG_BWD stream
         packed = flow.packed_weights(bwd=True)
         a.packed = packed.data_ptr()
@@ -287,13 +293,17 @@ def _per_parameter(flow, g):
     return [c[l] for l in range(g["W0"].shape[0]) for c in cols]
 
 
-def flow_backward(flow, U, ctx, g_z, g_lad, drop_seed=None):
+def flow_backward(flow, U, ctx, g_z, g_lad, drop_seed=None, nll=None):
     """(dL/dx, dL/dctx or None, per-parameter gradients in ``flow._ordered_parameters()`` order); drop_seed: the seed
     the training forward applied dropout with, or None.
     (Replaying the chain from a captured hipGraph was tried: inside a training step the launches are
     already hidden behind queued encoder work, so it bought nothing and was dropped.)"""
     drop = None if drop_seed is None else dropout_mask(flow, U.shape[1], drop_seed, U.device)
-    g = _flow_backward_batched(flow, U, ctx, g_z.contiguous().float(), g_lad.contiguous().float(), drop)
+    if nll is not None:
+        g = _flow_backward_batched(flow, U, ctx, None, None, drop,
+                                   (nll[0].float(), nll[1].float(), None if nll[2] is None else nll[2].float()))
+    else:
+        g = _flow_backward_batched(flow, U, ctx, g_z.contiguous().float(), g_lad.contiguous().float(), drop)
     return g["g_x"], g["g_ctx"], _per_parameter(flow, g)
 
 
@@ -318,6 +328,7 @@ class FlowNLL(torch.autograd.Function):
         ctx_.flow, ctx_.drop_seed = flow, seed
         ctx_.save_for_backward(x, context, log_sigma, U, z)
         ctx_.mark_non_differentiable(z, logdet)
+        ctx_.set_materialize_grads(False)          # no zero tensors for the unused outputs' gradients
         return nll, z, logdet
 
     @staticmethod
@@ -325,15 +336,15 @@ class FlowNLL(torch.autograd.Function):
         flow = ctx_.flow
         x, context, log_sigma, U, z = ctx_.saved_tensors
         params = [p for p in flow._ordered_parameters()]
+        if g_nll is None:
+            return (None,) * (4 + len(params))
         if U is not None:
             # nll = 0.5 sum (z e^-ls)^2 + sum ls + const - logdet
-            if log_sigma is None:
-                g_z, gl = g_nll[:, None] * z, None
-            else:
-                zs2 = (z * torch.exp(-log_sigma)).square()
-                g_z = g_nll[:, None] * z * torch.exp(-2.0 * log_sigma)
-                gl = g_nll[:, None] * (1.0 - zs2) if ctx_.needs_input_grad[3] else None
-            gx, gc, gp = flow_backward(flow, U, context, g_z, -g_nll, ctx_.drop_seed)
+            # (dL/dz = g_nll z e^{-2 ls} and dL/dlogdet = -g_nll are formed inside the chain kernel)
+            gl = None
+            if log_sigma is not None and ctx_.needs_input_grad[3]:
+                gl = g_nll[:, None] * (1.0 - (z * torch.exp(-log_sigma)).square())
+            gx, gc, gp = flow_backward(flow, U, context, None, None, ctx_.drop_seed, nll=(g_nll, z, log_sigma))
             return (None, gx if ctx_.needs_input_grad[1] else None,
                     gc if (context is not None and ctx_.needs_input_grad[2]) else None, gl,
                     *[g if p.requires_grad else None for g, p in zip(gp, params)])

@@ -25,7 +25,7 @@ PRECISIONS = {"fp32": PF_PREC_F32, "f32": PF_PREC_F32, "bf16": PF_PREC_BF16}
 class PfFlowBwdChainArgs(C.Structure):
     """include/pf_hip.h PfFlowBwdChainArgs (device pointers as integers)."""
     _fields_ = [("batch", C.c_int64)] + [(n, C.c_void_p) for n in (
-        "WfT", "W2T", "W1T", "W0T", "U", "params", "hs", "t1s", "t2s", "gates", "pc", "g_z", "g_lad",
+        "WfT", "W2T", "W1T", "W0T", "U", "params", "hs", "t1s", "t2s", "gates", "pc", "g_z", "g_lad", "g_nll", "nll_z", "log_sigma",
         "Gp", "Gh0", "Gt1", "Gt2", "Gc", "g_x", "drop", "packed")]
 
 

@@ -234,8 +234,10 @@ int pf_flow_backward_chain(const PfFlowDesc* desc, const PfFlowBwdChainArgs* a, 
     if (bf ? !a->packed : (!a->WfT || !a->W2T || !a->W1T || !a->W0T))
         return fail(PF_ERR_BAD_ARG, bf ? "bf16 desc: args.packed (the PF_FLAG_BWD stream) is null" : "null weight pointer");
     if (bf && H % 32) return fail(PF_ERR_UNSUPPORTED, "bf16 backward chain needs H % 32 == 0");
-    if (!a->U || !a->params || !a->hs || !a->t1s || !a->g_z || !a->g_lad || !a->Gp || !a->Gh0 || !a->Gt1 || !a->Gt2 || !a->g_x)
+    if (!a->U || !a->params || !a->hs || !a->t1s || !a->Gp || !a->Gh0 || !a->Gt1 || !a->Gt2 || !a->g_x)
         return fail(PF_ERR_BAD_ARG, "null pointer");
+    if (a->g_nll ? (!a->nll_z || a->g_z || a->g_lad) : (!a->g_z || !a->g_lad))
+        return fail(PF_ERR_BAD_ARG, "pass either (g_z, g_lad) or (g_nll, nll_z[, log_sigma])");
     const bool ctx = a->gates != nullptr;
     if (ctx != (a->t2s != nullptr) || ctx != (a->pc != nullptr) || ctx != (a->Gc != nullptr))
         return fail(PF_ERR_BAD_ARG, "t2s, gates, pc and Gc go together (all NULL for a context-free flow)");

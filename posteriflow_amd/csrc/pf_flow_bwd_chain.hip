@@ -95,7 +95,14 @@ __global__ __launch_bounds__(NW * 64) void flow_bwd_chain_kernel(const ChainArgs
     for (int s = tid; s < 256; s += NW * 64) {
         const int r = s >> 4, d = s & 15;
         const int64_t row = row0 + r < B ? row0 + r : B - 1;
-        s_gy[s] = d < D ? A.g_z[row * D + d] : 0.f;
+        float v = 0.f;
+        if (d < D) {
+            if (A.g_nll) {       // loss = nll: dL/dz = g_nll z e^{-2 ls}
+                const float ls = A.log_sigma ? A.log_sigma[row * D + d] : 0.f;
+                v = A.g_nll[row] * A.nll_z[row * D + d] * __expf(-2.f * ls);
+            } else v = A.g_z[row * D + d];
+        }
+        s_gy[s] = v;
     }
     __syncthreads();
 
@@ -235,7 +242,7 @@ __global__ __launch_bounds__(NW * 64) void flow_bwd_chain_kernel(const ChainArgs
             if constexpr (PF_CHAIN_ABLATE & 1) s_gu[r * 16 + f] = s_gy[r * 16 + f] + par[0];
             else
             s_gu[r * 16 + f] = rqs_backward_pair(par, par, A.U[((size_t)l * B + row) * D + f], s_gy[r * 16 + f],
-                                                 A.g_lad[row], p.c);
+                                                 A.g_nll ? -A.g_nll[row] : A.g_lad[row], p.c);
         }
         __syncthreads();
         const u32x4* lf = frags + (size_t)l * layer_frags * 64;   // BF: this layer's fragments (64 lanes x 16 B each)
