@@ -764,6 +764,18 @@ __device__ __forceinline__ void flow_body(const FwdParams& p) {
             *reinterpret_cast<f32x4*>(nb + tA * kBiasFloatsPerTile + 4 * lane) = nbA;
             *reinterpret_cast<f32x4*>(nb + tB * kBiasFloatsPerTile + 4 * lane) = nbB;
         }
+#ifndef PF_FWD_TOUCH
+#define PF_FWD_TOUCH 0          // timing experiment: fragments of the NEXT layer pulled towards L2 under the spline
+#endif
+        if constexpr (!INV && PF_FWD_TOUCH > 0) {
+            // no fragment is consumed during the spline, so the window does not move and the memory pipe idles: touch the
+            // next layer's entries W .. W + T - 1 (one dword per 16 bytes of a lane = all 8 lines of a fragment, LDS-DMA
+            // into the forward's unused x buffer: no register, nothing waits on it)
+#pragma unroll
+            for (int t = 0; t < PF_FWD_TOUCH; ++t)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)s_xb2, 4,
+                                                         lane * 16, nbase + (W + t) * kFragBytes, 0, 0);
+        }
         // ---- spline: transpose the parameters through LDS, one lane per (row, feature) pair ----
 #pragma unroll
         for (int r = 0; r < R; ++r) {
