@@ -198,7 +198,7 @@ inline int make_plan(const PfFlowDesc& d, FlowPlan& o) {
         o.bwd = 1;
     }
     o.hoist = (d.reserved & (PF_FLAG_HOIST_CTX | PF_FLAG_MASKED_CONTEXT)) && o.C > 0 ? 1 : 0;
-    o.CKM = o.hoist ? 0 : pick_ckm(o.bf16, o.NT, o.C);
+    o.CKM = (o.hoist || o.bwd) ? 0 : pick_ckm(o.bf16, o.NT, o.C);      // (the backward stream has no scheduled context slots)
     if (o.CKM < 0 || o.CK > 64) return PF_ERR_UNSUPPORTED;
     o.HK = o.H / o.kstep;
     int perm[256], deg_sorted[256];
