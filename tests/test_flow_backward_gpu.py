@@ -218,7 +218,7 @@ def test_flow_gradients_in_bf16_mode(D, C, H, L):
 
 
 @pytest.mark.parametrize("D,C,H,L,K", [(11, 288, 256, 3, 16), (15, 288, 256, 2, 16), (4, 0, 64, 3, 8), (7, 40, 128, 2, 10),
-                                       (11, 288, 192, 2, 16), (2, 5, 64, 1, 4)])
+                                       (11, 288, 192, 2, 16), (2, 5, 64, 1, 4), (9, 289, 192, 1, 7)])
 def test_hip_reevaluation_matches_tensor_ops(D, C, H, L, K):
     """pf_flow_reevaluate (one launch, grid = row blocks x layers, bf16 operands / fp32 accumulate like the bf16 forward
     kernel) against the same conditioners evaluated with tensor ops from the same layer inputs, every matrix-product operand
