@@ -14,7 +14,7 @@ for f in sorted(glob.glob(root + "/p*/**/*counter_collection.csv", recursive=Tru
             name = row.get("Kernel_Name", "")
             if match not in name:
                 continue
-            short = name.split("(")[0].replace("void pf::", "")[-60:]
+            short = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void pf::", "")[-60:]
             acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k, d in acc.items():
     print(f"== {k}")
