@@ -254,6 +254,23 @@ def extras(flow, dev, batch):
         nll = torch.empty(batch, device=dev)
         x, ctx = make_inputs(batch, 1, dev)
         out["config3_end_to_end_events_per_s"] = batch / (dt + timed(lambda: flow.nll_into(x, ctx, nll), 10))
+    # the training side of the same flow: forward + backward of the NLL at 2048 rows (the per-GPU share of a 1024-event
+    # batch with ~2 signals per event), LeanNPE's flow shape, in the mode being benchmarked
+    tf = npe.LeanNPE().to(dev).train().flow
+    tf.precision = flow.precision
+    xt = torch.rand(2048, tf.features, device=dev) * 2 - 1
+    ct = torch.randn(2048, tf.context_features, device=dev, requires_grad=True)
+    params = tf._ordered_parameters()
+
+    def fwd_bwd():
+        for q in params:
+            q.grad = None
+        ct.grad = None
+        tf.compute_psd_aware_nll(xt, ct, torch.zeros_like(xt)).mean().backward()
+
+    for _ in range(3):
+        fwd_bwd()
+    out[f"flow_fwd_bwd_ms_2048_{flow.precision}"] = timed(fwd_bwd, 10) * 1e3
     log("extras: " + ", ".join(f"{k}={v:.3g}" for k, v in out.items()))
     return out
 
