@@ -268,7 +268,7 @@ def _flow_backward_batched(flow, U, ctx, g_z, g_lad, drop=None, nll=None):
     gb1, gb2 = [gb5[j] for j in range(nb)], [gb5[nb + j] for j in range(nb)]
     g_ctx = gWcat = gbcat = None
     if has_ctx:
-        flat = Gc.permute(2, 0, 1, 3).reshape(B, -1)                            # [B, L (1+nb) H]
+        flat = Gc.permute(2, 0, 1, 3).reshape(B, Ln * (1 + nb) * H)             # [B, L (1+nb) H]
         gWcat = (flat.t() @ ctx).view(Ln, 1 + nb, H, C)
         gbcat = flat.sum(0).view(Ln, 1 + nb, H)
         g_ctx = flat @ Wcat.reshape(-1, C)

@@ -767,6 +767,8 @@ class NSFPosteriorFlow(nn.Module):
             raise NotImplementedError("inverse() has no backward (every reference caller runs it under no_grad)")
         z = z.contiguous().float()
         B = z.shape[0]
+        if B == 0:                                          # nothing to invert (the reference's tensor ops return empties too)
+            return z.clone(), torch.empty(0, dtype=torch.float32, device=dev)
         ctx_rows = B
         if self.context_features > 0:
             if context is None:

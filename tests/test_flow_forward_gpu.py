@@ -320,3 +320,29 @@ def test_rows_per_workgroup_choice_and_parity(B, rows):
         want = ref.compute_psd_aware_nll(x[idx], ctx[idx], torch.zeros(64, 15))
     err = (got.cpu()[idx] - want).abs() / want.abs().clamp_min(1.0)
     assert err.median() < 2e-2 and err.max() < 0.3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_empty_batch(precision):
+    """zero rows: every entry point returns empty tensors of the right shape and the backward yields zero gradients (the
+    reference's tensor ops do the same); nothing is launched with an empty grid."""
+    from helpers import make_pair
+    _, _, flow = make_pair(11, 288, 256, 2, 16, 5.0)
+    flow.precision = precision
+    x, ctx = torch.empty(0, 11, device="cuda"), torch.empty(0, 288, device="cuda")
+    with torch.no_grad():
+        z, ld = flow(x, ctx)
+        assert z.shape == (0, 11) and ld.shape == (0,)
+        assert flow.compute_psd_aware_nll(x, ctx, None).shape == (0,)
+        assert flow.log_prob(x, ctx).shape == (0,)
+        xi, ldi = flow.inverse(torch.empty(0, 11, device="cuda"), ctx)
+        assert xi.shape == (0, 11) and ldi.shape == (0,)
+        out = torch.empty(0, device="cuda")
+        assert flow.nll_into(x, ctx, out).shape == (0,)
+    xg, cg = x.clone().requires_grad_(True), ctx.clone().requires_grad_(True)
+    flow.compute_psd_aware_nll(xg, cg, None).sum().backward()
+    assert xg.grad.shape == (0, 11) and cg.grad.shape == (0, 288)
+    for name, p in flow.named_parameters():
+        if name.startswith("transform."):
+            assert p.grad is not None and torch.count_nonzero(p.grad) == 0, name
