@@ -290,7 +290,17 @@ class LeanStrainEncoder(nn.Module):
         on = self.precision == "bf16" and dev.type == "cuda"
         return torch.autocast("cuda", dtype=torch.bfloat16, enabled=on)
 
+    def _empty(self, strain):
+        """no events: [0, context_dim] (the reference's tensor ops give the same), nothing is launched"""
+        return strain.new_zeros(0, self._out_features(), dtype=torch.float32)
+
+    def _out_features(self) -> int:
+        last = self.out_proj[-1] if isinstance(self.out_proj, nn.Sequential) else self.out_proj
+        return last.out_features if hasattr(last, "out_features") else last.normalized_shape[0]
+
     def forward(self, strain, asd_bands=None):
+        if strain.shape[0] == 0:
+            return self._empty(strain)
         with self._autocast(strain.device):
             feats, _ = self._compute_feats(strain, asd_bands)
             return self.out_proj(feats).float()
@@ -352,6 +362,8 @@ class CoherentEncoder(LeanStrainEncoder):
         return torch.cat(feats, dim=-1)
 
     def forward(self, strain, asd_bands=None):
+        if strain.shape[0] == 0:
+            return self._empty(strain)
         clean = self._sanitize(strain)
         rel = self._geometry_rel(clean)                      # FFT features stay fp32
         with self._autocast(strain.device):

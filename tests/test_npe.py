@@ -180,3 +180,19 @@ def test_inference_sampling_loop_gpu():
     neg = ref_flow.compute_psd_aware_nll(y, full.expand(64, -1), torch.zeros_like(y))
     want = lean_ref.log_prob_physical(neg, y, lean_ref.ParamScalerRef())
     assert ((got - want).abs() / want.abs().clamp_min(1)).max() < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_encoder_and_npe_with_an_empty_batch(precision):
+    """zero events: the encoder returns [0, context_dim], LeanNPE.nll an empty loss vector -- no kernel is launched with
+    an empty grid"""
+    from posteriflow_amd import LeanNPE
+    model = LeanNPE(flow_layers=2).cuda().eval()
+    model.encoder.precision = model.flow.precision = precision
+    with torch.no_grad():
+        ctx = model.encode(torch.empty(0, 3, 16384, device="cuda"))
+        assert ctx.shape == (0, model.context_dim)
+        strain = torch.empty(0, 3, 16384, device="cuda")
+        nll = model.nll(strain, torch.empty(0, 11, device="cuda"), torch.empty(0, dtype=torch.long, device="cuda"), context=ctx)
+        assert nll.shape == (0,)
