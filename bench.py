@@ -201,7 +201,9 @@ def extras(flow, dev, batch):
     out = {}
 
     def timed(fn, reps):
-        fn(); torch.cuda.synchronize(dev)
+        for _ in range(3):                      # (one warm-up call once read 2.3x slow on a fresh box)
+            fn()
+        torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         for _ in range(reps):
             fn()
