@@ -201,6 +201,11 @@ typedef struct PfFlowBwdChainArgs {
     float* g_x;          /* [B][D]  dL/d(x[:, ar_perm]) */
     const float* drop;   /* [2][L][B][H] dropout factors of the forward (pf_flow_dropout_mask), or NULL:
                           * gt1 = (W2^T gt2) . drop . [t1 > 0] */
+    uint32_t compact;    /* bf16 descs only, 1: the activation tensors are the bf16 ones pf_flow_reevaluate writes in its compact
+                          * mode (hs = relu(h_j), t1s = relu(t1_j) . dropout factor, t2s, gates, pc = relu(pc): the chain only
+                          * needs their signs and products) and Gp, Gh0, Gt1, Gt2, Gc are written as bf16 -- the operands of
+                          * bf16 weight-gradient GEMMs; `drop` is not read (its factor is drop_scale where t1s > 0).  0: fp32. */
+    float drop_scale;    /* compact: 1 / (1 - p) of the forward's dropout, 1 without */
     const void* packed;  /* bf16 descs: the PF_FLAG_BWD stream (W*T above are ignored): the transposed GEMMs run on bf16
                           * MFMA with bf16-rounded gradient vectors as their second operand; the spline, the accumulators,
                           * the gate / ReLU algebra and every output stay fp32.  fp32 descs: ignored. */
@@ -227,6 +232,9 @@ typedef struct PfFlowReevalArgs {
     float* params;       /* [L][B][D (3K-1)] raw spline parameters */
     const float* drop;   /* [2][L][B][H] dropout factors the training forward applied (pf_flow_dropout_mask), or NULL:
                           * the second linear of block j sees relu(t1_j) . drop[j] */
+    uint32_t compact;    /* 1: hs, t1s, t2s, gates, pc, h2 are written as bf16 and already in the form the backward uses them:
+                          * hs = relu(h_j), t1s = relu(t1_j) . drop[j], pc = relu(pc) (params stay fp32): half the bytes, and
+                          * the operands of bf16 weight-gradient GEMMs without a cast.  0: fp32 raw values as described above. */
 } PfFlowReevalArgs;
 int pf_flow_reevaluate(const PfFlowDesc* desc, const PfFlowReevalArgs* args, void* stream);
 

@@ -130,17 +130,26 @@ def _rqs_backward(flow, u, params, gy, glad, gparams):
 
 
 REEVAL_HIP = True      # tests: False keeps the tensor-op re-evaluation in bf16 mode (isolates the bf16 chain kernel)
+COMPACT = True         # tests: False keeps fp32 activations / gradient vectors between the bf16 backward kernels
 
 
-def _reevaluate_hip(flow, U, ctx, drop=None):
+def _mm32(a, b):
+    """a @ b for bf16 operands with an fp32 result (2-D or batched): the library's out_dtype path"""
+    return (torch.bmm if a.dim() == 3 else torch.mm)(a, b, out_dtype=torch.float32)
+
+
+def _reevaluate_hip(flow, U, ctx, drop=None, compact=False):
     """bf16 mode: every layer's conditioner from its kept input in ONE launch (pf_flow_reevaluate, csrc/pf_flow_reeval.hip),
-    in the arithmetic of the bf16 forward kernel.  Returns (hs [h_0, h_1, h_2], t1s, t2s, gates, pc, params)."""
+    in the arithmetic of the bf16 forward kernel.  Returns (hs, t1s, t2s, gates, pc, h2, params): fp32 raw values, or with
+    ``compact`` bf16 tensors already in the form the backward uses them (hs = relu(h_j), t1s = relu(t1_j) . drop[j],
+    pc = relu(pc); params stay fp32)."""
     Ln, B, D = U.shape
     H, dev = flow.hidden_features, U.device
     has_ctx = ctx is not None
-    new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+    act = torch.bfloat16 if compact else torch.float32
+    new = lambda *shape: torch.empty(*shape, dtype=act, device=dev)
     HS, T1, H2 = new(2, Ln, B, H), new(2, Ln, B, H), new(Ln, B, H)
-    params = new(Ln, B, D * (3 * flow.num_bins - 1))
+    params = torch.empty(Ln, B, D * (3 * flow.num_bins - 1), dtype=torch.float32, device=dev)
     T2 = G = PC = None
     packed = flow.packed_weights(bwd=True)
     a = _lib.PfFlowReevalArgs()
@@ -151,6 +160,7 @@ def _reevaluate_hip(flow, U, ctx, drop=None):
         a.ctx, a.t2s, a.gates, a.pc = ctx.data_ptr(), T2.data_ptr(), G.data_ptr(), PC.data_ptr()
     if drop is not None:
         a.drop = drop.data_ptr()
+    a.compact = 1 if compact else 0
     _lib.check(_lib.lib().pf_flow_reevaluate(flow._desc("bf16"), a, torch.cuda.current_stream(dev).cuda_stream),
                "pf_flow_reevaluate")
     return HS, T1, T2, G, PC, H2, params
@@ -180,7 +190,11 @@ def _flow_backward_batched(flow, U, ctx, g_z, g_lad, drop=None, nll=None):
     bf = flow.precision == "bf16" and H % 32 == 0 and nb == 2 and U.is_contiguous() and (ctx is None or ctx.is_contiguous())
 
     # 1. conditioners
-    if bf and REEVAL_HIP:
+    cmp = bf and REEVAL_HIP and COMPACT
+    if cmp:          # bf16 activations in their backward form; bf16 gradient vectors; bf16 weight-gradient GEMMs
+        HSk, T1k, T2k, Gk, pck, h_last, params = _reevaluate_hip(flow, U, ctx, drop, compact=True)
+        relu_h, a1s = [HSk[j] for j in range(nb)], [T1k[j] for j in range(nb)]
+    elif bf and REEVAL_HIP:
         HSk, T1k, T2k, Gk, pck, h_last, params = _reevaluate_hip(flow, U, ctx, drop)
         relu_h = [F.relu(HSk[j]) for j in range(nb)]
         a1s = [F.relu(T1k[j]) if drop is None else F.relu(T1k[j]) * drop[j] for j in range(nb)]
@@ -217,9 +231,10 @@ def _flow_backward_batched(flow, U, ctx, g_z, g_lad, drop=None, nll=None):
     # 2. the chain, last layer first: ONE launch (pf_flow_backward_chain, csrc/pf_flow_bwd_chain.hip) instead of ~25
     #    small ones per layer -- spline backward, the transposed masked GEMMs on MFMA, the gate / ReLU algebra
     DM = params.shape[2]
-    Gp = torch.empty_like(params)
+    gdt = torch.bfloat16 if cmp else U.dtype
+    Gp = torch.empty(params.shape, dtype=gdt, device=U.device)
     # Gt1 | Gt2 | Gh0 in one buffer: their bias gradients are ONE column reduction instead of five
-    G5 = torch.empty(2 * nb + 1, Ln, B, H, dtype=U.dtype, device=U.device)
+    G5 = torch.empty(2 * nb + 1, Ln, B, H, dtype=gdt, device=U.device)
     GT1, GT2, Gh0 = G5[:nb], G5[nb:2 * nb], G5[2 * nb]
     gx_perm = torch.empty(B, D, dtype=U.dtype, device=U.device)
     a = _lib.PfFlowBwdChainArgs()
@@ -248,11 +263,16 @@ def _flow_backward_batched(flow, U, ctx, g_z, g_lad, drop=None, nll=None):
         keep += [WfT, W2T, W1T, W0T]
     if drop is not None:        # gt1 = (W2^T gt2) . factor . [t1 > 0]: the chain reads the forward's factors
         ops.append(("drop", drop))
+    if cmp:
+        a.compact, a.drop_scale = 1, (1.0 if drop is None else 1.0 / (1.0 - float(flow.dropout)))
+    half = {"hs", "t1s", "Gp", "Gh0", "Gt1", "Gt2"} if cmp else set()
     for name, t in ops:
-        assert t.is_contiguous() and t.dtype == torch.float32
+        if cmp and name == "drop":
+            continue                                   # compact: the factor is drop_scale where t1s > 0
+        assert t.is_contiguous() and t.dtype == (torch.bfloat16 if name in half else torch.float32), name
         setattr(a, name, t.data_ptr())
     if has_ctx:
-        Gc = torch.empty(Ln, 1 + nb, B, H, dtype=U.dtype, device=U.device)
+        Gc = torch.empty(Ln, 1 + nb, B, H, dtype=gdt, device=U.device)
         keep += [T2k, Gk, pck, Gc]
         a.t2s, a.gates, a.pc, a.Gc = T2k.data_ptr(), Gk.data_ptr(), pck.data_ptr(), Gc.data_ptr()
     _lib.check(_lib.lib().pf_flow_backward_chain(flow._desc("bf16" if bf else "fp32"), a,
@@ -260,18 +280,20 @@ def _flow_backward_batched(flow, U, ctx, g_z, g_lad, drop=None, nll=None):
     g_x = gx_perm[:, flow._ar_inv_perm]              # the kernel returns dL/d x[:, ar_perm]
 
     # 3. weight gradients, batched over layers
-    gb5 = G5.sum(2)                                                             # [2 nb + 1, L, H]
-    gWf, gbf = torch.bmm(Gp.transpose(1, 2), h_last) * mf, Gp.sum(1)
-    gW0, gb0 = torch.bmm(Gh0.transpose(1, 2), U) * m0, gb5[2 * nb]
-    gW1 = [torch.bmm(GT1[j].transpose(1, 2), relu_h[j]) * m1[j] for j in range(nb)]
-    gW2 = [torch.bmm(GT2[j].transpose(1, 2), a1s[j]) * m2[j] for j in range(nb)]
+    mm = _mm32 if cmp else (lambda x_, y_: torch.bmm(x_, y_) if x_.dim() == 3 else x_ @ y_)
+    f32 = dict(dtype=torch.float32) if cmp else {}
+    gb5 = G5.sum(2, **f32)                                                      # [2 nb + 1, L, H]
+    gWf, gbf = mm(Gp.transpose(1, 2), h_last) * mf, Gp.sum(1, **f32)
+    gW0, gb0 = mm(Gh0.transpose(1, 2), U.to(gdt)) * m0, gb5[2 * nb]
+    gW1 = [mm(GT1[j].transpose(1, 2), relu_h[j]) * m1[j] for j in range(nb)]
+    gW2 = [mm(GT2[j].transpose(1, 2), a1s[j]) * m2[j] for j in range(nb)]
     gb1, gb2 = [gb5[j] for j in range(nb)], [gb5[nb + j] for j in range(nb)]
     g_ctx = gWcat = gbcat = None
     if has_ctx:
         flat = Gc.permute(2, 0, 1, 3).reshape(B, Ln * (1 + nb) * H)             # [B, L (1+nb) H]
-        gWcat = (flat.t() @ ctx).view(Ln, 1 + nb, H, C)
-        gbcat = flat.sum(0).view(Ln, 1 + nb, H)
-        g_ctx = flat @ Wcat.reshape(-1, C)
+        gWcat = mm(flat.t(), ctx.to(gdt)).view(Ln, 1 + nb, H, C)
+        gbcat = flat.sum(0, **f32).view(Ln, 1 + nb, H)
+        g_ctx = mm(flat, Wcat.reshape(-1, C).to(gdt))
     return dict(g_x=g_x, g_ctx=g_ctx, W0=gW0, b0=gb0, Wf=gWf, bf=gbf, W1=gW1, b1=gb1, W2=gW2, b2=gb2,
                 Wcat=gWcat if has_ctx else None, bcat=gbcat if has_ctx else None)
 

@@ -26,13 +26,14 @@ class PfFlowBwdChainArgs(C.Structure):
     """include/pf_hip.h PfFlowBwdChainArgs (device pointers as integers)."""
     _fields_ = [("batch", C.c_int64)] + [(n, C.c_void_p) for n in (
         "WfT", "W2T", "W1T", "W0T", "U", "params", "hs", "t1s", "t2s", "gates", "pc", "g_z", "g_lad", "g_nll", "nll_z", "log_sigma",
-        "Gp", "Gh0", "Gt1", "Gt2", "Gc", "g_x", "drop", "packed")]
+        "Gp", "Gh0", "Gt1", "Gt2", "Gc", "g_x", "drop")] + [("compact", C.c_uint32), ("drop_scale", C.c_float),
+                                                           ("packed", C.c_void_p)]
 
 
 class PfFlowReevalArgs(C.Structure):
     """include/pf_hip.h PfFlowReevalArgs"""
     _fields_ = [("batch", C.c_int64)] + [(n, C.c_void_p) for n in (
-        "packed", "U", "ctx", "hs", "t1s", "t2s", "gates", "pc", "h2", "params", "drop")]
+        "packed", "U", "ctx", "hs", "t1s", "t2s", "gates", "pc", "h2", "params", "drop")] + [("compact", C.c_uint32)]
 
 
 class PfFlowDesc(C.Structure):

@@ -209,14 +209,24 @@ __global__ __launch_bounds__(NW * 64) void flow_bwd_chain_kernel(const ChainArgs
     // C-layout access of slab `idx` of a [slabs][B][H] tensor: units 16 t + 4 g .. + 3 of row my_row
     // ([L][B][H]: idx = l; [2][L][B][H]: idx = j L + l; Gc [L][3][B][H]: idx = 3 l + k)
     auto at = [&](const float* base, int idx, int t) { return base + ((size_t)idx * B + my_row) * H + 16 * t + 4 * g; };
+    const bool cmp = BF && A.compact != 0;                   // compact mode: bf16 activations in, bf16 gradients out
     auto ld4 = [&](const float* base, int idx, int t) {
         if constexpr (PF_CHAIN_ABLATE & 8) return f32x4{0.5f, 0.25f, 0.125f, 1.f};
-        else return *reinterpret_cast<const f32x4*>(at(base, idx, t));
+        else {
+            if (cmp) {
+                const bf16x4 v = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(base) +
+                                                                   ((size_t)idx * B + my_row) * H + 16 * t + 4 * g);
+                return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+            }
+            return *reinterpret_cast<const f32x4*>(at(base, idx, t));
+        }
     };
     auto cvt4 = [](const f32x4& v) { bf16x4 o; for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e]; return o; };
     auto st4 = [&](float* base, int idx, int t, const f32x4& v) {
         if constexpr (PF_CHAIN_ABLATE & 4) { if (v[0] == 1.2345e30f) *const_cast<float*>(at(base, idx, t)) = v[1]; return; }
-        if (live) *reinterpret_cast<f32x4*>(const_cast<float*>(at(base, idx, t))) = v;
+        if (!live) return;
+        if (cmp) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(base) + ((size_t)idx * B + my_row) * H + 16 * t + 4 * g) = cvt4(v);
+        else *reinterpret_cast<f32x4*>(const_cast<float*>(at(base, idx, t))) = v;
     };
     auto to_lds = [&](int which, int t, const f32x4& v) {               // exchange vector 0 / 1
         if constexpr (BF) *reinterpret_cast<bf16x4*>((which ? s_b1 : s_b0) + c * HSB + 16 * t + 4 * g) = cvt4(v);
@@ -251,8 +261,13 @@ __global__ __launch_bounds__(NW * 64) void flow_bwd_chain_kernel(const ChainArgs
             issue_phase(hh_phase(lf, 2));                     // block 1's W2^T, consumed after the final layer's transpose
         }
         if (row0 + sr < B) {                                    // Gp -> HBM (weight gradient of the final layer)
-            float* dst = A.Gp + ((size_t)l * B + row0 + sr) * (D * M);
-            for (int k = sk; k < D * M; k += TPR) dst[k] = s_gp[sr * PMS + k];
+            if (cmp) {
+                __bf16* dst = reinterpret_cast<__bf16*>(A.Gp) + ((size_t)l * B + row0 + sr) * (D * M);
+                for (int k = sk; k < D * M; k += TPR) dst[k] = (__bf16)s_gp[sr * PMS + k];
+            } else {
+                float* dst = A.Gp + ((size_t)l * B + row0 + sr) * (D * M);
+                for (int k = sk; k < D * M; k += TPR) dst[k] = s_gp[sr * PMS + k];
+            }
         }
         if constexpr (BF) {                                     // and its bf16 image, the B operand of the next GEMM
             for (int k = sk; k < 32 * KSF; k += TPR) s_gpb[sr * GSB + k] = (__bf16)(k < D * M ? s_gp[sr * PMS + k] : 0.f);
@@ -290,7 +305,12 @@ __global__ __launch_bounds__(NW * 64) void flow_bwd_chain_kernel(const ChainArgs
             f32x4 t1[TPW], hj[TPW];                          // requested ahead of the GEMMs whose epilogues use them
 #pragma unroll
             for (int i = 0; i < TPW; ++i) { t1[i] = ld4(A.t1s, j * L + l, wave + NW * i); hj[i] = ld4(A.hs, j * L + l, wave + NW * i); }
-            if (A.drop) {                                    // training dropout: fold the forward's factor into the ReLU mask
+            if (cmp) {                                       // t1s = relu(t1) . factor: positive where the unit was live and kept
+#pragma unroll
+                for (int i = 0; i < TPW; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t1[i][e] = t1[i][e] > 0.f ? A.drop_scale : 0.f;
+            } else if (A.drop) {                             // training dropout: fold the forward's factor into the ReLU mask
 #pragma unroll
                 for (int i = 0; i < TPW; ++i) {
                     const f32x4 dr = ld4(A.drop, j * L + l, wave + NW * i);

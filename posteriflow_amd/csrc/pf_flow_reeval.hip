@@ -128,9 +128,18 @@ __global__ __launch_bounds__(NW * 64) void flow_reeval_kernel(const ReevalArgs p
     };
     auto bias4 = [&](const float* b, int t) { return *reinterpret_cast<const f32x4*>(b + 16 * t + 4 * g); };
     // slab `idx` of a [slabs][B][H] fp32 tensor, units 16 t + 4 g .. + 3 of this lane's row
+    const bool cmp = A.compact != 0;                          // compact mode: bf16 outputs in the form the backward uses them
     auto st4 = [&](float* base, int idx, int t, const f32x4& v) {
-        if (live) *reinterpret_cast<f32x4*>(base + ((size_t)idx * B + my_row) * H + 16 * t + 4 * g) = v;
+        if (!live) return;
+        const size_t off = ((size_t)idx * B + my_row) * H + 16 * t + 4 * g;
+        if (cmp) {
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+            *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(base) + off) = o;
+        } else *reinterpret_cast<f32x4*>(base + off) = v;
     };
+    auto relu4 = [](const f32x4& v) { f32x4 o; for (int e = 0; e < 4; ++e) o[e] = fmaxf(v[e], 0.f); return o; };
     auto to_lds_relu = [&](int t, const f32x4& v) {
         bf16x4 o;
 #pragma unroll
@@ -158,7 +167,7 @@ __global__ __launch_bounds__(NW * 64) void flow_reeval_kernel(const ReevalArgs p
         for (int i = 0; i < TPW; ++i) {
             const int t = wave + NW * i;
             const f32x4 pc = acc[i] + bias4(b_ctx, t);
-            st4(A.pc, l, t, pc);
+            st4(A.pc, l, t, cmp ? relu4(pc) : pc);
 #pragma unroll
             for (int e = 0; e < 4; ++e) h[i][e] += fmaxf(pc[e], 0.f);
         }
@@ -179,7 +188,7 @@ __global__ __launch_bounds__(NW * 64) void flow_reeval_kernel(const ReevalArgs p
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
 #pragma unroll
-        for (int i = 0; i < TPW; ++i) { st4(A.hs, j * L + l, wave + NW * i, h[i]); to_lds_relu(wave + NW * i, h[i]); }
+        for (int i = 0; i < TPW; ++i) { st4(A.hs, j * L + l, wave + NW * i, cmp ? relu4(h[i]) : h[i]); to_lds_relu(wave + NW * i, h[i]); }
         __syncthreads();
         gemm(f_blk + (size_t)(2 * j) * NT * HK * 64, HK, 0, NT - 1, s_a, HSB, acc);
         __syncthreads();                                       // every wave has read relu(h) before it is overwritten
@@ -187,16 +196,13 @@ __global__ __launch_bounds__(NW * 64) void flow_reeval_kernel(const ReevalArgs p
         for (int i = 0; i < TPW; ++i) {
             const int t = wave + NW * i;
             const f32x4 t1 = acc[i] + bias4(b_blk + (2 * j) * H, t);
-            st4(A.t1s, j * L + l, t, t1);
+            f32x4 a1 = relu4(t1);
             if (A.drop) {                                      // training dropout, as flow_train_kernel applied it
                 const f32x4 dr = *reinterpret_cast<const f32x4*>(A.drop + ((size_t)(j * L + l) * B + my_row) * H + 16 * t + 4 * g);
-                f32x4 a1;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) a1[e] = fmaxf(t1[e], 0.f) * dr[e];
-                to_lds_relu(t, a1);
-            } else {
-                to_lds_relu(t, t1);
+                a1 *= dr;
             }
+            st4(A.t1s, j * L + l, t, cmp ? a1 : t1);
+            to_lds_relu(t, a1);
         }
         __syncthreads();
         gemm(f_blk + (size_t)(2 * j + 1) * NT * HK * 64, HK, 0, NT - 1, s_a, HSB, acc);

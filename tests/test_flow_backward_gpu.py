@@ -178,6 +178,22 @@ def test_flow_gradients_in_bf16_mode(D, C, H, L):
             r_, c_ = rel(b, a), cos(b, a)
             assert r_ < 1e-2 and c_ > 0.9999, (k, r_, c_)
             worst = (max(worst[0], r_), min(worst[1], c_))
+    # (a') the compact interface (bf16 activations between the kernels, bf16 gradient vectors into bf16 weight-gradient
+    #      GEMMs) against the fp32 interface of the same two kernels: bf16 rounding of stored activations / gradients only
+    flow.precision = "bf16"
+    both = {}
+    for compact in (False, True):
+        fa.COMPACT = compact
+        try:
+            both[compact] = fa._flow_backward_batched(flow, U, cg, gz, gl)
+        finally:
+            fa.COMPACT = True
+    for k, v in both[False].items():
+        if v is None:
+            continue
+        for a, b in zip(v if isinstance(v, list) else [v], both[True][k] if isinstance(v, list) else [both[True][k]]):
+            r_, c_ = rel(b, a), cos(b, a)
+            assert b.dtype == torch.float32 and r_ < 2e-2 and c_ > 0.9995, (k, r_, c_)
     # (b) end to end: against autograd through the oracle evaluated with the same operand rounding, and through the fp32 one
     from oracle import nflows_restated as nfr
     flow.precision = "bf16"
@@ -276,4 +292,11 @@ def test_hip_reevaluation_matches_tensor_ops(D, C, H, L, K):
             fp32_params = F.linear(H2[l], net.final_layer.weight * net.final_layer.mask, net.final_layer.bias)
             d = (params[l] - fp32_params).abs() / fp32_params.abs().max()
             worst["params vs fp32 operands (median)"] = max(worst.get("params vs fp32 operands (median)", 0.0), d.median().item())
+        # compact mode: the same values, bf16, in the form the backward uses them
+        HSc, T1c, T2c, Gc_, PCc, H2c, paramsc = fa._reevaluate_hip(flow, U, cg, compact=True)
+        rbf = lambda t: t.bfloat16()
+        assert HSc.dtype == torch.bfloat16 and torch.equal(HSc, rbf(F.relu(HS))) and torch.equal(T1c, rbf(F.relu(T1)))
+        assert torch.equal(H2c, rbf(H2)) and torch.equal(paramsc, params)
+        if C:
+            assert torch.equal(T2c, rbf(T2)) and torch.equal(Gc_, rbf(G)) and torch.equal(PCc, rbf(F.relu(PC)))
     print(f"\n[re-evaluation D{D} C{C} H{H} L{L}] worst relative error per tensor: " + ", ".join(f"{k} {v:.1e}" for k, v in worst.items()))
