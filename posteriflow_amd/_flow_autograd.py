@@ -133,9 +133,21 @@ REEVAL_HIP = True      # tests: False keeps the tensor-op re-evaluation in bf16 
 COMPACT = True         # tests: False keeps fp32 activations / gradient vectors between the bf16 backward kernels
 
 
+_OUT_DTYPE = [None]    # does this torch's library GEMM take out_dtype (bf16 operands, fp32 result)?  probed on first use
+
+
 def _mm32(a, b):
-    """a @ b for bf16 operands with an fp32 result (2-D or batched): the library's out_dtype path"""
-    return (torch.bmm if a.dim() == 3 else torch.mm)(a, b, out_dtype=torch.float32)
+    """a @ b for bf16 operands with an fp32 result (2-D or batched): the library's out_dtype path where this torch has it
+    (2.8+), else the bf16 product widened afterwards"""
+    f = torch.bmm if a.dim() == 3 else torch.mm
+    if _OUT_DTYPE[0] is None:
+        try:
+            out = f(a, b, out_dtype=torch.float32)
+            _OUT_DTYPE[0] = True
+            return out
+        except (TypeError, RuntimeError, NotImplementedError):
+            _OUT_DTYPE[0] = False
+    return f(a, b, out_dtype=torch.float32) if _OUT_DTYPE[0] else f(a, b).float()
 
 
 def _reevaluate_hip(flow, U, ctx, drop=None, compact=False):
