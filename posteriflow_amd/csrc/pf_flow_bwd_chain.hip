@@ -186,21 +186,27 @@ __global__ __launch_bounds__(NW * 64) void flow_bwd_chain_kernel(const ChainArgs
 #pragma unroll
         for (int i = 0; i < TPW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         const __bf16* brow = s_gpb + c * GSB + 8 * g;
+        // branch-free body: k-steps beyond KSF multiply a zero B operand and re-request the last fragment (an L1 hit).
+        // With `if (k < KSF)` around each step hipcc moved the accumulators between register sets behind every
+        // conditional block -- v_accvgpr_read / v_accvgpr_mov 5-7 wait states behind the MFMA where 8 are required
+        // (scripts/audit_accvgpr.py found 17 such sites in the bf16 variants of this kernel).
         for (int k0 = 0; k0 < KSF; k0 += PF) {
 #pragma unroll
             for (int q = 0; q < PF; ++q) {
                 const int k = k0 + q;
-                if (k < KSF) {
-                    const bf16x8 b = *reinterpret_cast<const bf16x8*>(brow + 32 * k);
+                const int kc = k < KSF ? k : KSF - 1;
+                u32x4 bu = *reinterpret_cast<const u32x4*>(brow + 32 * kc);
+                if (k >= KSF) bu = u32x4{0u, 0u, 0u, 0u};
+                const bf16x8 b = __builtin_bit_cast(bf16x8, bu);
 #pragma unroll
-                    for (int i = 0; i < TPW; ++i)
-                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, FA[q][i]), b, acc[i], 0, 0, 0);
-                    if (k + PF < KSF) {
+                for (int i = 0; i < TPW; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, FA[q][i]), b, acc[i], 0, 0, 0);
+                const int kn = k + PF < KSF ? k + PF : KSF - 1;
 #pragma unroll
-                        for (int i = 0; i < TPW; ++i) FA[q][i] = tile_ptr(fbase, KSF, i)[64 * (k + PF)];
-                    }
-                }
+                for (int i = 0; i < TPW; ++i) FA[q][i] = tile_ptr(fbase, KSF, i)[64 * kn];
             }
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) asm volatile("s_nop 7" : "+a"(acc[i]));   // loop-carried accumulators stay put
         }
         drain(acc);
     };
@@ -373,6 +379,7 @@ __global__ __launch_bounds__(NW * 64) void flow_bwd_chain_kernel(const ChainArgs
                 for (int ks = wave; ks < HK; ks += NW) {
                     const bf16x8 b = *reinterpret_cast<const bf16x8*>(s_b0 + c * HSB + 32 * ks + 8 * g);
                     part = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fr[64 * ks]), b, part, 0, 0, 0);
+                    asm volatile("s_nop 7" : "+a"(part));       // loop-carried accumulator: see f_run
                 }
             } else {
             const float* wrow = A.W0T + ((size_t)l * 16 + c) * H + 4 * g;
