@@ -222,6 +222,8 @@ def extras(flow, dev, batch):
             out[f"forward_samples_per_s_fp32_{batch}"] = batch / (ms * 1e-3)
             out[f"forward_kernel_us_fp32_{batch}"] = ms * 1e3
             out[f"forward_roofline_frac_fp32_{batch}"] = batch * flops_per_sample() / (ms * 1e-3) / 1e12 / PEAK_TFLOPS["fp32"]
+            out[f"forward_roofline_frac_mask_aware_fp32_{batch}"] = (batch * masked_flops_per_sample() / (ms * 1e-3) / 1e12
+                                                                      / PEAK_TFLOPS["fp32"])
         # the forward on a batch large enough to amortise the per-CU weight ingest
         nb = 65536
         xb, cb = make_inputs(nb, 3, dev)
@@ -231,6 +233,15 @@ def extras(flow, dev, batch):
         out["forward_samples_per_s_65536"] = nb / dt
         out["forward_tflops_65536"] = nb * flops_per_sample() / dt / 1e12
         out["forward_roofline_frac_65536"] = out["forward_tflops_65536"] / PEAK_TFLOPS[flow.precision]
+        out["forward_roofline_frac_mask_aware_65536"] = (nb * masked_flops_per_sample() / dt / 1e12
+                                                         / PEAK_TFLOPS[flow.precision])
+        del xb, cb, ob
+        nm = 16384                               # between the 16-row kernel's sweet spot and the large-batch kernel's
+        xb, cb = make_inputs(nm, 4, dev)
+        ob = torch.empty(nm, device=dev)
+        dt = timed(flow.bind_nll(xb, cb, ob), 20)
+        out["forward_samples_per_s_16384"] = nm / dt
+        out["forward_roofline_frac_16384"] = nm * flops_per_sample() / dt / 1e12 / PEAK_TFLOPS[flow.precision]
         del xb, cb, ob
         ctx1 = torch.randn(1, C, device=dev)
         for n in (4096, 131072):
@@ -273,8 +284,65 @@ def extras(flow, dev, batch):
     for _ in range(3):
         fwd_bwd()
     out[f"flow_fwd_bwd_ms_2048_{flow.precision}"] = timed(fwd_bwd, 10) * 1e3
+    out.update(config5_sampling(dev, flow.precision))
+    out.update(config4_train_step(dev, flow.precision))
     log("extras: " + ", ".join(f"{k}={v:.3g}" for k, v in out.items()))
     return out
+
+
+def config5_sampling(dev, precision, n_rank=125_000, reps=3):
+    """BASELINE config 5 on this GPU: the 12-layer D = 15 flow, one context row, this rank's share (125 000 draws = 1e6 / 8)
+    of the posterior draws through flow.inverse in chunks of 131 072 (inference/pipeline.py:169-173 uses 4096)."""
+    from posteriflow_amd import NSFPosteriorFlow
+    torch.manual_seed(0)
+    f5 = NSFPosteriorFlow(features=15, context_features=288, hidden_features=256, num_layers=12, num_bins=16,
+                          tail_bound=5.0).to(dev).eval()
+    f5.precision = precision
+    ctx = torch.randn(1, 288, generator=torch.Generator().manual_seed(1)).to(dev)
+    gen = torch.Generator(device=dev).manual_seed(1234)
+
+    def draw():
+        with torch.no_grad():
+            z = torch.randn(n_rank, 15, device=dev, generator=gen)
+            return f5.inverse(z, ctx)[0]
+
+    draw()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        draw()
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / reps
+    return {"config5_draws_per_s": n_rank / dt, "config5_ms_per_125000_draws": dt * 1e3}
+
+
+def config4_train_step(dev, precision, events=1024, reps=5):
+    """BASELINE config 4's per-GPU share: one training step at 1024 events -- on-GPU remix of resident pools ->
+    LeanNPE batch_nll (encoder + flow) -> backward -> clip + AdamW (experiments/train_lean_npe.py:357-368)."""
+    from posteriflow_amd import npe, train
+    from posteriflow_amd.remix import synthetic_dataset
+    ds = synthetic_dataset(dev, n_noise=512, n_events=512, seed=0)
+    torch.manual_seed(0)
+    model = npe.LeanNPE().to(dev).train().set_precision(precision)
+    opt = train.make_optimizer(model)
+    sched = train.make_scheduler(opt, 10000)
+    g = torch.Generator(device=dev).manual_seed(0)
+
+    def step():
+        idx = torch.randint(0, ds.n_events, (events,), device=dev, generator=g)
+        strain, labels, nsig, _ = ds.batch(idx, generator=g)
+        return train.train_step(model, opt, sched, strain, labels, nsig, row_cap=2 * events)["loss"]
+
+    for _ in range(2):
+        loss = step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        loss = step()
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / reps
+    assert torch.isfinite(torch.as_tensor(loss)).all(), "training step produced a non-finite loss"
+    return {f"train_step_ms_{events}": dt * 1e3, f"train_events_per_s_{events}": events / dt}
 
 
 def pmc_traffic(args):
@@ -475,6 +543,13 @@ def main():
         ach = args.batch * fl / (kernel_ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.precision]
         lib = __import__("posteriflow_amd")._lib.lib()
+        # the three FLOP conventions side by side: `achieved` / `frac` use SURVEY 8d's ALGORITHMIC dense-GEMM count (the
+        # contract's figure: masks not discounted); the MFMAs the dispatched kernel really issues multiply the packed stream,
+        # in which all-zero fragments of the autoregressive masks do not exist (pf_flow_issued_flop_per_row), and the useful
+        # share of those is the mask-aware count
+        fl_issued = int(lib.pf_flow_issued_flop_per_row(flow._desc(wide=flow._use_wide(args.batch))))
+        fl_masked = masked_flops_per_sample()
+        tf = lambda f: args.batch * f / (kernel_ms * 1e-3) / 1e12
         out = {
             "metric": "flow.log_prob samples/sec at batch 4096",
             "value": world * args.batch * args.steps / elapsed,
@@ -489,12 +564,17 @@ def main():
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "rows_per_workgroup": int(lib.pf_flow_rows_per_workgroup(flow._desc(wide=flow._use_wide(args.batch)), args.batch)),
                        "launch": "hipGraph" if graph is not None else (f"pre-bound launch, in-kernel (sum nll, rows) + async all-reduce every {max(1, args.allreduce_every)} steps" if collective else "pre-bound launch"),
+                       "settle": max(0, args.settle),   # untimed clock-settling launches in front of the W warm-up steps
                        "global_mean_nll": mean_nll,
                        "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                          "frac": ach / peak, "traffic": pmc_traffic(args),
                          "kernel": flow.forward_kernel_name(args.batch), "kernel_ms": kernel_ms,
-                         "flop_per_sample": fl, "flop_per_sample_mask_aware": masked_flops_per_sample(),
+                         "flop_convention": "achieved/frac: SURVEY 8d dense-GEMM count (masked zeros counted); *_issued: "
+                                            "MFMAs the kernel executes (mask-compressed stream); *_mask_aware: useful FLOP only",
+                         "flop_per_sample": fl, "flop_per_sample_issued": fl_issued, "flop_per_sample_mask_aware": fl_masked,
+                         "achieved_issued": tf(fl_issued), "frac_issued": tf(fl_issued) / peak,
+                         "achieved_mask_aware": tf(fl_masked), "frac_mask_aware": tf(fl_masked) / peak,
                          "device_ms_per_step": dev_ms / args.steps},
         }
         if windowed is not None:

@@ -340,6 +340,11 @@ const char* pf_version(void);
 /* name (as rocprofv3 prints it) of the kernel pf_flow_forward dispatches for `batch` rows; thread-local
  * storage, NULL for an unsupported desc (bench / profiling) */
 const char* pf_flow_forward_kernel_name(const PfFlowDesc* desc, int64_t batch);
+/* FLOP one batch row costs in the MFMAs pf_flow_forward actually ISSUES for this desc: 2 x 512 (fp32: 256) multiply-adds per
+ * 1-KiB fragment of the packed stream -- all-zero fragments of the autoregressive masks are neither stored nor multiplied,
+ * partly masked fragments are multiplied whole.  Lies between the mask-aware useful count and the dense-GEMM count of
+ * SURVEY 8d (bench.py reports all three). */
+int64_t pf_flow_issued_flop_per_row(const PfFlowDesc* desc);
 /* rows of the batch one workgroup processes for a given batch size (bench / tests) */
 int32_t pf_flow_rows_per_workgroup(const PfFlowDesc* desc, int64_t batch);
 

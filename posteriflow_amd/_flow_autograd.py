@@ -138,16 +138,21 @@ _OUT_DTYPE = [None]    # does this torch's library GEMM take out_dtype (bf16 ope
 
 def _mm32(a, b):
     """a @ b for bf16 operands with an fp32 result (2-D or batched): the library's out_dtype path where this torch has it
-    (2.8+), else the bf16 product widened afterwards"""
+    (2.8+).  Probed once on tiny tensors (an out-of-memory or HIP error of a real call must not be mistaken for a missing
+    feature); without it the operands are widened to fp32 -- never a bf16-rounded weight gradient -- and that is logged."""
     f = torch.bmm if a.dim() == 3 else torch.mm
     if _OUT_DTYPE[0] is None:
         try:
-            out = f(a, b, out_dtype=torch.float32)
+            t = torch.ones(1, 2, 2, dtype=torch.bfloat16, device=a.device)
+            torch.bmm(t, t, out_dtype=torch.float32)
+            torch.mm(t[0], t[0], out_dtype=torch.float32)
             _OUT_DTYPE[0] = True
-            return out
-        except (TypeError, RuntimeError, NotImplementedError):
+        except (TypeError, NotImplementedError):
             _OUT_DTYPE[0] = False
-    return f(a, b, out_dtype=torch.float32) if _OUT_DTYPE[0] else f(a, b).float()
+            import logging
+            logging.getLogger("posteriflow_amd").warning(
+                "torch.mm/bmm has no out_dtype here: bf16-mode weight-gradient GEMMs run on fp32-widened operands")
+    return f(a, b, out_dtype=torch.float32) if _OUT_DTYPE[0] else f(a.float(), b.float())
 
 
 def _reevaluate_hip(flow, U, ctx, drop=None, compact=False):
@@ -203,11 +208,17 @@ def _flow_backward_batched(flow, U, ctx, g_z, g_lad, drop=None, nll=None):
 
     # 1. conditioners
     cmp = bf and REEVAL_HIP and COMPACT
-    if cmp:          # bf16 activations in their backward form; bf16 gradient vectors; bf16 weight-gradient GEMMs
-        HSk, T1k, T2k, Gk, pck, h_last, params = _reevaluate_hip(flow, U, ctx, drop, compact=True)
+    hip_reeval = bf and REEVAL_HIP
+    if hip_reeval:
+        try:
+            re = _reevaluate_hip(flow, U, ctx, drop, compact=cmp)
+        except NotImplementedError:      # PF_ERR_UNSUPPORTED (e.g. a context too wide for the kernel's LDS image):
+            hip_reeval = cmp = False     # the tensor-op re-evaluation below, fp32 interface of the chain
+    if hip_reeval and cmp:   # bf16 activations in their backward form; bf16 gradient vectors; bf16 weight-gradient GEMMs
+        HSk, T1k, T2k, Gk, pck, h_last, params = re
         relu_h, a1s = [HSk[j] for j in range(nb)], [T1k[j] for j in range(nb)]
-    elif bf and REEVAL_HIP:
-        HSk, T1k, T2k, Gk, pck, h_last, params = _reevaluate_hip(flow, U, ctx, drop)
+    elif hip_reeval:
+        HSk, T1k, T2k, Gk, pck, h_last, params = re
         relu_h = [F.relu(HSk[j]) for j in range(nb)]
         a1s = [F.relu(T1k[j]) if drop is None else F.relu(T1k[j]) * drop[j] for j in range(nb)]
     else:

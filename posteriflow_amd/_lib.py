@@ -101,6 +101,7 @@ SYMBOLS = {
     "pf_last_error": (C.c_char_p, []),
     "pf_version": (C.c_char_p, []),
     "pf_flow_rows_per_workgroup": (C.c_int32, [_P, C.c_int64]),
+    "pf_flow_issued_flop_per_row": (C.c_int64, [_P]),
     "pf_flow_forward_kernel_name": (C.c_char_p, [_P, C.c_int64]),
 }
 

@@ -451,6 +451,15 @@ const char* pf_flow_forward_kernel_name(const PfFlowDesc* desc, int64_t batch) {
     return name;
 }
 
+int64_t pf_flow_issued_flop_per_row(const PfFlowDesc* desc) {
+    pf::FlowPlan L;
+    if (compute_layout_of(desc, L) != PF_OK) return -1;
+    // every 1-KiB fragment of the stream is multiplied with each row once: bf16 16 units x 32 k (wide: 32 x 16) = 512 MAC,
+    // fp32 16 x 16 = 256 MAC; the zero padding behind each wave's stream (kWindowPad) is never multiplied
+    const int64_t frags = L.wide ? L.fragsTotal : (int64_t)L.L * L.NF * L.NW;
+    return frags * (L.bf16 ? 1024 : 512);
+}
+
 int32_t pf_flow_rows_per_workgroup(const PfFlowDesc* desc, int64_t batch) {
     pf::FlowPlan L;
     if (compute_layout_of(desc, L) != PF_OK) return -1;

@@ -473,8 +473,7 @@ static int launch_layer(const ConvParams& p, hipStream_t s) {
     constexpr StemLayer L = stem_layer(LAYER);
     const size_t lds = stem_lds(LAYER, BF16);
     auto k = conv_gemm_kernel<BF16, LAYER, G.cg, G.nwaves>;
-    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k),
-            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PF_ERR_HIP;
+    if (lds > 64 * 1024 && !opt_in_lds(reinterpret_cast<const void*>(k), (int)lds)) return PF_ERR_HIP;
     const unsigned gx = (L.lout + G.cg * 16 - 1) / (G.cg * 16);
     hipLaunchKernelGGL(k, dim3(gx, (unsigned)p.n_seq), dim3(G.nwaves * 64), lds, s, p);
     return launch_status();
@@ -485,8 +484,7 @@ static int launch_fused12(const ConvParams& p, hipStream_t s) {
     constexpr StemLayer L = stem_layer(1);
     const size_t lds = stem_lds_fused(BF16);
     auto k = conv_gemm_kernel<BF16, 1, kFuseCG, 4, true>;
-    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k),
-            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PF_ERR_HIP;
+    if (lds > 64 * 1024 && !opt_in_lds(reinterpret_cast<const void*>(k), (int)lds)) return PF_ERR_HIP;
     const unsigned gx = (L.lout + kFuseCG * 16 - 1) / (kFuseCG * 16);
     hipLaunchKernelGGL(k, dim3(gx, (unsigned)p.n_seq), dim3(4 * 64), lds, s, p);
     return launch_status();

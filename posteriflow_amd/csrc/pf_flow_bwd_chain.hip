@@ -429,7 +429,7 @@ int flow_backward_chain(const PfFlowDesc& d, float deriv_const, const PfFlowBwdC
     const unsigned grid = (unsigned)((a.batch + 15) / 16);
     auto launch = [&](auto kern) {
         if (lds > 64 * 1024 &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            !opt_in_lds(reinterpret_cast<const void*>(kern), (int)lds))
             return PF_ERR_HIP;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(nw * 64), lds, s, p);
         return launch_status();

@@ -188,13 +188,11 @@ int launch_ctx_project(const FlowPlan& L, const char* packed, const float* ctx, 
     const size_t lds = (size_t)L.CK * kCtxRowGroups * kFragBytes;
     if (L.bf16) {
         auto k = ctx_project_kernel<true>;
-        if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k),
-                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PF_ERR_HIP;
+        if (lds > 64 * 1024 && !opt_in_lds(reinterpret_cast<const void*>(k), (int)lds)) return PF_ERR_HIP;
         hipLaunchKernelGGL(k, dim3(row_blocks, chunks), dim3(256), lds, s, p);
     } else {
         auto k = ctx_project_kernel<false>;
-        if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k),
-                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PF_ERR_HIP;
+        if (lds > 64 * 1024 && !opt_in_lds(reinterpret_cast<const void*>(k), (int)lds)) return PF_ERR_HIP;
         hipLaunchKernelGGL(k, dim3(row_blocks, chunks), dim3(256), lds, s, p);
     }
     return launch_status();

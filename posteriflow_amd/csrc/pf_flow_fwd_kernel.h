@@ -917,8 +917,7 @@ inline int launch_variant(const FwdParams& p, hipStream_t s) {
         else return flow_kernel<BF16, NT, R, CKM, DENSE, INV>;
     }();
     if (lds > 64 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess)
+        !opt_in_lds(reinterpret_cast<const void*>(kern), (int)lds))
         return PF_ERR_HIP;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT * 32), lds, s, p);
     return launch_status();

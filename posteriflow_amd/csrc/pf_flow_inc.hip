@@ -572,7 +572,7 @@ int flow_inverse_inc(const PfFlowDesc& d, float deriv_const, const int32_t* u1, 
         std::lock_guard<std::mutex> lock(mu);
         if (!configured[devid]) {
             for (const Kern k : kerns)
-                if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
+                if (!opt_in_lds(reinterpret_cast<const void*>(k), 96 * 1024))
                     return PF_ERR_HIP;
             configured[devid] = true;
         }

@@ -261,7 +261,9 @@ int flow_reevaluate(const FlowPlan& P, const PfFlowReevalArgs& a, hipStream_t s)
     const size_t lds = ((size_t)16 * (32 * CKB + 8) + 16 * 40 + 16 * (P.H + 8)) * 2;
     const dim3 grid((unsigned)((a.batch + 15) / 16), (unsigned)P.L);
     const int nw = P.H % 128 == 0 ? 8 : 4;
+    if (lds > 160 * 1024) return PF_ERR_UNSUPPORTED;        // context wider than the LDS image holds (C > ~2400)
     auto launch = [&](auto kern) {
+        if (lds > 64 * 1024 && !opt_in_lds(reinterpret_cast<const void*>(kern), (int)lds)) return (int)PF_ERR_HIP;
         hipLaunchKernelGGL(kern, grid, dim3(nw * 64), lds, s, p);
         return launch_status();
     };

@@ -14,7 +14,7 @@ int PF_CAT(launch_flow_wide_d, PF_WIDE_D)(const FwdParams& p, hipStream_t s) {
     if (p.plan.D != D || p.plan.CKM != CKS || !p.plan.wide) return PF_ERR_UNSUPPORTED;
     auto kern = flow_wide_kernel<D, CKS>;
     constexpr int lds = wide::lds_bytes();
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+    if (!opt_in_lds(reinterpret_cast<const void*>(kern), lds))
         return PF_ERR_HIP;
     const unsigned grid = (unsigned)((p.batch + wide::kRowsPerWG - 1) / wide::kRowsPerWG);
 #if PF_WIDE_TRACE

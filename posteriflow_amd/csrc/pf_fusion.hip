@@ -524,8 +524,7 @@ int fusion_forward(const char* packed, float* tokens, int n_tokens, const float*
                    int64_t n_events, float* pooled, hipStream_t s) {
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(fusion_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess)
+        if (!opt_in_lds(reinterpret_cast<const void*>(fusion_kernel), kLds))
             return PF_ERR_HIP;
         configured = true;
     }

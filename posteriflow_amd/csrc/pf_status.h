@@ -18,4 +18,13 @@ inline int hip_failed(hipError_t e) {       // for hipFuncSetAttribute and frien
     g_hip_error = static_cast<int>(e);
     return PF_ERR_HIP;
 }
+// opt a kernel in to more than 64 KiB of dynamic LDS; a failure is recorded for pf_last_error() (returning PF_ERR_HIP
+// without it used to print whatever stale code g_hip_error held, possibly "no error")
+inline bool opt_in_lds(const void* kernel, int bytes) {
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) return true;
+    g_hip_error = static_cast<int>(e);
+    (void)hipGetLastError();
+    return false;
+}
 }  // namespace pf

@@ -332,3 +332,27 @@ class RemixDataset:
 
     def __getitem__(self, i):
         return tuple(t[0] for t in self.batch([i], exact=True))
+
+
+def synthetic_dataset(device="cuda", n_noise: int = 512, n_events: int = 512, seed: int = 0, **kw) -> RemixDataset:
+    """A synthetic memmap cache in the reference's format (unit white noise rows, weak random "signals", 1-3 signals per
+    event, labels inside the prior box of lean_npe.py:54-66) written to a temporary directory and loaded as a
+    RemixDataset with its pools resident in HBM: the config-4 workload of bench.py / the tests (there is no network for
+    the real 22 GB dataset).  ``n_events`` is also available as ``ds.n_events``."""
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix="pf_remix_")
+    rng = np.random.default_rng(seed)
+    counts = rng.integers(1, 4, n_events)
+    m = int(counts.sum())
+    np.save(os.path.join(tmp, "noise.npy"), rng.standard_normal((n_noise, 3, T_LEN), dtype=np.float32).astype(np.float16))
+    np.save(os.path.join(tmp, "signals.npy"),
+            (0.1 * rng.standard_normal((m, 3, T_LEN), dtype=np.float32)).astype(np.float16))
+    lo = np.array([5, 5, 100, 0, -1.5, 0, 0, 0, -1.2, 0, 0], np.float32)
+    hi = np.array([80, 60, 1500, 6.2, 1.5, 3.1, 3.1, 6.2, 1.2, 1, 1], np.float32)
+    np.save(os.path.join(tmp, "params.npy"), lo + (hi - lo) * rng.random((m, 11), dtype=np.float32))
+    starts = np.concatenate([[0], np.cumsum(counts)[:-1]])
+    with open(os.path.join(tmp, "events.json"), "w") as fh:
+        json.dump({"n_noise": n_noise, "n_signals": m, "events": [[int(a), int(b)] for a, b in zip(starts, counts)]}, fh)
+    ds = RemixDataset(tmp, seed=seed, device=device, **kw)
+    ds.n_events = n_events
+    return ds

@@ -75,11 +75,19 @@ class OverlappedGradReducer:
 
     The gradients of all trainable parameters live in a few pre-allocated flat fp32 buckets (``p.grad`` is a view into
     its bucket, so nothing is concatenated or copied back); buckets are filled in reverse parameter order -- roughly
-    the order in which backward produces gradients -- and a post-accumulate hook launches the bucket's asynchronous
-    all-reduce (RCCL over xGMI; gloo in the CPU tests) the moment its last gradient has been accumulated, while
-    autograd is still working on the earlier layers.  ``finish()`` waits for the outstanding reductions and scales by
-    1 / world.  35 MB of fp32 gradients = 4 buckets of ~9 MB: a ring all-reduce of one bucket is ~0.1 ms per link
-    direction, hidden behind the ~30 ms backward of the encoder.
+    the order in which backward produces gradients -- and a post-accumulate hook marks a bucket ready the moment its
+    last gradient has been accumulated, while autograd is still working on the earlier layers.  ``finish()`` waits
+    for the outstanding reductions and scales by 1 / world.  35 MB of fp32 gradients = 4 buckets of ~9 MB: a ring
+    all-reduce of one bucket is ~0.1 ms per link direction, hidden behind the backward of the encoder.
+
+    Contract -- ONE ``backward()`` per ``zero()``:
+    * collectives are issued in bucket order on every rank (bucket i goes out only after buckets 0 .. i-1, whatever
+      order the hooks fire in; what is not out when backward ends goes out in ``finish()``, in order): ranks whose
+      graphs differ (a parameter unused on some of them) still issue the same sequence of all-reduces;
+    * a gradient that arrives for a bucket whose all-reduce is already in flight -- a second ``backward()`` before
+      ``finish()`` / ``zero()`` (gradient accumulation, several losses) -- would be added to a buffer that is being or has
+      been reduced and never be reduced itself: the hook raises instead.  Accumulate the LOSSES and call backward once,
+      or use ``allreduce_gradients`` after the last backward.
 
     Use: ``reducer.zero()`` instead of ``opt.zero_grad()``, ``loss.backward()``, ``reducer.finish()``, clip, step."""
 
@@ -101,6 +109,7 @@ class OverlappedGradReducer:
                 cur, size = [], 0
         if cur:
             self._close(cur, size)
+        self._next = 0                       # index of the first bucket whose all-reduce has not been issued
         self._hooks = []
         for bi, b in enumerate(self.buckets):
             for p in b["params"]:
@@ -120,10 +129,20 @@ class OverlappedGradReducer:
     def _make_hook(self, bi):
         def hook(param):
             b = self.buckets[bi]
+            if b["launched"]:
+                raise RuntimeError(
+                    "OverlappedGradReducer: a gradient arrived for a bucket whose all-reduce has already been issued "
+                    "(second backward() before finish()/zero()?): it would never be reduced. One backward per zero().")
             b["pending"] -= 1
             if b["pending"] == 0:
-                self._launch(b)
+                self._launch_ready()
         return hook
+
+    def _launch_ready(self):
+        """issue, in bucket order, the all-reduce of every leading bucket that is complete"""
+        while self._next < len(self.buckets) and self.buckets[self._next]["pending"] <= 0:
+            self._launch(self.buckets[self._next])
+            self._next += 1
 
     def _launch(self, b):
         if b["launched"]:
@@ -134,6 +153,7 @@ class OverlappedGradReducer:
 
     def zero(self):
         """zero the buckets (p.grad stay views into them) and re-arm the hooks' counters"""
+        self._next = 0
         for b in self.buckets:
             b["flat"].zero_()
             b["pending"], b["work"], b["launched"] = len(b["params"]), None, False
@@ -144,9 +164,11 @@ class OverlappedGradReducer:
                 off += p.numel()
 
     def finish(self):
-        """after backward(): reduce the buckets whose parameters did not all receive a gradient, wait, take the mean"""
-        for b in self.buckets:
+        """after backward(): reduce -- in bucket order -- the buckets that are not out yet (parameters without a gradient
+        this step), wait, take the mean"""
+        for b in self.buckets[self._next:]:
             self._launch(b)
+        self._next = len(self.buckets)
         for b in self.buckets:
             if b["work"] is not None:
                 b["work"].wait()
@@ -161,10 +183,11 @@ class OverlappedGradReducer:
 
 
 def train_step(model: LeanNPE, opt, sched, strain, params, nsig, asd_bands=None, group=None,
-               reducer: Optional[OverlappedGradReducer] = None) -> Dict[str, float]:
+               reducer: Optional[OverlappedGradReducer] = None, row_cap: Optional[int] = None) -> Dict[str, float]:
     """One optimisation step on this rank's shard of the batch.  With a ``reducer`` the gradient all-reduce overlaps
-    the backward pass; without one (single rank, or the simple path) it runs after it."""
-    loss = batch_nll(model, strain, params, nsig, asd_bands)
+    the backward pass (one backward per step: the reducer's contract); without one (single rank, or the simple path) it
+    runs after it.  ``row_cap``: static bound on the (event, rank) pairs that go through the flow (``batch_nll``)."""
+    loss = batch_nll(model, strain, params, nsig, asd_bands, row_cap=row_cap)
     if reducer is not None:
         reducer.zero()
         loss.backward()

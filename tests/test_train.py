@@ -56,6 +56,33 @@ for p, w in zip(net.parameters(), want):
     assert torch.allclose(p.grad, w, atol=1e-6)
 assert torch.equal(extra.grad, torch.zeros(5))
 red2.close()
+# the one-backward-per-zero() contract is enforced: a second backward would add to a bucket already being reduced
+red3 = OverlappedGradReducer(net.parameters(), n_buckets=2)
+red3.zero()
+torch.nn.functional.mse_loss(net(x[lo:hi]), y[lo:hi]).backward()
+try:
+    torch.nn.functional.mse_loss(net(x[lo:hi]), y[lo:hi]).backward()
+    raise SystemExit("second backward() before finish() was accepted")
+except RuntimeError as e:
+    assert "One backward per zero()" in str(e), e
+red3.finish()
+red3.close()
+# graphs that differ between ranks (rank 1 does not use the first layer's bias... here: the whole first Linear is
+# detached on rank 1): every rank still issues the all-reduces of buckets 0, 1, 2 in that order -- no hang, and the mean
+# counts the missing gradient as zero
+red4 = OverlappedGradReducer(net.parameters(), n_buckets=3)
+red4.zero()
+h = net[0](x[lo:hi])
+if rank == 1:
+    h = h.detach()
+torch.nn.functional.mse_loss(net[2](torch.relu(h)), y[lo:hi]).backward()
+red4.finish()
+g0 = torch.autograd.grad(torch.nn.functional.mse_loss(net(x[:32]), y[:32]), list(net[0].parameters()))
+for p, w in zip(net[0].parameters(), g0):
+    assert torch.allclose(p.grad, 0.5 * w, atol=1e-6), (p.grad - 0.5 * w).abs().max()
+for p, w in zip(net[2].parameters(), want[2:]):
+    assert torch.allclose(p.grad, w, atol=1e-6)
+red4.close()
 dist.destroy_process_group()
 print("ok", rank)
 """
