@@ -143,8 +143,9 @@ def test_flow_gradients_in_bf16_mode(D, C, H, L):
         0.99999).  The re-evaluation kernel has its own test (test_hip_reevaluation_matches_tensor_ops, 4e-6).
       * End to end against autograd through the fp32 oracle the bf16 FORWARD dominates: the layer inputs it keeps are
         ~1e-2 from the fp32 trajectory, and a spline gradient is not smooth across knots -- with the fp32 chain on those
-        same inputs the x-gradient's cosine is already 0.993-0.999 (scripts/debug_bwd_bf16.py).  Held to: cosine of the
-        whole parameter gradient > 0.98, of the x- and context gradients > 0.98.  The fp32 mode is the tight one
+        same inputs the x-gradient's cosine is already 0.993-0.999 (scripts/debug_bwd_bf16.py).  Held to: cosine > 0.999
+        against autograd through the oracle evaluated with the SAME operand rounding (measured 0.99999-1.00000 since the
+        re-evaluation kernel and the compact interface), and as close to the fp32 oracle as that same-rounding oracle is.  The fp32 mode is the tight one
         (test_flow_gradients_match_oracle_autograd)."""
     from helpers import flow_inputs, make_pair
     from posteriflow_amd import _flow_autograd as fa
@@ -230,7 +231,8 @@ def test_flow_gradients_in_bf16_mode(D, C, H, L):
         print(f"      {what}: cosine vs same-rounding oracle {c_emu:.5f}, vs fp32 oracle {c_32:.5f} (same-rounding oracle vs fp32 oracle: {c_inh:.5f})")
         # what bf16 operands cost is the emulation's own distance from fp32 (0.86 on the D7 case: three rows whose spline bin
         # flips carry the gradient): the kernel path must be as close to fp32 as the emulation is, and close to the emulation
-        assert c_emu > 0.95 and c_32 > c_inh - 0.05, (what, c_emu, c_32, c_inh)
+        # measured (final build of round 2, every shape): 0.99999 - 1.00000 against the same-rounding oracle
+        assert c_emu > 0.999 and c_32 > c_inh - 0.01, (what, c_emu, c_32, c_inh)
 
 
 @pytest.mark.parametrize("D,C,H,L,K", [(11, 288, 256, 3, 16), (15, 288, 256, 2, 16), (4, 0, 64, 3, 8), (7, 40, 128, 2, 10),

@@ -63,6 +63,8 @@ def run_case(name, precision, scale=1.0, hoist=True):
         eld_ref=(ld32.double() - ld64).abs().max().item(),
         ez_emu=(z - zemu.double()).abs().max(dim=1).values if precision == "bf16" else None,
         eld_emu=(ld - ldemu.double()).abs() if precision == "bf16" else None,
+        ez_emu64=(zemu.double() - z64).abs().max().item() if precision == "bf16" else None,
+        eld_emu64=(ldemu.double() - ld64).abs().max().item() if precision == "bf16" else None,
         z=z, z64=z64)
 
 
@@ -93,7 +95,11 @@ def test_forward_bf16_tolerance(name, hoist):
     # on a bf16 rounding boundary differ by one bf16 ulp there, amplified by later layers
     assert r["ez_emu"].median() < 5e-4 and r["eld_emu"].median() < 5e-3
     assert r["ez_emu"].max() < 0.1 and r["eld_emu"].max() < 0.5
-    assert r["ez"] < 1.0 and r["eld"] < 4.0
+    # against fp64 the bound is what the arithmetic itself costs: twice the distance of the CPU evaluation with the same
+    # operand rounding (measured over the four configs: kernel 4e-3 ... 0.5 on z, 2e-2 ... 2.1 on log-det, the emulation
+    # the same to two digits), not a flat "< 1.0 / < 4.0"
+    print(f"      same-rounding oracle vs fp64: |z| {r['ez_emu64']:.2e} |ld| {r['eld_emu64']:.2e}")
+    assert r["ez"] < 2.0 * r["ez_emu64"] + 1e-3 and r["eld"] < 2.0 * r["eld_emu64"] + 5e-3
 
 
 def test_tail_entries_are_identity_through_the_first_layer():

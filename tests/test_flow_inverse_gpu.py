@@ -176,6 +176,48 @@ def test_sharded_draw_statistics_match_the_oracle():
         assert (torch.quantile(a, qs.double()) - torch.quantile(b, qs.double())).abs().max().item() < 0.08 * scale
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_config5_draw_statistics_at_full_depth(precision):
+    """SURVEY 8d, BASELINE config 5 as prescribed: the 12-layer D = 15 flow, ONE context row, 1e5 draws from the GPU
+    (incremental inverse, sharded with per-rank generators exactly as the 8-GPU job shards 1e6) against 1e5 independent
+    draws of the CPU restatement (nflows' D-pass inverse): per-dimension mean / std / quantiles (5, 25, 50, 75, 95 %) and
+    a two-sample Kolmogorov-Smirnov test per dimension.  fp32 is the parity mode; bf16 (the throughput mode: bf16 GEMM
+    operands) is held to the same quantile bounds and a KS statistic < 0.01 -- at n = 1e5 the KS p-value resolves shifts of
+    0.5 % of a standard deviation, which is the size of bf16 operand rounding itself."""
+    from scipy.stats import ks_2samp
+    from posteriflow_amd.dist import rank_generator, shard_bounds
+    D, C, L, n = 15, 288, 12, 100_000
+    ref, _, flow = make_pair(D, C, 256, L, 16, 5.0, scale=2.0)
+    flow.precision = precision
+    ctx = torch.randn(1, C, generator=torch.Generator().manual_seed(5))
+    world, parts = 8, []
+    with torch.no_grad():
+        for rank in range(world):
+            lo, hi = shard_bounds(n, rank, world)
+            z = torch.randn(hi - lo, D, device="cuda", generator=rank_generator(100, rank, "cuda"))
+            parts.append(flow.inverse(z, ctx.cuda())[0].cpu())
+        got = torch.cat(parts)
+        want = torch.cat([ref.inverse(torch.randn(10_000, D, generator=torch.Generator().manual_seed(70 + i)),
+                                      ctx.expand(10_000, -1))[0] for i in range(n // 10_000)])
+    want = want.clamp(-3.0, 3.0)                   # NSFPosteriorFlow.inverse clamps to +-FLOW_NORM_BOUND (flows.py:654)
+    assert got.shape == want.shape == (n, D) and torch.isfinite(got).all()
+    qs = torch.tensor([0.05, 0.25, 0.5, 0.75, 0.95], dtype=torch.float64)
+    worst_ks, worst_q = 0.0, 0.0
+    for d in range(D):
+        a, b = got[:, d].double(), want[:, d].double()
+        ks = ks_2samp(a.numpy(), b.numpy())
+        scale = b.std().item()
+        dq = (torch.quantile(a, qs) - torch.quantile(b, qs)).abs().max().item() / scale
+        worst_ks, worst_q = max(worst_ks, ks.statistic), max(worst_q, dq)
+        if precision == "fp32":
+            assert ks.pvalue > 1e-4, (d, ks)
+        assert ks.statistic < 0.01, (d, ks)
+        assert abs(a.mean().item() - b.mean().item()) < 6 * scale * (2.0 / n) ** 0.5 + (0.0 if precision == "fp32" else 5e-3 * scale)
+        assert abs(a.std().item() / scale - 1.0) < 0.02
+        assert dq < 0.03, (d, dq)
+    print(f"\n[config 5 {precision}] 1e5 draws, 12 layers: worst KS statistic {worst_ks:.4f}, worst quantile gap {worst_q:.4f} sigma")
+
+
 INC_CONFIGS = {
     "leannpe_R": (11, 288, 256, 10, 16, 5.0, 200),
     "baseline_B5": (15, 288, 256, 12, 16, 5.0, 96),

@@ -121,3 +121,29 @@ def test_train_step_reduces_loss_gpu(precision):
     model.eval()
     with torch.no_grad():                       # inference path (HIP stem + flow) still works after updates
         assert torch.isfinite(model.sample_posterior(strain[:2], n_samples=16)).all()
+
+
+@pytest.mark.gpu
+def test_config4_training_step_at_per_gpu_size():
+    """BASELINE config 4 at its per-GPU size (8192 / 8 = 1024 events): on-GPU remix of resident pools -> batch_nll
+    (encoder + flow, one static-shape flow call) -> backward -> clip + AdamW, in the throughput mode; three steps, finite
+    loss and gradient norm, parameters really move (experiments/train_lean_npe.py:108-127, 357-368)."""
+    from posteriflow_amd import LeanNPE
+    from posteriflow_amd.remix import synthetic_dataset
+    from posteriflow_amd.train import make_optimizer, make_scheduler, train_step
+    dev = torch.device("cuda")
+    ds = synthetic_dataset(dev, n_noise=256, n_events=256, seed=0)
+    torch.manual_seed(0)
+    model = LeanNPE().to(dev).train().set_precision("bf16")
+    opt = make_optimizer(model)
+    sched = make_scheduler(opt, total_steps=1000, warmup_steps=2)
+    g = torch.Generator(device=dev).manual_seed(0)
+    before = [p.detach().clone() for p in list(model.parameters())[:4]]
+    out = []
+    for _ in range(3):
+        idx = torch.randint(0, ds.n_events, (1024,), device=dev, generator=g)
+        strain, labels, nsig, _ = ds.batch(idx, generator=g)
+        assert strain.shape == (1024, 3, 16384)
+        out.append(train_step(model, opt, sched, strain, labels, nsig, row_cap=2048))
+    assert all(math.isfinite(o["loss"]) and math.isfinite(o["grad_norm"]) and o["grad_norm"] > 0 for o in out), out
+    assert any(not torch.equal(b, p.detach()) for b, p in zip(before, list(model.parameters())[:4]))
