@@ -12,6 +12,8 @@
  *   pf_flow_pack      the per-call `weight * mask` of nflows MaskedLinear, done once
  *   pf_embed_fusion_forward  LeanStrainEncoder fusion transformer + pool attention  lean_npe.py:226-229
  *   pf_remix_forward  RemixDataset.__getitem__ (algebra)      experiments/remix_data.py:218-299
+ *   pf_embed_train_forward / _backward  LeanStrainEncoder._compute_feats under autograd (training)  lean_npe.py:199-233,
+ *                     experiments/train_lean_npe.py:363-364
  *   pf_embed_stem_forward  LeanStrainEncoder stem + energy windows  src/ahsd/models/lean_npe.py:207-217
  *
  * Conventions
@@ -314,6 +316,119 @@ int64_t pf_embed_fusion_packed_bytes(void);
 int pf_embed_fusion_pack(const float* raw, void* packed, void* stream);
 int pf_embed_fusion_forward(const void* packed, float* tokens, int32_t n_tokens, const float* token_bias,
                             const float* pool_queries, int64_t n_events, float* pooled, void* stream);
+
+/* ---- strain embedding: training path (forward that keeps what the backward needs, and the backward) --------------------
+ * One C call each for a differentiable / train()-mode evaluation of LeanStrainEncoder._compute_feats up to the pooled
+ * features (src/ahsd/models/lean_npe.py:199-233: stem, positional + detector embedding, optional extra tokens, 3 pre-norm
+ * TransformerEncoderLayers with dropout, K / V side of the attention pool) and for its backward -- what autograd records
+ * under experiments/train_lean_npe.py:363-364 for the reference.  Every kernel is enqueued on `stream`; nothing returns to
+ * the host in between.
+ * Raw parameters (fp32, flat; gradients come back in the same layout): stem.{0,2,4,6}.{weight,bias}; per layer l = 0..2:
+ * norm1.{weight,bias}, self_attn.in_proj_{weight,bias}, self_attn.out_proj.{weight,bias}, norm2.{weight,bias},
+ * linear1.{weight,bias}, linear2.{weight,bias}; pool_attn.in_proj_weight [576][192] and in_proj_bias [576] WHOLE (the query
+ * rows are not read; their gradient is zero).
+ * Dropout (nn.TransformerEncoderLayer: attention probabilities, both residual branches, the FFN's hidden layer) is a counter
+ * hash of (dropout_seed, site, element): the backward regenerates the factors, nothing is stored.
+ * extra_tokens [n_events][n_extra_tokens][192] or NULL; token_bias [n_extra + 61 n_det][192] or NULL (rows of extra tokens
+ * are not read); pool_q [8][192] = projected, scaled pool queries as for pf_embed_fusion_forward;
+ * pooled [n_events][8][192]; log_energy [n_events * n_det][16].
+ * The workspace written by the forward must reach the backward unchanged.  grad_raw is zeroed and filled by the backward
+ * (float atomics across workgroups: the last bits vary from run to run); grad_extra / grad_token_bias / grad_pool_q may be
+ * NULL. */
+typedef struct PfEmbedTrainDesc {
+    int32_t precision;        /* PF_PREC_* (bf16: bf16 activations in HBM, bf16 MFMA operands, fp32 accumulate / residual / LayerNorm) */
+    int32_t n_detectors;      /* 1..3 */
+    int32_t n_extra_tokens;   /* tokens prepended per event (CoherentEncoder: 4), n_extra + 61 n_det <= 192 */
+    int32_t training;         /* 1: dropout active */
+    float dropout_p;
+    uint64_t dropout_seed;
+} PfEmbedTrainDesc;
+int64_t pf_embed_train_raw_param_count(void);
+int64_t pf_embed_train_packed_bytes(int32_t precision);
+int pf_embed_train_pack(int32_t precision, const float* raw, void* packed, void* stream);
+int64_t pf_embed_train_workspace_bytes(const PfEmbedTrainDesc* desc, int64_t n_events);
+int pf_embed_train_forward(const PfEmbedTrainDesc* desc, const void* packed, const float* raw, const float* strain,
+                           const float* extra_tokens, const float* token_bias, const float* pool_q, int64_t n_events,
+                           float* pooled, float* log_energy, void* workspace, int64_t workspace_bytes, void* stream);
+int pf_embed_train_backward(const PfEmbedTrainDesc* desc, const void* packed, const float* raw, const float* pool_q,
+                            const float* grad_pooled, int64_t n_events, void* workspace, int64_t workspace_bytes,
+                            float* grad_raw, float* grad_extra_tokens, float* grad_token_bias, float* grad_pool_q,
+                            void* stream);
+
+/* ---- the building blocks of the training path (also used by the flow's weight gradients), exported for tests ------------
+ * "act type" = bf16 (PF_PREC_BF16) or fp32 (PF_PREC_F32).  Sequence-strided rows: row m of an operand = sequence
+ * m / rows_per_seq, position m % rows_per_seq, at base + seq * seq_stride + pos * ld (elements) -- with ld < K the rows are
+ * OVERLAPPING windows of a position-major activation array: a convolution's im2col matrix without materialising it. */
+#define PF_EPI_PLAIN 0   /* out = act(v),                         v = sum_k A[m,k] W[n,k] + bias[n]                   */
+#define PF_EPI_GELU 1    /* out = act(D gelu(v)), dact = act(D gelu'(v)),  D = dropout factor (1 when drop_p = 0)     */
+#define PF_EPI_RESID 2   /* out (fp32) = resid + D v                                                                  */
+#define PF_EPI_MUL 3     /* out = act(v * mul)                                                                        */
+typedef struct PfDenseArgs {
+    const void* A;            /* activations, act type */
+    int64_t M;                /* rows */
+    int64_t rows_per_seq;     /* = M for a plain matrix */
+    int64_t a_seq_stride;
+    int32_t lda;
+    int32_t K, N, KC;         /* reduction length, output units (multiple of 16), k-chunk staged in LDS (divides K, multiple of 64;
+                               * K / KC > 1 needs N <= 256) */
+    const void* wfrags;       /* W as MFMA A-fragments: pf_dense_pack_matrix */
+    const float* bias;        /* [N] or NULL */
+    void* out;                /* row m at out + seq * o_seq_stride + pos * ldo */
+    int64_t o_seq_stride;
+    int32_t ldo;
+    int64_t o_valid_per_seq;  /* > 0: elements of a sequence's output that exist (transposed convolution: Lin * Cin) */
+    int64_t x_seq_stride;     /* sequence stride of dact / resid / mul (0: o_seq_stride) */
+    void* dact;               /* PF_EPI_GELU, or NULL */
+    const float* resid;       /* PF_EPI_RESID */
+    const void* mul;          /* PF_EPI_MUL, act type */
+    float drop_p;
+    uint32_t seed, site;      /* dropout factor of element (m, n) = hash(seed, site, m * N + n) */
+    int32_t out_f32;          /* PF_EPI_PLAIN: fp32 output in either precision */
+} PfDenseArgs;
+typedef struct PfDenseTnArgs {  /* dW[n1][n2] += sum_m G[m][n1] A[m][n2],  db[n1] += sum_m G[m][n1]  (float atomics) */
+    const void* G; int64_t g_seq_stride; int32_t ldg;
+    const void* A; int64_t a_seq_stride; int32_t lda;
+    int64_t M, rows_per_seq;
+    int32_t N1, N2;           /* multiples of 8 (bf16) / 4 (fp32) */
+    float* dW; int32_t ldw;
+    int32_t conv_cin, conv_kw;   /* > 0: column n2 = tap * cin + ch lands at ch * kw + tap (Conv1d weight [cout][cin][kw]) */
+    float* db;                /* or NULL */
+    int32_t splits;           /* workgroups along M per output tile; <= 0: chosen by the library */
+} PfDenseTnArgs;
+/* mode 0: W[n][k] = src[n * ld + k]; 1: W[n][k] = src[k * ld + n]; out: pf_dense_frag_bytes(precision, N, K) bytes */
+int64_t pf_dense_frag_bytes(int32_t precision, int32_t N, int32_t K);
+int pf_dense_pack_matrix(int32_t precision, const float* src, int32_t mode, int32_t ld, int32_t N, int32_t K, void* out, void* stream);
+int pf_dense_nt(int32_t precision, int32_t epilogue, const PfDenseArgs* args, void* stream);
+int pf_dense_tn(int32_t precision, const PfDenseTnArgs* args, void* stream);
+/* dropout factor of the training path, for tests that rebuild the masks: 0 or 1 / (1 - p) */
+float pf_dropout_factor(float p, uint32_t seed, uint32_t site, uint32_t index);
+
+typedef struct PfLnArgs {       /* LayerNorm over 192 features, eps 1e-5 */
+    const float* x; const float* gamma; const float* beta; int64_t M;
+    void* y; float* mean; float* rstd;                      /* forward outputs: y act type [M][192] */
+    const void* dy; const float* dres; float* dx;           /* backward: dx = dres + LN'(dy) */
+    void* gout;                                             /* act(dx * dropout factor(seed, site, m * 192 + c)) or NULL */
+    float* dgamma; float* dbeta;                            /* += (float atomics) */
+    float drop_p; uint32_t seed, site;
+} PfLnArgs;
+int pf_enc_ln_forward(int32_t precision, const PfLnArgs* args, void* stream);
+int pf_enc_ln_backward(int32_t precision, const PfLnArgs* args, void* stream);
+typedef struct PfAttnArgs {     /* 6-head self-attention over T <= 192 tokens, head dimension 32 */
+    const void* qkv;          /* [B * T][576] act type: q | k | v */
+    int64_t B; int32_t T;
+    void* out;                /* [B * T][192] act type: forward output (read by the backward) */
+    float* lse;               /* [B][6][T] */
+    float drop_p; uint32_t seed, site;   /* factor of (event e, head h, query q, key k) = hash(seed, site, ((e 6 + h) T + q) T + k) */
+    const void* dout; void* dqkv;
+} PfAttnArgs;
+int pf_enc_attn_forward(int32_t precision, const PfAttnArgs* args, void* stream);
+int pf_enc_attn_backward(int32_t precision, const PfAttnArgs* args, void* stream);
+typedef struct PfPoolArgs {     /* 8 learned queries per head over the tokens of an event */
+    const void* kv; const float* q; int64_t B; int32_t T;
+    float* pooled; const float* dpooled; void* dkv; float* dq;
+} PfPoolArgs;
+int pf_enc_pool_forward(int32_t precision, const PfPoolArgs* args, void* stream);
+int pf_enc_pool_backward(int32_t precision, const PfPoolArgs* args, void* stream);
 
 /* ---- training-example remix ------------------------------------------
  * The deterministic half of RemixDataset.__getitem__ (experiments/remix_data.py:218-299) for a

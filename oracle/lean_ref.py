@@ -103,10 +103,11 @@ def _same(t):
     return t
 
 
-def _mha(q_in, kv_in, in_w, in_b, out_w, out_b, n_heads, rnd=_same):
-    """torch.nn.MultiheadAttention, batch_first, no mask, eval.  ``rnd`` is applied to every matrix-product
+def _mha(q_in, kv_in, in_w, in_b, out_w, out_b, n_heads, rnd=_same, attn_drop=None):
+    """torch.nn.MultiheadAttention, batch_first, no mask.  ``rnd`` is applied to every matrix-product
     operand (identity by default; the GPU tests pass a bf16 round trip to mirror the kernel's operand
-    rounding -- products and sums stay fp32 either way)."""
+    rounding -- products and sums stay fp32 either way).  ``attn_drop`` [B, heads, Lq, Lk] (or None = eval): the
+    factors nn.MultiheadAttention's dropout multiplies the attention probabilities with (0 or 1 / (1 - p))."""
     B, Lq, E = q_in.shape
     Lk = kv_in.shape[1]
     q = F.linear(rnd(q_in), rnd(in_w[:E]), in_b[:E])
@@ -116,30 +117,36 @@ def _mha(q_in, kv_in, in_w, in_b, out_w, out_b, n_heads, rnd=_same):
     q = q.reshape(B, Lq, n_heads, hd).transpose(1, 2) / math.sqrt(hd)
     k = k.reshape(B, Lk, n_heads, hd).transpose(1, 2)
     v = v.reshape(B, Lk, n_heads, hd).transpose(1, 2)
-    o = _softmax_weighted(rnd(q) @ rnd(k).transpose(-1, -2), v, rnd).transpose(1, 2).reshape(B, Lq, E)
+    o = _softmax_weighted(rnd(q) @ rnd(k).transpose(-1, -2), v, rnd, attn_drop).transpose(1, 2).reshape(B, Lq, E)
     return F.linear(rnd(o), rnd(out_w), out_b)
 
 
-def _softmax_weighted(scores, v, rnd=_same):
+def _softmax_weighted(scores, v, rnd=_same, drop=None):
     """softmax(scores) @ v written as (exp(s - max) @ v) / sum(exp(s - max)): the same value, with the
     matrix-product operand being the UN-normalised weights (where a reduced-precision kernel rounds)."""
     e = torch.exp(scores - scores.amax(dim=-1, keepdim=True))
+    if drop is not None:                      # dropout acts on the normalised probabilities
+        return rnd(e / e.sum(dim=-1, keepdim=True) * drop) @ rnd(v)
     return (rnd(e) @ rnd(v)) / e.sum(dim=-1, keepdim=True)
 
 
-def fusion_forward(w, tokens, n_layers=3, n_heads=6, rnd=_same):
-    """pre-norm TransformerEncoderLayer x n_layers, GELU FFN, eval (LN:167-172)."""
+def fusion_forward(w, tokens, n_layers=3, n_heads=6, rnd=_same, drop=None):
+    """pre-norm TransformerEncoderLayer x n_layers, GELU FFN (LN:167-172).  ``drop`` = None: eval.  Train mode with the
+    nn.Dropout modules replaced by given factors: drop[(layer, site)] for site in "attn" [B, heads, T, T], "res1" [B, T, E]
+    (dropout1, on the attention branch), "ffn" [B, T, 4E] (after the activation), "res2" [B, T, E] (dropout2)."""
     x = tokens
     E = x.shape[-1]
+    one = lambda l, k: 1.0 if drop is None else drop[(l, k)]
     for l in range(n_layers):
         p = f"fusion.layers.{l}."
         y = F.layer_norm(x, (E,), w[p + "norm1.weight"], w[p + "norm1.bias"], 1e-5)
-        x = x + _mha(y, y, w[p + "self_attn.in_proj_weight"], w[p + "self_attn.in_proj_bias"],
-                     w[p + "self_attn.out_proj.weight"], w[p + "self_attn.out_proj.bias"], n_heads, rnd)
+        x = x + one(l, "res1") * _mha(y, y, w[p + "self_attn.in_proj_weight"], w[p + "self_attn.in_proj_bias"],
+                                      w[p + "self_attn.out_proj.weight"], w[p + "self_attn.out_proj.bias"], n_heads, rnd,
+                                      None if drop is None else drop[(l, "attn")])
         y = F.layer_norm(x, (E,), w[p + "norm2.weight"], w[p + "norm2.bias"], 1e-5)
-        y = F.linear(rnd(F.gelu(F.linear(rnd(y), rnd(w[p + "linear1.weight"]), w[p + "linear1.bias"]))),
-                     rnd(w[p + "linear2.weight"]), w[p + "linear2.bias"])
-        x = x + y
+        h = one(l, "ffn") * F.gelu(F.linear(rnd(y), rnd(w[p + "linear1.weight"]), w[p + "linear1.bias"]))
+        y = F.linear(rnd(h), rnd(w[p + "linear2.weight"]), w[p + "linear2.bias"])
+        x = x + one(l, "res2") * y
     return x
 
 
@@ -149,7 +156,7 @@ def _mlp2(w, prefix, x):
 
 
 def encoder_features(w, strain, asd_bands=None, extra_tokens=None, n_heads=6,
-                     n_layers=3, n_energy_windows=16, psd_bands=0):
+                     n_layers=3, n_energy_windows=16, psd_bands=0, drop=None):
     """LN:199-243 -> (feats [B, 8*192 + 64 (+32)], sanitized strain)."""
     B, D, T = strain.shape
     clean = sanitize_strain(strain)
@@ -161,7 +168,7 @@ def encoder_features(w, strain, asd_bands=None, extra_tokens=None, n_heads=6,
     tok = tok.reshape(B, D * L, E)
     if extra_tokens is not None:
         tok = torch.cat([extra_tokens, tok], dim=1)
-    tok = fusion_forward(w, tok, n_layers, n_heads)
+    tok = fusion_forward(w, tok, n_layers, n_heads, drop=drop)
     q = w["pool_queries"].unsqueeze(0).expand(B, -1, -1)
     pooled = _mha(q, tok, w["pool_attn.in_proj_weight"], w["pool_attn.in_proj_bias"],
                   w["pool_attn.out_proj.weight"], w["pool_attn.out_proj.bias"], n_heads)

@@ -36,6 +36,44 @@ class PfFlowReevalArgs(C.Structure):
         "packed", "U", "ctx", "hs", "t1s", "t2s", "gates", "pc", "h2", "params", "drop")] + [("compact", C.c_uint32)]
 
 
+class PfEmbedTrainDesc(C.Structure):
+    """include/pf_hip.h PfEmbedTrainDesc"""
+    _fields_ = [("precision", C.c_int32), ("n_detectors", C.c_int32), ("n_extra_tokens", C.c_int32), ("training", C.c_int32),
+                ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64)]
+
+
+class PfDenseArgs(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("M", C.c_int64), ("rows_per_seq", C.c_int64), ("a_seq_stride", C.c_int64), ("lda", C.c_int32),
+                ("K", C.c_int32), ("N", C.c_int32), ("KC", C.c_int32), ("wfrags", C.c_void_p), ("bias", C.c_void_p),
+                ("out", C.c_void_p), ("o_seq_stride", C.c_int64), ("ldo", C.c_int32), ("o_valid_per_seq", C.c_int64),
+                ("x_seq_stride", C.c_int64), ("dact", C.c_void_p), ("resid", C.c_void_p), ("mul", C.c_void_p),
+                ("drop_p", C.c_float), ("seed", C.c_uint32), ("site", C.c_uint32), ("out_f32", C.c_int32)]
+
+
+class PfDenseTnArgs(C.Structure):
+    _fields_ = [("G", C.c_void_p), ("g_seq_stride", C.c_int64), ("ldg", C.c_int32), ("A", C.c_void_p), ("a_seq_stride", C.c_int64),
+                ("lda", C.c_int32), ("M", C.c_int64), ("rows_per_seq", C.c_int64), ("N1", C.c_int32), ("N2", C.c_int32),
+                ("dW", C.c_void_p), ("ldw", C.c_int32), ("conv_cin", C.c_int32), ("conv_kw", C.c_int32), ("db", C.c_void_p),
+                ("splits", C.c_int32)]
+
+
+class PfLnArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("M", C.c_int64), ("y", C.c_void_p),
+                ("mean", C.c_void_p), ("rstd", C.c_void_p), ("dy", C.c_void_p), ("dres", C.c_void_p), ("dx", C.c_void_p),
+                ("gout", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("drop_p", C.c_float), ("seed", C.c_uint32),
+                ("site", C.c_uint32)]
+
+
+class PfAttnArgs(C.Structure):
+    _fields_ = [("qkv", C.c_void_p), ("B", C.c_int64), ("T", C.c_int32), ("out", C.c_void_p), ("lse", C.c_void_p),
+                ("drop_p", C.c_float), ("seed", C.c_uint32), ("site", C.c_uint32), ("dout", C.c_void_p), ("dqkv", C.c_void_p)]
+
+
+class PfPoolArgs(C.Structure):
+    _fields_ = [("kv", C.c_void_p), ("q", C.c_void_p), ("B", C.c_int64), ("T", C.c_int32), ("pooled", C.c_void_p),
+                ("dpooled", C.c_void_p), ("dkv", C.c_void_p), ("dq", C.c_void_p)]
+
+
 class PfFlowDesc(C.Structure):
     _fields_ = [
         ("features", C.c_int32), ("context_features", C.c_int32),
@@ -93,6 +131,25 @@ SYMBOLS = {
     "pf_embed_fusion_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "pf_embed_fusion_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,
                                           C.c_void_p, C.c_void_p]),
+    "pf_embed_train_raw_param_count": (C.c_int64, []),
+    "pf_embed_train_packed_bytes": (C.c_int64, [C.c_int32]),
+    "pf_embed_train_pack": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pf_embed_train_workspace_bytes": (C.c_int64, [C.POINTER(PfEmbedTrainDesc), C.c_int64]),
+    "pf_embed_train_forward": (C.c_int, [C.POINTER(PfEmbedTrainDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "pf_embed_train_backward": (C.c_int, [C.POINTER(PfEmbedTrainDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                          C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pf_dense_frag_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "pf_dense_pack_matrix": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "pf_dense_nt": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(PfDenseArgs), C.c_void_p]),
+    "pf_dense_tn": (C.c_int, [C.c_int32, C.POINTER(PfDenseTnArgs), C.c_void_p]),
+    "pf_dropout_factor": (C.c_float, [C.c_float, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "pf_enc_ln_forward": (C.c_int, [C.c_int32, C.POINTER(PfLnArgs), C.c_void_p]),
+    "pf_enc_ln_backward": (C.c_int, [C.c_int32, C.POINTER(PfLnArgs), C.c_void_p]),
+    "pf_enc_attn_forward": (C.c_int, [C.c_int32, C.POINTER(PfAttnArgs), C.c_void_p]),
+    "pf_enc_attn_backward": (C.c_int, [C.c_int32, C.POINTER(PfAttnArgs), C.c_void_p]),
+    "pf_enc_pool_forward": (C.c_int, [C.c_int32, C.POINTER(PfPoolArgs), C.c_void_p]),
+    "pf_enc_pool_backward": (C.c_int, [C.c_int32, C.POINTER(PfPoolArgs), C.c_void_p]),
     "pf_remix_workspace_bytes": (C.c_int64, [C.c_int64]),
     "pf_remix_forward": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,

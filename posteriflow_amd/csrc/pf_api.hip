@@ -36,7 +36,19 @@ int rqs_backward(const PfFlowDesc& d, float deriv_const, const float* u, const f
 int launch_gather(bool bf16, const float* raw, const int32_t* map, void* out, int64_t n, hipStream_t s);
 int flow_backward_chain(const PfFlowDesc& d, float deriv_const, const PfFlowBwdChainArgs& a, hipStream_t s);
 int flow_reevaluate(const FlowPlan& P, const PfFlowReevalArgs& a, hipStream_t s);
+int64_t enc_train_raw_count();
+int64_t enc_train_packed_bytes(bool bf16);
+int enc_train_pack(bool bf16, const float* raw, void* packed, hipStream_t s);
+int64_t enc_train_workspace_bytes(const PfEmbedTrainDesc* desc, int64_t n_events);
+int enc_train_forward(const PfEmbedTrainDesc* desc, const void* packed, const float* raw, const float* strain,
+                      const float* extra_tokens, const float* token_bias, const float* pool_q, int64_t n_events, float* pooled,
+                      float* log_energy, void* workspace, hipStream_t s);
+int enc_train_backward(const PfEmbedTrainDesc* desc, const void* packed, const float* raw, const float* pool_q,
+                       const float* grad_pooled, int64_t n_events, void* workspace, float* grad_raw, float* grad_extra,
+                       float* grad_token_bias, float* grad_pool_q, hipStream_t s);
 }  // namespace pf
+#include "pf_dense.h"
+#include "pf_enc_ops.h"
 
 namespace pf {
 thread_local int g_hip_error = 0;
@@ -450,6 +462,111 @@ const char* pf_flow_forward_kernel_name(const PfFlowDesc* desc, int64_t batch) {
     pf::forward_kernel_name(L, batch, name, sizeof(name));
     return name;
 }
+
+// ---- strain embedding: training path ------------------------------------------------------------------------------------
+namespace {
+const char* hip_msg() { return hipGetErrorString(static_cast<hipError_t>(pf::g_hip_error)); }
+int finish(int rc, const char* unsupported) {
+    if (rc == PF_OK) return rc;
+    return fail(rc, rc == PF_ERR_HIP ? hip_msg() : rc == PF_ERR_UNSUPPORTED ? unsupported : "bad argument");
+}
+bool prec2(int32_t p) { return p == PF_PREC_F32 || p == PF_PREC_BF16; }
+}  // namespace
+
+int64_t pf_embed_train_raw_param_count(void) { return pf::enc_train_raw_count(); }
+int64_t pf_embed_train_packed_bytes(int32_t precision) { return prec2(precision) ? pf::enc_train_packed_bytes(precision == PF_PREC_BF16) : -1; }
+int pf_embed_train_pack(int32_t precision, const float* raw, void* packed, void* stream) {
+    if (!prec2(precision) || !raw || !packed) return fail(PF_ERR_BAD_ARG, "pf_embed_train_pack: null pointer or bad precision");
+    if (misaligned(packed, 16) || misaligned(raw, 4)) return fail(PF_ERR_BAD_ARG, "pf_embed_train_pack: misaligned pointer");
+    return finish(pf::enc_train_pack(precision == PF_PREC_BF16, raw, packed, static_cast<hipStream_t>(stream)), "");
+}
+int64_t pf_embed_train_workspace_bytes(const PfEmbedTrainDesc* desc, int64_t n_events) {
+    return pf::enc_train_workspace_bytes(desc, n_events);
+}
+int pf_embed_train_forward(const PfEmbedTrainDesc* desc, const void* packed, const float* raw, const float* strain,
+                           const float* extra_tokens, const float* token_bias, const float* pool_q, int64_t n_events,
+                           float* pooled, float* log_energy, void* workspace, int64_t workspace_bytes, void* stream) {
+    const int64_t need = pf::enc_train_workspace_bytes(desc, n_events);
+    if (need < 0) return fail(PF_ERR_BAD_ARG, "pf_embed_train_forward: bad desc (precision, 1..3 detectors, n_extra + 61 n_det <= 192, 0 <= p < 1)");
+    if (n_events == 0) return PF_OK;
+    if (!packed || !raw || !strain || !pool_q || !pooled || !log_energy || !workspace)
+        return fail(PF_ERR_BAD_ARG, "pf_embed_train_forward: null pointer");
+    if (desc->n_extra_tokens > 0 && !extra_tokens) return fail(PF_ERR_BAD_ARG, "pf_embed_train_forward: extra_tokens is null");
+    if (workspace_bytes < need) return fail(PF_ERR_BAD_ARG, "pf_embed_train_forward: workspace too small (pf_embed_train_workspace_bytes)");
+    if (misaligned(workspace, 256) || misaligned(packed, 16) || misaligned(strain, 16) || misaligned(raw, 16) ||
+        misaligned(pooled, 16) || misaligned(extra_tokens, 16) || misaligned(token_bias, 16))
+        return fail(PF_ERR_BAD_ARG, "pf_embed_train_forward: misaligned pointer (workspace 256 B, tensors 16 B)");
+    return finish(pf::enc_train_forward(desc, packed, raw, strain, extra_tokens, token_bias, pool_q, n_events, pooled, log_energy,
+                                        workspace, static_cast<hipStream_t>(stream)), "unsupported token count");
+}
+int pf_embed_train_backward(const PfEmbedTrainDesc* desc, const void* packed, const float* raw, const float* pool_q,
+                            const float* grad_pooled, int64_t n_events, void* workspace, int64_t workspace_bytes,
+                            float* grad_raw, float* grad_extra_tokens, float* grad_token_bias, float* grad_pool_q,
+                            void* stream) {
+    const int64_t need = pf::enc_train_workspace_bytes(desc, n_events);
+    if (need < 0) return fail(PF_ERR_BAD_ARG, "pf_embed_train_backward: bad desc");
+    if (!grad_raw) return fail(PF_ERR_BAD_ARG, "pf_embed_train_backward: grad_raw is null");
+    if (n_events > 0 && (!packed || !raw || !pool_q || !grad_pooled || !workspace))
+        return fail(PF_ERR_BAD_ARG, "pf_embed_train_backward: null pointer");
+    if (n_events > 0 && workspace_bytes < need) return fail(PF_ERR_BAD_ARG, "pf_embed_train_backward: workspace too small");
+    if (misaligned(workspace, 256) || misaligned(packed, 16) || misaligned(grad_raw, 16) || misaligned(grad_pooled, 16) ||
+        misaligned(grad_extra_tokens, 16) || misaligned(grad_token_bias, 16))
+        return fail(PF_ERR_BAD_ARG, "pf_embed_train_backward: misaligned pointer");
+    return finish(pf::enc_train_backward(desc, packed, raw, pool_q, grad_pooled, n_events, workspace, grad_raw, grad_extra_tokens,
+                                         grad_token_bias, grad_pool_q, static_cast<hipStream_t>(stream)), "unsupported token count");
+}
+
+// ---- building blocks -------------------------------------------------------------------------------------------------------
+int64_t pf_dense_frag_bytes(int32_t precision, int32_t N, int32_t K) {
+    const int ks = precision == PF_PREC_BF16 ? 32 : 16;
+    if (!prec2(precision) || N <= 0 || K <= 0 || N % 16 || K % ks) return -1;
+    return pf::dense_frag_count(precision == PF_PREC_BF16, N, K) * 16;
+}
+int pf_dense_pack_matrix(int32_t precision, const float* src, int32_t mode, int32_t ld, int32_t N, int32_t K, void* out, void* stream) {
+    if (pf_dense_frag_bytes(precision, N, K) < 0 || !src || !out || (mode != 0 && mode != 1) || misaligned(out, 16))
+        return fail(PF_ERR_BAD_ARG, "pf_dense_pack_matrix: N % 16, K % 32 (bf16) / 16 (fp32), mode 0 | 1, 16-byte aligned output");
+    pf::DensePackTable tab{};
+    tab.n = 1;
+    tab.e[0].src_off = 0; tab.e[0].dst_off = 0; tab.e[0].mode = mode; tab.e[0].ld = ld; tab.e[0].N = N; tab.e[0].K = K;
+    return finish(pf::dense_pack(precision == PF_PREC_BF16, src, tab, out, static_cast<hipStream_t>(stream)), "");
+}
+int pf_dense_nt(int32_t precision, int32_t epilogue, const PfDenseArgs* a, void* stream) {
+    if (!prec2(precision) || !a) return fail(PF_ERR_BAD_ARG, "pf_dense_nt: null args or bad precision");
+    if (a->M > 0 && (!a->A || !a->wfrags || !a->out || a->rows_per_seq <= 0)) return fail(PF_ERR_BAD_ARG, "pf_dense_nt: null pointer");
+    if ((epilogue == PF_EPI_RESID && !a->resid) || (epilogue == PF_EPI_MUL && !a->mul))
+        return fail(PF_ERR_BAD_ARG, "pf_dense_nt: the epilogue's operand is null");
+    const int esz = precision == PF_PREC_BF16 ? 2 : 4;
+    if (misaligned(a->A, 16) || misaligned(a->wfrags, 16) || misaligned(a->out, 16) || (a->lda * esz) % 16 || (a->a_seq_stride * esz) % 16 ||
+        (a->ldo * esz) % 8 || a->N % 16)
+        return fail(PF_ERR_BAD_ARG, "pf_dense_nt: rows of A must start on 16-byte boundaries, N % 16 == 0");
+    return finish(pf::dense_nt(precision == PF_PREC_BF16, epilogue, *a, static_cast<hipStream_t>(stream)),
+                  "pf_dense_nt: KC too large for LDS, or a chunked reduction with N > 256");
+}
+int pf_dense_tn(int32_t precision, const PfDenseTnArgs* a, void* stream) {
+    if (!prec2(precision) || !a) return fail(PF_ERR_BAD_ARG, "pf_dense_tn: null args or bad precision");
+    if (a->M > 0 && (!a->G || !a->A || !a->dW || a->rows_per_seq <= 0)) return fail(PF_ERR_BAD_ARG, "pf_dense_tn: null pointer");
+    const int esz = precision == PF_PREC_BF16 ? 2 : 4;
+    if (misaligned(a->G, 16) || misaligned(a->A, 16) || (a->ldg * esz) % 16 || (a->lda * esz) % 16 || (a->g_seq_stride * esz) % 16 ||
+        (a->a_seq_stride * esz) % 16)
+        return fail(PF_ERR_BAD_ARG, "pf_dense_tn: rows of G and A must start on 16-byte boundaries");
+    return finish(pf::dense_tn(precision == PF_PREC_BF16, *a, static_cast<hipStream_t>(stream)), "");
+}
+float pf_dropout_factor(float p, uint32_t seed, uint32_t site, uint32_t index) {
+    if (!(p > 0.f)) return 1.f;
+    return pf::enc_drop_hash(seed, site, index) >= pf::enc_drop_threshold(p) ? 1.f / (1.f - p) : 0.f;
+}
+#define PF_ENC_ENTRY(name, fn, T)                                                                              \
+    int name(int32_t precision, const T* a, void* stream) {                                                    \
+        if (!prec2(precision) || !a) return fail(PF_ERR_BAD_ARG, #name ": null args or bad precision");      \
+        return finish(pf::fn(precision == PF_PREC_BF16, *a, static_cast<hipStream_t>(stream)), #name ": 1 <= T <= 192"); \
+    }
+PF_ENC_ENTRY(pf_enc_ln_forward, ln_forward, PfLnArgs)
+PF_ENC_ENTRY(pf_enc_ln_backward, ln_backward, PfLnArgs)
+PF_ENC_ENTRY(pf_enc_attn_forward, attn_forward, PfAttnArgs)
+PF_ENC_ENTRY(pf_enc_attn_backward, attn_backward, PfAttnArgs)
+PF_ENC_ENTRY(pf_enc_pool_forward, pool_forward, PfPoolArgs)
+PF_ENC_ENTRY(pf_enc_pool_backward, pool_backward, PfPoolArgs)
+#undef PF_ENC_ENTRY
 
 int64_t pf_flow_issued_flop_per_row(const PfFlowDesc* desc) {
     pf::FlowPlan L;

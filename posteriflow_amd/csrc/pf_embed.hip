@@ -59,6 +59,9 @@ struct ConvParams {
     int64_t n_seq;
     const u32x4* wfrags0;   // FUSE (conv1 computed inside conv2's staging): conv1's fragments, bias; `in` is the strain
     const float* bias0;
+    // training forward (pf_embed_train_forward): what the backward kernels read
+    void* dact;             // [N][lout][cout] activation type: gelu'(pre-activation), or null
+    void* sig;              // FIRST: [N][16384] activation type: asinh(sanitised strain), the im2col source of conv1's weight gradient
 };
 
 __device__ __forceinline__ float gelu_exact(float x) {         // nn.GELU() default: erf form
@@ -115,13 +118,16 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_gemm_kernel(const ConvParams
                 if (i + e < P * S) sq[(i + e) >> 10] += x * x;             // own range: 2 windows of 1024
                 v[e] = BF16 ? asinh_fast(x) : asinhf(x);
             }
+            const bool keep = p.sig && i < P * S && in0 + i + 3 < LIN;     // this workgroup's own 2048 samples
             if (BF16) {
                 bf16x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
                 *reinterpret_cast<bf16x4*>(smem + (size_t)i * 2) = o;
+                if (keep) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p.sig) + n * LIN + in0 + i) = o;
             } else {
                 *reinterpret_cast<f32x4*>(smem + (size_t)i * 4) = v;
+                if (keep) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.sig) + n * LIN + in0 + i) = v;
             }
         }
         // window energies: wave shuffle reduction, then one atomic per wave into LDS
@@ -368,6 +374,24 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_gemm_kernel(const ConvParams
                     for (int e = 0; e < 4; ++e) v[e] = gelu_exact(acc[cg][e] + b4[e]);
                 }
                 const size_t off = ((size_t)n * LOUT + pos) * COUT + tile * 16 + 4 * g;
+                if (p.dact) {                                       // training: gelu'(pre-activation) for the backward
+                    f32x4 dv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float ye, de;
+                        if constexpr (BF16) gelu_fast_pair(acc[cg][e] + b4[e], ye, de);
+                        else de = gelu_grad_f32(acc[cg][e] + b4[e]);
+                        dv[e] = de;
+                    }
+                    if constexpr (BF16) {
+                        bf16x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = (__bf16)dv[e];
+                        *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p.dact) + off) = o;
+                    } else {
+                        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.dact) + off) = dv;
+                    }
+                }
                 if (BF16 && !LAST) {
                     bf16x4 o;
 #pragma unroll
@@ -520,6 +544,34 @@ static int stem_forward_t(const char* packed, const float* strain, int64_t n_seq
     }
     set(2, act1, act0);    if ((rc = launch_layer<BF16, 2>(p, s)) != PF_OK) return rc;
     set(3, act0, tokens);  return launch_layer<BF16, 3>(p, s);
+}
+
+// training forward: the four launches of the parity path in either precision, keeping for the backward every layer's
+// output act[l] ([N][lout][cout], activation type; the last layer's = the fp32 tokens), gelu'(pre-activation) dact[l] and
+// the asinh signal
+template <bool BF16>
+static int stem_forward_train_t(const void* const wfrags[4], const float* const bias[4], const float* strain, int64_t n_seq,
+                                void* sig, void* const act[3], void* const dact[4], float* tokens, float* log_energy,
+                                hipStream_t s) {
+    ConvParams p{};
+    p.n_seq = n_seq;
+    auto set = [&](int l, const void* in, void* out) {
+        p.in = in; p.out = out; p.wfrags = reinterpret_cast<const u32x4*>(wfrags[l]); p.bias = bias[l];
+        p.log_energy = l == 0 ? log_energy : nullptr;
+        p.dact = dact[l]; p.sig = l == 0 ? sig : nullptr;
+    };
+    int rc;
+    set(0, strain, act[0]);  if ((rc = launch_layer<BF16, 0>(p, s)) != PF_OK) return rc;
+    set(1, act[0], act[1]);  if ((rc = launch_layer<BF16, 1>(p, s)) != PF_OK) return rc;
+    set(2, act[1], act[2]);  if ((rc = launch_layer<BF16, 2>(p, s)) != PF_OK) return rc;
+    set(3, act[2], tokens);  return launch_layer<BF16, 3>(p, s);
+}
+// wfrags[l]: the layer's weights as im2col fragments [cout / 16][k-steps][64] (dense_pack mode 3 = pf_embed_stem_pack's
+// order); bias[l]: fp32 [cout]
+int stem_forward_train(bool bf16, const void* const wfrags[4], const float* const bias[4], const float* strain, int64_t n_seq,
+                       void* sig, void* const act[3], void* const dact[4], float* tokens, float* log_energy, hipStream_t s) {
+    return bf16 ? stem_forward_train_t<true>(wfrags, bias, strain, n_seq, sig, act, dact, tokens, log_energy, s)
+                : stem_forward_train_t<false>(wfrags, bias, strain, n_seq, sig, act, dact, tokens, log_energy, s);
 }
 
 int stem_forward(bool bf16, const char* packed, const float* strain, int64_t n_seq, float* tokens,

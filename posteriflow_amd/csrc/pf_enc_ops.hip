@@ -1,0 +1,660 @@
+// pf_enc_ops.hip -- LayerNorm, self-attention, attention pool (forward + backward) and the token assembly of the strain
+// embedding's training path: see pf_enc_ops.h.  GEMM-shaped work inside the attention runs on MFMA:
+//   bf16 mode  v_mfma_f32_16x16x32_bf16 for the head-dimension products (K = 32 = one instruction per 16 x 16 tile) and
+//              v_mfma_f32_16x16x16_bf16 for the products that reduce over tokens: its operand layout (k = 4 g + j) IS the
+//              accumulator layout (row = 4 g + r), so P / dS feed the second product straight from registers;
+//   f32 mode   v_mfma_f32_16x16x4_f32 in both places (the same trick: MFMA r of a group of four takes accumulator
+//              register r as its B operand).
+// Both orientations of the score tile are computed where a product needs the reduction on the other index (S^T for dQ,
+// S for dK / dV): the head dimension is 32, a score tile costs one MFMA, a transpose through LDS costs more.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+
+#include "pf_dense.h"
+#include "pf_enc_ops.h"
+#include "pf_status.h"
+
+namespace pf {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+template <bool BF16> __device__ __forceinline__ f32x4 load_act4(const void* base, int64_t off) {
+    if constexpr (BF16) {
+        const bf16x4 v = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(base) + off);
+        return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    } else {
+        return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + off);
+    }
+}
+template <bool BF16> __device__ __forceinline__ void store_act4(void* base, int64_t off, const f32x4& v) {
+    if constexpr (BF16) {
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+        *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(base) + off) = o;
+    } else {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + off) = v;
+    }
+}
+__device__ __forceinline__ s16x4 cvt_bf16x4(const f32x4& v) {
+    bf16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+    return __builtin_bit_cast(s16x4, o);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LayerNorm over 192 features: one wave per row, lanes 0..47 hold 4 consecutive features
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool BF16>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const LnArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool on = lane < 48;
+    const int col = 4 * (on ? lane : 0);
+    const f32x4 gm = *reinterpret_cast<const f32x4*>(a.gamma + col), bt = *reinterpret_cast<const f32x4*>(a.beta + col);
+    for (int64_t m = (int64_t)blockIdx.x * 4 + wave; m < a.M; m += (int64_t)gridDim.x * 4) {
+        f32x4 x = {0.f, 0.f, 0.f, 0.f};
+        if (on) x = *reinterpret_cast<const f32x4*>(a.x + m * kEncD + col);
+        const float mean = wave_sum(x[0] + x[1] + x[2] + x[3]) * (1.f / kEncD);
+        f32x4 d = x - mean;
+        if (!on) d = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float var = wave_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / kEncD);
+        const float rstd = 1.f / sqrtf(var + 1e-5f);
+        if (on) store_act4<BF16>(a.y, m * kEncD + col, d * rstd * gm + bt);
+        if (lane == 0) { a.mean[m] = mean; a.rstd[m] = rstd; }
+    }
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const LnArgs a) {
+    __shared__ float s_red[2][4][kEncD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool on = lane < 48;
+    const int col = 4 * (on ? lane : 0);
+    const f32x4 gm = *reinterpret_cast<const f32x4*>(a.gamma + col);
+    f32x4 dg = {0.f, 0.f, 0.f, 0.f}, db = {0.f, 0.f, 0.f, 0.f};
+    const uint32_t thr = enc_drop_threshold(a.drop_p);
+    const float dscale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+    for (int64_t m = (int64_t)blockIdx.x * 4 + wave; m < a.M; m += (int64_t)gridDim.x * 4) {
+        f32x4 x = {0.f, 0.f, 0.f, 0.f}, dy = {0.f, 0.f, 0.f, 0.f};
+        if (on) { x = *reinterpret_cast<const f32x4*>(a.x + m * kEncD + col); dy = load_act4<BF16>(a.dy, m * kEncD + col); }
+        const float mean = a.mean[m], rstd = a.rstd[m];
+        f32x4 xh = (x - mean) * rstd;
+        if (!on) xh = f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 gy = dy * gm;
+        const float s1 = wave_sum(gy[0] + gy[1] + gy[2] + gy[3]) * (1.f / kEncD);
+        const float s2 = wave_sum(gy[0] * xh[0] + gy[1] * xh[1] + gy[2] * xh[2] + gy[3] * xh[3]) * (1.f / kEncD);
+        dg += dy * xh;
+        db += dy;
+        if (on) {
+            f32x4 dx = (gy - s1 - xh * s2) * rstd;
+            if (a.dres) dx += *reinterpret_cast<const f32x4*>(a.dres + m * kEncD + col);
+            *reinterpret_cast<f32x4*>(a.dx + m * kEncD + col) = dx;
+            if (a.gout) {
+                if (a.drop_p > 0.f) {
+                    const uint32_t idx = (uint32_t)(m * kEncD + col);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dx[e] *= enc_drop_hash(a.seed, a.site, idx + e) >= thr ? dscale : 0.f;
+                }
+                store_act4<BF16>(a.gout, m * kEncD + col, dx);
+            }
+        }
+    }
+    if (on) {
+        *reinterpret_cast<f32x4*>(&s_red[0][wave][col]) = dg;
+        *reinterpret_cast<f32x4*>(&s_red[1][wave][col]) = db;
+    }
+    __syncthreads();
+    if (threadIdx.x < kEncD) {
+        const int cc = threadIdx.x;
+        atomicAdd(a.dgamma + cc, s_red[0][0][cc] + s_red[0][1][cc] + s_red[0][2][cc] + s_red[0][3][cc]);
+        atomicAdd(a.dbeta + cc, s_red[1][0][cc] + s_red[1][1][cc] + s_red[1][2][cc] + s_red[1][3][cc]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// self-attention, one workgroup per (head, event); T <= 192 tokens, head dimension 32
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kTS = 196;                        // row stride (elements) of the transposed [32][T] images
+constexpr float kScale = 0.17677669529663687f;  // 1 / sqrt(32)
+
+// operand of the head-dimension products: 8 bf16 (one 16-byte load) or 8 fp32 (k = 4 s + g) of row `row`
+template <bool BF16> struct HeadFrag { u32x4 v; float f[8]; };
+template <bool BF16>
+__device__ __forceinline__ void load_head_frag(HeadFrag<BF16>& fr, const void* base, int64_t row_off, bool valid, int g) {
+    if constexpr (BF16) {
+        fr.v = u32x4{0u, 0u, 0u, 0u};
+        if (valid) fr.v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const __bf16*>(base) + row_off + 8 * g);
+    } else {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) fr.f[s] = valid ? reinterpret_cast<const float*>(base)[row_off + 4 * s + g] : 0.f;
+    }
+}
+template <bool BF16>
+__device__ __forceinline__ f32x4 head_mma(const HeadFrag<BF16>& a, const HeadFrag<BF16>& b) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (BF16) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a.v), __builtin_bit_cast(bf16x8, b.v), acc, 0, 0, 0);
+    } else {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.f[s], b.f[s], acc, 0, 0, 0);
+    }
+    return acc;
+}
+// second product: acc += Img[16 dt + c][16 t + 4 g .. + 3] (A operand, from a transposed LDS image) x tile (B operand =
+// an accumulator tile whose ROW index is the reduction index)
+template <bool BF16>
+__device__ __forceinline__ f32x4 token_mma(const char* img, int dt, int t, int c, int g, const f32x4& tile, f32x4 acc) {
+    if constexpr (BF16) {
+        const s16x4 av = *reinterpret_cast<const s16x4*>(img + ((size_t)(16 * dt + c) * kTS + 16 * t + 4 * g) * 2);
+        return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, cvt_bf16x4(tile), acc, 0, 0, 0);
+    } else {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(img + ((size_t)(16 * dt + c) * kTS + 16 * t + 4 * g) * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], tile[r], acc, 0, 0, 0);
+        return acc;
+    }
+}
+// [T][32] slice (row stride 576 or 192 elements) -> transposed image [32][kTS], columns T .. 191 zeroed
+template <bool BF16>
+__device__ __forceinline__ void stage_transposed(char* img, const void* src, int64_t row0, int ld, int col0, int T, int tid) {
+    constexpr int ESZ = BF16 ? 2 : 4, EPC = 16 / ESZ, CPR = 32 / EPC;
+    for (int i = tid; i < kEncMaxTokens * CPR; i += 256) {
+        const int t = i / CPR, ch = i - t * CPR;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (t < T) v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(src) + ((row0 + t) * ld + col0 + ch * EPC) * ESZ);
+        if constexpr (BF16) {
+            const bf16x8 b = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) *reinterpret_cast<__bf16*>(img + ((size_t)(ch * 8 + j) * kTS + t) * 2) = b[j];
+        } else {
+            const f32x4 f = __builtin_bit_cast(f32x4, v);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<float*>(img + ((size_t)(ch * 4 + j) * kTS + t) * 4) = f[j];
+        }
+    }
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
+    constexpr int ESZ = BF16 ? 2 : 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* VT = smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, c = lane & 15;
+    const int h = blockIdx.x, T = a.T;
+    const int64_t e = blockIdx.y, r0 = e * T;
+    stage_transposed<BF16>(VT, a.qkv, r0, 3 * kEncD, 2 * kEncD + kEncHd * h, T, tid);
+    __syncthreads();
+    const uint32_t thr = enc_drop_threshold(a.drop_p);
+    const float dscale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+    const int ntile = (T + 15) >> 4;
+#pragma unroll 1
+    for (int qt = wave; qt < ntile; qt += 4) {
+        const int q = 16 * qt + c;
+        const bool qv = q < T;
+        HeadFrag<BF16> qf;
+        load_head_frag<BF16>(qf, a.qkv, (r0 + q) * (3 * kEncD) + kEncHd * h, qv, g);
+        f32x4 s[12];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 12; ++kt) {
+            const int key = 16 * kt + c;
+            HeadFrag<BF16> kf;
+            load_head_frag<BF16>(kf, a.qkv, (r0 + key) * (3 * kEncD) + kEncD + kEncHd * h, key < T, g);
+            s[kt] = head_mma<BF16>(kf, qf);                    // S^T[key = 16 kt + 4 g + r][q = 16 qt + c]
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = (16 * kt + 4 * g + r) < T ? s[kt][r] * kScale : -INFINITY;
+                s[kt][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float l = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 12; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pv = BF16 ? __expf(s[kt][r] - mx) : expf(s[kt][r] - mx);
+                s[kt][r] = pv;
+                l += pv;
+            }
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        const float inv = 1.f / l;
+        if (g == 0 && qv) a.lse[(e * kEncHeads + h) * T + q] = mx + logf(l);
+        f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int kt = 0; kt < 12; ++kt) {
+            f32x4 pd = s[kt] * inv;
+            if (a.drop_p > 0.f) {
+                const uint32_t idx = (uint32_t)(((e * kEncHeads + h) * T + q) * T + 16 * kt + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pd[r] *= enc_drop_hash(a.seed, a.site, idx + r) >= thr ? dscale : 0.f;
+            }
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) o[dt] = token_mma<BF16>(VT, dt, kt, c, g, pd, o[dt]);
+        }
+        if (qv) {
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) store_act4<BF16>(a.out, (r0 + q) * kEncD + kEncHd * h + 16 * dt + 4 * g, o[dt]);
+        }
+    }
+    (void)ESZ;
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnArgs a) {
+    constexpr int ESZ = BF16 ? 2 : 4;
+    constexpr size_t IMG = (size_t)32 * kTS * ESZ;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* QT = smem;
+    char* KT = smem + IMG;
+    char* DOT = smem + 2 * IMG;
+    float* s_delta = reinterpret_cast<float*>(smem + 3 * IMG);
+    float* s_lse = s_delta + kEncMaxTokens;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, c = lane & 15;
+    const int h = blockIdx.x, T = a.T;
+    const int64_t e = blockIdx.y, r0 = e * T;
+    stage_transposed<BF16>(QT, a.qkv, r0, 3 * kEncD, kEncHd * h, T, tid);
+    stage_transposed<BF16>(KT, a.qkv, r0, 3 * kEncD, kEncD + kEncHd * h, T, tid);
+    stage_transposed<BF16>(DOT, a.dout, r0, kEncD, kEncHd * h, T, tid);
+    if (tid < kEncMaxTokens) {
+        float dl = 0.f, ls = 0.f;
+        if (tid < T) {
+#pragma unroll
+            for (int d4 = 0; d4 < 8; ++d4) {
+                const f32x4 u = load_act4<BF16>(a.dout, (r0 + tid) * kEncD + kEncHd * h + 4 * d4);
+                const f32x4 w = load_act4<BF16>(a.out, (r0 + tid) * kEncD + kEncHd * h + 4 * d4);
+                dl += u[0] * w[0] + u[1] * w[1] + u[2] * w[2] + u[3] * w[3];
+            }
+            ls = a.lse[(e * kEncHeads + h) * T + tid];
+        }
+        s_delta[tid] = dl;
+        s_lse[tid] = ls;
+    }
+    __syncthreads();
+    const uint32_t thr = enc_drop_threshold(a.drop_p);
+    const float dscale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+    const int ntile = (T + 15) >> 4;
+    const uint32_t idx_base = (uint32_t)((e * kEncHeads + h) * T) * (uint32_t)T;
+
+    // ---- phase A: dQ, per query tile, key on the accumulator rows -------------------------------------------------
+#pragma unroll 1
+    for (int qt = wave; qt < ntile; qt += 4) {
+        const int q = 16 * qt + c;
+        const bool qv = q < T;
+        HeadFrag<BF16> qf, dof;
+        load_head_frag<BF16>(qf, a.qkv, (r0 + q) * (3 * kEncD) + kEncHd * h, qv, g);
+        load_head_frag<BF16>(dof, a.dout, (r0 + q) * kEncD + kEncHd * h, qv, g);
+        const float lse_q = s_lse[q < kEncMaxTokens ? q : 0], del_q = s_delta[q < kEncMaxTokens ? q : 0];
+        f32x4 dq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll 2
+        for (int kt = 0; kt < ntile; ++kt) {
+            const int key = 16 * kt + c;
+            HeadFrag<BF16> kf, vf;
+            load_head_frag<BF16>(kf, a.qkv, (r0 + key) * (3 * kEncD) + kEncD + kEncHd * h, key < T, g);
+            load_head_frag<BF16>(vf, a.qkv, (r0 + key) * (3 * kEncD) + 2 * kEncD + kEncHd * h, key < T, g);
+            const f32x4 st = head_mma<BF16>(kf, qf), dp = head_mma<BF16>(vf, dof);
+            f32x4 ds;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kk = 16 * kt + 4 * g + r;
+                const float pr = (kk < T && qv) ? (BF16 ? __expf(st[r] * kScale - lse_q) : expf(st[r] * kScale - lse_q)) : 0.f;
+                float fac = 1.f;
+                if (a.drop_p > 0.f) fac = enc_drop_hash(a.seed, a.site, idx_base + (uint32_t)(q * T + kk)) >= thr ? dscale : 0.f;
+                ds[r] = pr * (dp[r] * fac - del_q) * kScale;
+            }
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) dq[dt] = token_mma<BF16>(KT, dt, kt, c, g, ds, dq[dt]);
+        }
+        if (qv) {
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) store_act4<BF16>(a.dqkv, (r0 + q) * (3 * kEncD) + kEncHd * h + 16 * dt + 4 * g, dq[dt]);
+        }
+    }
+    // ---- phase B: dK, dV, per key tile, query on the accumulator rows ---------------------------------------------
+#pragma unroll 1
+    for (int kt = wave; kt < ntile; kt += 4) {
+        const int key = 16 * kt + c;
+        const bool kv = key < T;
+        HeadFrag<BF16> kf, vf;
+        load_head_frag<BF16>(kf, a.qkv, (r0 + key) * (3 * kEncD) + kEncD + kEncHd * h, kv, g);
+        load_head_frag<BF16>(vf, a.qkv, (r0 + key) * (3 * kEncD) + 2 * kEncD + kEncHd * h, kv, g);
+        f32x4 dk[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        f32x4 dv[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll 2
+        for (int qt = 0; qt < ntile; ++qt) {
+            const int qrow = 16 * qt + c;
+            HeadFrag<BF16> qf, dof;
+            load_head_frag<BF16>(qf, a.qkv, (r0 + qrow) * (3 * kEncD) + kEncHd * h, qrow < T, g);
+            load_head_frag<BF16>(dof, a.dout, (r0 + qrow) * kEncD + kEncHd * h, qrow < T, g);
+            const f32x4 sc = head_mma<BF16>(qf, kf), dp = head_mma<BF16>(dof, vf);   // [q = 16 qt + 4 g + r][key = 16 kt + c]
+            const f32x4 ls4 = *reinterpret_cast<const f32x4*>(s_lse + 16 * qt + 4 * g);
+            const f32x4 dl4 = *reinterpret_cast<const f32x4*>(s_delta + 16 * qt + 4 * g);
+            f32x4 pd, ds;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qq = 16 * qt + 4 * g + r;
+                const float pr = (qq < T && kv) ? (BF16 ? __expf(sc[r] * kScale - ls4[r]) : expf(sc[r] * kScale - ls4[r])) : 0.f;
+                float fac = 1.f;
+                if (a.drop_p > 0.f) fac = enc_drop_hash(a.seed, a.site, idx_base + (uint32_t)(qq * T + key)) >= thr ? dscale : 0.f;
+                pd[r] = pr * fac;
+                ds[r] = pr * (dp[r] * fac - dl4[r]) * kScale;
+            }
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                dv[dt] = token_mma<BF16>(DOT, dt, qt, c, g, pd, dv[dt]);
+                dk[dt] = token_mma<BF16>(QT, dt, qt, c, g, ds, dk[dt]);
+            }
+        }
+        if (kv) {
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                store_act4<BF16>(a.dqkv, (r0 + key) * (3 * kEncD) + kEncD + kEncHd * h + 16 * dt + 4 * g, dk[dt]);
+                store_act4<BF16>(a.dqkv, (r0 + key) * (3 * kEncD) + 2 * kEncD + kEncHd * h + 16 * dt + 4 * g, dv[dt]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// attention pool: 8 fixed queries per head over the T tokens of an event (vector ALU: 8 x T scores per head)
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kPS = 33;        // padded row of the fp32 K / V head images in LDS
+template <bool BF16, bool BWD>
+__global__ __launch_bounds__(256) void pool_kernel(const PoolArgs a) {
+    __shared__ float sK[kEncMaxTokens * kPS], sV[kEncMaxTokens * kPS];
+    __shared__ float sQ[kEncPoolQ * kEncHd], sP[kEncPoolQ * kEncMaxTokens], sDO[kEncPoolQ * kEncHd], sDS[kEncPoolQ * kEncMaxTokens];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int T = a.T;
+    const int64_t e = blockIdx.x, r0 = e * T;
+#pragma unroll 1
+    for (int h = 0; h < kEncHeads; ++h) {
+        __syncthreads();
+        for (int i = tid; i < T * 8; i += 256) {                // 8 groups of 4 features per token and operand
+            const int t = i >> 3, d4 = i & 7;
+            const f32x4 kx = load_act4<BF16>(a.kv, (r0 + t) * (2 * kEncD) + kEncHd * h + 4 * d4);
+            const f32x4 vx = load_act4<BF16>(a.kv, (r0 + t) * (2 * kEncD) + kEncD + kEncHd * h + 4 * d4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { sK[t * kPS + 4 * d4 + j] = kx[j]; sV[t * kPS + 4 * d4 + j] = vx[j]; }
+        }
+        {
+            const int qi = tid >> 5, d = tid & 31;
+            sQ[tid] = a.q[qi * kEncD + kEncHd * h + d];
+            if (BWD) sDO[tid] = a.dpooled[(e * kEncPoolQ + qi) * kEncD + kEncHd * h + d];
+        }
+        __syncthreads();
+        if (tid < T) {
+            float sc[kEncPoolQ];
+#pragma unroll
+            for (int qi = 0; qi < kEncPoolQ; ++qi) sc[qi] = 0.f;
+            for (int d = 0; d < kEncHd; ++d) {
+                const float kx = sK[tid * kPS + d];
+#pragma unroll
+                for (int qi = 0; qi < kEncPoolQ; ++qi) sc[qi] += sQ[qi * kEncHd + d] * kx;
+            }
+#pragma unroll
+            for (int qi = 0; qi < kEncPoolQ; ++qi) sP[qi * kEncMaxTokens + tid] = sc[qi];
+        }
+        __syncthreads();
+        // softmax over the keys: wave w handles queries 2 w, 2 w + 1
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int qi = 2 * wave + u;
+            float v[3], mx = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int t = lane + 64 * j;
+                v[j] = t < T ? sP[qi * kEncMaxTokens + t] : -INFINITY;
+                mx = fmaxf(mx, v[j]);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+            float l = 0.f;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { v[j] = expf(v[j] - mx); l += v[j]; }
+            l = wave_sum(l);
+            const float inv = 1.f / l;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int t = lane + 64 * j;
+                if (t < kEncMaxTokens) sP[qi * kEncMaxTokens + t] = t < T ? v[j] * inv : 0.f;
+            }
+        }
+        __syncthreads();
+        if constexpr (!BWD) {
+            const int qi = tid >> 5, d = tid & 31;
+            float o = 0.f;
+            for (int t = 0; t < T; ++t) o += sP[qi * kEncMaxTokens + t] * sV[t * kPS + d];
+            a.pooled[(e * kEncPoolQ + qi) * kEncD + kEncHd * h + d] = o;
+        } else {
+            // dp[qi][t] = dO[qi] . v[t];  ds = p (dp - sum_t p dp)
+            float dp[kEncPoolQ];
+            if (tid < T) {
+#pragma unroll
+                for (int qi = 0; qi < kEncPoolQ; ++qi) dp[qi] = 0.f;
+                for (int d = 0; d < kEncHd; ++d) {
+                    const float vx = sV[tid * kPS + d];
+#pragma unroll
+                    for (int qi = 0; qi < kEncPoolQ; ++qi) dp[qi] += sDO[qi * kEncHd + d] * vx;
+                }
+#pragma unroll
+                for (int qi = 0; qi < kEncPoolQ; ++qi) sDS[qi * kEncMaxTokens + tid] = dp[qi];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int qi = 2 * wave + u;
+                float dot = 0.f;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int t = lane + 64 * j;
+                    if (t < T) dot += sP[qi * kEncMaxTokens + t] * sDS[qi * kEncMaxTokens + t];
+                }
+                dot = wave_sum(dot);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int t = lane + 64 * j;
+                    if (t < T) sDS[qi * kEncMaxTokens + t] = sP[qi * kEncMaxTokens + t] * (sDS[qi * kEncMaxTokens + t] - dot);
+                }
+            }
+            __syncthreads();
+            if (tid < T) {                                       // dK[t] = sum_q ds[q][t] q[q],  dV[t] = sum_q p[q][t] dO[q]
+                float pq[kEncPoolQ], dsq[kEncPoolQ];
+#pragma unroll
+                for (int qi = 0; qi < kEncPoolQ; ++qi) { pq[qi] = sP[qi * kEncMaxTokens + tid]; dsq[qi] = sDS[qi * kEncMaxTokens + tid]; }
+#pragma unroll
+                for (int d4 = 0; d4 < 8; ++d4) {
+                    f32x4 gk = {0.f, 0.f, 0.f, 0.f}, gv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int qi = 0; qi < kEncPoolQ; ++qi)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            gk[j] += dsq[qi] * sQ[qi * kEncHd + 4 * d4 + j];
+                            gv[j] += pq[qi] * sDO[qi * kEncHd + 4 * d4 + j];
+                        }
+                    store_act4<BF16>(a.dkv, (r0 + tid) * (2 * kEncD) + kEncHd * h + 4 * d4, gk);
+                    store_act4<BF16>(a.dkv, (r0 + tid) * (2 * kEncD) + kEncD + kEncHd * h + 4 * d4, gv);
+                }
+            }
+            {                                                    // dq[qi][d] += sum_t ds[qi][t] k[t][d]
+                const int qi = tid >> 5, d = tid & 31;
+                float acc = 0.f;
+                for (int t = 0; t < T; ++t) acc += sDS[qi * kEncMaxTokens + t] * sK[t * kPS + d];
+                atomicAdd(a.dq + qi * kEncD + kEncHd * h + d, acc);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// token assembly and small element-wise kernels
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tok_assemble_kernel(const float* __restrict__ stem, const float* __restrict__ extra,
+                                                           const float* __restrict__ bias, int64_t B, int n_extra, int n_stem,
+                                                           float* __restrict__ x0) {
+    const int T = n_extra + n_stem;
+    const int64_t total = B * T * (kEncD / 4);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c4 = (int)(i % (kEncD / 4));
+        const int64_t row = i / (kEncD / 4);
+        const int t = (int)(row % T);
+        const int64_t e = row / T;
+        f32x4 v;
+        if (t < n_extra) v = *reinterpret_cast<const f32x4*>(extra + (e * n_extra + t) * kEncD + 4 * c4);
+        else {
+            v = *reinterpret_cast<const f32x4*>(stem + (e * n_stem + (t - n_extra)) * kEncD + 4 * c4);
+            if (bias) v += *reinterpret_cast<const f32x4*>(bias + (int64_t)t * kEncD + 4 * c4);
+        }
+        *reinterpret_cast<f32x4*>(x0 + row * kEncD + 4 * c4) = v;
+    }
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(192) void tok_backward_kernel(const float* __restrict__ dx0, const void* __restrict__ dact, int64_t B,
+                                                           int n_extra, int n_det, void* __restrict__ gpad, int64_t gseq,
+                                                           int64_t goff, float* __restrict__ dextra, float* __restrict__ dbias) {
+    const int T = n_extra + 61 * n_det;
+    const int t = blockIdx.x, cc = threadIdx.x;
+    const int64_t per = (B + gridDim.y - 1) / gridDim.y;
+    const int64_t e0 = (int64_t)blockIdx.y * per, e1 = e0 + per < B ? e0 + per : B;
+    float sum = 0.f;
+    const int j = t - n_extra, d = j >= 0 ? j / 61 : 0, pp = j >= 0 ? j - 61 * d : 0;
+    for (int64_t e = e0; e < e1; ++e) {
+        const float v = dx0[(e * T + t) * kEncD + cc];
+        sum += v;
+        if (t < n_extra) {
+            if (dextra) dextra[(e * n_extra + t) * kEncD + cc] = v;
+        } else {
+            const int64_t n = e * n_det + d;
+            const int64_t src = (n * 61 + pp) * kEncD + cc, dst = n * gseq + goff + (int64_t)pp * kEncD + cc;
+            if constexpr (BF16) {
+                reinterpret_cast<__bf16*>(gpad)[dst] = (__bf16)(v * (float)reinterpret_cast<const __bf16*>(dact)[src]);
+            } else {
+                reinterpret_cast<float*>(gpad)[dst] = v * reinterpret_cast<const float*>(dact)[src];
+            }
+        }
+    }
+    if (dbias && e0 < e1) atomicAdd(dbias + (int64_t)t * kEncD + cc, sum);
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * i);
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+        *reinterpret_cast<bf16x4*>(dst + 4 * i) = o;
+    }
+}
+
+unsigned grid_for(int64_t items, int per_block, unsigned cap = 2048) {
+    const int64_t b = (items + per_block - 1) / per_block;
+    return (unsigned)(b < 1 ? 1 : b > cap ? cap : b);
+}
+
+}  // namespace
+
+int ln_forward(bool bf16, const LnArgs& a, hipStream_t s) {
+    if (a.M <= 0) return PF_OK;
+    const unsigned grid = grid_for(a.M, 4 * 4);
+    if (bf16) hipLaunchKernelGGL(ln_fwd_kernel<true>, dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(ln_fwd_kernel<false>, dim3(grid), dim3(256), 0, s, a);
+    return launch_status();
+}
+int ln_backward(bool bf16, const LnArgs& a, hipStream_t s) {
+    if (a.M <= 0) return PF_OK;
+    const unsigned grid = grid_for(a.M, 4 * 16, 1024);
+    if (bf16) hipLaunchKernelGGL(ln_bwd_kernel<true>, dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(ln_bwd_kernel<false>, dim3(grid), dim3(256), 0, s, a);
+    return launch_status();
+}
+
+int attn_forward(bool bf16, const AttnArgs& a, hipStream_t s) {
+    if (a.B <= 0) return PF_OK;
+    if (a.T < 1 || a.T > kEncMaxTokens) return PF_ERR_UNSUPPORTED;
+    const size_t lds = (size_t)32 * kTS * (bf16 ? 2 : 4);
+    const dim3 grid(kEncHeads, (unsigned)a.B);
+    if (bf16) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), lds, s, a);
+    return launch_status();
+}
+int attn_backward(bool bf16, const AttnArgs& a, hipStream_t s) {
+    if (a.B <= 0) return PF_OK;
+    if (a.T < 1 || a.T > kEncMaxTokens) return PF_ERR_UNSUPPORTED;
+    const size_t lds = (size_t)3 * 32 * kTS * (bf16 ? 2 : 4) + 2 * kEncMaxTokens * sizeof(float);
+    const dim3 grid(kEncHeads, (unsigned)a.B);
+    if (bf16) {
+        hipLaunchKernelGGL(attn_bwd_kernel<true>, grid, dim3(256), lds, s, a);
+    } else {
+        if (!opt_in_lds(reinterpret_cast<const void*>(attn_bwd_kernel<false>), (int)lds)) return PF_ERR_HIP;
+        hipLaunchKernelGGL(attn_bwd_kernel<false>, grid, dim3(256), lds, s, a);
+    }
+    return launch_status();
+}
+
+int pool_forward(bool bf16, const PoolArgs& a, hipStream_t s) {
+    if (a.B <= 0) return PF_OK;
+    if (a.T < 1 || a.T > kEncMaxTokens) return PF_ERR_UNSUPPORTED;
+    if (bf16) hipLaunchKernelGGL((pool_kernel<true, false>), dim3((unsigned)a.B), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((pool_kernel<false, false>), dim3((unsigned)a.B), dim3(256), 0, s, a);
+    return launch_status();
+}
+int pool_backward(bool bf16, const PoolArgs& a, hipStream_t s) {
+    if (a.B <= 0) return PF_OK;
+    if (a.T < 1 || a.T > kEncMaxTokens) return PF_ERR_UNSUPPORTED;
+    if (bf16) hipLaunchKernelGGL((pool_kernel<true, true>), dim3((unsigned)a.B), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((pool_kernel<false, true>), dim3((unsigned)a.B), dim3(256), 0, s, a);
+    return launch_status();
+}
+
+int tok_assemble(const float* stem_tokens, const float* extra, const float* token_bias, int64_t B, int n_extra, int n_stem,
+                 float* x0, hipStream_t s) {
+    if (B <= 0) return PF_OK;
+    const int64_t total = B * (n_extra + n_stem) * (kEncD / 4);
+    hipLaunchKernelGGL(tok_assemble_kernel, dim3(grid_for(total, 256 * 4)), dim3(256), 0, s, stem_tokens, extra, token_bias, B, n_extra,
+                       n_stem, x0);
+    return launch_status();
+}
+int tok_backward(bool bf16, const float* dx0, const void* dact, int64_t B, int n_extra, int n_det, void* gpad, int64_t gpad_seq_stride,
+                 int64_t gpad_offset, float* dextra, float* dbias, hipStream_t s) {
+    if (B <= 0) return PF_OK;
+    const int T = n_extra + 61 * n_det;
+    const unsigned ny = (unsigned)(B < 16 ? B : 16);
+    if (bf16) hipLaunchKernelGGL(tok_backward_kernel<true>, dim3(T, ny), dim3(192), 0, s, dx0, dact, B, n_extra, n_det, gpad,
+                                 gpad_seq_stride, gpad_offset, dextra, dbias);
+    else hipLaunchKernelGGL(tok_backward_kernel<false>, dim3(T, ny), dim3(192), 0, s, dx0, dact, B, n_extra, n_det, gpad,
+                            gpad_seq_stride, gpad_offset, dextra, dbias);
+    return launch_status();
+}
+int cast_rows(bool bf16, const float* src, void* dst, int64_t n, hipStream_t s) {
+    if (n <= 0) return PF_OK;
+    if (!bf16) {
+        if (hipMemcpyAsync(dst, src, (size_t)n * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return PF_ERR_HIP;
+        return PF_OK;
+    }
+    if (n % 4) return PF_ERR_BAD_ARG;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(n / 4, 256 * 4)), dim3(256), 0, s, src, reinterpret_cast<__bf16*>(dst), n / 4);
+    return launch_status();
+}
+
+}  // namespace pf

@@ -32,6 +32,23 @@ __device__ __forceinline__ pf_f32x4 gelu_erf_fast4(pf_f32x4 v) {
     return v * 0.5f * (e + 1.f);
 }
 
+// GELU (erf form) and its derivative, exact fp32 (parity mode) ...
+__device__ __forceinline__ float gelu_f32(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f32(float x) {
+    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
+}
+// ... and the cheap pair for the bf16 paths: erf by A&S 7.1.28 as above, Phi(x) + x phi(x) with one hardware exponential
+__device__ __forceinline__ void gelu_fast_pair(float x, float& y, float& dy) {
+    const float a = fabsf(x) * 0.70710678118654752f;
+    float p = a * 0.0000430638f + 0.0002765672f;
+    p = p * a + 0.0001520143f; p = p * a + 0.0092705272f; p = p * a + 0.0422820123f; p = p * a + 0.0705230784f; p = p * a + 1.f;
+    p = p * p; p = p * p; p = p * p; p = p * p;
+    const float erf_abs = 1.f - __builtin_amdgcn_rcpf(p);
+    const float cdf = 0.5f * (1.f + copysignf(erf_abs, x));
+    y = x * cdf;
+    dy = cdf + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
 // asinh(x) = sign(x) log(|x| + sqrt(x^2 + 1)); below 1e-3 the identity (error x^3 / 6) avoids the
 // cancellation in log(1 + small).  Relative error < 1e-4 over |x| <= 100.
 __device__ __forceinline__ float asinh_fast(float x) {

@@ -241,42 +241,72 @@ class LeanStrainEncoder(nn.Module):
         return self.pool_attn.out_proj(pooled).reshape(b, -1)
 
     def _compute_feats(self, strain, asd_bands=None, extra_tokens=None):
-        """[B, 8*d_model + 64 (+32)] pre-projection features and the sanitised strain (LN:199-243)."""
-        b, d, _ = strain.shape
-        needs_grad = torch.is_grad_enabled() and (
-            strain.requires_grad or any(p.requires_grad for p in self._stem_params()))
-        clean = None
-        if self._allow_tensor_op_stem or (needs_grad and strain.device.type == "cuda"):
-            # differentiable call: the HIP stem has no backward kernels, so the stem is evaluated with
-            # device tensor ops under autograd (DESIGN.md 4.4); _allow_tensor_op_stem additionally opens
-            # this path off the GPU for CPU wiring tests only
-            clean = self._sanitize(strain)
-            tok, log_energy = self._stem(clean), self._window_log_energy(clean)
-        elif self.n_energy_windows != 16:
-            raise NotImplementedError("pf_embed_stem_forward computes 16 energy windows")
-        else:
-            tok, log_energy = self._stem_hip(strain)       # sanitises in-kernel; raises off the GPU: no CPU fallback
-        energy = self.energy_mlp(log_energy.reshape(b, -1))
-        n_tok, e = tok.shape[1], tok.shape[2]
-        # positional + detector embedding of every token of an event (LN:218-222); geometry tokens get none
-        tok_bias = (self.pos(n_tok)[None] + self.detector_embed.weight[:d, None, :]).reshape(d * n_tok, e)
+        """[B, 8*d_model + 64 (+32)] pre-projection features and the sanitised strain (LN:199-243).
+
+        On the GPU there are two HIP routes: the fused inference kernels (stem + one-launch token mixer; bf16 mode, eval, no
+        gradient wanted) and the TRAINING path (``_enc_train``: every differentiable or train()-mode call, and the fp32
+        parity mode) -- stem, token assembly, the Transformer layers with their dropout and the pool's K / V side forward and
+        backward in hand-written kernels behind one autograd node.  Tensor ops remain only for [B, .]-sized work (the MLPs,
+        the pool's query / output projections) and, behind ``_allow_tensor_op_stem``, for CPU wiring tests."""
+        from . import _enc_train
+        b, d, t_len = strain.shape
+        on_gpu = strain.device.type == "cuda"
+        wants_grad = torch.is_grad_enabled() and (
+            strain.requires_grad or (extra_tokens is not None and extra_tokens.requires_grad)
+            or any(p.requires_grad for p in _enc_train.train_parameters(self)) or self.detector_embed.weight.requires_grad
+            or self.pool_queries.requires_grad)
         n_extra = 0 if extra_tokens is None else extra_tokens.shape[1]
-        n_total = d * n_tok + n_extra
-        mixer_grad = torch.is_grad_enabled() and (tok.requires_grad or any(p.requires_grad for p in self._mixer_params()))
-        if (self.precision == "bf16" and tok.device.type == "cuda" and not self.training and not mixer_grad
-                and n_total <= 192 and self._mixer_supported()):
+        n_total = d * 61 + n_extra
+        clean = None
+        if self._allow_tensor_op_stem and not on_gpu:
+            return self._compute_feats_tensor_ops(strain, asd_bands, extra_tokens)
+        if not on_gpu:
+            raise _lib.PfError(f"LeanStrainEncoder runs on the MI355X only (input on {strain.device}); no CPU fallback")
+        fused_ok = (self.precision == "bf16" and not self.training and not wants_grad and n_total <= 192
+                    and self._mixer_supported() and self.n_energy_windows == 16)
+        if not fused_ok:
+            if not _enc_train.supported(self, n_total, t_len):
+                raise NotImplementedError("the HIP training path is built for d_model 192, 3 layers x 6 heads, FFN 768, 8 pool "
+                                          "queries, 16 energy windows, 16384-sample segments and at most 192 tokens")
+            e = self.stem[6].out_channels
+            # positional + detector embedding of every conv token of an event (LN:218-222); geometry tokens get none
+            tok_bias = (self.pos(61)[None] + self.detector_embed.weight[:d, None, :]).reshape(d * 61, e).float()
+            if n_extra:
+                tok_bias = torch.cat([tok_bias.new_zeros(n_extra, e), tok_bias], dim=0)
+            pooled, log_energy = _enc_train.encode_tokens(self, strain, None if extra_tokens is None else extra_tokens.float(),
+                                                            tok_bias, training=self.training)
+            pooled = self.pool_attn.out_proj(pooled)
+        else:
+            tok, log_energy = self._stem_hip(strain)       # sanitises in-kernel
+            n_tok, e = tok.shape[1], tok.shape[2]
+            tok_bias = (self.pos(n_tok)[None] + self.detector_embed.weight[:d, None, :]).reshape(d * n_tok, e)
             # fused HIP token mixer (DESIGN.md 4.7): embedding add + 3 Transformer layers + pool attention
             tok = tok.float().reshape(b, d * n_tok, e)
             if n_extra:
                 tok = torch.cat([extra_tokens.float(), tok], dim=1)
                 tok_bias = torch.cat([tok_bias.new_zeros(n_extra, e), tok_bias.float()], dim=0)
             pooled = self._mix_hip(tok.contiguous(), tok_bias)
-        else:      # fp32 parity mode, training (dropout, autograd) or another geometry: device tensor ops
-            tok = (tok.reshape(b, d, n_tok, e) + tok_bias.reshape(1, d, n_tok, e)).reshape(b, d * n_tok, e)
-            if extra_tokens is not None:
-                tok = torch.cat([extra_tokens, tok], dim=1)
-            tok = self._fuse(tok)
-            pooled, _ = self.pool_attn(self.pool_queries.unsqueeze(0).expand(b, -1, -1), tok, tok)
+        energy = self.energy_mlp(log_energy.reshape(b, -1))
+        parts = [pooled.reshape(b, -1), energy]
+        if self.psd_bands > 0:
+            if asd_bands is None:
+                asd_bands = strain.new_zeros(b, self.n_detectors, self.psd_bands)
+            parts.append(self.noise_mlp(asd_bands.reshape(b, -1)))
+        return torch.cat(parts, dim=1), clean
+
+    def _compute_feats_tensor_ops(self, strain, asd_bands=None, extra_tokens=None):
+        """the same function on device tensor ops: CPU wiring tests only (``_allow_tensor_op_stem``)"""
+        b, d, _ = strain.shape
+        clean = self._sanitize(strain)
+        tok, log_energy = self._stem(clean), self._window_log_energy(clean)
+        energy = self.energy_mlp(log_energy.reshape(b, -1))
+        n_tok, e = tok.shape[1], tok.shape[2]
+        tok_bias = (self.pos(n_tok)[None] + self.detector_embed.weight[:d, None, :]).reshape(d * n_tok, e)
+        tok = (tok.reshape(b, d, n_tok, e) + tok_bias.reshape(1, d, n_tok, e)).reshape(b, d * n_tok, e)
+        if extra_tokens is not None:
+            tok = torch.cat([extra_tokens, tok], dim=1)
+        tok = self._fuse(tok)
+        pooled, _ = self.pool_attn(self.pool_queries.unsqueeze(0).expand(b, -1, -1), tok, tok)
         parts = [pooled.reshape(b, -1), energy]
         if self.psd_bands > 0:
             if asd_bands is None:

@@ -1,0 +1,162 @@
+"""The strain embedding's HIP training path end to end (pf_embed_train_forward / _backward behind LeanStrainEncoder):
+forward against the reference-made golden contexts, every gradient against float64 autograd through the CPU oracle
+(oracle/lean_ref.py, itself pinned by those goldens), with and without dropout -- nn.Dropout replaced in the oracle by the
+factors the kernels' counter hash produced (oracle/enc_dropout.py), since nn.Dropout's stream is not reproducible across
+devices."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import recipe
+from oracle import lean_ref
+from oracle.enc_dropout import factors, seed32
+from posteriflow_amd import npe
+
+pytestmark = pytest.mark.gpu
+
+
+def _load(enc, seed, skip=("pos.pe",)):
+    shapes = {k: v.shape for k, v in enc.state_dict().items() if k not in skip}
+    sd = recipe.fill_state_dict(shapes, seed=seed)
+    missing = enc.load_state_dict(sd, strict=False)
+    assert sorted(missing.missing_keys) == sorted(skip)
+    return enc
+
+
+@pytest.mark.parametrize("tag,ndet,psd", [("det3", 3, 0), ("det1", 1, 0), ("det3_psd", 3, 16)])
+def test_fp32_parity_mode_runs_the_hip_path_and_matches_the_golden(golden_encoder, tag, ndet, psd):
+    """the fp32 mode no longer evaluates nn.TransformerEncoder: stem, Transformer layers and pooling are fp32-MFMA kernels.
+    Against the context the REFERENCE's own LeanStrainEncoder produced: 1e-5 relative (+ 2e-5 abs on values of scale ~4)."""
+    enc = _load(npe.LeanStrainEncoder(n_detectors=ndet, psd_bands=psd), 100 + ndet + psd).cuda().eval()
+    enc.precision = "fp32"
+    strain = recipe.strain_batch(4, ndet, seed=7).cuda()
+    asd = torch.from_numpy(golden_encoder[f"{tag}_asd"]).cuda() if psd else None
+    called = []
+    enc.fusion.register_forward_hook(lambda *a: called.append(1))
+    with torch.no_grad():
+        ctx = enc(strain, asd)
+    assert not called, "nn.TransformerEncoder was evaluated"
+    want = golden_encoder[f"{tag}_ctx"]
+    err = np.abs(ctx.cpu().numpy() - want).max()
+    print(f"\n[{tag}] fp32 HIP training-path forward vs reference golden: max abs {err:.2e} (scale {np.abs(want).max():.2f})")
+    np.testing.assert_allclose(ctx.cpu().numpy(), want, rtol=1e-5, atol=2e-5)
+    # bf16 training-path forward (the one a training step runs) against the same golden
+    enc.precision = "bf16"
+    for p in enc.parameters():
+        p.requires_grad_(True)
+    ctx16 = enc(strain, asd)
+    assert ctx16.requires_grad
+    e16 = np.abs(ctx16.detach().cpu().numpy() - want).max() / np.abs(want).max()
+    print(f"[{tag}] bf16 training-path forward: {e16:.2e} of scale")
+    assert e16 < 4e-2
+
+
+def _oracle_grads(enc, strain, weight, drop=None, asd=None, psd=0):
+    w = {k: v.detach().cpu().double().requires_grad_(v.dtype.is_floating_point) for k, v in enc.state_dict().items() if k != "pos.pe"}
+    feats, _ = lean_ref.encoder_features(w, strain.cpu().double(), asd, psd_bands=psd, drop=drop)
+    ctx = lean_ref.out_proj(w, feats)
+    (ctx * weight.cpu().double()).sum().backward()
+    return ctx.detach(), {k: v.grad for k, v in w.items() if v.requires_grad and v.grad is not None}
+
+
+def _drop_factors(p, seed64, B, T):
+    s = seed32(seed64)
+    out = {}
+    for l in range(3):
+        out[(l, "attn")] = torch.from_numpy(factors(p, s, 4 * l + 0, B * 6 * T * T)).reshape(B, 6, T, T).double()
+        out[(l, "res1")] = torch.from_numpy(factors(p, s, 4 * l + 1, B * T * 192)).reshape(B, T, 192).double()
+        out[(l, "ffn")] = torch.from_numpy(factors(p, s, 4 * l + 2, B * T * 768)).reshape(B, T, 768).double()
+        out[(l, "res2")] = torch.from_numpy(factors(p, s, 4 * l + 3, B * T * 192)).reshape(B, T, 192).double()
+    return out
+
+
+@pytest.mark.parametrize("ndet,train", [(3, False), (3, True), (1, True)])
+def test_every_encoder_gradient_matches_float64_autograd_through_the_oracle(ndet, train):
+    """fp32 mode: d(sum ctx * w) / d(parameter) for all 66 parameter tensors of LeanStrainEncoder (stem, embeddings, the
+    three Transformer layers, pool, MLPs) within 1e-3 of each tensor's largest entry; train=True:
+    train() mode, dropout 0.05 at the four sites of every layer, the oracle multiplying the kernels' own factors."""
+    torch.manual_seed(3)
+    enc = _load(npe.LeanStrainEncoder(n_detectors=ndet), 100 + ndet).cuda()
+    enc.precision = "fp32"
+    enc.train(train)
+    B, T = 2, 61 * ndet
+    strain = recipe.strain_batch(B, ndet, seed=7).cuda()
+    weight = torch.randn(B, 256, generator=torch.Generator().manual_seed(1)).cuda()
+    ctx = enc(strain)
+    (ctx * weight).sum().backward()
+    drop = None
+    if train:
+        seed = enc._train_state["last_seed"]
+        assert seed is not None
+        drop = _drop_factors(0.05, seed, B, T)
+        zero = float((drop[(0, "res1")] == 0).double().mean())
+        assert 0.03 < zero < 0.07
+    want_ctx, want = _oracle_grads(enc, strain, weight, drop)
+    e_ctx = ((ctx.detach().cpu().double() - want_ctx).abs().max() / want_ctx.abs().max()).item()
+    print(f"\n[encoder gradients ndet={ndet} train={train}] forward rel {e_ctx:.2e}")
+    assert e_ctx < 2e-5
+    worst = (0.0, "")
+    n = 0
+    for name, p in enc.named_parameters():
+        assert p.grad is not None and name in want, name
+        g, w = p.grad.detach().cpu().double(), want[name]
+        rel = ((g - w).abs().max() / w.abs().max().clamp_min(1e-30)).item()
+        worst = max(worst, (rel, name))
+        n += 1
+        assert rel < 1e-3, (name, rel)
+    print(f"  {n} parameter tensors, worst relative error {worst[0]:.2e} ({worst[1]})")
+    # the pool's query rows: gradient through the host-side projection only
+    assert enc.pool_attn.in_proj_weight.grad[:192].abs().max() > 0
+
+
+def test_bf16_training_gradients_follow_the_fp32_oracle():
+    """the throughput mode a trainer runs in: bf16 activations / MFMA operands, fp32 accumulation, weight gradients in fp32.
+    Per parameter tensor the cosine with float64 autograd through the fp32 oracle, dropout off (its factors act on
+    different roundings): > 0.98 for every tensor, > 0.995 for the whole gradient."""
+    torch.manual_seed(3)
+    enc = _load(npe.LeanStrainEncoder(n_detectors=3), 103).cuda().eval()
+    enc.precision = "bf16"
+    for p in enc.parameters():
+        p.requires_grad_(True)
+    B = 4
+    strain = recipe.strain_batch(B, 3, seed=7).cuda()
+    weight = torch.randn(B, 256, generator=torch.Generator().manual_seed(1)).cuda()
+    (enc(strain) * weight).sum().backward()
+    _, want = _oracle_grads(enc, strain, weight)
+    cos = lambda a, b: torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0).item()
+    got_all, want_all, worst = [], [], (1.0, "")
+    for name, p in enc.named_parameters():
+        g, w = p.grad.detach().cpu().double(), want[name]
+        assert torch.isfinite(g).all(), name
+        got_all.append(g.flatten()), want_all.append(w.flatten())
+        worst = min(worst, (cos(g, w), name))
+    total = cos(torch.cat(got_all), torch.cat(want_all))
+    print(f"\n[bf16 encoder gradients] whole-gradient cosine {total:.5f}, worst tensor {worst[0]:.5f} ({worst[1]})")
+    assert total > 0.995 and worst[0] > 0.98
+
+
+def test_coherent_encoder_trains_through_the_hip_path(golden_encoder):
+    """CoherentEncoder (4 geometry tokens prepended, 187 tokens): fp32 forward vs the reference-made golden, gradients of the
+    geometry branch (through grad_extra_tokens) and of the Transformer vs float64 autograd through the oracle"""
+    enc = _load(npe.CoherentEncoder(context_dim=256, psd_bands=16), 200, skip=("pos.pe", "Bsum", "bcount", "lags_norm")).cuda().eval()
+    enc.precision = "fp32"
+    strain = recipe.strain_batch(4, 3, seed=9).cuda()
+    asd = torch.from_numpy(golden_encoder["coh_asd"]).cuda()
+    for p in enc.parameters():
+        p.requires_grad_(True)
+    ctx = enc(strain, asd)
+    np.testing.assert_allclose(ctx.detach().cpu().numpy(), golden_encoder["coh_ctx"], rtol=2e-4, atol=5e-5)
+    weight = torch.randn(4, 256, generator=torch.Generator().manual_seed(2)).cuda()
+    (ctx * weight).sum().backward()
+    w = {k: v.detach().cpu().double().requires_grad_(v.dtype.is_floating_point) for k, v in enc.state_dict().items()
+         if k not in ("pos.pe", "Bsum", "bcount", "lags_norm")}
+    out = lean_ref.coherent_encoder_forward(w, strain.cpu().double(), asd.cpu().double())
+    (out * weight.cpu().double()).sum().backward()
+    for name in ("geom_to_tokens.weight", "geom_mlp.0.weight", "fusion.layers.0.self_attn.in_proj_weight", "stem.0.weight",
+                 "pool_queries", "detector_embed.weight"):
+        g, ww = dict(enc.named_parameters())[name].grad.cpu().double(), w[name].grad
+        rel = ((g - ww).abs().max() / ww.abs().max()).item()
+        print(f"[coherent] {name}: {rel:.2e}")
+        assert rel < 2e-3, (name, rel)

@@ -176,6 +176,32 @@ def test_sharded_draw_statistics_match_the_oracle():
         assert (torch.quantile(a, qs.double()) - torch.quantile(b, qs.double())).abs().max().item() < 0.08 * scale
 
 
+_CONFIG5_ORACLE = {}
+
+
+def _config5_oracle_draws(ref, ctx, D, n):
+    """1e5 draws of the CPU restatement (D-pass inverse), made ONCE for both precisions, on the box's CPU share (the
+    default thread count of a 256-core host oversubscribes a 16-core cgroup) and with a progress line per chunk"""
+    import os
+    import sys
+    if "want" not in _CONFIG5_ORACLE:
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            cores = os.cpu_count() or 1
+        old = torch.get_num_threads()
+        torch.set_num_threads(max(1, min(16, cores)))
+        parts = []
+        with torch.no_grad():
+            for i in range(n // 10_000):
+                parts.append(ref.inverse(torch.randn(10_000, D, generator=torch.Generator().manual_seed(70 + i)),
+                                         ctx.expand(10_000, -1))[0])
+                print(f"[config 5 oracle] {10_000 * (i + 1)} / {n} draws", file=sys.stderr, flush=True)
+        torch.set_num_threads(old)
+        _CONFIG5_ORACLE["want"] = torch.cat(parts)
+    return _CONFIG5_ORACLE["want"]
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_config5_draw_statistics_at_full_depth(precision):
     """SURVEY 8d, BASELINE config 5 as prescribed: the 12-layer D = 15 flow, ONE context row, 1e5 draws from the GPU
@@ -197,8 +223,7 @@ def test_config5_draw_statistics_at_full_depth(precision):
             z = torch.randn(hi - lo, D, device="cuda", generator=rank_generator(100, rank, "cuda"))
             parts.append(flow.inverse(z, ctx.cuda())[0].cpu())
         got = torch.cat(parts)
-        want = torch.cat([ref.inverse(torch.randn(10_000, D, generator=torch.Generator().manual_seed(70 + i)),
-                                      ctx.expand(10_000, -1))[0] for i in range(n // 10_000)])
+    want = _config5_oracle_draws(ref, ctx, D, n)
     want = want.clamp(-3.0, 3.0)                   # NSFPosteriorFlow.inverse clamps to +-FLOW_NORM_BOUND (flows.py:654)
     assert got.shape == want.shape == (n, D) and torch.isfinite(got).all()
     qs = torch.tensor([0.05, 0.25, 0.5, 0.75, 0.95], dtype=torch.float64)
