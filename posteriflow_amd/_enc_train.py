@@ -82,8 +82,9 @@ class _EncoderTrainFn(torch.autograd.Function):
         ctx.shapes = [p.shape for p in params]
         ctx.has_tb = token_bias is not None
         ctx.held = (raw, packed, ws, q)       # plain attributes: none of them is an input or output of this Function
+        log_energy = log_energy.reshape(b, n_det, 16)
         ctx.mark_non_differentiable(log_energy)
-        return pooled, log_energy.reshape(b, n_det, 16)
+        return pooled, log_energy
 
     @staticmethod
     def backward(ctx, g_pooled, _g_log_energy):
