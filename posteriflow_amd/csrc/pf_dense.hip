@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <type_traits>
 
 #include "pf_dense.h"
 #include "pf_math.h"
@@ -77,8 +78,12 @@ int dense_pack(bool bf16, const float* raw, const DensePackTable& tab, void* pac
 // =====================================================================================================================
 // dense_nt: the strip kernel
 // =====================================================================================================================
-template <bool BF16, int EPI, int TP>
-__global__ __launch_bounds__(256) void dense_strip_kernel(const DenseArgs p) {
+// RD = depth of the weight-fragment register ring in k-steps: fragment (tile i, k-step t + RD) is requested the moment
+// (tile i, k-step t) has been multiplied -- across chunk, pass and epilogue boundaries -- so a wave always has RD * TP
+// one-KiB loads in flight.  (First version: one k-step ahead = 24 MFMAs = 0.16 us of cover for a ~1 us L2 round trip; the
+// QKV projection of 187 K rows took 180 us against 17 us of MFMA time and 58 us of HBM time.)
+template <bool BF16, int EPI, int TP, int RD>
+__global__ __launch_bounds__(256, TP <= 3 ? 2 : 1) void dense_strip_kernel(const DenseArgs p) {
     constexpr int BM = 128, CG = 8;
     constexpr int KSTEP = BF16 ? 32 : 16, ESZ = BF16 ? 2 : 4, EPC = 16 / ESZ;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -91,6 +96,40 @@ __global__ __launch_bounds__(256) void dense_strip_kernel(const DenseArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, c = lane & 15;
     const int64_t m0 = (int64_t)blockIdx.x * BM;
+
+    const int ntiles = p.N >> 4;
+    const int nks_total = p.K / KSTEP;
+    const int nks = p.KC / KSTEP;                      // k-steps per chunk (a multiple of RD: host-checked)
+    const int nchunks = p.K / p.KC;
+    const int n_pass = (ntiles + 4 * TP - 1) / (4 * TP);
+    const int cpr = p.KC / EPC;                        // 16-byte slots per image row
+    const int rowbytes = p.KC * ESZ;
+    const char* Abase = reinterpret_cast<const char*>(p.A);
+
+    // ---- the fragment ring: requested before anything else so that the first chunk's staging runs under it ----------
+    int f_pass = 0, f_kk = 0;
+    const u32x4* fwf[TP];
+    auto set_fetch_pass = [&](int ps) {
+#pragma unroll
+        for (int i = 0; i < TP; ++i) {
+            const int t = ps * 4 * TP + wave * TP + i;
+            const int tcl = t < ntiles ? t : ntiles - 1;                 // tail: a valid tile is fetched, nothing is stored
+            fwf[i] = reinterpret_cast<const u32x4*>(p.wfrags) + (size_t)tcl * nks_total * 64 + lane;
+        }
+    };
+    set_fetch_pass(0);
+    u32x4 ring[RD][TP];
+    auto fetch = [&](u32x4 (&dst)[TP]) {
+#pragma unroll
+        for (int i = 0; i < TP; ++i) dst[i] = fwf[i][(size_t)f_kk * 64];
+        if (++f_kk == nks_total) {
+            f_kk = 0;
+            ++f_pass;
+            set_fetch_pass(f_pass < n_pass ? f_pass : n_pass - 1);
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < RD; ++j) fetch(ring[j]);
 
     if (tid < BM) {
         const int64_t m = m0 + tid;
@@ -107,38 +146,37 @@ __global__ __launch_bounds__(256) void dense_strip_kernel(const DenseArgs p) {
     }
     __syncthreads();
 
-    const int ntiles = p.N >> 4;
-    const int nks_total = p.K / KSTEP;
-    const int nks = p.KC / KSTEP;                      // k-steps per chunk
-    const int nchunks = p.K / p.KC;
-    const int n_pass = (ntiles + 4 * TP - 1) / (4 * TP);
-    const int cpr = p.KC / EPC;                        // 16-byte slots per image row
-    const int rowbytes = p.KC * ESZ;
-    const char* Abase = reinterpret_cast<const char*>(p.A);
-
-    // staging: 8 threads per row (128 contiguous bytes of one row per wave instruction group), 32 rows per sweep
+    // staging: 8 threads per row (128 contiguous bytes of one row per wave instruction group), 32 rows per sweep; RB
+    // sweeps are requested before the first store (the first chunk, with no accumulators alive yet, takes all four)
     const int st_sub = tid & 7, st_row = tid >> 3;
-    auto stage = [&](int ch) {
+    auto stage = [&](int ch, auto rb_tag) {
+        constexpr int RB = decltype(rb_tag)::value;
+        constexpr int U = BF16 ? 4 : 8;                         // slots per thread and sweep (KC <= 256)
         const int64_t k0 = (int64_t)ch * p.KC;
 #pragma unroll 1
-        for (int rr = 0; rr < BM / 32; ++rr) {
-            const int row = st_row + 32 * rr;
-            const int64_t ao = s_aoff[row];
-            const char* src = Abase + (ao + k0) * ESZ;
-            char* dst = img + (size_t)row * rowbytes;
-            const int sw = row & 7;
-            for (int cc0 = 0; cc0 < cpr; cc0 += 32) {          // up to 4 slots in flight per thread
-                u32x4 v[4];
+        for (int rr0 = 0; rr0 < BM / 32; rr0 += RB) {
+            u32x4 v[RB][U];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int cc = cc0 + st_sub + 8 * u;
-                    v[u] = u32x4{0u, 0u, 0u, 0u};
-                    if (cc < cpr && ao >= 0) v[u] = *reinterpret_cast<const u32x4*>(src + (size_t)cc * 16);
+            for (int r = 0; r < RB; ++r) {
+                const int row = st_row + 32 * (rr0 + r);
+                const int64_t ao = s_aoff[row];
+                const char* src = Abase + (ao + k0) * ESZ;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int cc = st_sub + 8 * u;
+                    v[r][u] = u32x4{0u, 0u, 0u, 0u};
+                    if (cc < cpr && ao >= 0) v[r][u] = *reinterpret_cast<const u32x4*>(src + (size_t)cc * 16);
                 }
+            }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int cc = cc0 + st_sub + 8 * u;
-                    if (cc < cpr) *reinterpret_cast<u32x4*>(dst + ((cc ^ sw) << 4)) = v[u];
+            for (int r = 0; r < RB; ++r) {
+                const int row = st_row + 32 * (rr0 + r);
+                char* dst = img + (size_t)row * rowbytes;
+                const int sw = row & 7;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int cc = st_sub + 8 * u;
+                    if (cc < cpr) *reinterpret_cast<u32x4*>(dst + ((cc ^ sw) << 4)) = v[r][u];
                 }
             }
         }
@@ -155,49 +193,44 @@ __global__ __launch_bounds__(256) void dense_strip_kernel(const DenseArgs p) {
 #pragma unroll
             for (int cg = 0; cg < CG; ++cg) acc[i][cg] = f32x4{0.f, 0.f, 0.f, 0.f};
         int tile[TP];
-        const u32x4* wf[TP];
 #pragma unroll
-        for (int i = 0; i < TP; ++i) {
-            tile[i] = pass * 4 * TP + wave * TP + i;
-            const int tcl = tile[i] < ntiles ? tile[i] : ntiles - 1;    // tail: a valid tile is computed, nothing stored
-            wf[i] = reinterpret_cast<const u32x4*>(p.wfrags) + (size_t)tcl * nks_total * 64 + lane;
-        }
+        for (int i = 0; i < TP; ++i) tile[i] = pass * 4 * TP + wave * TP + i;
 #pragma unroll 1
         for (int ch = 0; ch < nchunks; ++ch) {
             if (pass == 0) {                                             // (nchunks > 1 implies n_pass == 1: host-checked)
-                if (ch > 0) __syncthreads();
-                stage(ch);
+                if (ch == 0) stage(0, std::integral_constant<int, BF16 ? 2 : 1>{});
+                else { __syncthreads(); stage(ch, std::integral_constant<int, 1>{}); }
                 __syncthreads();
             }
-            const int ksb = ch * nks;
-            u32x4 a_cur[TP], a_nxt[TP];
+#pragma unroll 1
+            for (int ks0 = 0; ks0 < nks; ks0 += RD) {
 #pragma unroll
-            for (int i = 0; i < TP; ++i) a_cur[i] = wf[i][(size_t)ksb * 64];
-            for (int ks = 0; ks < nks; ++ks) {
-                const int kn = ks + 1 < nks ? ks + 1 : ks;
+                for (int j = 0; j < RD; ++j) {
+                    const int ks = ks0 + j;
+                    const int slot = ((4 * ks + g) ^ swl) << 4;
 #pragma unroll
-                for (int i = 0; i < TP; ++i) a_nxt[i] = wf[i][(size_t)(ksb + kn) * 64];
-                const int slot = ((4 * ks + g) ^ swl) << 4;
-                u32x4 b[CG];
+                    for (int hf = 0; hf < 2; ++hf) {                     // B fragments in two halves: 16 registers, not 32
+                        u32x4 b[CG / 2];
 #pragma unroll
-                for (int cg = 0; cg < CG; ++cg)
-                    b[cg] = *reinterpret_cast<const u32x4*>(brow + (size_t)(16 * cg) * rowbytes + slot);
+                        for (int cg = 0; cg < CG / 2; ++cg)
+                            b[cg] = *reinterpret_cast<const u32x4*>(brow + (size_t)(16 * (cg + 4 * hf)) * rowbytes + slot);
 #pragma unroll
-                for (int i = 0; i < TP; ++i)
+                        for (int i = 0; i < TP; ++i)
 #pragma unroll
-                    for (int cg = 0; cg < CG; ++cg) {
-                        if constexpr (BF16) {
-                            acc[i][cg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                                __builtin_bit_cast(bf16x8, a_cur[i]), __builtin_bit_cast(bf16x8, b[cg]), acc[i][cg], 0, 0, 0);
-                        } else {
-                            const f32x4 af = __builtin_bit_cast(f32x4, a_cur[i]), bf = __builtin_bit_cast(f32x4, b[cg]);
+                            for (int cg = 0; cg < CG / 2; ++cg) {
+                                f32x4& ac = acc[i][cg + 4 * hf];
+                                if constexpr (BF16) {
+                                    ac = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                        __builtin_bit_cast(bf16x8, ring[j][i]), __builtin_bit_cast(bf16x8, b[cg]), ac, 0, 0, 0);
+                                } else {
+                                    const f32x4 af = __builtin_bit_cast(f32x4, ring[j][i]), bf = __builtin_bit_cast(f32x4, b[cg]);
 #pragma unroll
-                            for (int q = 0; q < 4; ++q)
-                                acc[i][cg] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q], bf[q], acc[i][cg], 0, 0, 0);
-                        }
+                                    for (int q = 0; q < 4; ++q) ac = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q], bf[q], ac, 0, 0, 0);
+                                }
+                            }
                     }
-#pragma unroll
-                for (int i = 0; i < TP; ++i) a_cur[i] = a_nxt[i];
+                    fetch(ring[j]);                                      // k-step t + RD of the flattened (pass, chunk) walk
+                }
             }
         }
         // ---- epilogue: lane (g, c) holds units 16 tile + 4 g .. + 3 of row 16 cg + c -------------------------------
@@ -276,10 +309,10 @@ __global__ __launch_bounds__(256) void dense_strip_kernel(const DenseArgs p) {
     }
 }
 
-template <bool BF16, int EPI, int TP>
+template <bool BF16, int EPI, int TP, int RD>
 static int launch_strip(const DenseArgs& a, hipStream_t s) {
     const size_t lds = 3 * 128 * sizeof(int64_t) + (size_t)128 * a.KC * (BF16 ? 2 : 4);
-    auto k = dense_strip_kernel<BF16, EPI, TP>;
+    auto k = dense_strip_kernel<BF16, EPI, TP, RD>;
     if (lds > 160 * 1024) return PF_ERR_UNSUPPORTED;
     if (lds > 64 * 1024 && !opt_in_lds(reinterpret_cast<const void*>(k), (int)lds)) return PF_ERR_HIP;
     const unsigned grid = (unsigned)((a.M + 127) / 128);
@@ -288,24 +321,27 @@ static int launch_strip(const DenseArgs& a, hipStream_t s) {
     return launch_status();
 }
 
+template <bool BF16, int EPI, int TP>
+static int launch_strip_rd(const DenseArgs& a, hipStream_t s) {
+    const int nks = a.KC / (BF16 ? 32 : 16);
+    if constexpr (BF16) {
+        // ring depth: 3 k-steps = 72 MFMAs (1150 cycles) of cover per wave, two waves per SIMD; 6 spilled 30-40 registers
+        if (nks % 3 == 0) return launch_strip<BF16, EPI, TP, 3>(a, s);
+        if (nks % 4 == 0) return launch_strip<BF16, EPI, TP, 4>(a, s);
+        return launch_strip<BF16, EPI, TP, 2>(a, s);
+    } else {
+        return launch_strip<BF16, EPI, TP, 4>(a, s);          // KC % 64 == 0: nks % 4 == 0
+    }
+}
+
 template <bool BF16, int EPI>
 static int launch_strip_tp(const DenseArgs& a, hipStream_t s) {
     const int ntiles = a.N / 16, nchunks = a.K / a.KC;
-    // a chunked reduction keeps its accumulators across chunks: one pass over all tiles; otherwise the tile count per
-    // wave and pass that leaves the fewest waves idle in the last pass
-    int tp;
-    if (nchunks > 1) {
-        tp = (ntiles + 3) / 4;
-        if (tp > 4) return PF_ERR_UNSUPPORTED;
-    } else if (ntiles % 12 == 0) tp = 3;
-    else if (ntiles % 16 == 0) tp = 4;
-    else tp = std::min(4, (ntiles + 3) / 4);
-    switch (tp) {
-    case 1: return launch_strip<BF16, EPI, 1>(a, s);
-    case 2: return launch_strip<BF16, EPI, 2>(a, s);
-    case 3: return launch_strip<BF16, EPI, 3>(a, s);
-    default: return launch_strip<BF16, EPI, 4>(a, s);
-    }
+    // a chunked reduction keeps its accumulators across chunks: one pass over all tiles (<= 16); otherwise 3 tiles per
+    // wave and pass, 4 where that divides the tile count evenly
+    if (nchunks > 1 && ntiles > 16) return PF_ERR_UNSUPPORTED;
+    const bool four = (nchunks > 1 && ntiles > 12) || (nchunks == 1 && ntiles % 16 == 0 && ntiles % 12 != 0);
+    return four ? launch_strip_rd<BF16, EPI, 4>(a, s) : launch_strip_rd<BF16, EPI, 3>(a, s);
 }
 
 int dense_nt(bool bf16, int epilogue, const DenseArgs& a, hipStream_t s) {
@@ -335,71 +371,91 @@ struct SeqCursor {                 // row m -> (sequence, position) advanced inc
     __device__ void advance(int64_t d, int64_t rps) { pos += d; while (pos >= rps) { pos -= rps; ++seq; } }
 };
 
-__global__ __launch_bounds__(256) void dense_tn_bf16_kernel(const DenseTnArgs p) {
-    constexpr int BK = 64, BN = 128;
-    __shared__ __attribute__((aligned(16))) char smem[2 * BK * BN * 2];
+// WG tile = (16 TI WR) x (16 TJ WC) outputs, WR x WC waves of TI x TJ MFMA tiles.  Every operand byte is read once per
+// output tile of the OTHER dimension, so the tile decides the traffic: at 128 x 128 the FFN weight gradients (192 x 768)
+// moved 1.0 GB for 360 MB of operands; 192 x 256 / 256 x 192 with eight waves move 504 MB.
+template <int WR, int WC, int TI, int TJ>
+__global__ __launch_bounds__(64 * WR * WC) void dense_tn_bf16_kernel(const DenseTnArgs p) {
+    constexpr int BK = 64, NT = 64 * WR * WC;
+    constexpr int BN1 = 16 * TI * WR, BN2 = 16 * TJ * WC;
+    constexpr int SUB1 = (BN1 + 127) / 128, SUB2 = (BN2 + 127) / 128;        // [64][128] sub-images per operand
+    constexpr int SPR1 = BN1 / 8, SPR2 = BN2 / 8;                            // 16-byte slots per tile row
+    constexpr int IT1 = (BK * SPR1 + NT - 1) / NT, IT2 = (BK * SPR2 + NT - 1) / NT;
+    constexpr int SUBB = BK * 128 * 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sG = smem;
-    char* sA = smem + BK * BN * 2;
+    char* sA = smem + SUB1 * SUBB;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / WC, wc = wave - wr * WC;
     const int g = lane >> 4, lam = lane & 15, q = lam >> 2, pq = lam & 3;
-    const int tiles2 = (p.N2 + BN - 1) / BN;
+    const int tiles2 = (p.N2 + BN2 - 1) / BN2;
     const int t1 = blockIdx.x / tiles2, t2 = blockIdx.x - t1 * tiles2;
-    const int n1_0 = t1 * BN, n2_0 = t2 * BN;
+    const int n1_0 = t1 * BN1, n2_0 = t2 * BN2;
 
     const int64_t total_chunks = (p.M + BK - 1) / BK;
     const int64_t per = (total_chunks + p.splits - 1) / p.splits;
     const int64_t c_lo = (int64_t)blockIdx.y * per, c_hi = c_lo + per < total_chunks ? c_lo + per : total_chunks;
     if (c_lo >= c_hi) return;
 
-    // staging map: 16 slots per row, 16 rows per sweep, 4 sweeps
-    const int st_slot = tid & 15, st_row = tid >> 4;
-    const bool g_ok = n1_0 + 8 * st_slot + 8 <= p.N1, a_ok = n2_0 + 8 * st_slot + 8 <= p.N2;
-    const __bf16* Gb = reinterpret_cast<const __bf16*>(p.G) + n1_0 + 8 * st_slot;
-    const __bf16* Ab = reinterpret_cast<const __bf16*>(p.A) + n2_0 + 8 * st_slot;
-    SeqCursor cur[4];
+    const __bf16* Gb = reinterpret_cast<const __bf16*>(p.G) + n1_0;
+    const __bf16* Ab = reinterpret_cast<const __bf16*>(p.A) + n2_0;
+    // staging map: slot i of the tile (row-major over [64][slots per row]) for i = tid, tid + NT, ...
+    int g_row[IT1], g_slot[IT1], a_row[IT2], a_slot[IT2];
+    SeqCursor gc[IT1], ac[IT2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) cur[i].init(c_lo * BK + st_row + 16 * i, p.rows_per_seq);
+    for (int i = 0; i < IT1; ++i) {
+        const int idx = tid + NT * i;
+        g_row[i] = idx / SPR1; g_slot[i] = idx - g_row[i] * SPR1;
+        gc[i].init(c_lo * BK + (g_row[i] < BK ? g_row[i] : 0), p.rows_per_seq);
+    }
+#pragma unroll
+    for (int i = 0; i < IT2; ++i) {
+        const int idx = tid + NT * i;
+        a_row[i] = idx / SPR2; a_slot[i] = idx - a_row[i] * SPR2;
+        ac[i].init(c_lo * BK + (a_row[i] < BK ? a_row[i] : 0), p.rows_per_seq);
+    }
 
-    f32x4 acc[4][4];
+    f32x4 acc[TI][TJ];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float bsum = 0.f;                                  // db: thread = column tid & 127, rows half tid >> 7
+        for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;                                  // db: thread = column tid (< BN1), all 64 rows of a chunk
 
-    u32x4 vg[4], va[4];
+    u32x4 vg[IT1], va[IT2];
     auto fetch = [&](int64_t chunk) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int64_t m = chunk * BK + st_row + 16 * i;
+        for (int i = 0; i < IT1; ++i) {
             vg[i] = u32x4{0u, 0u, 0u, 0u};
+            if (g_row[i] < BK && chunk * BK + g_row[i] < p.M && n1_0 + 8 * g_slot[i] + 8 <= p.N1)
+                vg[i] = *reinterpret_cast<const u32x4*>(Gb + gc[i].seq * p.g_seq_stride + gc[i].pos * p.ldg + 8 * g_slot[i]);
+            gc[i].advance(BK, p.rows_per_seq);
+        }
+#pragma unroll
+        for (int i = 0; i < IT2; ++i) {
             va[i] = u32x4{0u, 0u, 0u, 0u};
-            if (m < p.M) {
-                if (g_ok) vg[i] = *reinterpret_cast<const u32x4*>(Gb + cur[i].seq * p.g_seq_stride + cur[i].pos * p.ldg);
-                if (a_ok) va[i] = *reinterpret_cast<const u32x4*>(Ab + cur[i].seq * p.a_seq_stride + cur[i].pos * p.lda);
-            }
-            cur[i].advance(BK, p.rows_per_seq);
+            if (a_row[i] < BK && chunk * BK + a_row[i] < p.M && n2_0 + 8 * a_slot[i] + 8 <= p.N2)
+                va[i] = *reinterpret_cast<const u32x4*>(Ab + ac[i].seq * p.a_seq_stride + ac[i].pos * p.lda + 8 * a_slot[i]);
+            ac[i].advance(BK, p.rows_per_seq);
         }
     };
     auto put = [&]() {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = st_row + 16 * i;
-            *reinterpret_cast<u32x4*>(sG + tn_off(row, st_slot)) = vg[i];
-            *reinterpret_cast<u32x4*>(sA + tn_off(row, st_slot)) = va[i];
-        }
+        for (int i = 0; i < IT1; ++i)
+            if (g_row[i] < BK) *reinterpret_cast<u32x4*>(sG + (g_slot[i] >> 4) * SUBB + tn_off(g_row[i], g_slot[i] & 15)) = vg[i];
+#pragma unroll
+        for (int i = 0; i < IT2; ++i)
+            if (a_row[i] < BK) *reinterpret_cast<u32x4*>(sA + (a_slot[i] >> 4) * SUBB + tn_off(a_row[i], a_slot[i] & 15)) = va[i];
     };
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
     auto tr_frag = [&](const char* tile, int col0, int kk) -> bf16x8 {
         // rows 32 kk + 8 g .. + 7 of column col0 + lam: two 4 x 16 blocks
+        const char* sub = tile + (col0 >> 7) * SUBB;
         const int r0 = 32 * kk + 8 * g;
-        const int slot = (col0 >> 3) + (pq >> 1);
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (lds_s16x4*)(tile + tn_off(r0 + q, slot) + 8 * (pq & 1)));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (lds_s16x4*)(tile + tn_off(r0 + 4 + q, slot) + 8 * (pq & 1)));
+        const int slot = ((col0 & 127) >> 3) + (pq >> 1);
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sub + tn_off(r0 + q, slot) + 8 * (pq & 1)));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sub + tn_off(r0 + 4 + q, slot) + 8 * (pq & 1)));
         const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         return __builtin_bit_cast(bf16x8, v);
     };
@@ -411,45 +467,46 @@ __global__ __launch_bounds__(256) void dense_tn_bf16_kernel(const DenseTnArgs p)
         put();
         __syncthreads();
         if (chunk + 1 < c_hi) fetch(chunk + 1);        // in flight under the MFMAs below
-        if (p.db && t2 == 0) {
-            const int col = tid & 127, half = tid >> 7;
+        if (p.db && t2 == 0 && tid < BN1) {
+            const char* sub = sG + (tid >> 7) * SUBB;
+            const int col = tid & 127;
             float sacc = 0.f;
 #pragma unroll 8
-            for (int r = 32 * half; r < 32 * half + 32; ++r)
-                sacc += (float)*reinterpret_cast<const __bf16*>(sG + tn_off(r, col >> 3) + 2 * (col & 7));
+            for (int r = 0; r < BK; ++r)
+                sacc += (float)*reinterpret_cast<const __bf16*>(sub + tn_off(r, col >> 3) + 2 * (col & 7));
             bsum += sacc;
         }
 #pragma unroll
         for (int kk = 0; kk < BK / 32; ++kk) {
-            bf16x8 af[4], bfr[4];
+            bf16x8 af[TI], bfr[TJ];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = tr_frag(sG, 64 * wr + 16 * i, kk);
+            for (int i = 0; i < TI; ++i) af[i] = tr_frag(sG, 16 * TI * wr + 16 * i, kk);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bfr[j] = tr_frag(sA, 64 * wc + 16 * j, kk);
+            for (int j = 0; j < TJ; ++j) bfr[j] = tr_frag(sA, 16 * TJ * wc + 16 * j, kk);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < TI; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < TJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
     }
-    // lane (g, lam): dW[n1_0 + 64 wr + 16 i + 4 g + r][n2_0 + 64 wc + 16 j + lam]
+    // lane (g, lam): dW[n1_0 + 16 TI wr + 16 i + 4 g + r][n2_0 + 16 TJ wc + 16 j + lam]
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n2 = n2_0 + 64 * wc + 16 * j + lam;
+        for (int j = 0; j < TJ; ++j) {
+            const int n2 = n2_0 + 16 * TJ * wc + 16 * j + lam;
             if (n2 >= p.N2) continue;
             int col = n2;
             if (p.conv_cin > 0) { const int tap = n2 / p.conv_cin, chn = n2 - tap * p.conv_cin; col = chn * p.conv_kw + tap; }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int n1 = n1_0 + 64 * wr + 16 * i + 4 * g + r;
+                const int n1 = n1_0 + 16 * TI * wr + 16 * i + 4 * g + r;
                 if (n1 < p.N1) atomicAdd(p.dW + (int64_t)n1 * p.ldw + col, acc[i][j][r]);
             }
         }
-    if (p.db && t2 == 0) {
-        const int n1 = n1_0 + (tid & 127);
+    if (p.db && t2 == 0 && tid < BN1) {
+        const int n1 = n1_0 + tid;
         if (n1 < p.N1) atomicAdd(p.db + n1, bsum);
     }
 }
@@ -550,22 +607,52 @@ __global__ __launch_bounds__(256) void dense_tn_f32_kernel(const DenseTnArgs p) 
     }
 }
 
+template <int WR, int WC, int TI, int TJ>
+static int launch_tn_bf16(DenseTnArgs a, hipStream_t s) {
+    constexpr int BN1 = 16 * TI * WR, BN2 = 16 * TJ * WC, BK = 64;
+    constexpr int lds = (((BN1 + 127) / 128) + ((BN2 + 127) / 128)) * BK * 128 * 2;
+    auto k = dense_tn_bf16_kernel<WR, WC, TI, TJ>;
+    if (lds > 64 * 1024 - 256 && !opt_in_lds(reinterpret_cast<const void*>(k), lds)) return PF_ERR_HIP;
+    const int tiles = ((a.N1 + BN1 - 1) / BN1) * ((a.N2 + BN2 - 1) / BN2);
+    const int64_t chunks = (a.M + BK - 1) / BK;
+    if (a.splits <= 0) {
+        // one workgroup of 8 waves (two of 4) per CU and round, a few rounds, each workgroup at least 4 row chunks deep
+        // never a few workgroups MORE than a whole number of rounds (513 workgroups = three rounds for the work of two)
+        const int per_cu = WR * WC >= 8 ? 1 : 2;
+        int64_t sp = (256 * per_cu * 2) / tiles;
+        sp = std::min<int64_t>(sp, std::max<int64_t>(1, chunks / 4));
+        a.splits = (int)std::max<int64_t>(1, sp);
+    }
+    hipLaunchKernelGGL(k, dim3((unsigned)tiles, (unsigned)a.splits), dim3(64 * WR * WC), lds, s, a);
+    return launch_status();
+}
+
 int dense_tn(bool bf16, const DenseTnArgs& a0, hipStream_t s) {
     if (a0.M <= 0) return PF_OK;
     if (a0.N1 <= 0 || a0.N2 <= 0 || a0.N1 % (bf16 ? 8 : 4) || a0.N2 % (bf16 ? 8 : 4)) return PF_ERR_BAD_ARG;
     DenseTnArgs a = a0;
-    const int bn = bf16 ? 128 : 64, bk = bf16 ? 64 : 32;
+    if (bf16) {
+        // operand traffic of a tiling: every G byte is read once per N2 tile, every A byte once per N1 tile
+        auto cost = [&](int bn1, int bn2) {
+            return (int64_t)a.N1 * ((a.N2 + bn2 - 1) / bn2) + (int64_t)a.N2 * ((a.N1 + bn1 - 1) / bn1);
+        };
+        const int64_t c128 = cost(128, 128), ca = cost(192, 256), cb = cost(256, 192);
+        // narrow gradients (the convolutions: 32 - 128 channels): two 4-wave workgroups per CU overlap their load latency,
+        // one 8-wave workgroup with a third of its MFMA rows empty does not (conv3: 421 vs 559 us)
+        if (a.N1 <= 128) return launch_tn_bf16<2, 2, 4, 4>(a, s);
+        if (ca <= cb && ca < c128) return launch_tn_bf16<2, 4, 6, 4>(a, s);
+        if (cb < c128) return launch_tn_bf16<4, 2, 4, 6>(a, s);
+        return launch_tn_bf16<2, 2, 4, 4>(a, s);
+    }
+    const int bn = 64, bk = 32;
     const int tiles = ((a.N1 + bn - 1) / bn) * ((a.N2 + bn - 1) / bn);
     const int64_t chunks = (a.M + bk - 1) / bk;
     if (a.splits <= 0) {
-        // ~3 workgroups per CU over all tiles, each at least 4 row chunks deep
         int64_t sp = (768 + tiles - 1) / tiles;
         sp = std::min<int64_t>(sp, std::max<int64_t>(1, chunks / 4));
         a.splits = (int)std::max<int64_t>(1, sp);
     }
-    const dim3 grid((unsigned)tiles, (unsigned)a.splits);
-    if (bf16) hipLaunchKernelGGL(dense_tn_bf16_kernel, grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(dense_tn_f32_kernel, grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(dense_tn_f32_kernel, dim3((unsigned)tiles, (unsigned)a.splits), dim3(256), 0, s, a);
     return launch_status();
 }
 

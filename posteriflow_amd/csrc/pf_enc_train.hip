@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/pf_hip.h"
@@ -112,7 +113,7 @@ struct Ws {
     struct Layer { int64_t x, mean1, rstd1, y1, qkv, lse, o, xmid, mean2, rstd2, y2, hd, gd; } L[kEncLayers];
     int64_t x3, x3a, kv;
     // backward temporaries
-    int64_t dxa, dxb, g192a, g192b, g768, dqkv, dkv, dy, gpad[4], g1, total;
+    int64_t dxa, dxb, g192a[kEncLayers], g192b[kEncLayers], g768[kEncLayers], dqkv[kEncLayers], dkv, dy, gpad[4], g1, total;
 };
 struct Dims { int64_t B, N, R; int T, D, n_extra; bool bf16; int esz; };
 constexpr int kGpadRows[4] = {0, 514, 128, 64};                // rows per sequence of the padded gradient images of conv2..4
@@ -139,8 +140,11 @@ Ws ws_layout(const Dims& d) {
     w.x3a = d.bf16 ? take(d.R * kEncD * e) : w.x3;
     w.kv = take(d.R * 2 * kEncD * e);
     w.dxa = take(d.R * kEncD * 4); w.dxb = take(d.R * kEncD * 4);
-    w.g192a = take(d.R * kEncD * e); w.g192b = take(d.R * kEncD * e);
-    w.g768 = take(d.R * kEncFF * e); w.dqkv = take(d.R * 3 * kEncD * e); w.dkv = take(d.R * 2 * kEncD * e);
+    for (int l = 0; l < kEncLayers; ++l) {       // per layer: the weight-gradient GEMMs read them on a second stream while
+        w.g192a[l] = take(d.R * kEncD * e); w.g192b[l] = take(d.R * kEncD * e);      // the chain moves on to the layer below
+        w.g768[l] = take(d.R * kEncFF * e); w.dqkv[l] = take(d.R * 3 * kEncD * e);
+    }
+    w.dkv = take(d.R * 2 * kEncD * e);
     w.dy = take(d.R * kEncD * e);
     for (int l = 1; l < 4; ++l) w.gpad[l] = take(d.N * kGpadRows[l] * kConv[l].cout * e);
     w.g1 = take(d.N * kConv[0].lout * kConv[0].cout * e);
@@ -162,6 +166,35 @@ int dims_of(const PfEmbedTrainDesc* desc, int64_t n_events, Dims& d) {
 }
 
 #define PF_TRY(x) do { const int rc_ = (x); if (rc_ != PF_OK) return rc_; } while (0)
+
+// The weight-gradient GEMMs are off the backward's critical path (nothing downstream reads dW) and individually latency-bound
+// (1 - 2 workgroups per CU): they run on a second stream, forked from and joined back into the caller's stream with events,
+// under the data-gradient chain.  One side stream and a small ring of events per host thread and device, created on first use.
+struct SideStream {
+    static constexpr int kEvents = 32;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[kEvents];
+    int device = -1, next = 0;
+    int ensure() {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return hip_failed(hipGetLastError());
+        if (stream && dev == device) return PF_OK;
+        if (stream) return PF_ERR_UNSUPPORTED;            // one device per host thread (one process per GPU)
+        if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return hip_failed(hipGetLastError());
+        for (int i = 0; i < kEvents; ++i)
+            if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return hip_failed(hipGetLastError());
+        device = dev;
+        return PF_OK;
+    }
+    // everything enqueued on `from` so far happens before what is enqueued on `to` from now on
+    int order(hipStream_t from, hipStream_t to) {
+        hipEvent_t e = ev[next];
+        next = (next + 1) % kEvents;
+        if (hipEventRecord(e, from) != hipSuccess || hipStreamWaitEvent(to, e, 0) != hipSuccess) return hip_failed(hipGetLastError());
+        return PF_OK;
+    }
+};
+thread_local SideStream g_side;
 
 // a plain [R][K] x W^T GEMM
 int linear(const Dims& d, int epi, const void* A, int K, int N, const void* frags, const float* bias, void* out, hipStream_t s,
@@ -294,22 +327,38 @@ int enc_train_backward(const PfEmbedTrainDesc* desc, const void* packed, const f
     float* dxa = reinterpret_cast<float*>(ws + w.dxa);
     float* dxb = reinterpret_cast<float*>(ws + w.dxb);
 
+    // weight-gradient GEMMs go to the side stream (PF_ENC_ONE_STREAM=1 keeps everything on the caller's stream: A/B timing)
+    static const bool one_stream = std::getenv("PF_ENC_ONE_STREAM") != nullptr;
+    hipStream_t side = s;
+    if (!one_stream) {
+        PF_TRY(g_side.ensure());
+        side = g_side.stream;
+        PF_TRY(g_side.order(s, side));                  // the zeroing of grad_raw above, and whatever produced our inputs
+    }
+    // run `tn` on the side stream once everything enqueued on the main stream so far (its operands) is done
+    auto on_side = [&](auto&& tn) -> int {
+        if (side != s) PF_TRY(g_side.order(s, side));
+        return tn(side);
+    };
+
     // ---- pool ----------------------------------------------------------------------------------------------------------
     PoolArgs po{};
     po.kv = ws + w.kv; po.q = pool_q; po.B = d.B; po.T = d.T; po.dpooled = grad_pooled; po.dkv = ws + w.dkv;
     po.dq = grad_pool_q ? grad_pool_q : dxb;          // (dxb is scratch here when the caller does not want dq; zeroed below)
     if (!grad_pool_q && hipMemsetAsync(dxb, 0, kEncPoolQ * kEncD * 4, s) != hipSuccess) return hip_failed(hipGetLastError());
     PF_TRY(pool_backward(d.bf16, po, s));
-    PF_TRY(weight_grad(d, ws + w.dkv, 2 * kEncD, ws + w.x3a, kEncD, grad_raw + r.pool_w + (int64_t)kEncD * kEncD,
-                       grad_raw + r.pool_b + kEncD, s));
+    PF_TRY(on_side([&](hipStream_t q) {
+        return weight_grad(d, ws + w.dkv, 2 * kEncD, ws + w.x3a, kEncD, grad_raw + r.pool_w + (int64_t)kEncD * kEncD,
+                           grad_raw + r.pool_b + kEncD, q);
+    }));
     PF_TRY(linear(d, kEpiPlain, ws + w.dkv, 2 * kEncD, kEncD, fr + pk.kv_t, nullptr, dxa, s, nullptr, nullptr, nullptr, 0.f, 0, 0, true));
 
     // ---- token mixer, last layer first ---------------------------------------------------------------------------------
-    // entering layer l: dxa = dL/dx_{l+1} (fp32), g192a = act(dxa . dropout factor of the layer's second residual branch)
+    // entering layer l: dxa = dL/dx_{l+1} (fp32), g192a[l] = act(dxa . dropout factor of the layer's second residual branch)
     {
         const int64_t n4 = d.R * kEncD / 4;
         const unsigned grid = (unsigned)((n4 + 1023) / 1024 > 2048 ? 2048 : (n4 + 1023) / 1024);
-        hipLaunchKernelGGL(drop_cast_kernel, dim3(grid), dim3(256), 0, s, dxa, ws + w.g192a, n4, d.bf16 ? 1 : 0, p, seed,
+        hipLaunchKernelGGL(drop_cast_kernel, dim3(grid), dim3(256), 0, s, dxa, ws + w.g192a[kEncLayers - 1], n4, d.bf16 ? 1 : 0, p, seed,
                            (uint32_t)(4 * (kEncLayers - 1) + 3));
         PF_TRY(launch_status());
     }
@@ -317,29 +366,33 @@ int enc_train_backward(const PfEmbedTrainDesc* desc, const void* packed, const f
         const auto& L = w.L[l];
         const auto& R = r.L[l];
         const auto& P = pk.L[l];
+        char* g192a = ws + w.g192a[l];
+        char* g192b = ws + w.g192b[l];
+        char* g768 = ws + w.g768[l];
+        char* dqkv = ws + w.dqkv[l];
         // FFN: x_{l+1} = xmid + D3 . (W2 hd + b2),  hd = D2 . gelu(W1 y2 + b1)
-        PF_TRY(weight_grad(d, ws + w.g192a, kEncD, ws + L.hd, kEncFF, grad_raw + R.w2, grad_raw + R.b2, s));
-        PF_TRY(linear(d, kEpiMul, ws + w.g192a, kEncD, kEncFF, fr + P.w2_t, nullptr, ws + w.g768, s, nullptr, nullptr, ws + L.gd));
-        PF_TRY(weight_grad(d, ws + w.g768, kEncFF, ws + L.y2, kEncD, grad_raw + R.w1, grad_raw + R.b1, s));
-        PF_TRY(linear(d, kEpiPlain, ws + w.g768, kEncFF, kEncD, fr + P.w1_t, nullptr, ws + w.dy, s));
+        PF_TRY(on_side([&](hipStream_t q) { return weight_grad(d, g192a, kEncD, ws + L.hd, kEncFF, grad_raw + R.w2, grad_raw + R.b2, q); }));
+        PF_TRY(linear(d, kEpiMul, g192a, kEncD, kEncFF, fr + P.w2_t, nullptr, g768, s, nullptr, nullptr, ws + L.gd));
+        PF_TRY(on_side([&](hipStream_t q) { return weight_grad(d, g768, kEncFF, ws + L.y2, kEncD, grad_raw + R.w1, grad_raw + R.b1, q); }));
+        PF_TRY(linear(d, kEpiPlain, g768, kEncFF, kEncD, fr + P.w1_t, nullptr, ws + w.dy, s));
         LnArgs ln{};
         ln.x = reinterpret_cast<const float*>(ws + L.xmid); ln.gamma = raw + R.n2w; ln.M = d.R;
         ln.mean = reinterpret_cast<float*>(ws + L.mean2); ln.rstd = reinterpret_cast<float*>(ws + L.rstd2);
-        ln.dy = ws + w.dy; ln.dres = dxa; ln.dx = dxb; ln.gout = ws + w.g192b;
+        ln.dy = ws + w.dy; ln.dres = dxa; ln.dx = dxb; ln.gout = g192b;
         ln.dgamma = grad_raw + R.n2w; ln.dbeta = grad_raw + R.n2b; ln.drop_p = p; ln.seed = seed; ln.site = 4 * l + 1;
         PF_TRY(ln_backward(d.bf16, ln, s));
         // attention: xmid = x + D1 . (Wo O + bo)
-        PF_TRY(weight_grad(d, ws + w.g192b, kEncD, ws + L.o, kEncD, grad_raw + R.ow, grad_raw + R.ob, s));
-        PF_TRY(linear(d, kEpiPlain, ws + w.g192b, kEncD, kEncD, fr + P.o_t, nullptr, ws + w.dy, s));
+        PF_TRY(on_side([&](hipStream_t q) { return weight_grad(d, g192b, kEncD, ws + L.o, kEncD, grad_raw + R.ow, grad_raw + R.ob, q); }));
+        PF_TRY(linear(d, kEpiPlain, g192b, kEncD, kEncD, fr + P.o_t, nullptr, ws + w.dy, s));
         AttnArgs at{};
         at.qkv = ws + L.qkv; at.B = d.B; at.T = d.T; at.out = ws + L.o; at.lse = reinterpret_cast<float*>(ws + L.lse);
-        at.drop_p = p; at.seed = seed; at.site = 4 * l + 0; at.dout = ws + w.dy; at.dqkv = ws + w.dqkv;
+        at.drop_p = p; at.seed = seed; at.site = 4 * l + 0; at.dout = ws + w.dy; at.dqkv = dqkv;
         PF_TRY(attn_backward(d.bf16, at, s));
-        PF_TRY(weight_grad(d, ws + w.dqkv, 3 * kEncD, ws + L.y1, kEncD, grad_raw + R.inw, grad_raw + R.inb, s));
-        PF_TRY(linear(d, kEpiPlain, ws + w.dqkv, 3 * kEncD, kEncD, fr + P.in_t, nullptr, ws + w.dy, s));
+        PF_TRY(on_side([&](hipStream_t q) { return weight_grad(d, dqkv, 3 * kEncD, ws + L.y1, kEncD, grad_raw + R.inw, grad_raw + R.inb, q); }));
+        PF_TRY(linear(d, kEpiPlain, dqkv, 3 * kEncD, kEncD, fr + P.in_t, nullptr, ws + w.dy, s));
         ln.x = reinterpret_cast<const float*>(ws + L.x); ln.gamma = raw + R.n1w;
         ln.mean = reinterpret_cast<float*>(ws + L.mean1); ln.rstd = reinterpret_cast<float*>(ws + L.rstd1);
-        ln.dy = ws + w.dy; ln.dres = dxb; ln.dx = dxa; ln.gout = l > 0 ? ws + w.g192a : nullptr;
+        ln.dy = ws + w.dy; ln.dres = dxb; ln.dx = dxa; ln.gout = l > 0 ? ws + w.g192a[l - 1] : nullptr;
         ln.dgamma = grad_raw + R.n1w; ln.dbeta = grad_raw + R.n1b; ln.site = l > 0 ? 4 * (l - 1) + 3 : 0;
         PF_TRY(ln_backward(d.bf16, ln, s));
     }
@@ -363,7 +416,7 @@ int enc_train_backward(const PfEmbedTrainDesc* desc, const void* packed, const f
         t.ldg = c.cout; t.lda = c.s * c.cin; t.M = d.N * c.lout; t.rows_per_seq = c.lout; t.N1 = c.cout; t.N2 = c.kw * c.cin;
         t.dW = grad_raw + r.conv_w[l]; t.ldw = c.cin * c.kw; t.conv_cin = c.cin; t.conv_kw = c.kw; t.db = grad_raw + r.conv_b[l];
         t.splits = 0;
-        PF_TRY(dense_tn(d.bf16, t, s));
+        PF_TRY(on_side([&](hipStream_t q) { return dense_tn(d.bf16, t, q); }));
         if (l == 0) break;
         // data gradient: transposed convolution as a GEMM over windows of the padded gradient image, times gelu' of the
         // previous layer, written into that layer's padded image (or the plain G1 of the first layer)
@@ -381,6 +434,7 @@ int enc_train_backward(const PfEmbedTrainDesc* desc, const void* packed, const f
         a.mul = ws + w.dact[l - 1];
         PF_TRY(dense_nt(d.bf16, kEpiMul, a, s));
     }
+    if (side != s) PF_TRY(g_side.order(side, s));       // join: the caller's stream continues after the last weight gradient
     return PF_OK;
 }
 

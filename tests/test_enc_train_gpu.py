@@ -152,7 +152,14 @@ def test_coherent_encoder_trains_through_the_hip_path(golden_encoder):
     (ctx * weight).sum().backward()
     w = {k: v.detach().cpu().double().requires_grad_(v.dtype.is_floating_point) for k, v in enc.state_dict().items()
          if k not in ("pos.pe", "Bsum", "bcount", "lags_norm")}
-    out = lean_ref.coherent_encoder_forward(w, strain.cpu().double(), asd.cpu().double())
+    # coherent_encoder_forward (CE:118-123) step by step: the FFT geometry features are fp32 by construction (CE:93),
+    # everything downstream in float64
+    geom = lean_ref.CoherentGeometry()
+    clean = lean_ref.sanitize_strain(strain.cpu())
+    gfeat = lean_ref._mlp2(w, "geom_mlp", geom.rel(clean).double())
+    gtok = torch.nn.functional.linear(gfeat, w["geom_to_tokens.weight"], w["geom_to_tokens.bias"]).reshape(-1, 4, 192)
+    feats, _ = lean_ref.encoder_features(w, clean.double(), asd.cpu().double(), extra_tokens=gtok, psd_bands=16)
+    out = lean_ref.out_proj(w, feats)
     (out * weight.cpu().double()).sum().backward()
     for name in ("geom_to_tokens.weight", "geom_mlp.0.weight", "fusion.layers.0.self_attn.in_proj_weight", "stem.0.weight",
                  "pool_queries", "detector_embed.weight"):

@@ -232,15 +232,20 @@ def test_config5_draw_statistics_at_full_depth(precision):
         a, b = got[:, d].double(), want[:, d].double()
         ks = ks_2samp(a.numpy(), b.numpy())
         scale = b.std().item()
-        dq = (torch.quantile(a, qs) - torch.quantile(b, qs)).abs().max().item() / scale
+        # a quantile estimate has standard error sqrt(q (1 - q) / n) / pdf(x_q): the density at each quantile is estimated
+        # from the oracle's own sample (a +-1 % probability window); gaps are measured in units of that error (two samples)
+        qa, qb = torch.quantile(a, qs), torch.quantile(b, qs)
+        pdf = 0.02 / (torch.quantile(b, (qs + 0.01).clamp(max=0.999)) - torch.quantile(b, (qs - 0.01).clamp(min=0.001))).clamp_min(1e-9)
+        se = torch.sqrt(2 * qs * (1 - qs) / n) / pdf
+        dq = ((qa - qb).abs() / (se + 2e-3 * scale)).max().item()
         worst_ks, worst_q = max(worst_ks, ks.statistic), max(worst_q, dq)
         if precision == "fp32":
             assert ks.pvalue > 1e-4, (d, ks)
         assert ks.statistic < 0.01, (d, ks)
         assert abs(a.mean().item() - b.mean().item()) < 6 * scale * (2.0 / n) ** 0.5 + (0.0 if precision == "fp32" else 5e-3 * scale)
         assert abs(a.std().item() / scale - 1.0) < 0.02
-        assert dq < 0.03, (d, dq)
-    print(f"\n[config 5 {precision}] 1e5 draws, 12 layers: worst KS statistic {worst_ks:.4f}, worst quantile gap {worst_q:.4f} sigma")
+        assert dq < (5.0 if precision == "fp32" else 8.0), (d, dq, qa.tolist(), qb.tolist())
+    print(f"\n[config 5 {precision}] 1e5 draws, 12 layers: worst KS statistic {worst_ks:.4f}, worst quantile gap {worst_q:.2f} standard errors")
 
 
 INC_CONFIGS = {
