@@ -418,7 +418,7 @@ typedef struct PfAttnArgs {     /* 6-head self-attention over T <= 192 tokens, h
     int64_t B; int32_t T;
     void* out;                /* [B * T][192] act type: forward output (read by the backward) */
     float* lse;               /* [B][6][T] */
-    float drop_p; uint32_t seed, site;   /* factor of (event e, head h, query q, key k) = hash(seed, site, ((e 6 + h) T + q) T + k) */
+    float drop_p; uint32_t seed, site;   /* factor of (event e, head h, query q, key k) = hash(seed, site, ((e 6 + h) T + q) 192 + k) */
     const void* dout; void* dqkv;
 } PfAttnArgs;
 int pf_enc_attn_forward(int32_t precision, const PfAttnArgs* args, void* stream);

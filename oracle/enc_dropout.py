@@ -6,16 +6,28 @@ devices)."""
 import numpy as np
 
 
+def _u32(x):
+    return np.uint32(x & 0xFFFFFFFF)
+
+
+def drop_key(seed: int, site: int) -> int:
+    k = (seed * 0x9E3779B9 + site * 0x85EBCA6B + 0x7F4A7C15) & 0xFFFFFFFF
+    k ^= k >> 15
+    k = (k * 0x2C1B3C6D) & 0xFFFFFFFF
+    k ^= k >> 13
+    return k
+
+
 def drop_hash(seed: int, site: int, idx: np.ndarray) -> np.ndarray:
-    """24-bit hash of (seed, site, element index); uint32 arithmetic throughout"""
+    """16-bit hash of (seed, site, element index): elements 2 j and 2 j + 1 take the low / high half of
+    lowbias32(j ^ key); uint32 arithmetic throughout"""
     idx = np.asarray(idx, dtype=np.uint32)
     with np.errstate(over="ignore"):
-        h = np.uint32(seed & 0xFFFFFFFF) ^ np.uint32((site * 0x9E3779B9) & 0xFFFFFFFF)
-        h = np.uint32(h)
-        h = h ^ (idx + np.uint32(0x7F4A7C15) + np.uint32((int(h) << 6) & 0xFFFFFFFF) + np.uint32(int(h) >> 2))
-        h = h * np.uint32(0x85EBCA6B); h = h ^ (h >> np.uint32(13)); h = h * np.uint32(0xC2B2AE35); h = h ^ (h >> np.uint32(16))
-        h = h + idx * np.uint32(0x27D4EB2F); h = h ^ (h >> np.uint32(15)); h = h * np.uint32(0x2C1B3C6D); h = h ^ (h >> np.uint32(12))
-    return h >> np.uint32(8)
+        x = (idx >> np.uint32(1)) ^ _u32(drop_key(seed & 0xFFFFFFFF, site))
+        x = x ^ (x >> np.uint32(16)); x = x * np.uint32(0x7FEB352D)
+        x = x ^ (x >> np.uint32(15)); x = x * np.uint32(0x846CA68B)
+        x = x ^ (x >> np.uint32(16))
+    return np.where(idx & np.uint32(1), x >> np.uint32(16), x & np.uint32(0xFFFF)).astype(np.uint32)
 
 
 def seed32(seed64: int) -> int:
@@ -27,7 +39,7 @@ def factors(p: float, seed32_: int, site: int, n: int, start: int = 0) -> np.nda
     """float32 [n]: the factor of elements start .. start + n - 1 of dropout layer `site`"""
     if not p > 0.0:
         return np.ones(n, dtype=np.float32)
-    thr = np.uint32(int(np.float32(p) * np.float32(16777216.0) + np.float32(0.5)))
+    thr = np.uint32(int(np.float32(p) * np.float32(65536.0) + np.float32(0.5)))
     idx = (np.arange(n, dtype=np.uint64) + np.uint64(start)).astype(np.uint32)
     keep = drop_hash(seed32_, site, idx) >= thr
     return np.where(keep, np.float32(1.0) / (np.float32(1.0) - np.float32(p)), np.float32(0.0)).astype(np.float32)

@@ -52,15 +52,34 @@ int dense_pack(bool bf16, const float* raw, const DensePackTable& tab, void* pac
 int dense_nt(bool bf16, int epilogue, const DenseArgs& a, hipStream_t s);
 int dense_tn(bool bf16, const DenseTnArgs& a, hipStream_t s);
 
-// counter-hash dropout shared by every kernel of the training path: keep <=> hash >= p * 2^24 (24 bits), kept values are
-// scaled by 1 / (1 - p).  `site` numbers the dropout layers of the model, `idx` the element inside the layer's tensor.
-__host__ __device__ inline uint32_t enc_drop_hash(uint32_t seed, uint32_t site, uint32_t idx) {
-    uint32_t h = seed ^ (site * 0x9E3779B9u);
-    h ^= idx + 0x7F4A7C15u + (h << 6) + (h >> 2);
-    h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
-    h += idx * 0x27D4EB2Fu; h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
-    return h >> 8;
+// counter-hash dropout shared by every kernel of the training path.  `site` numbers the dropout layers of the model,
+// `idx` the element inside the layer's tensor.  Elements 2 j and 2 j + 1 share ONE 32-bit hash (lowbias32 of j ^ key) and
+// take its low / high 16 bits: keep <=> bits >= p * 2^16, kept values are scaled by 1 / (1 - p).  (The first version spent
+// five 32-bit multiplies per element; in the attention kernels the hash was two thirds of the vector instructions.)
+__host__ __device__ inline uint32_t enc_drop_key(uint32_t seed, uint32_t site) {
+    uint32_t k = seed * 0x9E3779B9u + site * 0x85EBCA6Bu + 0x7F4A7C15u;
+    k ^= k >> 15; k *= 0x2C1B3C6Du; k ^= k >> 13;
+    return k;
 }
-__host__ __device__ inline uint32_t enc_drop_threshold(float p) { return (uint32_t)(p * 16777216.0f + 0.5f); }
+__host__ __device__ inline uint32_t enc_drop_pair(uint32_t key, uint32_t pair) {
+    uint32_t x = pair ^ key;
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+__host__ __device__ inline uint32_t enc_drop_hash(uint32_t seed, uint32_t site, uint32_t idx) {       // 16 bits
+    const uint32_t x = enc_drop_pair(enc_drop_key(seed, site), idx >> 1);
+    return (idx & 1u) ? (x >> 16) : (x & 0xFFFFu);
+}
+__host__ __device__ inline uint32_t enc_drop_threshold(float p) { return (uint32_t)(p * 65536.0f + 0.5f); }
+// the four factors of elements idx .. idx + 3, idx a multiple of 4: two hashes
+template <typename V4>
+__device__ inline void enc_drop4(uint32_t seed, uint32_t site, uint32_t idx, uint32_t thr, float scale, V4& fac) {
+    const uint32_t key = enc_drop_key(seed, site);
+    const uint32_t a = enc_drop_pair(key, idx >> 1), b = enc_drop_pair(key, (idx >> 1) + 1);
+    fac[0] = (a & 0xFFFFu) >= thr ? scale : 0.f;
+    fac[1] = (a >> 16) >= thr ? scale : 0.f;
+    fac[2] = (b & 0xFFFFu) >= thr ? scale : 0.f;
+    fac[3] = (b >> 16) >= thr ? scale : 0.f;
+}
 
 }  // namespace pf

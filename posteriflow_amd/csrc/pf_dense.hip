@@ -105,6 +105,8 @@ __global__ __launch_bounds__(256, TP <= 3 ? 2 : 1) void dense_strip_kernel(const
     const int cpr = p.KC / EPC;                        // 16-byte slots per image row
     const int rowbytes = p.KC * ESZ;
     const char* Abase = reinterpret_cast<const char*>(p.A);
+    constexpr int PC = 4 * TP * 16;                    // output columns of one pass
+    char* stg = img + (size_t)BM * rowbytes;           // epilogue staging: 2 x (1 | 2 outputs) x 16 rows (sized by the host)
 
     // ---- the fragment ring: requested before anything else so that the first chunk's staging runs under it ----------
     int f_pass = 0, f_kk = 0;
@@ -234,84 +236,117 @@ __global__ __launch_bounds__(256, TP <= 3 ? 2 : 1) void dense_strip_kernel(const
             }
         }
         // ---- epilogue: lane (g, c) holds units 16 tile + 4 g .. + 3 of row 16 cg + c -------------------------------
+        // The results of a 16-row group go through a small LDS buffer and leave as WHOLE ROWS of the pass's 4 TP 16
+        // columns (16 bytes per lane, consecutive lanes on consecutive bytes).  Stored straight from the accumulator
+        // layout -- 8 bytes per lane, 16 rows x 32-byte pieces per instruction -- the kernels were bound by their store
+        // instructions: 192 -> 768 plain 183 us, with GELU + its derivative (two outputs) 438 us, for 17 us of MFMAs.
         const uint32_t thr = enc_drop_threshold(p.drop_p);
         const float dscale = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
+        const bool f32o = EPI == kEpiResid || !BF16 || p.out_f32;
+        const int oesz = f32o ? 4 : 2;
+        const int srow = PC * oesz + 16;                                 // staged row (bytes), 16-byte aligned
+        const int sbuf = 16 * srow;                                      // one output's 16 rows
+        constexpr int NOUT = EPI == kEpiGelu ? 2 : 1;
+        const int pcol0 = pass * PC;
+        f32x4 b4[TP];
 #pragma unroll
         for (int i = 0; i < TP; ++i) {
-            if (tile[i] >= ntiles) continue;
-            const int n0 = tile[i] * 16 + 4 * g;
-            f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-            if (p.bias) b4 = *reinterpret_cast<const f32x4*>(p.bias + n0);
+            b4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p.bias && tile[i] < ntiles) b4[i] = *reinterpret_cast<const f32x4*>(p.bias + tile[i] * 16 + 4 * g);
+        }
 #pragma unroll
-            for (int cg = 0; cg < CG; ++cg) {
-                const int row = 16 * cg + c;
-                const int64_t oo = s_ooff[row];
-                if (oo < 0) continue;
-                if (p.o_valid_per_seq > 0) {
-                    const int64_t m = m0 + row;
-                    const int64_t pos = m - (m / p.rows_per_seq) * p.rows_per_seq;
-                    if (pos * p.ldo + n0 + 4 > p.o_valid_per_seq) continue;
-                }
-                const int64_t off = oo + n0, xoff = s_xoff[row] + n0;
-                f32x4 v = acc[i][cg] + b4;
+        for (int cg = 0; cg < CG; ++cg) {
+            char* buf = stg + (cg & 1) * NOUT * sbuf;
+            const int row = 16 * cg + c;
+            const int64_t xo = s_xoff[row];
+#pragma unroll
+            for (int i = 0; i < TP; ++i) {
+                const int n0 = tile[i] * 16 + 4 * g;
+                const bool live = tile[i] < ntiles && xo >= 0;
+                f32x4 v = acc[i][cg] + b4[i];
                 f32x4 dfac = {1.f, 1.f, 1.f, 1.f};
                 if constexpr (EPI == kEpiGelu || EPI == kEpiResid) {
                     if (p.drop_p > 0.f) {
-                        const uint32_t idx = (uint32_t)((m0 + row) * p.N + n0);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) dfac[e] = enc_drop_hash(p.seed, p.site, idx + e) >= thr ? dscale : 0.f;
+                        enc_drop4(p.seed, p.site, (uint32_t)((m0 + row) * p.N + n0), thr, dscale, dfac);
                     }
                 }
+                f32x4 v2 = {0.f, 0.f, 0.f, 0.f};
                 if constexpr (EPI == kEpiGelu) {
-                    f32x4 y, dy;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float ye, de;
                         if constexpr (BF16) gelu_fast_pair(v[e], ye, de);
                         else { ye = gelu_f32(v[e]); de = gelu_grad_f32(v[e]); }
-                        y[e] = ye; dy[e] = de;
-                    }
-                    y = y * dfac; dy = dy * dfac;
-                    if constexpr (BF16) {
-                        bf16x4 o, d;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { o[e] = (__bf16)y[e]; d[e] = (__bf16)dy[e]; }
-                        *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p.out) + off) = o;
-                        if (p.dact) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p.dact) + xoff) = d;
-                    } else {
-                        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + off) = y;
-                        if (p.dact) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.dact) + xoff) = dy;
+                        v[e] = ye * dfac[e]; v2[e] = de * dfac[e];
                     }
                 } else if constexpr (EPI == kEpiResid) {
-                    const f32x4 r = *reinterpret_cast<const f32x4*>(p.resid + xoff);
-                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + off) = r + v * dfac;
-                } else {
-                    if constexpr (EPI == kEpiMul) {
+                    f32x4 r = {0.f, 0.f, 0.f, 0.f};
+                    if (live) r = *reinterpret_cast<const f32x4*>(p.resid + xo + n0);
+                    v = r + v * dfac;
+                } else if constexpr (EPI == kEpiMul) {
+                    if (live) {
                         if constexpr (BF16) {
-                            const bf16x4 mv = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(p.mul) + xoff);
+                            const bf16x4 mv = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(p.mul) + xo + n0);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] *= (float)mv[e];
                         } else {
-                            v = v * *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.mul) + xoff);
+                            v = v * *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.mul) + xo + n0);
                         }
                     }
-                    if (BF16 && !p.out_f32) {
-                        bf16x4 o;
+                }
+                char* dst = buf + c * srow + ((wave * TP + i) * 16 + 4 * g) * oesz;
+                if (f32o) {
+                    *reinterpret_cast<f32x4*>(dst) = v;
+                    if constexpr (NOUT == 2) *reinterpret_cast<f32x4*>(dst + sbuf) = v2;
+                } else {
+                    bf16x4 o;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
-                        *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p.out) + off) = o;
-                    } else {
-                        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + off) = v;
+                    for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+                    *reinterpret_cast<bf16x4*>(dst) = o;
+                    if constexpr (NOUT == 2) {
+                        bf16x4 o2;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o2[e] = (__bf16)v2[e];
+                        *reinterpret_cast<bf16x4*>(dst + sbuf) = o2;
+                    }
+                }
+            }
+            // LDS only: the global stores of the previous group (and the weight ring) stay in flight across the barrier
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const int cprow = PC * oesz / 16;                            // 16-byte pieces per staged row
+            const int epc = 16 / oesz;
+            for (int idx = tid; idx < 16 * cprow; idx += 256) {
+                const int r16 = idx / cprow, ch = idx - r16 * cprow;
+                const int grow = 16 * cg + r16;
+                const int64_t oo = s_ooff[grow];
+                const int col = pcol0 + ch * epc;
+                if (oo < 0 || col >= p.N) continue;
+                if (p.o_valid_per_seq > 0) {
+                    const int64_t m = m0 + grow;
+                    const int64_t pos = m - (m / p.rows_per_seq) * p.rows_per_seq;
+                    if (pos * p.ldo + col + epc > p.o_valid_per_seq) continue;
+                }
+                const u32x4 val = *reinterpret_cast<const u32x4*>(buf + r16 * srow + ch * 16);
+                *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(p.out) + (oo + col) * oesz) = val;
+                if constexpr (NOUT == 2) {
+                    if (p.dact) {
+                        const u32x4 val2 = *reinterpret_cast<const u32x4*>(buf + sbuf + r16 * srow + ch * 16);
+                        *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(p.dact) + (s_xoff[grow] + col) * oesz) = val2;
                     }
                 }
             }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the last group's LDS reads, before the next pass
+        __builtin_amdgcn_s_barrier();                                    // (or chunk) may touch LDS again
     }
 }
 
 template <bool BF16, int EPI, int TP, int RD>
 static int launch_strip(const DenseArgs& a, hipStream_t s) {
-    const size_t lds = 3 * 128 * sizeof(int64_t) + (size_t)128 * a.KC * (BF16 ? 2 : 4);
+    const int oesz = (EPI == kEpiResid || !BF16 || a.out_f32) ? 4 : 2;
+    const size_t stage = (size_t)2 * (EPI == kEpiGelu ? 2 : 1) * 16 * (4 * TP * 16 * oesz + 16);
+    const size_t lds = 3 * 128 * sizeof(int64_t) + (size_t)128 * a.KC * (BF16 ? 2 : 4) + stage;
     auto k = dense_strip_kernel<BF16, EPI, TP, RD>;
     if (lds > 160 * 1024) return PF_ERR_UNSUPPORTED;
     if (lds > 64 * 1024 && !opt_in_lds(reinterpret_cast<const void*>(k), (int)lds)) return PF_ERR_HIP;
@@ -344,9 +379,18 @@ static int launch_strip_tp(const DenseArgs& a, hipStream_t s) {
     return four ? launch_strip_rd<BF16, EPI, 4>(a, s) : launch_strip_rd<BF16, EPI, 3>(a, s);
 }
 
-int dense_nt(bool bf16, int epilogue, const DenseArgs& a, hipStream_t s) {
-    if (a.N % 16 || a.KC % 64 || a.K % a.KC || a.KC <= 0 || a.M < 0) return PF_ERR_BAD_ARG;
-    if (a.M == 0) return PF_OK;
+int dense_nt(bool bf16, int epilogue, const DenseArgs& a0, hipStream_t s) {
+    if (a0.N % 16 || a0.KC % 64 || a0.K % a0.KC || a0.KC <= 0 || a0.M < 0) return PF_ERR_BAD_ARG;
+    if (a0.M == 0) return PF_OK;
+    DenseArgs a = a0;
+    // the strip image (128 rows x KC) + the epilogue's staging must fit 160 KiB of LDS: halve the chunk while it does not
+    // (fp32 with KC = 256: 128 KiB of image alone)
+    auto lds_of = [&](int kc) {
+        const int tp = (a.N / 16) % 16 == 0 && (a.N / 16) % 12 != 0 ? 4 : 3;
+        const int oesz = (epilogue == kEpiResid || !bf16 || a.out_f32) ? 4 : 2;
+        return (size_t)3 * 128 * 8 + (size_t)128 * kc * (bf16 ? 2 : 4) + (size_t)2 * (epilogue == kEpiGelu ? 2 : 1) * 16 * (4 * tp * 16 * oesz + 16);
+    };
+    while (lds_of(a.KC) > 160 * 1024 && a.KC % 128 == 0) a.KC /= 2;
     switch (epilogue) {
     case kEpiPlain: return bf16 ? launch_strip_tp<true, kEpiPlain>(a, s) : launch_strip_tp<false, kEpiPlain>(a, s);
     case kEpiGelu: return bf16 ? launch_strip_tp<true, kEpiGelu>(a, s) : launch_strip_tp<false, kEpiGelu>(a, s);
@@ -617,9 +661,11 @@ static int launch_tn_bf16(DenseTnArgs a, hipStream_t s) {
     const int64_t chunks = (a.M + BK - 1) / BK;
     if (a.splits <= 0) {
         // one workgroup of 8 waves (two of 4) per CU and round, a few rounds, each workgroup at least 4 row chunks deep
-        // never a few workgroups MORE than a whole number of rounds (513 workgroups = three rounds for the work of two)
+        // ONE round of workgroups: every workgroup ends in float atomics of its whole tile (1.3 TB/s chip-wide against
+        // 5 TB/s of operand reads), so the split count is the atomic volume: 170 splits of the FFN weight gradient were
+        // 92 MB of atomics = 70 of its 160 us; and never a few workgroups more than a whole round
         const int per_cu = WR * WC >= 8 ? 1 : 2;
-        int64_t sp = (256 * per_cu * 2) / tiles;
+        int64_t sp = (256 * per_cu) / tiles;
         sp = std::min<int64_t>(sp, std::max<int64_t>(1, chunks / 4));
         a.splits = (int)std::max<int64_t>(1, sp);
     }
@@ -637,8 +683,11 @@ int dense_tn(bool bf16, const DenseTnArgs& a0, hipStream_t s) {
             return (int64_t)a.N1 * ((a.N2 + bn2 - 1) / bn2) + (int64_t)a.N2 * ((a.N1 + bn1 - 1) / bn1);
         };
         const int64_t c128 = cost(128, 128), ca = cost(192, 256), cb = cost(256, 192);
-        // narrow gradients (the convolutions: 32 - 128 channels): two 4-wave workgroups per CU overlap their load latency,
-        // one 8-wave workgroup with a third of its MFMA rows empty does not (conv3: 421 vs 559 us)
+        // narrow gradients against wide (overlapping-window) inputs = the convolutions' weight gradients: a tile as wide as
+        // the im2col row, so that the 4-8x redundant window reads happen once (conv2: 64 x 512 outputs, 600 us with
+        // 128 x 128 tiles of which half the rows were empty and the input was read four times)
+        if (a.N1 <= 32 && a.N2 <= 64) return launch_tn_bf16<1, 4, 2, 1>(a, s);
+        if (a.N1 <= 128 && a.N2 > 256) return launch_tn_bf16<1, 8, 4, 4>(a, s);       // (128 x 512 per workgroup spills 160 registers)
         if (a.N1 <= 128) return launch_tn_bf16<2, 2, 4, 4>(a, s);
         if (ca <= cb && ca < c128) return launch_tn_bf16<2, 4, 6, 4>(a, s);
         if (cb < c128) return launch_tn_bf16<4, 2, 4, 6>(a, s);

@@ -105,9 +105,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnArgs a) {
             *reinterpret_cast<f32x4*>(a.dx + m * kEncD + col) = dx;
             if (a.gout) {
                 if (a.drop_p > 0.f) {
-                    const uint32_t idx = (uint32_t)(m * kEncD + col);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) dx[e] *= enc_drop_hash(a.seed, a.site, idx + e) >= thr ? dscale : 0.f;
+                    f32x4 fac;
+                    enc_drop4(a.seed, a.site, (uint32_t)(m * kEncD + col), thr, dscale, fac);
+                    dx = dx * fac;
                 }
                 store_act4<BF16>(a.gout, m * kEncD + col, dx);
             }
@@ -128,19 +128,38 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnArgs a) {
 // ---------------------------------------------------------------------------------------------------------------------
 // self-attention, one workgroup per (head, event); T <= 192 tokens, head dimension 32
 // ---------------------------------------------------------------------------------------------------------------------
+// Every operand a loop re-reads lives in LDS, in the two forms the MFMAs take it:
+//   row images  [192 tokens][32]: bf16 64-byte rows with the 16-byte slot XOR-ed by (row >> 2) & 3 (ds_read_b128, conflict-free),
+//               fp32 rows padded to 33 floats (ds_read_b32);  = operands of the head-dimension products (k = head dim);
+//   transposed  [32][kTS tokens]: operands of the token-dimension products (k = token), read 4 tokens at a time.
+// (First version: the inner-loop operands came from global memory -- 47 KB of Q, K, V, dO per workgroup, five workgroups
+// per CU against a 32 KB L1: every tile pair waited out an L2 round trip; backward 612 us per layer at 1024 events.)
 constexpr int kTS = 196;                        // row stride (elements) of the transposed [32][T] images
+constexpr int kRF = 33;                         // row stride (floats) of the fp32 row images
 constexpr float kScale = 0.17677669529663687f;  // 1 / sqrt(32)
+template <bool BF16> constexpr size_t row_img_bytes() { return BF16 ? (size_t)kEncMaxTokens * 64 : (size_t)kEncMaxTokens * kRF * 4; }
+template <bool BF16> constexpr size_t tr_img_bytes() { return (size_t)32 * kTS * (BF16 ? 2 : 4); }
 
-// operand of the head-dimension products: 8 bf16 (one 16-byte load) or 8 fp32 (k = 4 s + g) of row `row`
+// operand of the head-dimension products: 8 bf16 (one 16-byte read) or 8 fp32 (k = 4 s + g) of one token row
 template <bool BF16> struct HeadFrag { u32x4 v; float f[8]; };
 template <bool BF16>
-__device__ __forceinline__ void load_head_frag(HeadFrag<BF16>& fr, const void* base, int64_t row_off, bool valid, int g) {
+__device__ __forceinline__ void global_head_frag(HeadFrag<BF16>& fr, const void* base, int64_t row_off, bool valid, int g) {
     if constexpr (BF16) {
         fr.v = u32x4{0u, 0u, 0u, 0u};
         if (valid) fr.v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const __bf16*>(base) + row_off + 8 * g);
     } else {
 #pragma unroll
         for (int s = 0; s < 8; ++s) fr.f[s] = valid ? reinterpret_cast<const float*>(base)[row_off + 4 * s + g] : 0.f;
+    }
+}
+template <bool BF16>
+__device__ __forceinline__ void lds_head_frag(HeadFrag<BF16>& fr, const char* img, int row, int g) {
+    if constexpr (BF16) {
+        fr.v = *reinterpret_cast<const u32x4*>(img + row * 64 + ((g ^ ((row >> 2) & 3)) << 4));
+    } else {
+        const float* r = reinterpret_cast<const float*>(img) + row * kRF + g;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) fr.f[s] = r[4 * s];
     }
 }
 template <bool BF16>
@@ -168,37 +187,44 @@ __device__ __forceinline__ f32x4 token_mma(const char* img, int dt, int t, int c
         return acc;
     }
 }
-// [T][32] slice (row stride 576 or 192 elements) -> transposed image [32][kTS], columns T .. 191 zeroed
+// one [T][32] slice (row stride ld elements) -> row image and / or transposed image; rows / columns T .. 191 zeroed
 template <bool BF16>
-__device__ __forceinline__ void stage_transposed(char* img, const void* src, int64_t row0, int ld, int col0, int T, int tid) {
+__device__ __forceinline__ void stage_slice(char* rows, char* tr, const void* src, int64_t row0, int ld, int col0, int T, int tid) {
     constexpr int ESZ = BF16 ? 2 : 4, EPC = 16 / ESZ, CPR = 32 / EPC;
     for (int i = tid; i < kEncMaxTokens * CPR; i += 256) {
         const int t = i / CPR, ch = i - t * CPR;
         u32x4 v = {0u, 0u, 0u, 0u};
         if (t < T) v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(src) + ((row0 + t) * ld + col0 + ch * EPC) * ESZ);
         if constexpr (BF16) {
-            const bf16x8 b = __builtin_bit_cast(bf16x8, v);
+            if (rows) *reinterpret_cast<u32x4*>(rows + t * 64 + ((ch ^ ((t >> 2) & 3)) << 4)) = v;
+            if (tr) {
+                const bf16x8 b = __builtin_bit_cast(bf16x8, v);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) *reinterpret_cast<__bf16*>(img + ((size_t)(ch * 8 + j) * kTS + t) * 2) = b[j];
+                for (int j = 0; j < 8; ++j) *reinterpret_cast<__bf16*>(tr + ((size_t)(ch * 8 + j) * kTS + t) * 2) = b[j];
+            }
         } else {
             const f32x4 f = __builtin_bit_cast(f32x4, v);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) *reinterpret_cast<float*>(img + ((size_t)(ch * 4 + j) * kTS + t) * 4) = f[j];
+            for (int j = 0; j < 4; ++j) {
+                if (rows) reinterpret_cast<float*>(rows)[t * kRF + ch * 4 + j] = f[j];
+                if (tr) *reinterpret_cast<float*>(tr + ((size_t)(ch * 4 + j) * kTS + t) * 4) = f[j];
+            }
         }
     }
 }
 
 template <bool BF16>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
-    constexpr int ESZ = BF16 ? 2 : 4;
+__global__ __launch_bounds__(256, BF16 ? 3 : 1) void attn_fwd_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* VT = smem;
+    char* KR = smem;
+    char* VT = smem + row_img_bytes<BF16>();
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, c = lane & 15;
     const int h = blockIdx.x, T = a.T;
     const int64_t e = blockIdx.y, r0 = e * T;
-    stage_transposed<BF16>(VT, a.qkv, r0, 3 * kEncD, 2 * kEncD + kEncHd * h, T, tid);
+    stage_slice<BF16>(KR, nullptr, a.qkv, r0, 3 * kEncD, kEncD + kEncHd * h, T, tid);
+    stage_slice<BF16>(nullptr, VT, a.qkv, r0, 3 * kEncD, 2 * kEncD + kEncHd * h, T, tid);
     __syncthreads();
     const uint32_t thr = enc_drop_threshold(a.drop_p);
     const float dscale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
@@ -208,14 +234,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
         const int q = 16 * qt + c;
         const bool qv = q < T;
         HeadFrag<BF16> qf;
-        load_head_frag<BF16>(qf, a.qkv, (r0 + q) * (3 * kEncD) + kEncHd * h, qv, g);
+        global_head_frag<BF16>(qf, a.qkv, (r0 + q) * (3 * kEncD) + kEncHd * h, qv, g);
         f32x4 s[12];
         float mx = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < 12; ++kt) {
-            const int key = 16 * kt + c;
             HeadFrag<BF16> kf;
-            load_head_frag<BF16>(kf, a.qkv, (r0 + key) * (3 * kEncD) + kEncD + kEncHd * h, key < T, g);
+            lds_head_frag<BF16>(kf, KR, 16 * kt + c, g);
             s[kt] = head_mma<BF16>(kf, qf);                    // S^T[key = 16 kt + 4 g + r][q = 16 qt + c]
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -223,6 +248,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
                 s[kt][r] = v;
                 mx = fmaxf(mx, v);
             }
+            // (keeps hipcc from hoisting all twelve K fragments -- 48 registers -- in front of the first MFMA)
+            if ((kt & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
         mx = fmaxf(mx, __shfl_xor(mx, 16));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
@@ -243,10 +270,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
 #pragma unroll
         for (int kt = 0; kt < 12; ++kt) {
             f32x4 pd = s[kt] * inv;
-            if (a.drop_p > 0.f) {
-                const uint32_t idx = (uint32_t)(((e * kEncHeads + h) * T + q) * T + 16 * kt + 4 * g);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) pd[r] *= enc_drop_hash(a.seed, a.site, idx + r) >= thr ? dscale : 0.f;
+            if (a.drop_p > 0.f) {     // factor index: [event][head][query][192 key slots]: 4-aligned, two hashes per four keys
+                f32x4 fac;
+                enc_drop4(a.seed, a.site, (uint32_t)(((e * kEncHeads + h) * T + q) * kEncMaxTokens + 16 * kt + 4 * g), thr, dscale, fac);
+                pd = pd * fac;
             }
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) o[dt] = token_mma<BF16>(VT, dt, kt, c, g, pd, o[dt]);
@@ -256,27 +283,91 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
             for (int dt = 0; dt < 2; ++dt) store_act4<BF16>(a.out, (r0 + q) * kEncD + kEncHd * h + 16 * dt + 4 * g, o[dt]);
         }
     }
-    (void)ESZ;
 }
 
+// backward, part 1: dQ.  Per query tile, key on the accumulator rows: S^T and dP^T tiles, dS^T feeds dQ^T = K^T dS^T.
 template <bool BF16>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnArgs a) {
-    constexpr int ESZ = BF16 ? 2 : 4;
-    constexpr size_t IMG = (size_t)32 * kTS * ESZ;
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* QT = smem;
-    char* KT = smem + IMG;
-    char* DOT = smem + 2 * IMG;
-    float* s_delta = reinterpret_cast<float*>(smem + 3 * IMG);
+    char* KR = smem;
+    char* VR = smem + row_img_bytes<BF16>();
+    char* KT = smem + 2 * row_img_bytes<BF16>();
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, c = lane & 15;
+    const int h = blockIdx.x, T = a.T;
+    const int64_t e = blockIdx.y, r0 = e * T;
+    stage_slice<BF16>(KR, KT, a.qkv, r0, 3 * kEncD, kEncD + kEncHd * h, T, tid);
+    stage_slice<BF16>(VR, nullptr, a.qkv, r0, 3 * kEncD, 2 * kEncD + kEncHd * h, T, tid);
+    __syncthreads();
+    const uint32_t thr = enc_drop_threshold(a.drop_p);
+    const float dscale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+    const int ntile = (T + 15) >> 4;
+    const uint32_t idx_base = (uint32_t)((e * kEncHeads + h) * T) * (uint32_t)kEncMaxTokens;
+#pragma unroll 1
+    for (int qt = wave; qt < ntile; qt += 4) {
+        const int q = 16 * qt + c;
+        const bool qv = q < T;
+        HeadFrag<BF16> qf, dof, of;
+        global_head_frag<BF16>(qf, a.qkv, (r0 + q) * (3 * kEncD) + kEncHd * h, qv, g);
+        global_head_frag<BF16>(dof, a.dout, (r0 + q) * kEncD + kEncHd * h, qv, g);
+        global_head_frag<BF16>(of, a.out, (r0 + q) * kEncD + kEncHd * h, qv, g);
+        // delta_q = dO[q] . O[q] over the head's 32 features: this lane's 8, then across the four lane groups
+        float del_q = 0.f;
+        if constexpr (BF16) {
+            const bf16x8 u = __builtin_bit_cast(bf16x8, dof.v), w = __builtin_bit_cast(bf16x8, of.v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) del_q += (float)u[j] * (float)w[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) del_q += dof.f[j] * of.f[j];
+        }
+        del_q += __shfl_xor(del_q, 16);
+        del_q += __shfl_xor(del_q, 32);
+        const float lse_q = qv ? a.lse[(e * kEncHeads + h) * T + q] : 0.f;
+        f32x4 dq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll 2
+        for (int kt = 0; kt < ntile; ++kt) {
+            HeadFrag<BF16> kf, vf;
+            lds_head_frag<BF16>(kf, KR, 16 * kt + c, g);
+            lds_head_frag<BF16>(vf, VR, 16 * kt + c, g);
+            const f32x4 st = head_mma<BF16>(kf, qf), dp = head_mma<BF16>(vf, dof);
+            f32x4 ds, fac = {1.f, 1.f, 1.f, 1.f};
+            if (a.drop_p > 0.f) enc_drop4(a.seed, a.site, idx_base + (uint32_t)(q * kEncMaxTokens + 16 * kt + 4 * g), thr, dscale, fac);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kk = 16 * kt + 4 * g + r;
+                const float pr = (kk < T && qv) ? (BF16 ? __expf(st[r] * kScale - lse_q) : expf(st[r] * kScale - lse_q)) : 0.f;
+                ds[r] = pr * (dp[r] * fac[r] - del_q) * kScale;
+            }
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) dq[dt] = token_mma<BF16>(KT, dt, kt, c, g, ds, dq[dt]);
+        }
+        if (qv) {
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) store_act4<BF16>(a.dqkv, (r0 + q) * (3 * kEncD) + kEncHd * h + 16 * dt + 4 * g, dq[dt]);
+        }
+    }
+}
+
+// backward, part 2: dK, dV.  Per key tile, query on the accumulator rows: S and dP tiles; P . D feeds dV^T = dO^T (P . D),
+// dS feeds dK^T = Q^T dS.
+template <bool BF16>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* QR = smem;
+    char* DOR = smem + row_img_bytes<BF16>();
+    char* QT = smem + 2 * row_img_bytes<BF16>();
+    char* DOT = QT + tr_img_bytes<BF16>();
+    float* s_delta = reinterpret_cast<float*>(DOT + tr_img_bytes<BF16>());
     float* s_lse = s_delta + kEncMaxTokens;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, c = lane & 15;
     const int h = blockIdx.x, T = a.T;
     const int64_t e = blockIdx.y, r0 = e * T;
-    stage_transposed<BF16>(QT, a.qkv, r0, 3 * kEncD, kEncHd * h, T, tid);
-    stage_transposed<BF16>(KT, a.qkv, r0, 3 * kEncD, kEncD + kEncHd * h, T, tid);
-    stage_transposed<BF16>(DOT, a.dout, r0, kEncD, kEncHd * h, T, tid);
+    stage_slice<BF16>(QR, QT, a.qkv, r0, 3 * kEncD, kEncHd * h, T, tid);
+    stage_slice<BF16>(DOR, DOT, a.dout, r0, kEncD, kEncHd * h, T, tid);
     if (tid < kEncMaxTokens) {
         float dl = 0.f, ls = 0.f;
         if (tid < T) {
@@ -295,58 +386,21 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnArgs a) {
     const uint32_t thr = enc_drop_threshold(a.drop_p);
     const float dscale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
     const int ntile = (T + 15) >> 4;
-    const uint32_t idx_base = (uint32_t)((e * kEncHeads + h) * T) * (uint32_t)T;
-
-    // ---- phase A: dQ, per query tile, key on the accumulator rows -------------------------------------------------
-#pragma unroll 1
-    for (int qt = wave; qt < ntile; qt += 4) {
-        const int q = 16 * qt + c;
-        const bool qv = q < T;
-        HeadFrag<BF16> qf, dof;
-        load_head_frag<BF16>(qf, a.qkv, (r0 + q) * (3 * kEncD) + kEncHd * h, qv, g);
-        load_head_frag<BF16>(dof, a.dout, (r0 + q) * kEncD + kEncHd * h, qv, g);
-        const float lse_q = s_lse[q < kEncMaxTokens ? q : 0], del_q = s_delta[q < kEncMaxTokens ? q : 0];
-        f32x4 dq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll 2
-        for (int kt = 0; kt < ntile; ++kt) {
-            const int key = 16 * kt + c;
-            HeadFrag<BF16> kf, vf;
-            load_head_frag<BF16>(kf, a.qkv, (r0 + key) * (3 * kEncD) + kEncD + kEncHd * h, key < T, g);
-            load_head_frag<BF16>(vf, a.qkv, (r0 + key) * (3 * kEncD) + 2 * kEncD + kEncHd * h, key < T, g);
-            const f32x4 st = head_mma<BF16>(kf, qf), dp = head_mma<BF16>(vf, dof);
-            f32x4 ds;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int kk = 16 * kt + 4 * g + r;
-                const float pr = (kk < T && qv) ? (BF16 ? __expf(st[r] * kScale - lse_q) : expf(st[r] * kScale - lse_q)) : 0.f;
-                float fac = 1.f;
-                if (a.drop_p > 0.f) fac = enc_drop_hash(a.seed, a.site, idx_base + (uint32_t)(q * T + kk)) >= thr ? dscale : 0.f;
-                ds[r] = pr * (dp[r] * fac - del_q) * kScale;
-            }
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) dq[dt] = token_mma<BF16>(KT, dt, kt, c, g, ds, dq[dt]);
-        }
-        if (qv) {
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) store_act4<BF16>(a.dqkv, (r0 + q) * (3 * kEncD) + kEncHd * h + 16 * dt + 4 * g, dq[dt]);
-        }
-    }
-    // ---- phase B: dK, dV, per key tile, query on the accumulator rows ---------------------------------------------
+    const uint32_t idx_base = (uint32_t)((e * kEncHeads + h) * T) * (uint32_t)kEncMaxTokens;
 #pragma unroll 1
     for (int kt = wave; kt < ntile; kt += 4) {
         const int key = 16 * kt + c;
         const bool kv = key < T;
         HeadFrag<BF16> kf, vf;
-        load_head_frag<BF16>(kf, a.qkv, (r0 + key) * (3 * kEncD) + kEncD + kEncHd * h, kv, g);
-        load_head_frag<BF16>(vf, a.qkv, (r0 + key) * (3 * kEncD) + 2 * kEncD + kEncHd * h, kv, g);
+        global_head_frag<BF16>(kf, a.qkv, (r0 + key) * (3 * kEncD) + kEncD + kEncHd * h, kv, g);
+        global_head_frag<BF16>(vf, a.qkv, (r0 + key) * (3 * kEncD) + 2 * kEncD + kEncHd * h, kv, g);
         f32x4 dk[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
         f32x4 dv[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll 2
         for (int qt = 0; qt < ntile; ++qt) {
-            const int qrow = 16 * qt + c;
             HeadFrag<BF16> qf, dof;
-            load_head_frag<BF16>(qf, a.qkv, (r0 + qrow) * (3 * kEncD) + kEncHd * h, qrow < T, g);
-            load_head_frag<BF16>(dof, a.dout, (r0 + qrow) * kEncD + kEncHd * h, qrow < T, g);
+            lds_head_frag<BF16>(qf, QR, 16 * qt + c, g);
+            lds_head_frag<BF16>(dof, DOR, 16 * qt + c, g);
             const f32x4 sc = head_mma<BF16>(qf, kf), dp = head_mma<BF16>(dof, vf);   // [q = 16 qt + 4 g + r][key = 16 kt + c]
             const f32x4 ls4 = *reinterpret_cast<const f32x4*>(s_lse + 16 * qt + 4 * g);
             const f32x4 dl4 = *reinterpret_cast<const f32x4*>(s_delta + 16 * qt + 4 * g);
@@ -356,7 +410,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnArgs a) {
                 const int qq = 16 * qt + 4 * g + r;
                 const float pr = (qq < T && kv) ? (BF16 ? __expf(sc[r] * kScale - ls4[r]) : expf(sc[r] * kScale - ls4[r])) : 0.f;
                 float fac = 1.f;
-                if (a.drop_p > 0.f) fac = enc_drop_hash(a.seed, a.site, idx_base + (uint32_t)(qq * T + key)) >= thr ? dscale : 0.f;
+                if (a.drop_p > 0.f) fac = enc_drop_hash(a.seed, a.site, idx_base + (uint32_t)(qq * kEncMaxTokens + key)) >= thr ? dscale : 0.f;
                 pd[r] = pr * fac;
                 ds[r] = pr * (dp[r] * fac - dl4[r]) * kScale;
             }
@@ -589,27 +643,28 @@ int ln_backward(bool bf16, const LnArgs& a, hipStream_t s) {
     return launch_status();
 }
 
+template <bool BF16>
+static int attn_launch(const AttnArgs& a, bool backward, hipStream_t s) {
+    const dim3 grid(kEncHeads, (unsigned)a.B);
+    auto go = [&](auto kern, size_t lds) {
+        if (lds > 64 * 1024 && !opt_in_lds(reinterpret_cast<const void*>(kern), (int)lds)) return (int)PF_ERR_HIP;
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+        return launch_status();
+    };
+    if (!backward) return go(attn_fwd_kernel<BF16>, row_img_bytes<BF16>() + tr_img_bytes<BF16>());
+    const int rc = go(attn_bwd_dq_kernel<BF16>, 2 * row_img_bytes<BF16>() + tr_img_bytes<BF16>());
+    if (rc != PF_OK) return rc;
+    return go(attn_bwd_dkv_kernel<BF16>, 2 * row_img_bytes<BF16>() + 2 * tr_img_bytes<BF16>() + 2 * kEncMaxTokens * sizeof(float));
+}
 int attn_forward(bool bf16, const AttnArgs& a, hipStream_t s) {
     if (a.B <= 0) return PF_OK;
     if (a.T < 1 || a.T > kEncMaxTokens) return PF_ERR_UNSUPPORTED;
-    const size_t lds = (size_t)32 * kTS * (bf16 ? 2 : 4);
-    const dim3 grid(kEncHeads, (unsigned)a.B);
-    if (bf16) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), lds, s, a);
-    else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), lds, s, a);
-    return launch_status();
+    return bf16 ? attn_launch<true>(a, false, s) : attn_launch<false>(a, false, s);
 }
 int attn_backward(bool bf16, const AttnArgs& a, hipStream_t s) {
     if (a.B <= 0) return PF_OK;
     if (a.T < 1 || a.T > kEncMaxTokens) return PF_ERR_UNSUPPORTED;
-    const size_t lds = (size_t)3 * 32 * kTS * (bf16 ? 2 : 4) + 2 * kEncMaxTokens * sizeof(float);
-    const dim3 grid(kEncHeads, (unsigned)a.B);
-    if (bf16) {
-        hipLaunchKernelGGL(attn_bwd_kernel<true>, grid, dim3(256), lds, s, a);
-    } else {
-        if (!opt_in_lds(reinterpret_cast<const void*>(attn_bwd_kernel<false>), (int)lds)) return PF_ERR_HIP;
-        hipLaunchKernelGGL(attn_bwd_kernel<false>, grid, dim3(256), lds, s, a);
-    }
-    return launch_status();
+    return bf16 ? attn_launch<true>(a, true, s) : attn_launch<false>(a, true, s);
 }
 
 int pool_forward(bool bf16, const PoolArgs& a, hipStream_t s) {

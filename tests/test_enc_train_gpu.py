@@ -65,7 +65,7 @@ def _drop_factors(p, seed64, B, T):
     s = seed32(seed64)
     out = {}
     for l in range(3):
-        out[(l, "attn")] = torch.from_numpy(factors(p, s, 4 * l + 0, B * 6 * T * T)).reshape(B, 6, T, T).double()
+        out[(l, "attn")] = torch.from_numpy(factors(p, s, 4 * l + 0, B * 6 * T * 192)).reshape(B, 6, T, 192)[..., :T].double()
         out[(l, "res1")] = torch.from_numpy(factors(p, s, 4 * l + 1, B * T * 192)).reshape(B, T, 192).double()
         out[(l, "ffn")] = torch.from_numpy(factors(p, s, 4 * l + 2, B * T * 768)).reshape(B, T, 768).double()
         out[(l, "res2")] = torch.from_numpy(factors(p, s, 4 * l + 3, B * T * 192)).reshape(B, T, 192).double()
