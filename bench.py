@@ -269,11 +269,11 @@ def extras(flow, dev, batch):
         out["config3_end_to_end_events_per_s"] = batch / (dt + timed(lambda: flow.nll_into(x, ctx, nll), 10))
     # the training side of the same flow: forward + backward of the NLL at 2048 rows (the per-GPU share of a 1024-event
     # batch with ~2 signals per event), LeanNPE's flow shape, in the mode being benchmarked
-    tf = npe.LeanNPE().to(dev).train().flow
+    tf = npe.LeanNPE().to(dev).train().flow.flatten_parameters()     # one flat leaf: what a trainer should use (flows.py)
     tf.precision = flow.precision
     xt = torch.rand(2048, tf.features, device=dev) * 2 - 1
     ct = torch.randn(2048, tf.context_features, device=dev, requires_grad=True)
-    params = tf._ordered_parameters()
+    params = list(tf.parameters())
 
     def fwd_bwd():
         for q in params:
@@ -324,6 +324,7 @@ def config4_train_step(dev, precision, events=1024, reps=5):
     ds = synthetic_dataset(dev, n_noise=512, n_events=512, seed=0)
     torch.manual_seed(0)
     model = npe.LeanNPE().to(dev).train().set_precision(precision)
+    model.flow.flatten_parameters()
     opt = train.make_optimizer(model)
     sched = train.make_scheduler(opt, 10000)
     g = torch.Generator(device=dev).manual_seed(0)

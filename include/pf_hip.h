@@ -240,6 +240,15 @@ typedef struct PfFlowReevalArgs {
 } PfFlowReevalArgs;
 int pf_flow_reevaluate(const PfFlowDesc* desc, const PfFlowReevalArgs* args, void* stream);
 
+/* ---- backward: the context gradient's weight operand ---------------------------------------------------------------------
+ * All layers' context weights transposed and packed as ONE matrix P[c][(layer, j, unit)] = W_{layer, j}[unit][c] (j = 0: MADE
+ * context_layer, 1 / 2: the residual blocks' gates) in pf_dense_nt's fragment format, so that
+ *   g_ctx[row][c] = sum_{layer, j, unit} Gc[layer][j][row][unit] W_{layer, j}[unit][c]
+ * is pf_dense_nt over the 3 L slabs of pf_flow_backward_chain's Gc (PfDenseArgs.a_chunk_stride = batch * H, KC = H).
+ * Plain conditioner, C % 16 == 0, L <= 16; -1 / PF_ERR_UNSUPPORTED otherwise.  desc->precision selects the operand type. */
+int64_t pf_flow_ctx_transposed_bytes(const PfFlowDesc* desc);
+int pf_flow_pack_ctx_transposed(const PfFlowDesc* desc, const float* raw, void* out, void* stream);
+
 /* ---- inverse / sampling -----------------------------------------------------
  * x = transform^-1(z, ctx)[:, ar_inv_perm], logdet of the inverse map
  * (nflows returns the log-det of the last autoregressive pass of each layer,
@@ -384,6 +393,8 @@ typedef struct PfDenseArgs {
     float drop_p;
     uint32_t seed, site;      /* dropout factor of element (m, n) = hash(seed, site, m * N + n) */
     int32_t out_f32;          /* PF_EPI_PLAIN: fp32 output in either precision */
+    int64_t a_chunk_stride;   /* > 0: k-chunk c of every row starts at A + c * a_chunk_stride (+ the row's offset) instead of
+                               * c * KC elements into the row: the reduction runs over K / KC separate [rows][KC] slabs */
 } PfDenseArgs;
 typedef struct PfDenseTnArgs {  /* dW[n1][n2] += sum_m G[m][n1] A[m][n2],  db[n1] += sum_m G[m][n1]  (float atomics) */
     const void* G; int64_t g_seq_stride; int32_t ldg;
@@ -394,6 +405,12 @@ typedef struct PfDenseTnArgs {  /* dW[n1][n2] += sum_m G[m][n1] A[m][n2],  db[n1
     int32_t conv_cin, conv_kw;   /* > 0: column n2 = tap * cin + ch lands at ch * kw + tap (Conv1d weight [cout][cin][kw]) */
     float* db;                /* or NULL */
     int32_t splits;           /* workgroups along M per output tile; <= 0: chosen by the library */
+    /* batched form (e.g. the layers of the flow): problem z = 0 .. batch - 1 reads G + z g_batch_stride, A + z a_batch_stride
+     * (elements) and accumulates into dW + z w_batch_stride, db + z b_batch_stride (floats); batch <= 1: one problem */
+    int32_t batch;
+    int64_t g_batch_stride, a_batch_stride, w_batch_stride, b_batch_stride;
+    int32_t n1_rows, n2_cols; /* > 0: only rows < n1_rows / columns < n2_cols of dW (and db) exist -- N1 / N2 then describe the
+                               * (zero-padded) operand widths only */
 } PfDenseTnArgs;
 /* mode 0: W[n][k] = src[n * ld + k]; 1: W[n][k] = src[k * ld + n]; out: pf_dense_frag_bytes(precision, N, K) bytes */
 int64_t pf_dense_frag_bytes(int32_t precision, int32_t N, int32_t K);

@@ -133,28 +133,6 @@ REEVAL_HIP = True      # tests: False keeps the tensor-op re-evaluation in bf16 
 COMPACT = True         # tests: False keeps fp32 activations / gradient vectors between the bf16 backward kernels
 
 
-_OUT_DTYPE = [None]    # does this torch's library GEMM take out_dtype (bf16 operands, fp32 result)?  probed on first use
-
-
-def _mm32(a, b):
-    """a @ b for bf16 operands with an fp32 result (2-D or batched): the library's out_dtype path where this torch has it
-    (2.8+).  Probed once on tiny tensors (an out-of-memory or HIP error of a real call must not be mistaken for a missing
-    feature); without it the operands are widened to fp32 -- never a bf16-rounded weight gradient -- and that is logged."""
-    f = torch.bmm if a.dim() == 3 else torch.mm
-    if _OUT_DTYPE[0] is None:
-        try:
-            t = torch.ones(1, 2, 2, dtype=torch.bfloat16, device=a.device)
-            torch.bmm(t, t, out_dtype=torch.float32)
-            torch.mm(t[0], t[0], out_dtype=torch.float32)
-            _OUT_DTYPE[0] = True
-        except (TypeError, NotImplementedError):
-            _OUT_DTYPE[0] = False
-            import logging
-            logging.getLogger("posteriflow_amd").warning(
-                "torch.mm/bmm has no out_dtype here: bf16-mode weight-gradient GEMMs run on fp32-widened operands")
-    return f(a, b, out_dtype=torch.float32) if _OUT_DTYPE[0] else f(a.float(), b.float())
-
-
 def _reevaluate_hip(flow, U, ctx, drop=None, compact=False):
     """bf16 mode: every layer's conditioner from its kept input in ONE launch (pf_flow_reevaluate, csrc/pf_flow_reeval.hip),
     in the arithmetic of the bf16 forward kernel.  Returns (hs, t1s, t2s, gates, pc, h2, params): fp32 raw values, or with
@@ -201,8 +179,13 @@ def _flow_backward_batched(flow, U, ctx, g_z, g_lad, drop=None, nll=None):
     m2 = [net0.blocks[j].linear_layers[1].mask for j in range(nb)]
     if has_ctx:
         C = ctx.shape[1]
-        Wcat = torch.cat([st(lambda n: n.context_layer.weight)]
-                         + [st(lambda n: n.blocks[j].context_layer.weight) for j in range(nb)], dim=1)
+    Wcat_ = []
+
+    def wcat():      # [L, 1 + nb, H, C] context weights stacked (tensor-op re-evaluation / library fallback only)
+        if not Wcat_:
+            Wcat_.append(torch.cat([st(lambda n: n.context_layer.weight)]
+                                   + [st(lambda n: n.blocks[j].context_layer.weight) for j in range(nb)], dim=1))
+        return Wcat_[0]
     # bf16 mode: re-evaluation and chain are HIP kernels reading the packed PF_FLAG_BWD stream (one gather per weight update)
     bf = flow.precision == "bf16" and H % 32 == 0 and nb == 2 and U.is_contiguous() and (ctx is None or ctx.is_contiguous())
 
@@ -231,7 +214,7 @@ def _flow_backward_batched(flow, U, ctx, g_z, g_lad, drop=None, nll=None):
         if has_ctx:       # batched over layers: one GEMM for all context projections
             bcat = torch.cat([st(lambda n: n.context_layer.bias)]
                              + [st(lambda n: n.blocks[j].context_layer.bias) for j in range(nb)], dim=1)
-            proj = torch.addmm(bcat.reshape(-1), ctx, Wcat.reshape(-1, C).t())
+            proj = torch.addmm(bcat.reshape(-1), ctx, wcat().reshape(-1, C).t())
             proj = proj.view(B, Ln, 1 + nb, H).permute(1, 2, 0, 3)                   # [L, 1+nb, B, H]
             pc = proj[:, 0]
             gates = [torch.sigmoid(proj[:, 1 + j]) for j in range(nb)]
@@ -302,40 +285,79 @@ def _flow_backward_batched(flow, U, ctx, g_z, g_lad, drop=None, nll=None):
                                                  torch.cuda.current_stream(U.device).cuda_stream), "pf_flow_backward_chain")
     g_x = gx_perm[:, flow._ar_inv_perm]              # the kernel returns dL/d x[:, ar_perm]
 
-    # 3. weight gradients, batched over layers
-    mm = _mm32 if cmp else (lambda x_, y_: torch.bmm(x_, y_) if x_.dim() == 3 else x_ @ y_)
-    f32 = dict(dtype=torch.float32) if cmp else {}
-    gb5 = G5.sum(2, **f32)                                                      # [2 nb + 1, L, H]
-    gWf, gbf = mm(Gp.transpose(1, 2), h_last) * mf, Gp.sum(1, **f32)
-    gW0, gb0 = mm(Gh0.transpose(1, 2), U.to(gdt)) * m0, gb5[2 * nb]
-    gW1 = [mm(GT1[j].transpose(1, 2), relu_h[j]) * m1[j] for j in range(nb)]
-    gW2 = [mm(GT2[j].transpose(1, 2), a1s[j]) * m2[j] for j in range(nb)]
-    gb1, gb2 = [gb5[j] for j in range(nb)], [gb5[nb + j] for j in range(nb)]
-    g_ctx = gWcat = gbcat = None
-    if has_ctx:
-        flat = Gc.permute(2, 0, 1, 3).reshape(B, Ln * (1 + nb) * H)             # [B, L (1+nb) H]
-        gWcat = mm(flat.t(), ctx.to(gdt)).view(Ln, 1 + nb, H, C)
-        gbcat = flat.sum(0, **f32).view(Ln, 1 + nb, H)
-        g_ctx = mm(flat, Wcat.reshape(-1, C).to(gdt))
-    return dict(g_x=g_x, g_ctx=g_ctx, W0=gW0, b0=gb0, Wf=gWf, bf=gbf, W1=gW1, b1=gb1, W2=gW2, b2=gb2,
-                Wcat=gWcat if has_ctx else None, bcat=gbcat if has_ctx else None)
+    # 3. weight gradients: hand-written split-M GEMMs (pf_dense_tn, csrc/pf_dense.hip), batched over the layers, accumulating
+    #    straight into ONE flat gradient buffer in the raw parameter layout (include/pf_hip.h) -- bias gradients come out of the
+    #    same launches (column sums of the gradient operand); 9 launches + one masking multiply replaced 18 library GEMMs,
+    #    6 reductions and the per-parameter bookkeeping.  The context gradient is pf_dense_nt over the 3 L slabs of Gc.
+    lay = flow._raw_layout()
+    P = lay["P"]
+    dev = U.device
+    prec = _lib.PF_PREC_BF16 if cmp else _lib.PF_PREC_F32
+    adt = torch.bfloat16 if cmp else torch.float32
+    lanes = 8 if cmp else 4
+    up = lambda n: (n + lanes - 1) // lanes * lanes
+    g_flat = torch.zeros(Ln, P, dtype=torch.float32, device=dev)
+    L_ = _lib.lib()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    keep2 = []
 
+    def tn(G, g_off, g_bs, ldg, A, a_bs, lda, n1, n2, w_off, b_off, ldw, n1_rows=0, n2_cols=0):
+        t = _lib.PfDenseTnArgs()
+        t.G, t.g_seq_stride, t.ldg = G.data_ptr() + g_off * G.element_size(), 0, ldg
+        t.A, t.a_seq_stride, t.lda = A.data_ptr(), 0, lda
+        t.M, t.rows_per_seq, t.N1, t.N2 = B, B, n1, n2
+        t.dW, t.ldw, t.db, t.splits = g_flat.data_ptr() + 4 * w_off, ldw, g_flat.data_ptr() + 4 * b_off, 0
+        t.batch, t.g_batch_stride, t.a_batch_stride, t.w_batch_stride, t.b_batch_stride = Ln, g_bs, a_bs, P, P
+        t.n1_rows, t.n2_cols = n1_rows, n2_cols
+        _lib.check(L_.pf_dense_tn(prec, t, stream), "pf_dense_tn")
 
-def _per_parameter(flow, g):
-    """the layer-batched gradients as one tensor per parameter, in ``flow._ordered_parameters()`` order."""
-    has_ctx, nb = g["Wcat"] is not None, len(g["W1"])
-    # one unbind per batched tensor (a view per layer) instead of one indexing call per parameter
-    ub = lambda t: t.unbind(0)
-    cols = [ub(g["W0"]), ub(g["b0"])]
-    if has_ctx:
-        wc, bc = [ub(t) for t in g["Wcat"].unbind(1)], [ub(t) for t in g["bcat"].unbind(1)]
-        cols += [wc[0], bc[0]]
+    Dp, DMp = up(D), up(DM)
+    Upad = F.pad(U.to(adt), (0, Dp - D)) if (Dp != D or U.dtype != adt) else U
+    Gpp = F.pad(Gp, (0, DMp - DM)) if DMp != DM else Gp
+    keep2 += [Upad, Gpp]
+    tn(Gh0, 0, B * H, H, Upad, B * Dp, Dp, H, Dp, lay["W0"], lay["b0"], D, n2_cols=D)
     for j in range(nb):
-        if has_ctx:
-            cols += [wc[1 + j], bc[1 + j]]
-        cols += [ub(g["W1"][j]), ub(g["b1"][j]), ub(g["W2"][j]), ub(g["b2"][j])]
-    cols += [ub(g["Wf"]), ub(g["bf"])]
-    return [c[l] for l in range(g["W0"].shape[0]) for c in cols]
+        tn(GT1[j], 0, B * H, H, relu_h[j], B * H, H, H, H, lay["W1"][j], lay["b1"][j], H)
+        tn(GT2[j], 0, B * H, H, a1s[j], B * H, H, H, H, lay["W2"][j], lay["b2"][j], H)
+    tn(Gpp, 0, B * DMp, DMp, h_last, B * H, H, DMp, H, lay["Wf"], lay["bf"], H, n1_rows=DM)
+    g_ctx = None
+    if has_ctx:
+        Cp = up(C)
+        ctxa = F.pad(ctx.to(adt), (0, Cp - C)) if (Cp != C or ctx.dtype != adt) else ctx
+        keep2.append(ctxa)
+        for j in range(1 + nb):
+            tn(Gc, j * B * H, (1 + nb) * B * H, H, ctxa, 0, Cp, H, Cp, lay["Wc"][j], lay["bc"][j], C, n2_cols=C)
+        wt = flow.packed_ctx_transposed("bf16" if cmp else "fp32")
+        if wt is not None:
+            g_ctx = torch.empty(B, C, dtype=torch.float32, device=dev)
+            nks_total = (1 + nb) * Ln * (H // (32 if cmp else 16))
+            tiles = C // 16
+            per_call = 12
+            for t0 in range(0, tiles, per_call):
+                nt = min(per_call, tiles - t0)
+                a2 = _lib.PfDenseArgs()
+                a2.A, a2.M, a2.rows_per_seq, a2.a_seq_stride, a2.lda = Gc.data_ptr(), B, B, 0, H
+                a2.K, a2.N, a2.KC, a2.a_chunk_stride = (1 + nb) * Ln * H, 16 * nt, H, B * H
+                a2.wfrags = wt.data_ptr() + t0 * nks_total * 64 * 16
+                a2.out, a2.o_seq_stride, a2.ldo, a2.out_f32 = g_ctx.data_ptr() + 4 * 16 * t0, 0, C, 1
+                _lib.check(L_.pf_dense_nt(prec, _lib.PF_EPI_PLAIN, a2, stream), "pf_dense_nt (context gradient)")
+        else:       # a context width the packed form is not built for: one library GEMM
+            flat = Gc.permute(2, 0, 1, 3).reshape(B, Ln * (1 + nb) * H)
+            g_ctx = (flat @ wcat().reshape(-1, C).to(gdt)).float()
+    g_flat.mul_(flow._raw_mask(dev))
+    return dict(g_x=g_x, g_ctx=g_ctx, flat=g_flat)
+
+
+def _per_parameter(flow, g_flat):
+    """the flat gradient [L, P] as one VIEW per parameter, in ``flow._ordered_parameters()`` order (no copies)."""
+    shapes = flow._raw_layout()["shapes"]
+    out = []
+    for l in range(g_flat.shape[0]):
+        row, off = g_flat[l], 0
+        for shp, n in shapes:
+            out.append(row[off:off + n].view(shp))
+            off += n
+    return out
 
 
 def flow_backward(flow, U, ctx, g_z, g_lad, drop_seed=None, nll=None):
@@ -349,7 +371,9 @@ def flow_backward(flow, U, ctx, g_z, g_lad, drop_seed=None, nll=None):
                                    (nll[0].float(), nll[1].float(), None if nll[2] is None else nll[2].float()))
     else:
         g = _flow_backward_batched(flow, U, ctx, g_z.contiguous().float(), g_lad.contiguous().float(), drop)
-    return g["g_x"], g["g_ctx"], _per_parameter(flow, g)
+    if flow._theta is not None:               # flat-parameter mode: the gradient of the one leaf
+        return g["g_x"], g["g_ctx"], [g["flat"].reshape(-1)]
+    return g["g_x"], g["g_ctx"], _per_parameter(flow, g["flat"])
 
 
 def _fast(flow) -> bool:
@@ -380,7 +404,7 @@ class FlowNLL(torch.autograd.Function):
     def backward(ctx_, g_nll, _gz, _gld):
         flow = ctx_.flow
         x, context, log_sigma, U, z = ctx_.saved_tensors
-        params = [p for p in flow._ordered_parameters()]
+        params = flow._autograd_parameters()
         if g_nll is None:
             return (None,) * (4 + len(params))
         if U is not None:
@@ -434,7 +458,7 @@ class FlowForward(torch.autograd.Function):
     def backward(ctx_, gz, gld):
         flow = ctx_.flow
         x, context, U = ctx_.saved_tensors
-        params = [p for p in flow._ordered_parameters()]
+        params = flow._autograd_parameters()
         if U is not None:
             gz = torch.zeros_like(x) if gz is None else gz
             gld = torch.zeros(x.shape[0], device=x.device) if gld is None else gld

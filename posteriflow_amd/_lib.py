@@ -19,6 +19,7 @@ PF_FLAG_HOIST_CTX = 1
 PF_FLAG_MASKED_CONTEXT = 2
 PF_FLAG_WIDE = 4
 PF_FLAG_BWD = 8
+PF_EPI_PLAIN, PF_EPI_GELU, PF_EPI_RESID, PF_EPI_MUL = 0, 1, 2, 3
 PRECISIONS = {"fp32": PF_PREC_F32, "f32": PF_PREC_F32, "bf16": PF_PREC_BF16}
 
 
@@ -47,14 +48,16 @@ class PfDenseArgs(C.Structure):
                 ("K", C.c_int32), ("N", C.c_int32), ("KC", C.c_int32), ("wfrags", C.c_void_p), ("bias", C.c_void_p),
                 ("out", C.c_void_p), ("o_seq_stride", C.c_int64), ("ldo", C.c_int32), ("o_valid_per_seq", C.c_int64),
                 ("x_seq_stride", C.c_int64), ("dact", C.c_void_p), ("resid", C.c_void_p), ("mul", C.c_void_p),
-                ("drop_p", C.c_float), ("seed", C.c_uint32), ("site", C.c_uint32), ("out_f32", C.c_int32)]
+                ("drop_p", C.c_float), ("seed", C.c_uint32), ("site", C.c_uint32), ("out_f32", C.c_int32),
+                ("a_chunk_stride", C.c_int64)]
 
 
 class PfDenseTnArgs(C.Structure):
     _fields_ = [("G", C.c_void_p), ("g_seq_stride", C.c_int64), ("ldg", C.c_int32), ("A", C.c_void_p), ("a_seq_stride", C.c_int64),
                 ("lda", C.c_int32), ("M", C.c_int64), ("rows_per_seq", C.c_int64), ("N1", C.c_int32), ("N2", C.c_int32),
                 ("dW", C.c_void_p), ("ldw", C.c_int32), ("conv_cin", C.c_int32), ("conv_kw", C.c_int32), ("db", C.c_void_p),
-                ("splits", C.c_int32)]
+                ("splits", C.c_int32), ("batch", C.c_int32), ("g_batch_stride", C.c_int64), ("a_batch_stride", C.c_int64),
+                ("w_batch_stride", C.c_int64), ("b_batch_stride", C.c_int64), ("n1_rows", C.c_int32), ("n2_cols", C.c_int32)]
 
 
 class PfLnArgs(C.Structure):
@@ -111,6 +114,8 @@ SYMBOLS = {
                                        C.c_void_p, C.c_void_p, C.c_void_p]),
     "pf_flow_backward_chain": (C.c_int, [_P, C.POINTER(PfFlowBwdChainArgs), C.c_void_p]),
     "pf_flow_reevaluate": (C.c_int, [_P, C.POINTER(PfFlowReevalArgs), C.c_void_p]),
+    "pf_flow_ctx_transposed_bytes": (C.c_int64, [_P]),
+    "pf_flow_pack_ctx_transposed": (C.c_int, [_P, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pf_flow_inverse": (C.c_int, [_P, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                   C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_int64, C.c_void_p]),

@@ -568,6 +568,41 @@ PF_ENC_ENTRY(pf_enc_pool_forward, pool_forward, PfPoolArgs)
 PF_ENC_ENTRY(pf_enc_pool_backward, pool_backward, PfPoolArgs)
 #undef PF_ENC_ENTRY
 
+// transposed context weights of ALL layers as ONE packed matrix P[c][(layer, j, hidden unit)] = W_{layer, j}[unit][c]
+// (j = 0: MADE context layer, 1 / 2: the gates of the residual blocks): the weight operand of the context gradient
+// g_ctx[row][c] = sum_{layer, j, unit} Gc[layer][j][row][unit] W_{layer, j}[unit][c]  (pf_dense_nt over 3 L slabs of Gc)
+namespace {
+int ctx_t_plan(const PfFlowDesc* desc, pf::FlowPlan& L) {
+    const int rc = layout_of(desc, L);
+    if (rc != PF_OK) return rc;
+    if (L.C <= 0 || L.C % 16 || L.NB != 2 || 3 * L.L > pf::kMaxPackEntries || (desc->reserved & PF_FLAG_MASKED_CONTEXT))
+        return fail(PF_ERR_UNSUPPORTED, "context gradient GEMM: plain conditioner, C % 16 == 0, at most 16 layers");
+    return PF_OK;
+}
+}  // namespace
+int64_t pf_flow_ctx_transposed_bytes(const PfFlowDesc* desc) {
+    pf::FlowPlan L;
+    if (ctx_t_plan(desc, L) != PF_OK) return -1;
+    return pf::dense_frag_count(L.bf16 != 0, L.C, 3 * L.L * L.H) * 16;
+}
+int pf_flow_pack_ctx_transposed(const PfFlowDesc* desc, const float* raw, void* out, void* stream) {
+    pf::FlowPlan L;
+    const int rc = ctx_t_plan(desc, L);
+    if (rc != PF_OK) return rc;
+    if (!raw || !out || misaligned(out, 16)) return fail(PF_ERR_BAD_ARG, "pf_flow_pack_ctx_transposed: null or misaligned pointer");
+    const int kstep = L.bf16 ? 32 : 16;
+    const int64_t ctxp = (int64_t)L.H * L.C + L.H, hh = 2 * ((int64_t)L.H * L.H + L.H);
+    pf::DensePackTable tab{};
+    for (int l = 0; l < L.L; ++l)
+        for (int j = 0; j < 3; ++j) {
+            pf::DensePackEntry& e = tab.e[tab.n++];
+            e.src_off = (int64_t)l * L.rawPerLayer + (int64_t)L.H * L.D + L.H + (j == 0 ? 0 : ctxp + (j - 1) * (ctxp + hh));
+            e.dst_off = 0; e.mode = 1; e.ld = L.C; e.N = L.C; e.K = L.H;
+            e.nks_total = 3 * L.L * (L.H / kstep); e.ks_off = (3 * l + j) * (L.H / kstep);
+        }
+    return finish(pf::dense_pack(L.bf16 != 0, raw, tab, out, static_cast<hipStream_t>(stream)), "");
+}
+
 int64_t pf_flow_issued_flop_per_row(const PfFlowDesc* desc) {
     pf::FlowPlan L;
     if (compute_layout_of(desc, L) != PF_OK) return -1;

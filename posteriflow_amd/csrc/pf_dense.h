@@ -43,6 +43,7 @@ struct DensePackEntry {
                               // 3: convolution as im2col GEMM, P[co][tap cin + ci] = raw[off + (co cin + ci) kw + tap]
     int32_t ld, N, K;
     int32_t cin, cout, kw, s;
+    int32_t nks_total, ks_off;    // > 0: this matrix is k-steps ks_off .. of a wider packed matrix with nks_total k-steps per tile
 };
 constexpr int kMaxPackEntries = 48;
 struct DensePackTable { int32_t n; DensePackEntry e[kMaxPackEntries]; };

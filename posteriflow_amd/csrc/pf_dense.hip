@@ -63,7 +63,8 @@ __global__ __launch_bounds__(256) void dense_pack_kernel(const float* __restrict
         } else {
             o = __builtin_bit_cast(u32x4, f32x4{v[0], v[1], v[2], v[3]});
         }
-        packed[e.dst_off + i] = o;
+        if (e.nks_total > 0) packed[e.dst_off + ((int64_t)tile * e.nks_total + e.ks_off + ks) * 64 + lane] = o;
+        else packed[e.dst_off + i] = o;
     }
 }
 
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(256, TP <= 3 ? 2 : 1) void dense_strip_kernel(const
     auto stage = [&](int ch, auto rb_tag) {
         constexpr int RB = decltype(rb_tag)::value;
         constexpr int U = BF16 ? 4 : 8;                         // slots per thread and sweep (KC <= 256)
-        const int64_t k0 = (int64_t)ch * p.KC;
+        const int64_t k0 = (int64_t)ch * (p.a_chunk_stride > 0 ? p.a_chunk_stride : (int64_t)p.KC);
 #pragma unroll 1
         for (int rr0 = 0; rr0 < BM / 32; rr0 += RB) {
             u32x4 v[RB][U];
@@ -442,8 +443,12 @@ __global__ __launch_bounds__(64 * WR * WC) void dense_tn_bf16_kernel(const Dense
     const int64_t c_lo = (int64_t)blockIdx.y * per, c_hi = c_lo + per < total_chunks ? c_lo + per : total_chunks;
     if (c_lo >= c_hi) return;
 
-    const __bf16* Gb = reinterpret_cast<const __bf16*>(p.G) + n1_0;
-    const __bf16* Ab = reinterpret_cast<const __bf16*>(p.A) + n2_0;
+    const int64_t bz = blockIdx.z;
+    const __bf16* Gb = reinterpret_cast<const __bf16*>(p.G) + bz * p.g_batch_stride + n1_0;
+    const __bf16* Ab = reinterpret_cast<const __bf16*>(p.A) + bz * p.a_batch_stride + n2_0;
+    float* const dWz = p.dW + bz * p.w_batch_stride;
+    float* const dbz = p.db ? p.db + bz * p.b_batch_stride : nullptr;
+    const int n1_lim = p.n1_rows > 0 ? p.n1_rows : p.N1, n2_lim = p.n2_cols > 0 ? p.n2_cols : p.N2;
     // staging map: slot i of the tile (row-major over [64][slots per row]) for i = tid, tid + NT, ...
     int g_row[IT1], g_slot[IT1], a_row[IT2], a_slot[IT2];
     SeqCursor gc[IT1], ac[IT2];
@@ -540,18 +545,18 @@ __global__ __launch_bounds__(64 * WR * WC) void dense_tn_bf16_kernel(const Dense
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
             const int n2 = n2_0 + 16 * TJ * wc + 16 * j + lam;
-            if (n2 >= p.N2) continue;
+            if (n2 >= n2_lim) continue;
             int col = n2;
             if (p.conv_cin > 0) { const int tap = n2 / p.conv_cin, chn = n2 - tap * p.conv_cin; col = chn * p.conv_kw + tap; }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int n1 = n1_0 + 16 * TI * wr + 16 * i + 4 * g + r;
-                if (n1 < p.N1) atomicAdd(p.dW + (int64_t)n1 * p.ldw + col, acc[i][j][r]);
+                if (n1 < n1_lim) atomicAdd(dWz + (int64_t)n1 * p.ldw + col, acc[i][j][r]);
             }
         }
-    if (p.db && t2 == 0 && tid < BN1) {
+    if (dbz && t2 == 0 && tid < BN1) {
         const int n1 = n1_0 + tid;
-        if (n1 < p.N1) atomicAdd(p.db + n1, bsum);
+        if (n1 < n1_lim) atomicAdd(dbz + n1, bsum);
     }
 }
 
@@ -576,8 +581,12 @@ __global__ __launch_bounds__(256) void dense_tn_f32_kernel(const DenseTnArgs p) 
     // staging: 16 slots of 4 floats per row, 16 rows per sweep, 2 sweeps
     const int st_slot = tid & 15, st_row = tid >> 4;
     const bool g_ok = n1_0 + 4 * st_slot + 4 <= p.N1, a_ok = n2_0 + 4 * st_slot + 4 <= p.N2;
-    const float* Gb = reinterpret_cast<const float*>(p.G) + n1_0 + 4 * st_slot;
-    const float* Ab = reinterpret_cast<const float*>(p.A) + n2_0 + 4 * st_slot;
+    const int64_t bz = blockIdx.z;
+    const float* Gb = reinterpret_cast<const float*>(p.G) + bz * p.g_batch_stride + n1_0 + 4 * st_slot;
+    const float* Ab = reinterpret_cast<const float*>(p.A) + bz * p.a_batch_stride + n2_0 + 4 * st_slot;
+    float* const dWz = p.dW + bz * p.w_batch_stride;
+    float* const dbz = p.db ? p.db + bz * p.b_batch_stride : nullptr;
+    const int n1_lim = p.n1_rows > 0 ? p.n1_rows : p.N1, n2_lim = p.n2_cols > 0 ? p.n2_cols : p.N2;
     SeqCursor cur[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) cur[i].init(c_lo * BK + st_row + 16 * i, p.rows_per_seq);
@@ -636,18 +645,18 @@ __global__ __launch_bounds__(256) void dense_tn_f32_kernel(const DenseTnArgs p) 
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int n2 = n2_0 + 32 * wc + 16 * j + lam;
-            if (n2 >= p.N2) continue;
+            if (n2 >= n2_lim) continue;
             int col = n2;
             if (p.conv_cin > 0) { const int tap = n2 / p.conv_cin, chn = n2 - tap * p.conv_cin; col = chn * p.conv_kw + tap; }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int n1 = n1_0 + 32 * wr + 16 * i + 4 * g + r;
-                if (n1 < p.N1) atomicAdd(p.dW + (int64_t)n1 * p.ldw + col, acc[i][j][r]);
+                if (n1 < n1_lim) atomicAdd(dWz + (int64_t)n1 * p.ldw + col, acc[i][j][r]);
             }
         }
-    if (p.db && t2 == 0 && tid < BN) {
+    if (dbz && t2 == 0 && tid < BN) {
         const int n1 = n1_0 + tid;
-        if (n1 < p.N1) atomicAdd(p.db + n1, bsum);
+        if (n1 < n1_lim) atomicAdd(dbz + n1, bsum);
     }
 }
 
@@ -659,17 +668,17 @@ static int launch_tn_bf16(DenseTnArgs a, hipStream_t s) {
     if (lds > 64 * 1024 - 256 && !opt_in_lds(reinterpret_cast<const void*>(k), lds)) return PF_ERR_HIP;
     const int tiles = ((a.N1 + BN1 - 1) / BN1) * ((a.N2 + BN2 - 1) / BN2);
     const int64_t chunks = (a.M + BK - 1) / BK;
+    const int nb = a.batch > 1 ? a.batch : 1;
     if (a.splits <= 0) {
-        // one workgroup of 8 waves (two of 4) per CU and round, a few rounds, each workgroup at least 4 row chunks deep
         // ONE round of workgroups: every workgroup ends in float atomics of its whole tile (1.3 TB/s chip-wide against
         // 5 TB/s of operand reads), so the split count is the atomic volume: 170 splits of the FFN weight gradient were
         // 92 MB of atomics = 70 of its 160 us; and never a few workgroups more than a whole round
         const int per_cu = WR * WC >= 8 ? 1 : 2;
-        int64_t sp = (256 * per_cu) / tiles;
+        int64_t sp = (256 * per_cu) / ((int64_t)tiles * nb);
         sp = std::min<int64_t>(sp, std::max<int64_t>(1, chunks / 4));
         a.splits = (int)std::max<int64_t>(1, sp);
     }
-    hipLaunchKernelGGL(k, dim3((unsigned)tiles, (unsigned)a.splits), dim3(64 * WR * WC), lds, s, a);
+    hipLaunchKernelGGL(k, dim3((unsigned)tiles, (unsigned)a.splits, (unsigned)nb), dim3(64 * WR * WC), lds, s, a);
     return launch_status();
 }
 
@@ -696,12 +705,13 @@ int dense_tn(bool bf16, const DenseTnArgs& a0, hipStream_t s) {
     const int bn = 64, bk = 32;
     const int tiles = ((a.N1 + bn - 1) / bn) * ((a.N2 + bn - 1) / bn);
     const int64_t chunks = (a.M + bk - 1) / bk;
+    const int nb = a.batch > 1 ? a.batch : 1;
     if (a.splits <= 0) {
-        int64_t sp = (768 + tiles - 1) / tiles;
+        int64_t sp = std::max<int64_t>(1, 768 / ((int64_t)tiles * nb));
         sp = std::min<int64_t>(sp, std::max<int64_t>(1, chunks / 4));
         a.splits = (int)std::max<int64_t>(1, sp);
     }
-    hipLaunchKernelGGL(dense_tn_f32_kernel, dim3((unsigned)tiles, (unsigned)a.splits), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(dense_tn_f32_kernel, dim3((unsigned)tiles, (unsigned)a.splits, (unsigned)nb), dim3(256), 0, s, a);
     return launch_status();
 }
 

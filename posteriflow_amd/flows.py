@@ -264,6 +264,184 @@ class NSFPosteriorFlow(nn.Module):
         self._packed: Dict[tuple, _Packed] = {}
         self._perm_i32 = None
         self._frozen = False
+        self._theta = None           # flatten_parameters(): the one leaf all transform parameters are views of
+
+    # ---- flat parameter storage (opt-in) ---------------------------------------------------------------------------
+    def flatten_parameters(self) -> "NSFPosteriorFlow":
+        """Re-home every parameter of the transform into ONE flat leaf ``_theta`` (the raw parameter layout of
+        include/pf_hip.h: what ``pf_flow_pack`` reads and the backward writes) and turn ``weight`` / ``bias`` of the
+        sub-modules into views of it.  What it buys: a differentiable call hands autograd 1 parameter tensor instead of
+        18 per layer (180 ``AccumulateGrad`` nodes were ~0.5 ms of host time per backward at LeanNPE's size, more than
+        the kernels took), the packing reads the leaf directly (no concatenation per weight update) and an optimiser
+        steps one tensor.  What changes: ``parameters()`` / ``named_parameters()`` yield ``_theta`` (+ ``temperature``)
+        instead of the per-tensor names -- ``state_dict()`` / ``load_state_dict()`` keep nflows' names (hooks below),
+        ``named_parameter_views()`` lists (name, view) pairs and ``named_gradient_views()`` the matching slices of
+        ``_theta.grad``.  Plain conditioner only.  Call it before building the optimiser."""
+        if self._theta is not None:
+            return self
+        if self.use_masked_context:
+            raise NotImplementedError("flatten_parameters: plain conditioner only (the masked-context variant differentiates "
+                                      "tensor ops over its own parameters)")
+        params = self._ordered_parameters()
+        with torch.no_grad():
+            flat = torch.cat([p.detach().reshape(-1).float() for p in params])
+        theta = nn.Parameter(flat, requires_grad=any(p.requires_grad for p in params))
+        for mod, name in self._param_slots():
+            del mod._parameters[name]
+        self._theta = theta
+        self.register_parameter("_theta", theta)
+        self._refresh_views()
+        self._packed.clear()
+        self.__dict__.pop("_raw_cache", None)
+        return self
+
+    def _param_slots(self):
+        """(module, attribute) of every transform parameter in raw-layout order"""
+        out = []
+        for layer in self._ar_transforms:
+            net = layer.autoregressive_net
+            out += [(net.initial_layer, "weight"), (net.initial_layer, "bias")]
+            if hasattr(net, "context_layer"):
+                out += [(net.context_layer, "weight"), (net.context_layer, "bias")]
+            for b in net.blocks:
+                if hasattr(b, "context_layer"):
+                    out += [(b.context_layer, "weight"), (b.context_layer, "bias")]
+                for lin in b.linear_layers:
+                    out += [(lin, "weight"), (lin, "bias")]
+            out += [(net.final_layer, "weight"), (net.final_layer, "bias")]
+        return out
+
+    def _refresh_views(self):
+        """flat mode: (re)create the sub-modules' weight / bias views of ``_theta`` (after construction, .to(), loading)"""
+        lay = self._raw_layout()
+        off = 0
+        slots = self._param_slots()
+        per = len(lay["shapes"])
+        for i, (mod, name) in enumerate(slots):
+            shp, n = lay["shapes"][i % per]
+            mod.__dict__[name] = self._theta[off:off + n].view(shp)
+            off += n
+        self.__dict__.pop("_ordered_cache", None)
+
+    def _slot_names(self):
+        """nflows state_dict names of the transform parameters (relative to this module), raw-layout order"""
+        names = []
+        step = 1 if self.use_masked_context else 2
+        for l in range(self.num_layers):
+            pre = f"transform._transforms.{step * l + step - 1}.autoregressive_net."
+            names += [pre + "initial_layer.weight", pre + "initial_layer.bias"]
+            if self.context_features > 0:
+                names += [pre + "context_layer.weight", pre + "context_layer.bias"]
+            for b in range(2):
+                if self.context_features > 0:
+                    names += [pre + f"blocks.{b}.context_layer.weight", pre + f"blocks.{b}.context_layer.bias"]
+                for k in range(2):
+                    names += [pre + f"blocks.{b}.linear_layers.{k}.weight", pre + f"blocks.{b}.linear_layers.{k}.bias"]
+            names += [pre + "final_layer.weight", pre + "final_layer.bias"]
+        return names
+
+    def named_parameter_views(self):
+        """(nflows name, tensor) for every transform parameter: views of ``_theta`` in flat mode, the Parameters otherwise"""
+        return list(zip(self._slot_names(), self._ordered_parameters()))
+
+    def named_gradient_views(self):
+        """(nflows name, gradient) pairs: slices of ``_theta.grad`` in flat mode, ``p.grad`` otherwise"""
+        if self._theta is None:
+            return [(n, p.grad) for n, p in self.named_parameter_views()]
+        g = self._theta.grad
+        out, off = [], 0
+        for n, p in self.named_parameter_views():
+            out.append((n, None if g is None else g[off:off + p.numel()].view(p.shape)))
+            off += p.numel()
+        return out
+
+    def _autograd_parameters(self) -> List[torch.Tensor]:
+        """what a differentiable call hands to autograd: the one leaf in flat mode, else every Parameter"""
+        return [self._theta] if self._theta is not None else self._ordered_parameters()
+
+    def _raw_layout(self) -> dict:
+        """offsets (floats) of one layer's tensors inside the raw parameter layout + their shapes"""
+        lay = self.__dict__.get("_raw_layout_cache")
+        if lay is None:
+            H, D, C = self.hidden_features, self.features, self.context_features
+            DM = D * (3 * self.num_bins - 1)
+            o, shapes = 0, []
+            lay = {"W1": [], "b1": [], "W2": [], "b2": [], "Wc": [], "bc": []}
+
+            def take(key, shp, lst=False):
+                nonlocal o
+                n = 1
+                for v in shp:
+                    n *= v
+                (lay[key].append(o) if lst else lay.__setitem__(key, o))
+                shapes.append((tuple(shp), n))
+                o += n
+            take("W0", (H, D)); take("b0", (H,))
+            if C > 0:
+                take("Wc", (H, C), True); take("bc", (H,), True)
+            for _ in range(2):
+                if C > 0:
+                    take("Wc", (H, C), True); take("bc", (H,), True)
+                take("W1", (H, H), True); take("b1", (H,), True)
+                take("W2", (H, H), True); take("b2", (H,), True)
+            take("Wf", (DM, H)); take("bf", (DM,))
+            lay["P"], lay["shapes"] = o, shapes
+            self.__dict__["_raw_layout_cache"] = lay
+        return lay
+
+    def _raw_mask(self, dev) -> torch.Tensor:
+        """[P] multiplier of one layer's flat gradient: the autoregressive masks on the masked weights, 1 elsewhere"""
+        m = self.__dict__.get("_raw_mask_cache")
+        if m is None or m.device != dev:
+            net = self._ar_transforms[0].autoregressive_net
+            parts = []
+            for mod, name in self._param_slots()[:len(self._raw_layout()["shapes"])]:
+                t = getattr(mod, name)
+                if name == "weight" and isinstance(mod, _MaskedLinear):
+                    parts.append(mod.mask.detach().reshape(-1).float())
+                else:
+                    parts.append(torch.ones(t.numel(), dtype=torch.float32, device=t.device))
+            m = torch.cat([p.to(dev) for p in parts])
+            self.__dict__["_raw_mask_cache"] = m
+            del net
+        return m
+
+    def packed_ctx_transposed(self, precision: str):
+        """all layers' context weights transposed, as pf_dense_nt fragments (pf_flow_pack_ctx_transposed): the weight
+        operand of the context gradient; None where the packed form is not built (C % 16, masked-context, L > 16)"""
+        desc = self._desc(precision)
+        L = _lib.lib()
+        nbytes = L.pf_flow_ctx_transposed_bytes(desc)
+        if nbytes < 0:
+            return None
+        dev = self._device()
+        raw, key = self._raw_flat(dev)
+        st = self.__dict__.setdefault("_ctxT", {})
+        ent = st.get(precision)
+        if ent is None or ent[0] != key:
+            buf = ent[1] if ent is not None and ent[1].device == dev and ent[1].numel() == nbytes else \
+                torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            _lib.check(L.pf_flow_pack_ctx_transposed(desc, raw.data_ptr(), buf.data_ptr(),
+                                                     torch.cuda.current_stream(dev).cuda_stream), "pf_flow_pack_ctx_transposed")
+            st[precision] = ent = (key, buf)
+        return ent[1]
+
+    def _raw_flat(self, dev):
+        """(flat fp32 copy of the transform parameters in raw-layout order, key of the weights it was made from); in flat
+        mode the leaf itself"""
+        if self._theta is not None:
+            key = (dev, self._theta._version, self._theta.data_ptr())
+            return self._theta.detach(), key
+        params = self._ordered_parameters()
+        key = (dev, tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
+        rk = self.__dict__.get("_raw_cache")          # one flat copy of the parameters serves every stream of a weight update
+        if rk is not None and rk[0] == key:
+            return rk[1], key
+        with torch.no_grad():
+            packing = [t for layer in self._ar_transforms for t in layer.autoregressive_net.ordered_parameters(True)]
+            raw = torch.cat([p.detach().reshape(-1).float() for p in packing])
+        self.__dict__["_raw_cache"] = (key, raw)
+        return raw, key
 
     def freeze_packed(self, frozen: bool = True) -> "NSFPosteriorFlow":
         """Inference: keep the packed weights as they are and skip the per-call scan for
@@ -426,8 +604,7 @@ class NSFPosteriorFlow(nn.Module):
             return self._packed[ck].buf
         dev = self._device()
         L = _lib.lib()
-        params = self._ordered_parameters()
-        key = (dev, tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
+        raw, key = self._raw_flat(dev)
         pk = self._packed.setdefault((desc.precision, desc.reserved), _Packed())
         if pk.key == key:
             return pk.buf
@@ -439,14 +616,6 @@ class NSFPosteriorFlow(nn.Module):
             _lib.check(L.pf_flow_build_pack_map(desc, host.data_ptr()), "pf_flow_build_pack_map")
             pk.map = host.to(dev)
             pk.buf = torch.empty(L.pf_flow_packed_bytes(desc), dtype=torch.uint8, device=dev)
-        rk = self.__dict__.get("_raw_cache")          # one flat copy of the parameters serves every stream of a weight update
-        if rk is not None and rk[0] == key:
-            raw = rk[1]
-        else:
-            with torch.no_grad():
-                packing = [t for layer in self._ar_transforms for t in layer.autoregressive_net.ordered_parameters(True)]
-                raw = torch.cat([p.detach().reshape(-1).float() for p in packing])
-            self.__dict__["_raw_cache"] = (key, raw)
         assert raw.numel() == L.pf_flow_raw_param_count(desc)
         _lib.check(L.pf_flow_pack(desc, raw.data_ptr(), pk.map.data_ptr(), pk.buf.data_ptr(),
                                   torch.cuda.current_stream(dev).cuda_stream), "pf_flow_pack")
@@ -467,10 +636,40 @@ class NSFPosteriorFlow(nn.Module):
 
     def _apply(self, fn, *args, **kwargs):
         self.__dict__.pop("_ordered_cache", None)     # .to() / .cuda() may swap Parameter objects
-        return super()._apply(fn, *args, **kwargs)
+        out = super()._apply(fn, *args, **kwargs)
+        if self._theta is not None:
+            self._theta = self._parameters["_theta"]
+            self._refresh_views()
+        self.__dict__.pop("_raw_mask_cache", None)
+        return out
 
-    def _load_from_state_dict(self, *args, **kwargs):
-        super()._load_from_state_dict(*args, **kwargs)
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+        if self._theta is not None:        # flat mode: nflows' names (both registration paths, flows.py:529, 532), not "_theta"
+            destination.pop(prefix + "_theta", None)
+            for name, view in self.named_parameter_views():
+                t = view if keep_vars else view.detach()
+                destination[prefix + name] = t
+                destination[prefix + "flow._" + name] = t
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        if self._theta is not None:        # flat mode: gather nflows-named tensors into the leaf
+            with torch.no_grad():
+                for name, view in self.named_parameter_views():
+                    src = state_dict.pop(prefix + name, None)
+                    alias = state_dict.pop(prefix + "flow._" + name, None)
+                    src = alias if src is None else src
+                    if src is None:
+                        if strict:
+                            missing_keys.append(prefix + name)
+                        continue
+                    if tuple(src.shape) != tuple(view.shape):
+                        error_msgs.append(f"size mismatch for {prefix + name}: {tuple(src.shape)} vs {tuple(view.shape)}")
+                        continue
+                    view.copy_(src)
+            state_dict = dict(state_dict)
+            state_dict[prefix + "_theta"] = self._theta.detach()
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
         self.__dict__.pop("_ordered_cache", None)
         self._perm_i32 = None          # _ar_perm may have come from the checkpoint
         self._frozen = False
@@ -499,7 +698,7 @@ class NSFPosteriorFlow(nn.Module):
     def _needs_grad(self, *tensors) -> bool:
         need = torch.is_grad_enabled() and (
             any(t is not None and t.requires_grad for t in tensors)
-            or any(p.requires_grad for p in self._ordered_parameters()))
+            or any(p.requires_grad for p in self._autograd_parameters()))
         return need
 
     # ---- conditioner dropout (train mode) ---------------------------------------------
@@ -562,7 +761,7 @@ class NSFPosteriorFlow(nn.Module):
         if self._needs_grad(x, context, log_sigma):
             from ._flow_autograd import FlowNLL
             dev, x, context = self._check_inputs(x, context, "NSFPosteriorFlow.compute_psd_aware_nll")
-            return FlowNLL.apply(self, x, context, log_sigma, *self._ordered_parameters())[0]
+            return FlowNLL.apply(self, x, context, log_sigma, *self._autograd_parameters())[0]
         return self._forward_call(x, context, log_sigma, want_z=False)[2]
 
     # ---- reference API ------------------------------------------------------------
@@ -588,7 +787,7 @@ class NSFPosteriorFlow(nn.Module):
         if self._needs_grad(x, context):
             from ._flow_autograd import FlowForward
             dev, x, context = self._check_inputs(x, context, "NSFPosteriorFlow.forward")
-            return FlowForward.apply(self, x, context, *self._ordered_parameters())
+            return FlowForward.apply(self, x, context, *self._autograd_parameters())
         z, logdet, _ = self._forward_call(x, context, None)
         return z, logdet
 

@@ -6,11 +6,13 @@ prec = sys.argv[1] if len(sys.argv) > 1 else "bf16"
 dev = torch.device("cuda"); torch.manual_seed(0)
 model = npe.LeanNPE().to(dev).train(); model.flow.precision = prec
 flow = model.flow
+if os.environ.get("PF_FLAT", "1") != "0":
+    flow.flatten_parameters()                  # one flat leaf (PF_FLAT=0: 180 per-tensor Parameters through autograd)
 n_rows = 2048
 ctx = torch.randn(n_rows, flow.context_features, device=dev, requires_grad=True)
 x = (torch.rand(n_rows, flow.features, device=dev) * 2 - 1)
 def flow_fb():
-    for p_ in flow._ordered_parameters(): p_.grad = None        # what optimizer.zero_grad() does (set_to_none)
+    for p_ in flow.parameters(): p_.grad = None        # what optimizer.zero_grad() does (set_to_none)
     ctx.grad = None
     flow.compute_psd_aware_nll(x, ctx, torch.zeros_like(x)).mean().backward()
 for _ in range(3): flow_fb()

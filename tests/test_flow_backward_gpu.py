@@ -302,3 +302,44 @@ def test_hip_reevaluation_matches_tensor_ops(D, C, H, L, K):
         if C:
             assert torch.equal(T2c, rbf(T2)) and torch.equal(Gc_, rbf(G)) and torch.equal(PCc, rbf(F.relu(PC)))
     print(f"\n[re-evaluation D{D} C{C} H{H} L{L}] worst relative error per tensor: " + ", ".join(f"{k} {v:.1e}" for k, v in worst.items()))
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_flat_parameter_mode_gives_the_same_gradients_and_state_dict(precision):
+    """flatten_parameters(): one leaf ``_theta`` for the whole transform.  Same loss, the gradient of the leaf equals the
+    per-parameter gradients of the default mode laid end to end (both come from the same flat buffer the weight-gradient
+    GEMMs write), state_dict keeps nflows' names in both directions, an optimiser step moves the views."""
+    from helpers import flow_inputs, make_pair
+    D, C, H, L = 11, 288, 256, 3
+    _, _, flow = make_pair(D, C, H, L, 16, 5.0, scale=2.0)
+    flow.precision = precision
+    B = 300
+    x, ctx = flow_inputs(B, D, C, 5.0)
+    w = torch.rand(B, generator=torch.Generator().manual_seed(3)) + 0.5
+    xg, cg = x.cuda().requires_grad_(True), ctx.cuda().requires_grad_(True)
+    nll = flow.compute_psd_aware_nll(xg, cg, None)
+    (nll * w.cuda()).sum().backward()
+    want = torch.cat([g.flatten() for _, g in flow.named_gradient_views()])
+    gx, gc = xg.grad.clone(), cg.grad.clone()
+    sd = {k: v.clone() for k, v in flow.state_dict().items()}
+    flat = flow.flatten_parameters()
+    assert [n for n, _ in flat.named_parameters()] == ["temperature", "_theta"]
+    assert set(flat.state_dict()) == set(sd) and all(torch.equal(flat.state_dict()[k], sd[k]) for k in sd)
+    xg2, cg2 = x.cuda().requires_grad_(True), ctx.cuda().requires_grad_(True)
+    nll2 = flat.compute_psd_aware_nll(xg2, cg2, None)
+    assert torch.equal(nll2, nll)
+    (nll2 * w.cuda()).sum().backward()
+    got = flat._theta.grad
+    assert got.shape == want.shape
+    rel = ((got - want).abs().max() / want.abs().max()).item()        # float atomics: summation order varies run to run
+    print(f"\n[flat mode {precision}] |grad - per-parameter grad| / max = {rel:.2e}")
+    assert rel < 1e-5 and torch.allclose(xg2.grad, gx, rtol=1e-5, atol=1e-6) and torch.allclose(cg2.grad, gc, rtol=1e-4, atol=1e-6)
+    names = dict(flat.named_gradient_views())
+    assert names["transform._transforms.1.autoregressive_net.final_layer.weight"].shape == (D * 47, H)
+    before = flat._ar_transforms[0].autoregressive_net.initial_layer.weight.detach().clone()
+    torch.optim.SGD(flat.parameters(), lr=1e-2).step()
+    assert not torch.equal(flat._ar_transforms[0].autoregressive_net.initial_layer.weight.detach(), before)
+    fresh = make_pair(D, C, H, L, 16, 5.0)[2]
+    fresh.load_state_dict(flat.state_dict())                           # back into a per-parameter flow
+    assert torch.equal(fresh._ar_transforms[0].autoregressive_net.initial_layer.weight.detach(),
+                       flat._ar_transforms[0].autoregressive_net.initial_layer.weight.detach())
