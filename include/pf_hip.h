@@ -211,6 +211,9 @@ typedef struct PfFlowBwdChainArgs {
     const void* packed;  /* bf16 descs: the PF_FLAG_BWD stream (W*T above are ignored): the transposed GEMMs run on bf16
                           * MFMA with bf16-rounded gradient vectors as their second operand; the spline, the accumulators,
                           * the gate / ReLU algebra and every output stay fp32.  fp32 descs: ignored. */
+    uint32_t gp_ld;      /* row stride of Gp in elements; 0: D (3K-1).  A stride that is a multiple of 8 (compact) lets the rows
+                          * leave as 16-byte stores and be the operand of pf_dense_tn without a padding copy; elements
+                          * D (3K-1) .. gp_ld - 1 of every row are written as zeros */
 } PfFlowBwdChainArgs;
 int pf_flow_backward_chain(const PfFlowDesc* desc, const PfFlowBwdChainArgs* args, void* stream);
 
@@ -395,6 +398,9 @@ typedef struct PfDenseArgs {
     int32_t out_f32;          /* PF_EPI_PLAIN: fp32 output in either precision */
     int64_t a_chunk_stride;   /* > 0: k-chunk c of every row starts at A + c * a_chunk_stride (+ the row's offset) instead of
                                * c * KC elements into the row: the reduction runs over K / KC separate [rows][KC] slabs */
+    int32_t k_splits;         /* > 1 (PF_EPI_PLAIN, out_f32, K / KC chunks): the chunks are divided over k_splits workgroups per
+                               * strip which ADD their partial sums into out with float atomics -- out must hold zeros (or the
+                               * value to accumulate onto); for few-row, long-reduction products that would leave CUs idle */
 } PfDenseArgs;
 typedef struct PfDenseTnArgs {  /* dW[n1][n2] += sum_m G[m][n1] A[m][n2],  db[n1] += sum_m G[m][n1]  (float atomics) */
     const void* G; int64_t g_seq_stride; int32_t ldg;
@@ -411,6 +417,8 @@ typedef struct PfDenseTnArgs {  /* dW[n1][n2] += sum_m G[m][n1] A[m][n2],  db[n1
     int64_t g_batch_stride, a_batch_stride, w_batch_stride, b_batch_stride;
     int32_t n1_rows, n2_cols; /* > 0: only rows < n1_rows / columns < n2_cols of dW (and db) exist -- N1 / N2 then describe the
                                * (zero-padded) operand widths only */
+    const float* mask;        /* or NULL: dW[n1][col] += mask[n1 * ldw + col] * (the sum) -- one mask for every problem of a batch
+                               * (the autoregressive masks of the flow's weights) */
 } PfDenseTnArgs;
 /* mode 0: W[n][k] = src[n * ld + k]; 1: W[n][k] = src[k * ld + n]; out: pf_dense_frag_bytes(precision, N, K) bytes */
 int64_t pf_dense_frag_bytes(int32_t precision, int32_t N, int32_t K);

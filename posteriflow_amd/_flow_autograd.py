@@ -238,7 +238,8 @@ def _flow_backward_batched(flow, U, ctx, g_z, g_lad, drop=None, nll=None):
     #    small ones per layer -- spline backward, the transposed masked GEMMs on MFMA, the gate / ReLU algebra
     DM = params.shape[2]
     gdt = torch.bfloat16 if cmp else U.dtype
-    Gp = torch.empty(params.shape, dtype=gdt, device=U.device)
+    DMp = (DM + 7) // 8 * 8 if cmp else (DM + 3) // 4 * 4    # rows padded to whole 16-byte pieces (the GEMM operand form)
+    Gp = torch.empty(Ln, B, DMp, dtype=gdt, device=U.device)
     # Gt1 | Gt2 | Gh0 in one buffer: their bias gradients are ONE column reduction instead of five
     G5 = torch.empty(2 * nb + 1, Ln, B, H, dtype=gdt, device=U.device)
     GT1, GT2, Gh0 = G5[:nb], G5[nb:2 * nb], G5[2 * nb]
@@ -269,6 +270,7 @@ def _flow_backward_batched(flow, U, ctx, g_z, g_lad, drop=None, nll=None):
         keep += [WfT, W2T, W1T, W0T]
     if drop is not None:        # gt1 = (W2^T gt2) . factor . [t1 > 0]: the chain reads the forward's factors
         ops.append(("drop", drop))
+    a.gp_ld = DMp
     if cmp:
         a.compact, a.drop_scale = 1, (1.0 if drop is None else 1.0 / (1.0 - float(flow.dropout)))
     half = {"hs", "t1s", "Gp", "Gh0", "Gt1", "Gt2"} if cmp else set()
@@ -287,8 +289,8 @@ def _flow_backward_batched(flow, U, ctx, g_z, g_lad, drop=None, nll=None):
 
     # 3. weight gradients: hand-written split-M GEMMs (pf_dense_tn, csrc/pf_dense.hip), batched over the layers, accumulating
     #    straight into ONE flat gradient buffer in the raw parameter layout (include/pf_hip.h) -- bias gradients come out of the
-    #    same launches (column sums of the gradient operand); 9 launches + one masking multiply replaced 18 library GEMMs,
-    #    6 reductions and the per-parameter bookkeeping.  The context gradient is pf_dense_nt over the 3 L slabs of Gc.
+    #    same launches (column sums of the gradient operand) and the autoregressive masks are applied to the partial sums;
+    #    9 launches replaced 18 library GEMMs, 6 reductions and the per-parameter bookkeeping.  The context gradient is pf_dense_nt over the 3 L slabs of Gc.
     lay = flow._raw_layout()
     P = lay["P"]
     dev = U.device
@@ -301,7 +303,9 @@ def _flow_backward_batched(flow, U, ctx, g_z, g_lad, drop=None, nll=None):
     stream = torch.cuda.current_stream(dev).cuda_stream
     keep2 = []
 
-    def tn(G, g_off, g_bs, ldg, A, a_bs, lda, n1, n2, w_off, b_off, ldw, n1_rows=0, n2_cols=0):
+    mask = flow._raw_mask(dev)
+
+    def tn(G, g_off, g_bs, ldg, A, a_bs, lda, n1, n2, w_off, b_off, ldw, n1_rows=0, n2_cols=0, masked=False):
         t = _lib.PfDenseTnArgs()
         t.G, t.g_seq_stride, t.ldg = G.data_ptr() + g_off * G.element_size(), 0, ldg
         t.A, t.a_seq_stride, t.lda = A.data_ptr(), 0, lda
@@ -309,17 +313,19 @@ def _flow_backward_batched(flow, U, ctx, g_z, g_lad, drop=None, nll=None):
         t.dW, t.ldw, t.db, t.splits = g_flat.data_ptr() + 4 * w_off, ldw, g_flat.data_ptr() + 4 * b_off, 0
         t.batch, t.g_batch_stride, t.a_batch_stride, t.w_batch_stride, t.b_batch_stride = Ln, g_bs, a_bs, P, P
         t.n1_rows, t.n2_cols = n1_rows, n2_cols
+        t.mask = mask.data_ptr() + 4 * w_off if masked else None
         _lib.check(L_.pf_dense_tn(prec, t, stream), "pf_dense_tn")
 
-    Dp, DMp = up(D), up(DM)
+    Dp = up(D)
     Upad = F.pad(U.to(adt), (0, Dp - D)) if (Dp != D or U.dtype != adt) else U
-    Gpp = F.pad(Gp, (0, DMp - DM)) if DMp != DM else Gp
+    Gpp = F.pad(Gp, (0, up(DMp) - DMp)) if up(DMp) != DMp else Gp
+    DMp = up(DMp)
     keep2 += [Upad, Gpp]
-    tn(Gh0, 0, B * H, H, Upad, B * Dp, Dp, H, Dp, lay["W0"], lay["b0"], D, n2_cols=D)
+    tn(Gh0, 0, B * H, H, Upad, B * Dp, Dp, H, Dp, lay["W0"], lay["b0"], D, n2_cols=D, masked=True)
     for j in range(nb):
-        tn(GT1[j], 0, B * H, H, relu_h[j], B * H, H, H, H, lay["W1"][j], lay["b1"][j], H)
-        tn(GT2[j], 0, B * H, H, a1s[j], B * H, H, H, H, lay["W2"][j], lay["b2"][j], H)
-    tn(Gpp, 0, B * DMp, DMp, h_last, B * H, H, DMp, H, lay["Wf"], lay["bf"], H, n1_rows=DM)
+        tn(GT1[j], 0, B * H, H, relu_h[j], B * H, H, H, H, lay["W1"][j], lay["b1"][j], H, masked=True)
+        tn(GT2[j], 0, B * H, H, a1s[j], B * H, H, H, H, lay["W2"][j], lay["b2"][j], H, masked=True)
+    tn(Gpp, 0, B * DMp, DMp, h_last, B * H, H, DMp, H, lay["Wf"], lay["bf"], H, n1_rows=DM, masked=True)
     g_ctx = None
     if has_ctx:
         Cp = up(C)
@@ -329,10 +335,14 @@ def _flow_backward_batched(flow, U, ctx, g_z, g_lad, drop=None, nll=None):
             tn(Gc, j * B * H, (1 + nb) * B * H, H, ctxa, 0, Cp, H, Cp, lay["Wc"][j], lay["bc"][j], C, n2_cols=C)
         wt = flow.packed_ctx_transposed("bf16" if cmp else "fp32")
         if wt is not None:
-            g_ctx = torch.empty(B, C, dtype=torch.float32, device=dev)
+            # few rows, long reduction: B / 128 strips x ceil(tiles / 12) calls would leave most CUs idle (2048 rows: 32
+            # workgroups, 307 us), so the 3 L slabs are divided over workgroups that add into a zeroed g_ctx
             nks_total = (1 + nb) * Ln * (H // (32 if cmp else 16))
             tiles = C // 16
             per_call = 12
+            wgs = -(-B // 128) * -(-tiles // per_call)
+            splits = max(1, min((1 + nb) * Ln, 256 // max(wgs, 1)))
+            g_ctx = (torch.zeros if splits > 1 else torch.empty)(B, C, dtype=torch.float32, device=dev)
             for t0 in range(0, tiles, per_call):
                 nt = min(per_call, tiles - t0)
                 a2 = _lib.PfDenseArgs()
@@ -340,11 +350,11 @@ def _flow_backward_batched(flow, U, ctx, g_z, g_lad, drop=None, nll=None):
                 a2.K, a2.N, a2.KC, a2.a_chunk_stride = (1 + nb) * Ln * H, 16 * nt, H, B * H
                 a2.wfrags = wt.data_ptr() + t0 * nks_total * 64 * 16
                 a2.out, a2.o_seq_stride, a2.ldo, a2.out_f32 = g_ctx.data_ptr() + 4 * 16 * t0, 0, C, 1
+                a2.k_splits = splits
                 _lib.check(L_.pf_dense_nt(prec, _lib.PF_EPI_PLAIN, a2, stream), "pf_dense_nt (context gradient)")
         else:       # a context width the packed form is not built for: one library GEMM
             flat = Gc.permute(2, 0, 1, 3).reshape(B, Ln * (1 + nb) * H)
             g_ctx = (flat @ wcat().reshape(-1, C).to(gdt)).float()
-    g_flat.mul_(flow._raw_mask(dev))
     return dict(g_x=g_x, g_ctx=g_ctx, flat=g_flat)
 
 

@@ -28,7 +28,7 @@ class PfFlowBwdChainArgs(C.Structure):
     _fields_ = [("batch", C.c_int64)] + [(n, C.c_void_p) for n in (
         "WfT", "W2T", "W1T", "W0T", "U", "params", "hs", "t1s", "t2s", "gates", "pc", "g_z", "g_lad", "g_nll", "nll_z", "log_sigma",
         "Gp", "Gh0", "Gt1", "Gt2", "Gc", "g_x", "drop")] + [("compact", C.c_uint32), ("drop_scale", C.c_float),
-                                                           ("packed", C.c_void_p)]
+                                                           ("packed", C.c_void_p), ("gp_ld", C.c_uint32)]
 
 
 class PfFlowReevalArgs(C.Structure):
@@ -49,7 +49,7 @@ class PfDenseArgs(C.Structure):
                 ("out", C.c_void_p), ("o_seq_stride", C.c_int64), ("ldo", C.c_int32), ("o_valid_per_seq", C.c_int64),
                 ("x_seq_stride", C.c_int64), ("dact", C.c_void_p), ("resid", C.c_void_p), ("mul", C.c_void_p),
                 ("drop_p", C.c_float), ("seed", C.c_uint32), ("site", C.c_uint32), ("out_f32", C.c_int32),
-                ("a_chunk_stride", C.c_int64)]
+                ("a_chunk_stride", C.c_int64), ("k_splits", C.c_int32)]
 
 
 class PfDenseTnArgs(C.Structure):
@@ -57,7 +57,7 @@ class PfDenseTnArgs(C.Structure):
                 ("lda", C.c_int32), ("M", C.c_int64), ("rows_per_seq", C.c_int64), ("N1", C.c_int32), ("N2", C.c_int32),
                 ("dW", C.c_void_p), ("ldw", C.c_int32), ("conv_cin", C.c_int32), ("conv_kw", C.c_int32), ("db", C.c_void_p),
                 ("splits", C.c_int32), ("batch", C.c_int32), ("g_batch_stride", C.c_int64), ("a_batch_stride", C.c_int64),
-                ("w_batch_stride", C.c_int64), ("b_batch_stride", C.c_int64), ("n1_rows", C.c_int32), ("n2_cols", C.c_int32)]
+                ("w_batch_stride", C.c_int64), ("b_batch_stride", C.c_int64), ("n1_rows", C.c_int32), ("n2_cols", C.c_int32), ("mask", C.c_void_p)]
 
 
 class PfLnArgs(C.Structure):

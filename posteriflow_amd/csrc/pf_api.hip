@@ -248,6 +248,7 @@ int pf_flow_backward_chain(const PfFlowDesc* desc, const PfFlowBwdChainArgs* a, 
     if (bf && H % 32) return fail(PF_ERR_UNSUPPORTED, "bf16 backward chain needs H % 32 == 0");
     if (!a->U || !a->params || !a->hs || !a->t1s || !a->Gp || !a->Gh0 || !a->Gt1 || !a->Gt2 || !a->g_x)
         return fail(PF_ERR_BAD_ARG, "null pointer");
+    if (a->gp_ld && (int)a->gp_ld < D * (3 * K - 1)) return fail(PF_ERR_BAD_ARG, "gp_ld is shorter than a row of Gp");
     if (a->g_nll ? (!a->nll_z || a->g_z || a->g_lad) : (!a->g_z || !a->g_lad))
         return fail(PF_ERR_BAD_ARG, "pass either (g_z, g_lad) or (g_nll, nll_z[, log_sigma])");
     const bool ctx = a->gates != nullptr;

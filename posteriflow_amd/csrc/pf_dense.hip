@@ -7,6 +7,7 @@
 #include <type_traits>
 
 #include "pf_dense.h"
+#include <cstdlib>
 #include "pf_math.h"
 #include "pf_status.h"
 
@@ -121,6 +122,11 @@ __global__ __launch_bounds__(256, TP <= 3 ? 2 : 1) void dense_strip_kernel(const
         }
     };
     set_fetch_pass(0);
+    // split reduction: workgroup y of a strip takes chunks [ch_lo, ch_hi) and adds its partial sums into out
+    const int ksp = p.k_splits > 1 ? p.k_splits : 1;
+    const int cps = (nchunks + ksp - 1) / ksp;
+    const int ch_lo = (int)blockIdx.y * cps, ch_hi = ch_lo + cps < nchunks ? ch_lo + cps : nchunks;
+    f_kk = ch_lo * nks;
     u32x4 ring[RD][TP];
     auto fetch = [&](u32x4 (&dst)[TP]) {
 #pragma unroll
@@ -199,9 +205,9 @@ __global__ __launch_bounds__(256, TP <= 3 ? 2 : 1) void dense_strip_kernel(const
 #pragma unroll
         for (int i = 0; i < TP; ++i) tile[i] = pass * 4 * TP + wave * TP + i;
 #pragma unroll 1
-        for (int ch = 0; ch < nchunks; ++ch) {
+        for (int ch = ch_lo; ch < ch_hi; ++ch) {
             if (pass == 0) {                                             // (nchunks > 1 implies n_pass == 1: host-checked)
-                if (ch == 0) stage(0, std::integral_constant<int, BF16 ? 2 : 1>{});
+                if (ch == ch_lo) stage(ch, std::integral_constant<int, BF16 ? 2 : 1>{});
                 else { __syncthreads(); stage(ch, std::integral_constant<int, 1>{}); }
                 __syncthreads();
             }
@@ -253,7 +259,7 @@ __global__ __launch_bounds__(256, TP <= 3 ? 2 : 1) void dense_strip_kernel(const
 #pragma unroll
         for (int i = 0; i < TP; ++i) {
             b4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (p.bias && tile[i] < ntiles) b4[i] = *reinterpret_cast<const f32x4*>(p.bias + tile[i] * 16 + 4 * g);
+            if (p.bias && tile[i] < ntiles && blockIdx.y == 0) b4[i] = *reinterpret_cast<const f32x4*>(p.bias + tile[i] * 16 + 4 * g);
         }
 #pragma unroll
         for (int cg = 0; cg < CG; ++cg) {
@@ -329,6 +335,15 @@ __global__ __launch_bounds__(256, TP <= 3 ? 2 : 1) void dense_strip_kernel(const
                     if (pos * p.ldo + col + epc > p.o_valid_per_seq) continue;
                 }
                 const u32x4 val = *reinterpret_cast<const u32x4*>(buf + r16 * srow + ch * 16);
+                if constexpr (EPI == kEpiPlain) {
+                    if (ksp > 1) {                                       // (fp32 output: host-checked)
+                        const f32x4 fv = __builtin_bit_cast(f32x4, val);
+                        float* o = reinterpret_cast<float*>(p.out) + oo + col;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) atomicAdd(o + e, fv[e]);
+                        continue;
+                    }
+                }
                 *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(p.out) + (oo + col) * oesz) = val;
                 if constexpr (NOUT == 2) {
                     if (p.dact) {
@@ -353,7 +368,7 @@ static int launch_strip(const DenseArgs& a, hipStream_t s) {
     if (lds > 64 * 1024 && !opt_in_lds(reinterpret_cast<const void*>(k), (int)lds)) return PF_ERR_HIP;
     const unsigned grid = (unsigned)((a.M + 127) / 128);
     if (grid == 0) return PF_OK;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(k, dim3(grid, a.k_splits > 1 ? a.k_splits : 1), dim3(256), lds, s, a);
     return launch_status();
 }
 
@@ -384,6 +399,7 @@ int dense_nt(bool bf16, int epilogue, const DenseArgs& a0, hipStream_t s) {
     if (a0.N % 16 || a0.KC % 64 || a0.K % a0.KC || a0.KC <= 0 || a0.M < 0) return PF_ERR_BAD_ARG;
     if (a0.M == 0) return PF_OK;
     DenseArgs a = a0;
+    if (a.k_splits > 1 && (epilogue != kEpiPlain || !(a.out_f32 || !bf16) || a.k_splits > a.K / a.KC)) return PF_ERR_BAD_ARG;
     // the strip image (128 rows x KC) + the epilogue's staging must fit 160 KiB of LDS: halve the chunk while it does not
     // (fp32 with KC = 256: 128 KiB of image alone)
     auto lds_of = [&](int kc) {
@@ -391,7 +407,7 @@ int dense_nt(bool bf16, int epilogue, const DenseArgs& a0, hipStream_t s) {
         const int oesz = (epilogue == kEpiResid || !bf16 || a.out_f32) ? 4 : 2;
         return (size_t)3 * 128 * 8 + (size_t)128 * kc * (bf16 ? 2 : 4) + (size_t)2 * (epilogue == kEpiGelu ? 2 : 1) * 16 * (4 * tp * 16 * oesz + 16);
     };
-    while (lds_of(a.KC) > 160 * 1024 && a.KC % 128 == 0) a.KC /= 2;
+    while (lds_of(a.KC) > 160 * 1024 && a.KC % 128 == 0 && a.a_chunk_stride <= 0 && a.k_splits <= 1) a.KC /= 2;
     switch (epilogue) {
     case kEpiPlain: return bf16 ? launch_strip_tp<true, kEpiPlain>(a, s) : launch_strip_tp<false, kEpiPlain>(a, s);
     case kEpiGelu: return bf16 ? launch_strip_tp<true, kEpiGelu>(a, s) : launch_strip_tp<false, kEpiGelu>(a, s);
@@ -551,7 +567,10 @@ __global__ __launch_bounds__(64 * WR * WC) void dense_tn_bf16_kernel(const Dense
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int n1 = n1_0 + 16 * TI * wr + 16 * i + 4 * g + r;
-                if (n1 < n1_lim) atomicAdd(dWz + (int64_t)n1 * p.ldw + col, acc[i][j][r]);
+                if (n1 < n1_lim) {
+                    const int64_t o = (int64_t)n1 * p.ldw + col;
+                    atomicAdd(dWz + o, p.mask ? p.mask[o] * acc[i][j][r] : acc[i][j][r]);
+                }
             }
         }
     if (dbz && t2 == 0 && tid < BN1) {
@@ -651,7 +670,10 @@ __global__ __launch_bounds__(256) void dense_tn_f32_kernel(const DenseTnArgs p) 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int n1 = n1_0 + 32 * wr + 16 * i + 4 * g + r;
-                if (n1 < n1_lim) atomicAdd(dWz + (int64_t)n1 * p.ldw + col, acc[i][j][r]);
+                if (n1 < n1_lim) {
+                    const int64_t o = (int64_t)n1 * p.ldw + col;
+                    atomicAdd(dWz + o, p.mask ? p.mask[o] * acc[i][j][r] : acc[i][j][r]);
+                }
             }
         }
     if (dbz && t2 == 0 && tid < BN) {
@@ -695,7 +717,22 @@ int dense_tn(bool bf16, const DenseTnArgs& a0, hipStream_t s) {
         // narrow gradients against wide (overlapping-window) inputs = the convolutions' weight gradients: a tile as wide as
         // the im2col row, so that the 4-8x redundant window reads happen once (conv2: 64 x 512 outputs, 600 us with
         // 128 x 128 tiles of which half the rows were empty and the input was read four times)
+        if (const char* e = getenv("PF_TN_CFG")) {       // tuning runs only (scripts/time_tn_flow.py)
+            switch (atoi(e)) {
+            case 0: return launch_tn_bf16<1, 4, 2, 1>(a, s);
+            case 1: return launch_tn_bf16<2, 2, 2, 2>(a, s);
+            case 2: return launch_tn_bf16<2, 2, 4, 4>(a, s);
+            case 3: return launch_tn_bf16<2, 4, 6, 4>(a, s);
+            case 4: return launch_tn_bf16<4, 2, 4, 6>(a, s);
+            case 5: return launch_tn_bf16<1, 8, 4, 4>(a, s);
+            case 6: return launch_tn_bf16<2, 2, 2, 4>(a, s);
+            }
+        }
         if (a.N1 <= 32 && a.N2 <= 64) return launch_tn_bf16<1, 4, 2, 1>(a, s);
+        // few rows (the flow's weight gradients: 2048 rows x 10 layers per launch): a workgroup's time is its chain of
+        // chunk round trips (~2 us each, one chunk prefetched), so many small tiles with few chunks each beat the
+        // traffic-optimal large ones (256 x 256 x 10 at 2048 rows: 64 x 128 tiles 20.8 us, 192 x 256 tiles 30.9 us)
+        if (a.M <= 4096) return a.N2 <= 64 ? launch_tn_bf16<2, 2, 2, 2>(a, s) : launch_tn_bf16<2, 2, 2, 4>(a, s);
         if (a.N1 <= 128 && a.N2 > 256) return launch_tn_bf16<1, 8, 4, 4>(a, s);       // (128 x 512 per workgroup spills 160 registers)
         if (a.N1 <= 128) return launch_tn_bf16<2, 2, 4, 4>(a, s);
         if (ca <= cb && ca < c128) return launch_tn_bf16<2, 4, 6, 4>(a, s);

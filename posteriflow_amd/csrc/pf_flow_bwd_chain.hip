@@ -267,12 +267,22 @@ __global__ __launch_bounds__(NW * 64) void flow_bwd_chain_kernel(const ChainArgs
             issue_phase(hh_phase(lf, 2));                     // block 1's W2^T, consumed after the final layer's transpose
         }
         if (row0 + sr < B) {                                    // Gp -> HBM (weight gradient of the final layer)
+            const int gld = A.gp_ld ? (int)A.gp_ld : D * M;
             if (cmp) {
-                __bf16* dst = reinterpret_cast<__bf16*>(A.Gp) + ((size_t)l * B + row0 + sr) * (D * M);
-                for (int k = sk; k < D * M; k += TPR) dst[k] = (__bf16)s_gp[sr * PMS + k];
+                __bf16* dst = reinterpret_cast<__bf16*>(A.Gp) + ((size_t)l * B + row0 + sr) * gld;
+                if (gld % 8 == 0) {                             // 16-byte stores (2-byte ones: 517 store instructions per row)
+                    for (int k8 = 8 * sk; k8 < gld; k8 += 8 * TPR) {
+                        bf16x8 o;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = (__bf16)(k8 + e < D * M ? s_gp[sr * PMS + k8 + e] : 0.f);
+                        *reinterpret_cast<bf16x8*>(dst + k8) = o;
+                    }
+                } else {
+                    for (int k = sk; k < gld; k += TPR) dst[k] = (__bf16)(k < D * M ? s_gp[sr * PMS + k] : 0.f);
+                }
             } else {
-                float* dst = A.Gp + ((size_t)l * B + row0 + sr) * (D * M);
-                for (int k = sk; k < D * M; k += TPR) dst[k] = s_gp[sr * PMS + k];
+                float* dst = A.Gp + ((size_t)l * B + row0 + sr) * gld;
+                for (int k = sk; k < gld; k += TPR) dst[k] = k < D * M ? s_gp[sr * PMS + k] : 0.f;
             }
         }
         if constexpr (BF) {                                     // and its bf16 image, the B operand of the next GEMM
