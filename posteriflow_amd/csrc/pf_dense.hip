@@ -435,17 +435,34 @@ struct SeqCursor {                 // row m -> (sequence, position) advanced inc
 // WG tile = (16 TI WR) x (16 TJ WC) outputs, WR x WC waves of TI x TJ MFMA tiles.  Every operand byte is read once per
 // output tile of the OTHER dimension, so the tile decides the traffic: at 128 x 128 the FFN weight gradients (192 x 768)
 // moved 1.0 GB for 360 MB of operands; 192 x 256 / 256 x 192 with eight waves move 504 MB.
-template <int WR, int WC, int TI, int TJ>
-__global__ __launch_bounds__(64 * WR * WC) void dense_tn_bf16_kernel(const DenseTnArgs p) {
-    constexpr int BK = 64, NT = 64 * WR * WC;
+//
+// Staging: LDS-DMA into a ring of NS stages.  (First version: staged through registers, ONE chunk in flight -- a chunk's
+// MFMAs, a few hundred cycles, cannot cover a global round trip, and a workgroup took 2.0-2.8 us per 64-row chunk whatever
+// its tile; the mixer's 768 x 192 weight gradient 155 us, 126 us in this form, of which ~85 us are the 504 MB of operand
+// reads at 5.9 TB/s and the rest the atomics of the tail.)  The operands go global -> LDS directly (global_load_lds_dwordx4:
+// one wave instruction = 1 KiB = 4 rows of a [BK][128] sub-image) into a ring of NS stages, NS - 1 chunks in flight across
+// the (raw) barriers, with a counted vmcnt.  The DMA writes lane-linearly, so the XOR swizzle of tn_off sits on the SOURCE
+// address: the lane that fills physical slot s of row r fetches logical slot s ^ f(r) of that row (the same involution as
+// the reads).  Rows beyond M and columns beyond the matrix read a 16-byte page of zeros instead.
+__device__ __attribute__((aligned(16))) const uint32_t tn_zero16[4] = {0u, 0u, 0u, 0u};
+
+__device__ __forceinline__ uint32_t tn_lds_addr(const void* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int WR, int WC, int TI, int TJ, int BK, int NS>
+__global__ __launch_bounds__(64 * WR * WC) void dense_tn_bf16_dma_kernel(const DenseTnArgs p) {
+    constexpr int NW = WR * WC;
     constexpr int BN1 = 16 * TI * WR, BN2 = 16 * TJ * WC;
-    constexpr int SUB1 = (BN1 + 127) / 128, SUB2 = (BN2 + 127) / 128;        // [64][128] sub-images per operand
-    constexpr int SPR1 = BN1 / 8, SPR2 = BN2 / 8;                            // 16-byte slots per tile row
-    constexpr int IT1 = (BK * SPR1 + NT - 1) / NT, IT2 = (BK * SPR2 + NT - 1) / NT;
-    constexpr int SUBB = BK * 128 * 2;
+    constexpr int SUB1 = (BN1 + 127) / 128, SUB2 = (BN2 + 127) / 128, NSUB = SUB1 + SUB2;
+    constexpr int SUBB = BK * 256;                     // one [BK][128] bf16 sub-image
+    constexpr int STB = NSUB * SUBB;                   // one stage
+    constexpr int RG = BK / 4;                         // 4-row pieces per sub-image
+    constexpr int PPS = NSUB * RG;                     // 1-KiB pieces per stage
+    constexpr int PW = PPS / NW;                       // pieces per wave and stage
+    static_assert(PPS % NW == 0 && BK % 32 == 0 && NS >= 2 && PW * (NS - 2) < 64, "piece schedule");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sG = smem;
-    char* sA = smem + SUB1 * SUBB;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WC, wc = wave - wr * WC;
@@ -458,124 +475,170 @@ __global__ __launch_bounds__(64 * WR * WC) void dense_tn_bf16_kernel(const Dense
     const int64_t per = (total_chunks + p.splits - 1) / p.splits;
     const int64_t c_lo = (int64_t)blockIdx.y * per, c_hi = c_lo + per < total_chunks ? c_lo + per : total_chunks;
     if (c_lo >= c_hi) return;
+    const int nch = (int)(c_hi - c_lo);
 
     const int64_t bz = blockIdx.z;
-    const __bf16* Gb = reinterpret_cast<const __bf16*>(p.G) + bz * p.g_batch_stride + n1_0;
-    const __bf16* Ab = reinterpret_cast<const __bf16*>(p.A) + bz * p.a_batch_stride + n2_0;
+    const char* Gb = reinterpret_cast<const char*>(reinterpret_cast<const __bf16*>(p.G) + bz * p.g_batch_stride + n1_0);
+    const char* Ab = reinterpret_cast<const char*>(reinterpret_cast<const __bf16*>(p.A) + bz * p.a_batch_stride + n2_0);
     float* const dWz = p.dW + bz * p.w_batch_stride;
     float* const dbz = p.db ? p.db + bz * p.b_batch_stride : nullptr;
     const int n1_lim = p.n1_rows > 0 ? p.n1_rows : p.N1, n2_lim = p.n2_cols > 0 ? p.n2_cols : p.N2;
-    // staging map: slot i of the tile (row-major over [64][slots per row]) for i = tid, tid + NT, ...
-    int g_row[IT1], g_slot[IT1], a_row[IT2], a_slot[IT2];
-    SeqCursor gc[IT1], ac[IT2];
+
+    // this lane's part of piece k of a stage (piece index wave + NW k: sub-image, 4-row group): the byte offset of its 16
+    // bytes inside a row of the operand (or -1: outside the tile / the matrix) and the row's (sequence, position) cursor
+    int coff[PW];
+    SeqCursor base, cur[PW];
+    base.init(c_lo * BK, p.rows_per_seq);              // (wave-uniform: one scalar division)
+    int64_t mrow[PW];
 #pragma unroll
-    for (int i = 0; i < IT1; ++i) {
-        const int idx = tid + NT * i;
-        g_row[i] = idx / SPR1; g_slot[i] = idx - g_row[i] * SPR1;
-        gc[i].init(c_lo * BK + (g_row[i] < BK ? g_row[i] : 0), p.rows_per_seq);
+    for (int k = 0; k < PW; ++k) {
+        const int pi = wave + NW * k, sub = pi / RG, rg = pi - sub * RG;
+        const int logical = lam ^ ((g << 2) | (rg & 3));
+        const bool isg = sub < SUB1;
+        const int col = 128 * (isg ? sub : sub - SUB1) + 8 * logical;
+        const bool ok = isg ? (col < BN1 && n1_0 + col + 8 <= p.N1) : (col < BN2 && n2_0 + col + 8 <= p.N2);
+        coff[k] = ok ? 2 * col : -1;
+        mrow[k] = c_lo * BK + 4 * rg + g;
+        cur[k] = base;
+        cur[k].advance(4 * rg + g, p.rows_per_seq);
     }
+    const uint32_t lds0 = tn_lds_addr(smem);
+    auto issue = [&](int stage) {                      // the next chunk in order (the cursors advance)
 #pragma unroll
-    for (int i = 0; i < IT2; ++i) {
-        const int idx = tid + NT * i;
-        a_row[i] = idx / SPR2; a_slot[i] = idx - a_row[i] * SPR2;
-        ac[i].init(c_lo * BK + (a_row[i] < BK ? a_row[i] : 0), p.rows_per_seq);
-    }
+        for (int k = 0; k < PW; ++k) {
+            const int pi = wave + NW * k;
+            const bool isg = pi / RG < SUB1;
+            const char* src = reinterpret_cast<const char*>(tn_zero16);
+            if (coff[k] >= 0 && mrow[k] < p.M)
+                src = (isg ? Gb + 2 * (cur[k].seq * p.g_seq_stride + cur[k].pos * p.ldg)
+                           : Ab + 2 * (cur[k].seq * p.a_seq_stride + cur[k].pos * p.lda)) + coff[k];
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             reinterpret_cast<__attribute__((address_space(3))) void*>(lds0 + stage * STB + pi * 1024),
+                                             16, 0, 0);
+            mrow[k] += BK;
+            cur[k].advance(BK, p.rows_per_seq);
+        }
+    };
 
     f32x4 acc[TI][TJ];
 #pragma unroll
     for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float bsum = 0.f;                                  // db: thread = column tid (< BN1), all 64 rows of a chunk
-
-    u32x4 vg[IT1], va[IT2];
-    auto fetch = [&](int64_t chunk) {
+    // db = column sums of G: one more MFMA per G fragment against a vector of ones, in the waves of tile column 0
+    f32x4 accb[TI];
 #pragma unroll
-        for (int i = 0; i < IT1; ++i) {
-            vg[i] = u32x4{0u, 0u, 0u, 0u};
-            if (g_row[i] < BK && chunk * BK + g_row[i] < p.M && n1_0 + 8 * g_slot[i] + 8 <= p.N1)
-                vg[i] = *reinterpret_cast<const u32x4*>(Gb + gc[i].seq * p.g_seq_stride + gc[i].pos * p.ldg + 8 * g_slot[i]);
-            gc[i].advance(BK, p.rows_per_seq);
-        }
+    for (int i = 0; i < TI; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool want_db = p.db && t2 == 0 && wc == 0;
+    const bf16x8 ones = {(__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f};
+    // The fragment reads are inline asm: in front of an LDS read it can see, the compiler waits vmcnt(0) for every DMA in
+    // flight (it cannot tell which stage a DMA writes), which would drain the ring at every chunk.
+    // fragment (column block col0, k-step kk): rows 32 kk + 8 g .. + 7 of column col0 + lam = two 4 x 16 blocks
+    uint32_t aoff[BK / 32][TI][2], boff[BK / 32][TJ][2];
 #pragma unroll
-        for (int i = 0; i < IT2; ++i) {
-            va[i] = u32x4{0u, 0u, 0u, 0u};
-            if (a_row[i] < BK && chunk * BK + a_row[i] < p.M && n2_0 + 8 * a_slot[i] + 8 <= p.N2)
-                va[i] = *reinterpret_cast<const u32x4*>(Ab + ac[i].seq * p.a_seq_stride + ac[i].pos * p.lda + 8 * a_slot[i]);
-            ac[i].advance(BK, p.rows_per_seq);
-        }
-    };
-    auto put = [&]() {
-#pragma unroll
-        for (int i = 0; i < IT1; ++i)
-            if (g_row[i] < BK) *reinterpret_cast<u32x4*>(sG + (g_slot[i] >> 4) * SUBB + tn_off(g_row[i], g_slot[i] & 15)) = vg[i];
-#pragma unroll
-        for (int i = 0; i < IT2; ++i)
-            if (a_row[i] < BK) *reinterpret_cast<u32x4*>(sA + (a_slot[i] >> 4) * SUBB + tn_off(a_row[i], a_slot[i] & 15)) = va[i];
-    };
-    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-    auto tr_frag = [&](const char* tile, int col0, int kk) -> bf16x8 {
-        // rows 32 kk + 8 g .. + 7 of column col0 + lam: two 4 x 16 blocks
-        const char* sub = tile + (col0 >> 7) * SUBB;
+    for (int kk = 0; kk < BK / 32; ++kk) {
         const int r0 = 32 * kk + 8 * g;
-        const int slot = ((col0 & 127) >> 3) + (pq >> 1);
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sub + tn_off(r0 + q, slot) + 8 * (pq & 1)));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sub + tn_off(r0 + 4 + q, slot) + 8 * (pq & 1)));
-        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        return __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            const int col0 = 16 * TI * wr + 16 * i, slot = ((col0 & 127) >> 3) + (pq >> 1);
+            aoff[kk][i][0] = (col0 >> 7) * SUBB + tn_off(r0 + q, slot) + 8 * (pq & 1);
+            aoff[kk][i][1] = (col0 >> 7) * SUBB + tn_off(r0 + 4 + q, slot) + 8 * (pq & 1);
+        }
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int col0 = 16 * TJ * wc + 16 * j, slot = ((col0 & 127) >> 3) + (pq >> 1);
+            boff[kk][j][0] = SUB1 * SUBB + (col0 >> 7) * SUBB + tn_off(r0 + q, slot) + 8 * (pq & 1);
+            boff[kk][j][1] = SUB1 * SUBB + (col0 >> 7) * SUBB + tn_off(r0 + 4 + q, slot) + 8 * (pq & 1);
+        }
+    }
+    auto rd_tr = [&](uint32_t addr) -> u32x2 {
+        u32x2 v;
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
+        return v;
     };
 
-    fetch(c_lo);
+#pragma unroll
+    for (int s0 = 0; s0 < NS - 1; ++s0)
+        if (s0 < nch) issue(s0);
+    int stage = 0, fill = NS - 1;                      // stage read by this iteration / filled by it
 #pragma unroll 1
-    for (int64_t chunk = c_lo; chunk < c_hi; ++chunk) {
-        __syncthreads();                               // everyone is done reading the previous tiles
-        put();
-        __syncthreads();
-        if (chunk + 1 < c_hi) fetch(chunk + 1);        // in flight under the MFMAs below
-        if (p.db && t2 == 0 && tid < BN1) {
-            const char* sub = sG + (tid >> 7) * SUBB;
-            const int col = tid & 127;
-            float sacc = 0.f;
-#pragma unroll 8
-            for (int r = 0; r < BK; ++r)
-                sacc += (float)*reinterpret_cast<const __bf16*>(sub + tn_off(r, col >> 3) + 2 * (col & 7));
-            bsum += sacc;
-        }
+    for (int it = 0; it < nch; ++it) {
+        // this wave's pieces of chunk `it` have landed when at most the later chunks' pieces are outstanding
+        const int later = nch - 1 - it;
+        if (NS >= 4 && later >= 2) wait_vmcnt<PW * (NS >= 4 ? 2 : 0)>();
+        else if (NS >= 3 && later >= 1) wait_vmcnt<PW * (NS >= 3 ? 1 : 0)>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();                  // everyone's pieces; and everyone is done reading stage `fill`
+        if (it + NS - 1 < nch) issue(fill);
+        const uint32_t sbase = lds0 + stage * STB;
 #pragma unroll
         for (int kk = 0; kk < BK / 32; ++kk) {
+            u32x2 al[TI][2], bl[TJ][2];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) { al[i][0] = rd_tr(sbase + aoff[kk][i][0]); al[i][1] = rd_tr(sbase + aoff[kk][i][1]); }
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) { bl[j][0] = rd_tr(sbase + boff[kk][j][0]); bl[j][1] = rd_tr(sbase + boff[kk][j][1]); }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             bf16x8 af[TI], bfr[TJ];
 #pragma unroll
-            for (int i = 0; i < TI; ++i) af[i] = tr_frag(sG, 16 * TI * wr + 16 * i, kk);
+            for (int i = 0; i < TI; ++i) {
+                asm volatile("" : "+v"(al[i][0]), "+v"(al[i][1]));        // (uses stay behind the wait)
+                af[i] = __builtin_bit_cast(bf16x8, u32x4{al[i][0][0], al[i][0][1], al[i][1][0], al[i][1][1]});
+            }
 #pragma unroll
-            for (int j = 0; j < TJ; ++j) bfr[j] = tr_frag(sA, 16 * TJ * wc + 16 * j, kk);
+            for (int j = 0; j < TJ; ++j) {
+                asm volatile("" : "+v"(bl[j][0]), "+v"(bl[j][1]));
+                bfr[j] = __builtin_bit_cast(bf16x8, u32x4{bl[j][0][0], bl[j][0][1], bl[j][1][0], bl[j][1][1]});
+            }
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
                 for (int j = 0; j < TJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            if (want_db) {
+#pragma unroll
+                for (int i = 0; i < TI; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, accb[i], 0, 0, 0);
+            }
         }
+        stage = stage + 1 == NS ? 0 : stage + 1;
+        fill = fill + 1 == NS ? 0 : fill + 1;
     }
-    // lane (g, lam): dW[n1_0 + 16 TI wr + 16 i + 4 g + r][n2_0 + 16 TJ wc + 16 j + lam]
+    // lane (g, lam): dW[n1_0 + 16 TI wr + 16 i + 4 g + r][n2_0 + 16 TJ wc + 16 j + lam]; the mask values of a tile are
+    // requested together, ahead of its atomics (one load + wait per element otherwise)
+    auto flush = [&](auto masked_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
 #pragma unroll
-    for (int i = 0; i < TI; ++i)
+        for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < TJ; ++j) {
-            const int n2 = n2_0 + 16 * TJ * wc + 16 * j + lam;
-            if (n2 >= n2_lim) continue;
-            int col = n2;
-            if (p.conv_cin > 0) { const int tap = n2 / p.conv_cin, chn = n2 - tap * p.conv_cin; col = chn * p.conv_kw + tap; }
+            for (int j = 0; j < TJ; ++j) {
+                const int n2 = n2_0 + 16 * TJ * wc + 16 * j + lam;
+                int col = n2;
+                if (p.conv_cin > 0) { const int tap = n2 / p.conv_cin, chn = n2 - tap * p.conv_cin; col = chn * p.conv_kw + tap; }
+                float mk[4] = {1.f, 1.f, 1.f, 1.f};
+                if constexpr (MASKED) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int n1 = n1_0 + 16 * TI * wr + 16 * i + 4 * g + r;
+                        if (n2 < n2_lim && n1 < n1_lim) mk[r] = p.mask[(int64_t)n1 * p.ldw + col];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n1 = n1_0 + 16 * TI * wr + 16 * i + 4 * g + r;
+                    if (n2 < n2_lim && n1 < n1_lim) atomicAdd(dWz + (int64_t)n1 * p.ldw + col, mk[r] * acc[i][j][r]);
+                }
+            }
+    };
+    if (p.mask) flush(std::true_type{});
+    else flush(std::false_type{});
+    if (want_db && lam == 0) {                         // every column of accb holds the sums: lane (g, 0) adds rows 4 g + r
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int n1 = n1_0 + 16 * TI * wr + 16 * i + 4 * g + r;
-                if (n1 < n1_lim) {
-                    const int64_t o = (int64_t)n1 * p.ldw + col;
-                    atomicAdd(dWz + o, p.mask ? p.mask[o] * acc[i][j][r] : acc[i][j][r]);
-                }
+                if (n1 < n1_lim) atomicAdd(dbz + n1, accb[i][r]);
             }
-        }
-    if (dbz && t2 == 0 && tid < BN1) {
-        const int n1 = n1_0 + tid;
-        if (n1 < n1_lim) atomicAdd(dbz + n1, bsum);
     }
 }
 
@@ -682,22 +745,25 @@ __global__ __launch_bounds__(256) void dense_tn_f32_kernel(const DenseTnArgs p) 
     }
 }
 
-template <int WR, int WC, int TI, int TJ>
+template <int WR, int WC, int TI, int TJ, int BK = 32, int NS = 4>
 static int launch_tn_bf16(DenseTnArgs a, hipStream_t s) {
-    constexpr int BN1 = 16 * TI * WR, BN2 = 16 * TJ * WC, BK = 64;
-    constexpr int lds = (((BN1 + 127) / 128) + ((BN2 + 127) / 128)) * BK * 128 * 2;
-    auto k = dense_tn_bf16_kernel<WR, WC, TI, TJ>;
+    constexpr int BN1 = 16 * TI * WR, BN2 = 16 * TJ * WC;
+    constexpr int NSUB = (BN1 + 127) / 128 + (BN2 + 127) / 128;
+    constexpr int bk = BK;
+    constexpr int lds = NS * NSUB * BK * 256;
+    auto k = dense_tn_bf16_dma_kernel<WR, WC, TI, TJ, BK, NS>;
+    if (lds > 160 * 1024) return PF_ERR_UNSUPPORTED;
     if (lds > 64 * 1024 - 256 && !opt_in_lds(reinterpret_cast<const void*>(k), lds)) return PF_ERR_HIP;
     const int tiles = ((a.N1 + BN1 - 1) / BN1) * ((a.N2 + BN2 - 1) / BN2);
-    const int64_t chunks = (a.M + BK - 1) / BK;
+    const int64_t chunks = (a.M + bk - 1) / bk;
     const int nb = a.batch > 1 ? a.batch : 1;
     if (a.splits <= 0) {
         // ONE round of workgroups: every workgroup ends in float atomics of its whole tile (1.3 TB/s chip-wide against
         // 5 TB/s of operand reads), so the split count is the atomic volume: 170 splits of the FFN weight gradient were
         // 92 MB of atomics = 70 of its 160 us; and never a few workgroups more than a whole round
-        const int per_cu = WR * WC >= 8 ? 1 : 2;
+        const int per_cu = lds > 80 * 1024 ? 1 : 2;
         int64_t sp = (256 * per_cu) / ((int64_t)tiles * nb);
-        sp = std::min<int64_t>(sp, std::max<int64_t>(1, chunks / 4));
+        sp = std::min<int64_t>(sp, std::max<int64_t>(1, chunks * bk / 256));
         a.splits = (int)std::max<int64_t>(1, sp);
     }
     hipLaunchKernelGGL(k, dim3((unsigned)tiles, (unsigned)a.splits, (unsigned)nb), dim3(64 * WR * WC), lds, s, a);
@@ -724,7 +790,7 @@ int dense_tn(bool bf16, const DenseTnArgs& a0, hipStream_t s) {
             case 2: return launch_tn_bf16<2, 2, 4, 4>(a, s);
             case 3: return launch_tn_bf16<2, 4, 6, 4>(a, s);
             case 4: return launch_tn_bf16<4, 2, 4, 6>(a, s);
-            case 5: return launch_tn_bf16<1, 8, 4, 4>(a, s);
+            case 5: return launch_tn_bf16<1, 8, 4, 4, 32, 3>(a, s);
             case 6: return launch_tn_bf16<2, 2, 2, 4>(a, s);
             }
         }
@@ -733,8 +799,11 @@ int dense_tn(bool bf16, const DenseTnArgs& a0, hipStream_t s) {
         // chunk round trips (~2 us each, one chunk prefetched), so many small tiles with few chunks each beat the
         // traffic-optimal large ones (256 x 256 x 10 at 2048 rows: 64 x 128 tiles 20.8 us, 192 x 256 tiles 30.9 us)
         if (a.M <= 4096) return a.N2 <= 64 ? launch_tn_bf16<2, 2, 2, 2>(a, s) : launch_tn_bf16<2, 2, 2, 4>(a, s);
-        if (a.N1 <= 128 && a.N2 > 256) return launch_tn_bf16<1, 8, 4, 4>(a, s);       // (128 x 512 per workgroup spills 160 registers)
+        if (a.N1 <= 128 && a.N2 > 256) return launch_tn_bf16<1, 8, 4, 4, 32, 3>(a, s);  // (128 x 512 per workgroup spills 160 registers)
         if (a.N1 <= 128) return launch_tn_bf16<2, 2, 4, 4>(a, s);
+        // one large tile = every workgroup adds the WHOLE matrix at the end: 192 x 192 as one 192 x 256 tile 84 us (256 x 147 KB
+        // of atomics), as four 128 x 128 tiles 72 us
+        if (a.N1 <= 192 && a.N2 <= 256) return launch_tn_bf16<2, 2, 4, 4>(a, s);
         if (ca <= cb && ca < c128) return launch_tn_bf16<2, 4, 6, 4>(a, s);
         if (cb < c128) return launch_tn_bf16<4, 2, 4, 6>(a, s);
         return launch_tn_bf16<2, 2, 4, 4>(a, s);

@@ -30,6 +30,11 @@ def run(name, n1, n2, batch, splits, reps=30):
     print(f"{name:22s} cfg {os.environ.get('PF_TN_CFG', '-'):>2s} splits {splits:3d}: {us:7.1f} us   rel err {err:.1e}", flush=True)
 
 
+if len(sys.argv) > 3 and sys.argv[3] == "enc":      # the token mixer's weight gradients: 1024 events x 183 tokens
+    B = 1024 * 183
+    for n1, n2 in ((768, 192), (192, 768), (576, 192), (192, 192), (192, 576)):
+        run(f"{n1}x{n2} (mixer)", n1, n2, 1, 0, reps=10)
+    sys.exit(0)
 for sp in [int(x) for x in (sys.argv[2].split(",") if len(sys.argv) > 2 else "0,1,2,4,8,16".split(","))]:
     run("256x256 x10 (W1/W2)", 256, 256, 10, sp)
     run("256x288 x10 (Wc)", 256, 288, 10, sp)
