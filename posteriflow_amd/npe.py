@@ -22,6 +22,7 @@ from typing import Dict, List, Optional
 import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from . import _lib
 from .flows import NSFPosteriorFlow
@@ -315,10 +316,11 @@ class LeanStrainEncoder(nn.Module):
         return torch.cat(parts, dim=1), clean
 
     def _autocast(self, dev):
-        """bf16 mode: the tensor-op part (fusion transformer, pooling, MLPs) runs its GEMMs in bf16
-        too (fp32 accumulate), like the HIP stem; fp32 mode: nothing changes."""
-        on = self.precision == "bf16" and dev.type == "cuda"
-        return torch.autocast("cuda", dtype=torch.bfloat16, enabled=on)
+        """The [B, .]-sized tensor-op remainder (the pool's output projection, the energy / noise MLPs, the context head:
+        < 2 GFLOP per 1024 events) runs in fp32 in BOTH precisions: under bf16 autocast its forward + backward were ~70
+        launches of which 27 were dtype casts of weights and activations (130 us of a 15 ms training step) for GEMMs of
+        5-15 us each.  The precision switch acts on the HIP kernels (stem, token mixer, flow)."""
+        return torch.autocast("cuda", enabled=False)
 
     def _empty(self, strain):
         """no events: [0, context_dim] (the reference's tensor ops give the same), nothing is launched"""
@@ -439,7 +441,14 @@ class LeanNPE(nn.Module):
         return self
 
     def _full_context(self, context: torch.Tensor, rank: torch.Tensor) -> torch.Tensor:
-        return torch.cat([context, self.rank_embed(rank)], dim=1)
+        w = self.rank_embed.weight
+        if w.requires_grad and torch.is_grad_enabled():
+            # the same rows as rank_embed(rank), as a one-hot product: its backward is one small GEMM instead of the
+            # embedding's sort-and-segment-reduce (about 20 launches for 5 x 32 numbers)
+            emb = F.one_hot(rank, w.shape[0]).to(w.dtype) @ w
+        else:
+            emb = self.rank_embed(rank)
+        return torch.cat([context, emb], dim=1)
 
     def encode(self, strain, asd_bands=None):
         return self.encoder(strain, asd_bands) if self.psd_cond else self.encoder(strain)
