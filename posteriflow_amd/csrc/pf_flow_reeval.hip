@@ -121,7 +121,7 @@ __global__ __launch_bounds__(NW * 64) void flow_reeval_kernel(const ReevalArgs p
         }
         // let the matrix pipe drain before the epilogue reads the accumulators: behind a loop exit hipcc (ROCm 7.2) placed
         // v_accvgpr_read right after the last MFMA with too few wait states and three of four values came back stale
-        // (pf_flow_reeval.hip's final layer, found on the hardware)
+        // (pf_flow_reeval.hip's final layer, found on the hardware; LABLOG.md pitfall 15)
 #pragma unroll
         for (int i = 0; i < TPW; ++i) asm volatile("s_nop 7" : "+a"(acc[i]));
         asm volatile("s_nop 15");

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Static audit of libpfhip.so's gfx950 code objects for the "accumulator read too soon behind an MFMA" hazard
-(DESIGN.md pitfall 15: `v_accvgpr_read` of elements 0-2 directly behind a loop-exit MFMA came back stale).
+(LABLOG.md pitfall 15: `v_accvgpr_read` of elements 0-2 directly behind a loop-exit MFMA came back stale).
 
 For every v_mfma_* instruction the script walks ALL control-flow successors (basic blocks are rebuilt from the
 branch targets llvm-objdump prints) and counts wait states the way the compiler's hazard recognizer does -- one per
