@@ -423,16 +423,18 @@ def main():
     # N > 1: (sum nll, count) all-reduced over RCCL -- the path's only exchange.  The flow kernel reduces the pair
     # itself (wave shuffle + one pair of atomics per workgroup) and zeroes the accumulator of the NEXT window, so a
     # step is exactly one kernel launch (a pre-bound C call: the Python wrapper's per-call work would make the loop
-    # host-bound at ~250 us) and one asynchronous 8-byte all-reduce that overlaps the next steps' kernels (three
+    # host-bound at ~250 us) and one asynchronous 128-byte all-reduce that overlaps the next steps' kernels (three
     # rotating accumulators).  --allreduce-every M > 1 reduces a window of M steps at once.
     NBUF = 3
-    red = [torch.zeros(2, device=dev, dtype=torch.float32) for _ in range(NBUF)]
+    red = [torch.zeros(16, 2, device=dev, dtype=torch.float32) for _ in range(NBUF)]    # PF_REDUCE_SLOTS pairs each
     works = [None] * NBUF
     state = {"k": 0, "last": 0, "M": max(1, args.allreduce_every)}
 
     use_graph = args.graph and not collective
     graph = None
-    stream = torch.cuda.Stream(dev)
+    # N > 1: the flow's stream gets the HIGH priority, so that when a step's kernel and the previous step's RCCL kernel
+    # become ready together the flow's 256 workgroups are placed first and the collective fills in behind them
+    stream = torch.cuda.Stream(dev, priority=-1 if (collective and not os.environ.get("PF_BENCH_FLAT_PRIORITY")) else 0)
     with torch.cuda.stream(stream):
         plain = flow.bind_nll(x, ctx, nll, stream=stream)
         reduce_launch = flow.bind_nll(x, ctx, nll, sum_count=red, stream=stream) if collective else None
@@ -523,7 +525,7 @@ def main():
         log(f"timed {args.steps} steps: {elapsed * 1e3 / args.steps:.4f} ms/step (device {dev_ms / args.steps:.4f})")
         mean_nll = None
         if collective:
-            last = red[state["last"]].cpu()         # (sum nll, count) of the last window over all ranks, both all-reduced
+            last = red[state["last"]].double().sum(0).cpu()   # (sum nll, count) of the last window over all ranks and slots
             mean_nll = (last[0] / last[1]).item()
         windowed = None
         if collective and state["M"] == 1:               # beside the contract number: one all-reduce per 16 steps

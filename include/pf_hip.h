@@ -152,13 +152,15 @@ int pf_flow_forward_train_dropout(const PfFlowDesc* desc, const void* packed,
                                   void* workspace, int64_t workspace_bytes, void* stream);
 int pf_flow_dropout_mask(const PfFlowDesc* desc, float dropout_p, uint64_t dropout_seed, int64_t batch,
                          float* mask, void* stream);
-/* pf_flow_forward_reduce: pf_flow_forward for a loss -- nll (may be NULL) as there, and
- * nll_sum_count[0] += sum of nll over the batch, nll_sum_count[1] += batch (float atomics, one pair per
- * workgroup after a wave shuffle reduction): the 8-byte vector a data-parallel rank all-reduces
- * (train_lean_npe.py:108-127 computes sum / count on the host).  The accumulator must be zero before the
- * launch: either the caller zeroes it, or an EARLIER launch did through zero_pair (float[2] or NULL, set to
- * zero by this launch; must differ from nll_sum_count) -- with three rotating pairs a step of a
- * data-parallel loop is exactly one kernel launch and one asynchronous all-reduce. */
+/* pf_flow_forward_reduce: pf_flow_forward for a loss -- nll (may be NULL) as there, and the kernel adds (sum of nll over
+ * the batch, batch) to the accumulator nll_sum_count = float[PF_REDUCE_SLOTS][2]: workgroup b adds its rows' pair to slot
+ * b mod PF_REDUCE_SLOTS (float atomics after a wave shuffle reduction; spread over slots because 256 workgroups ending
+ * together on one address pair serialise), so (sum, count) = the column sums over the slots.  The 128-byte vector is what a
+ * data-parallel rank all-reduces (train_lean_npe.py:108-127 computes sum / count on the host).  The accumulator must be
+ * zero before the launch: either the caller zeroes it, or an EARLIER launch did through zero_pair (an accumulator of the
+ * same size or NULL, set to zero by this launch; must differ from nll_sum_count) -- with three rotating accumulators a step
+ * of a data-parallel loop is exactly one kernel launch and one asynchronous all-reduce. */
+#define PF_REDUCE_SLOTS 16
 int pf_flow_forward_reduce(const PfFlowDesc* desc, const void* packed,
                            const float* x, const float* ctx, const int32_t* ar_perm,
                            const float* log_sigma, int64_t batch, float* nll, float* nll_sum_count,

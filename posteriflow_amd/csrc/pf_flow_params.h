@@ -20,7 +20,7 @@ struct FwdParams {
     int64_t ctx_rows;        // inverse: context rows (divides batch); forward: == batch
     uint32_t* fail_flags;    // inverse: [B] or null, bit 0 = negative discriminant
     float* nll_sum;          // forward: float[2], (sum of nll, rows) accumulated with atomics, or null
-    float* zero_pair;        // forward: float[2] set to zero by the kernel (the accumulator of a LATER launch), or null
+    float* zero_pair;        // forward: float[2 PF_REDUCE_SLOTS] set to zero by the kernel (the accumulator of a LATER launch), or null
     float* u_save;           // forward: [L, B, D] input of every layer's conditioner (training), or null
     const void* cproj;       // hoisted plans: fp32 projections in fragment order (else null)
     FlowPlan plan;

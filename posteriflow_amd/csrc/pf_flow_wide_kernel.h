@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void flow_wide_kernel(const FwdParams p) {
     const float* gbias = reinterpret_cast<const float*>(p.packed + W::stream_frags(D, CKS, NL) * W::kFrag);
     for (int s = tid; s < W::kBiasFloats / 4; s += 256)
         reinterpret_cast<f32x4*>(s_bias)[s] = reinterpret_cast<const f32x4*>(gbias)[s];
-    if (p.zero_pair && blockIdx.x == 0 && tid == 0) { p.zero_pair[0] = 0.f; p.zero_pair[1] = 0.f; }
+    if (p.zero_pair && blockIdx.x == 0 && tid < 2 * PF_REDUCE_SLOTS) p.zero_pair[tid] = 0.f;
 
     // ---- fragment queue -----------------------------------------------------------------------------------------
     wu32x4 aq[P];
@@ -541,7 +541,7 @@ __global__ __launch_bounds__(256) void flow_wide_kernel(const FwdParams p) {
     if (p.nll_sum) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { my_nll += __shfl_xor(my_nll, o, 64); my_cnt += __shfl_xor(my_cnt, o, 64); }
-        if (lane == 0) { atomicAdd(p.nll_sum, my_nll); atomicAdd(p.nll_sum + 1, my_cnt); }
+        if (lane == 0) { float* acc = p.nll_sum + 2 * ((4 * blockIdx.x + wave) % PF_REDUCE_SLOTS); atomicAdd(acc, my_nll); atomicAdd(acc + 1, my_cnt); }
     }
 }
 

@@ -460,8 +460,9 @@ class NSFPosteriorFlow(nn.Module):
         """compute_psd_aware_nll into a preallocated fp32 ``out[B]`` with no allocation and no
         host-side checks beyond shapes: the call a serving / benchmark loop (or a HIP-graph
         capture) issues.  Inputs must already be contiguous fp32 on the flow's device.
-        ``sum_count`` (fp32 [2], zeroed by the caller): the kernel also adds (sum of nll, B) to it --
-        the 8-byte vector a data-parallel rank all-reduces."""
+        ``sum_count`` (fp32 [PF_REDUCE_SLOTS, 2] = [16, 2], zeroed by the caller): the kernel also adds (sum of nll, B) to
+        it, spread over the slots -- ``sum_count.sum(0)`` is the pair; the 128-byte vector is what a data-parallel rank
+        all-reduces."""
         B = x.shape[0]
         self._eval_only("nll_into")
         if x.shape[1] != self.features or out.shape[0] != B or not x.is_contiguous():
@@ -475,8 +476,8 @@ class NSFPosteriorFlow(nn.Module):
         desc = self._desc(wide=wide)
         ws, ws_bytes = self._ws(desc, B, dev)
         if sum_count is not None:
-            if sum_count.dtype != torch.float32 or sum_count.numel() != 2 or not sum_count.is_contiguous():
-                raise ValueError("nll_into: sum_count must be a contiguous fp32 tensor of 2 elements")
+            if sum_count.dtype != torch.float32 or sum_count.numel() != 2 * _lib.PF_REDUCE_SLOTS or not sum_count.is_contiguous():
+                raise ValueError(f"nll_into: sum_count must be a contiguous fp32 tensor of [{_lib.PF_REDUCE_SLOTS}, 2] elements")
             _lib.check(_lib.lib().pf_flow_forward_reduce(
                 desc, self.packed_weights(wide=wide).data_ptr(), x.data_ptr(), _dev_ptr(context),
                 _dev_ptr(perm), _dev_ptr(log_sigma), B, out.data_ptr(), sum_count.data_ptr(), None,
@@ -492,7 +493,7 @@ class NSFPosteriorFlow(nn.Module):
                  sum_count: Optional[List[torch.Tensor]] = None, stream: Optional[torch.cuda.Stream] = None):
         """A launcher with every argument of ``nll_into`` resolved once (descriptor, packed weights,
         workspace, pointers): ``launch(i)`` is one C call, a few microseconds of host time, for loops whose
-        step is a single ~100 us kernel.  ``sum_count``: rotating fp32 [2] accumulators; launch i adds
+        step is a single ~100 us kernel.  ``sum_count``: rotating fp32 [16, 2] accumulators (``nll_into``); launch i adds
         (sum nll, B) to ``sum_count[i % n]`` and zeroes ``sum_count[(i + 1) % n]`` for the next launch
         (``n >= 2``; the caller zeroes ``sum_count[0]`` before launch 0).  The tensors must stay alive and
         the weights frozen (``freeze_packed``) while the launcher is used."""

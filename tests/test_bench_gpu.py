@@ -71,3 +71,23 @@ def test_collective_step_reports_the_same_loss(every):
     elif hasattr(test_collective_step_reports_the_same_loss, "ref"):
         assert abs(loss - test_collective_step_reports_the_same_loss.ref) < 1e-3 * abs(loss)
     assert d["value"] > 5e6
+
+
+def test_gpus_flag_nccl_world2():
+    """The same two-rank run over RCCL (backend nccl, one GPU per rank): runs wherever two GPUs are visible, skips on the
+    one-GPU boxes of the pool.  Weak scaling: the global batch doubles, the mean NLL is the one-rank value of the same
+    seeds' union, and both ranks' per-step all-reduce completes."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(MASTER_PORT="29549", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "2",
+                          "--no-extras", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8192 and d["config"]["parallelism"] == "dp2"
+    assert d["scaling"] == "weak" and 50.0 < d["config"]["global_mean_nll"] < 500.0
+    assert d["value"] > 2e7                                   # two GPUs: more than one GPU's 4e7 / 2

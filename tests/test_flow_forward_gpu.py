@@ -289,11 +289,13 @@ def test_in_kernel_loss_reduction(B):
     x, ctx = flow_inputs(B, 11, 288, 5.0)
     x, ctx = x.cuda().contiguous(), ctx.cuda().contiguous()
     nll = torch.empty(B, device="cuda")
-    acc = torch.zeros(2, device="cuda")
-    flow.nll_into(x, ctx, nll, sum_count=acc)
-    flow.nll_into(x, ctx, nll, sum_count=acc)                 # accumulates
+    slots = torch.zeros(16, 2, device="cuda")                 # PF_REDUCE_SLOTS pairs: workgroup b adds to slot b mod 16
+    flow.nll_into(x, ctx, nll, sum_count=slots)
+    flow.nll_into(x, ctx, nll, sum_count=slots)               # accumulates
     want = flow.compute_psd_aware_nll(x, ctx, None)
     assert torch.equal(nll, want)
+    acc = slots.double().sum(0)
+    assert (slots[:, 1] > 0).sum().item() == min(16, (B + 15) // 16)
     assert acc[1].item() == 2 * B
     assert abs(acc[0].item() - 2 * want.double().sum().item()) <= 2e-5 * want.double().abs().sum().item() + 1e-3
     with pytest.raises(ValueError):

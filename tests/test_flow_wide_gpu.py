@@ -86,8 +86,9 @@ def test_wide_ragged_order_log_sigma_reduction_and_layer_inputs():
             assert err.median() < 1e-4 and err.max() < 5e-2, (B, err.max())
             # in-kernel (sum nll, rows) of the wide kernel
             nll = torch.empty(B, device="cuda")
-            acc = torch.zeros(2, device="cuda")
-            flow.nll_into(xg, cg, nll, sum_count=acc)
+            slots = torch.zeros(16, 2, device="cuda")
+            flow.nll_into(xg, cg, nll, sum_count=slots)
+            acc = slots.double().sum(0)
             want = flow.compute_psd_aware_nll(xg, cg, None)
             assert torch.equal(nll, want) and acc[1].item() == B
             assert abs(acc[0].item() - want.double().sum().item()) <= 2e-5 * want.double().abs().sum().item() + 1e-3
