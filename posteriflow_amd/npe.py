@@ -480,7 +480,17 @@ class LeanNPE(nn.Module):
         return out
 
 
-def batch_nll(model: LeanNPE, strain, params, nsig, asd_bands=None, row_cap: Optional[int] = None):
+_SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    i = device.index if device.index is not None else torch.cuda.current_device()
+    if i not in _SIDE_STREAMS:
+        _SIDE_STREAMS[i] = torch.cuda.Stream(device)
+    return _SIDE_STREAMS[i]
+
+
+def batch_nll(model: LeanNPE, strain, params, nsig, asd_bands=None, row_cap=None):
     """Mean per-signal NLL of a batch of events with up to ``max_signals`` signals each
     (experiments/train_lean_npe.py:108-127), as ONE flow call over all (event, rank) pairs with a
     0/1 weight for rank < nsig, instead of looping over ranks with a boolean-index host sync per rank
@@ -491,11 +501,39 @@ def batch_nll(model: LeanNPE, strain, params, nsig, asd_bands=None, row_cap: Opt
     the reference's mix of 1-5 signals, mean ~1.8).  The existing pairs are moved to the front by a stable sort (no
     host sync) and only the first ``row_cap`` rows go through the flow, forward and backward -- instead of
     ``max_signals`` = 5 rows per event whatever ``nsig`` is.  Pairs beyond the cap would be dropped from the mean:
-    ``batch_nll.last_overflow`` (a device scalar, read it when convenient) counts them."""
-    context = model.encode(strain, asd_bands)
+    ``batch_nll.last_overflow`` (a device scalar, read it when convenient) counts them.
+
+    ``row_cap="exact"``: what the reference's loop evaluates -- exactly the existing pairs and nothing else.  Their indices
+    come from ONE ``nonzero`` on the [B, max_signals] mask (one host sync on data the remix kernel produced, taken BEFORE
+    the encoder is queued so that nothing waits behind it; the reference syncs once per rank); the flow then runs on
+    ~1.8 rows per event instead of 5, forward and backward."""
     b, r_max = params.shape[0], params.shape[1]
     ranks = torch.arange(r_max, device=nsig.device)[None, :].expand(b, r_max)
     keep = (ranks < nsig[:, None]).reshape(-1)
+    if isinstance(row_cap, str):
+        if row_cap != "exact":
+            raise ValueError(f"row_cap must be None, an int or 'exact', got {row_cap!r}")
+        # The encoder is queued FIRST; the pair indices are resolved on a side stream that waits only for what was queued
+        # before this call (the remix kernel), so the host sync of nonzero() returns while the encoder is running and
+        # the GPU never idles behind it (in program order "nonzero, then encode" the GPU waited ~0.4 ms for the host).
+        main = torch.cuda.current_stream(strain.device)
+        entry = torch.cuda.Event()
+        entry.record(main)
+        context = model.encode(strain, asd_bands)
+        side = _side_stream(strain.device)
+        side.wait_event(entry)
+        with torch.cuda.stream(side):
+            idx = torch.nonzero(keep).squeeze(1)                 # (host sync on `side`: the number of pairs is a shape)
+        keep.record_stream(side)
+        main.wait_stream(side)
+        idx.record_stream(main)
+        if idx.numel() == 0:
+            return context.sum() * 0.0
+        event = torch.div(idx, r_max, rounding_mode="floor")
+        nll = model.nll(None, params.reshape(b * r_max, -1)[idx], ranks.reshape(-1)[idx],
+                        context=torch.index_select(context, 0, event))  # (backward: one index_add, not a sort)
+        return nll.mean()
+    context = model.encode(strain, asd_bands)
     # rows of absent ranks are all-zero labels (remix_data.py:229): give them a valid stand-in (rank 0 of
     # the same event) so that the unused rows stay finite; their weight is 0
     rows = torch.where(keep[:, None], params.reshape(b * r_max, -1), params[:, :1].expand(-1, r_max, -1).reshape(b * r_max, -1))

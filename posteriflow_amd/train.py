@@ -183,10 +183,11 @@ class OverlappedGradReducer:
 
 
 def train_step(model: LeanNPE, opt, sched, strain, params, nsig, asd_bands=None, group=None,
-               reducer: Optional[OverlappedGradReducer] = None, row_cap: Optional[int] = None) -> Dict[str, float]:
+               reducer: Optional[OverlappedGradReducer] = None, row_cap="exact") -> Dict[str, float]:
     """One optimisation step on this rank's shard of the batch.  With a ``reducer`` the gradient all-reduce overlaps
     the backward pass (one backward per step: the reducer's contract); without one (single rank, or the simple path) it
-    runs after it.  ``row_cap``: static bound on the (event, rank) pairs that go through the flow (``batch_nll``)."""
+    runs after it.  ``row_cap`` (``batch_nll``): "exact" (default: the existing (event, rank) pairs, one host sync per step), an int
+    (static bound, no sync) or None (all max_signals rows per event)."""
     loss = batch_nll(model, strain, params, nsig, asd_bands, row_cap=row_cap)
     if reducer is not None:
         reducer.zero()

@@ -1,6 +1,6 @@
 """Config-4 rehearsal on one GPU: on-GPU remix -> LeanNPE batch_nll -> backward -> AdamW, 1024 examples
 per step (the per-GPU share of batch 8192 on 8 GPUs).  Prints ms per phase and examples/s."""
-import json, sys, tempfile, time
+import json, os, sys, tempfile, time
 import numpy as np, torch
 sys.path.insert(0, ".")
 from posteriflow_amd import npe, train
@@ -29,6 +29,9 @@ model.flow.flatten_parameters()
 opt = train.make_optimizer(model); sched = train.make_scheduler(opt, 10000)
 g = torch.Generator(device="cuda").manual_seed(0)
 
+ROW_CAP = {"exact": "exact", "none": None}.get(os.environ.get("PF_ROW_CAP", "exact"), "exact")     # PF_ROW_CAP=none: 5 rows per event
+
+
 def phase_times(n):
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(n)]
     for it in range(n):
@@ -37,7 +40,7 @@ def phase_times(n):
         e[0].record()
         strain, labels, nsig, snr = ds.batch(idx, generator=g)
         e[1].record()
-        loss = npe.batch_nll(model, strain, labels, nsig)
+        loss = npe.batch_nll(model, strain, labels, nsig, row_cap=ROW_CAP)
         e[2].record()
         opt.zero_grad(set_to_none=True); loss.backward()
         e[3].record()

@@ -149,6 +149,12 @@ def test_lean_npe_nll_and_sampling_gpu(golden_encoder):
         assert abs(got_c - want_b) / abs(want_b) < 1e-3 and int(npe.batch_nll.last_overflow) == 0
         npe.batch_nll(model, strain.cuda(), params.cuda(), nsig.cuda(), row_cap=8)
         assert int(npe.batch_nll.last_overflow) == 3
+        # "exact": only the 11 existing pairs go through the flow (what the reference's per-rank loop evaluates); the
+        # gradient of the context agrees with the padded form's
+        got_e = npe.batch_nll(model, strain.cuda(), params.cuda(), nsig.cuda(), row_cap="exact").item()
+        assert abs(got_e - want_b) / abs(want_b) < 1e-3
+        with pytest.raises(ValueError):
+            npe.batch_nll(model, strain.cuda(), params.cuda(), nsig.cuda(), row_cap="all")
 
 
 @pytest.mark.gpu
