@@ -88,28 +88,49 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnArgs a) {
     f32x4 dg = {0.f, 0.f, 0.f, 0.f}, db = {0.f, 0.f, 0.f, 0.f};
     const uint32_t thr = enc_drop_threshold(a.drop_p);
     const float dscale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
-    for (int64_t m = (int64_t)blockIdx.x * 4 + wave; m < a.M; m += (int64_t)gridDim.x * 4) {
-        f32x4 x = {0.f, 0.f, 0.f, 0.f}, dy = {0.f, 0.f, 0.f, 0.f};
-        if (on) { x = *reinterpret_cast<const f32x4*>(a.x + m * kEncD + col); dy = load_act4<BF16>(a.dy, m * kEncD + col); }
-        const float mean = a.mean[m], rstd = a.rstd[m];
-        f32x4 xh = (x - mean) * rstd;
-        if (!on) xh = f32x4{0.f, 0.f, 0.f, 0.f};
-        const f32x4 gy = dy * gm;
-        const float s1 = wave_sum(gy[0] + gy[1] + gy[2] + gy[3]) * (1.f / kEncD);
-        const float s2 = wave_sum(gy[0] * xh[0] + gy[1] * xh[1] + gy[2] * xh[2] + gy[3] * xh[3]) * (1.f / kEncD);
-        dg += dy * xh;
-        db += dy;
-        if (on) {
-            f32x4 dx = (gy - s1 - xh * s2) * rstd;
-            if (a.dres) dx += *reinterpret_cast<const f32x4*>(a.dres + m * kEncD + col);
-            *reinterpret_cast<f32x4*>(a.dx + m * kEncD + col) = dx;
-            if (a.gout) {
-                if (a.drop_p > 0.f) {
-                    f32x4 fac;
-                    enc_drop4(a.seed, a.site, (uint32_t)(m * kEncD + col), thr, dscale, fac);
-                    dx = dx * fac;
+    // U rows per iteration, every load requested before the first row's arithmetic: with one row in flight a wave's
+    // ~46 rows were 46 global round trips in a row (228 us per 187 K rows = 2.9 TB/s)
+    constexpr int U = 4;
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    for (int64_t m0 = (int64_t)blockIdx.x * 4 + wave; m0 < a.M; m0 += stride * U) {
+        f32x4 x[U], dy[U], dr[U];
+        float mean[U], rstd[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t m = m0 + u * stride;
+            const bool live = on && m < a.M;
+            const int64_t mc = m < a.M ? m : a.M - 1;
+            x[u] = dy[u] = dr[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (live) {
+                x[u] = *reinterpret_cast<const f32x4*>(a.x + m * kEncD + col);
+                dy[u] = load_act4<BF16>(a.dy, m * kEncD + col);
+                if (a.dres) dr[u] = *reinterpret_cast<const f32x4*>(a.dres + m * kEncD + col);
+            }
+            mean[u] = a.mean[mc];
+            rstd[u] = a.rstd[mc];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t m = m0 + u * stride;
+            if (m >= a.M) break;                               // (wave-uniform)
+            f32x4 xh = (x[u] - mean[u]) * rstd[u];
+            if (!on) xh = f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 gy = dy[u] * gm;
+            const float s1 = wave_sum(gy[0] + gy[1] + gy[2] + gy[3]) * (1.f / kEncD);
+            const float s2 = wave_sum(gy[0] * xh[0] + gy[1] * xh[1] + gy[2] * xh[2] + gy[3] * xh[3]) * (1.f / kEncD);
+            dg += dy[u] * xh;
+            db += dy[u];
+            if (on) {
+                f32x4 dx = (gy - s1 - xh * s2) * rstd[u] + dr[u];
+                *reinterpret_cast<f32x4*>(a.dx + m * kEncD + col) = dx;
+                if (a.gout) {
+                    if (a.drop_p > 0.f) {
+                        f32x4 fac;
+                        enc_drop4(a.seed, a.site, (uint32_t)(m * kEncD + col), thr, dscale, fac);
+                        dx = dx * fac;
+                    }
+                    store_act4<BF16>(a.gout, m * kEncD + col, dx);
                 }
-                store_act4<BF16>(a.gout, m * kEncD + col, dx);
             }
         }
     }
@@ -593,18 +614,33 @@ __global__ __launch_bounds__(192) void tok_backward_kernel(const float* __restri
     const int64_t e0 = (int64_t)blockIdx.y * per, e1 = e0 + per < B ? e0 + per : B;
     float sum = 0.f;
     const int j = t - n_extra, d = j >= 0 ? j / 61 : 0, pp = j >= 0 ? j - 61 * d : 0;
-    for (int64_t e = e0; e < e1; ++e) {
-        const float v = dx0[(e * T + t) * kEncD + cc];
-        sum += v;
-        if (t < n_extra) {
-            if (dextra) dextra[(e * n_extra + t) * kEncD + cc] = v;
-        } else {
-            const int64_t n = e * n_det + d;
-            const int64_t src = (n * 61 + pp) * kEncD + cc, dst = n * gseq + goff + (int64_t)pp * kEncD + cc;
-            if constexpr (BF16) {
-                reinterpret_cast<__bf16*>(gpad)[dst] = (__bf16)(v * (float)reinterpret_cast<const __bf16*>(dact)[src]);
+    // 8 events per iteration, loads first (one event at a time = 64 dependent round trips per thread: 142 us)
+    constexpr int U = 8;
+    for (int64_t eb = e0; eb < e1; eb += U) {
+        float v[U], da[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t e = eb + u < e1 ? eb + u : e1 - 1;
+            v[u] = dx0[(e * T + t) * kEncD + cc];
+            da[u] = 1.f;
+            if (t >= n_extra) {
+                const int64_t src = ((e * n_det + d) * 61 + pp) * kEncD + cc;
+                if constexpr (BF16) da[u] = (float)reinterpret_cast<const __bf16*>(dact)[src];
+                else da[u] = reinterpret_cast<const float*>(dact)[src];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t e = eb + u;
+            if (e >= e1) break;
+            sum += v[u];
+            if (t < n_extra) {
+                if (dextra) dextra[(e * n_extra + t) * kEncD + cc] = v[u];
             } else {
-                reinterpret_cast<float*>(gpad)[dst] = v * reinterpret_cast<const float*>(dact)[src];
+                const int64_t n = e * n_det + d;
+                const int64_t dst = n * gseq + goff + (int64_t)pp * kEncD + cc;
+                if constexpr (BF16) reinterpret_cast<__bf16*>(gpad)[dst] = (__bf16)(v[u] * da[u]);
+                else reinterpret_cast<float*>(gpad)[dst] = v[u] * da[u];
             }
         }
     }
