@@ -324,7 +324,7 @@ def config4_train_step(dev, precision, events=1024, reps=5):
     ds = synthetic_dataset(dev, n_noise=512, n_events=512, seed=0)
     torch.manual_seed(0)
     model = npe.LeanNPE().to(dev).train().set_precision(precision)
-    model.flow.flatten_parameters()
+    model.flatten_parameters()                       # one flat leaf each for the flow and the encoder
     opt = train.make_optimizer(model)
     sched = train.make_scheduler(opt, 10000)
     g = torch.Generator(device=dev).manual_seed(0)

@@ -19,7 +19,8 @@ D_MODEL, N_POOL_Q, TOK_PER_DET = 192, 8, 61
 
 
 def train_parameters(enc) -> List[torch.nn.Parameter]:
-    """the encoder's parameters in the raw layout of pf_embed_train_* (include/pf_hip.h)"""
+    """the encoder's parameters in the raw layout of pf_embed_train_* (include/pf_hip.h); in flat mode
+    (``enc.flatten_parameters()``) these are views of the one leaf ``enc._theta``"""
     out = [p for i in (0, 2, 4, 6) for p in (enc.stem[i].weight, enc.stem[i].bias)]
     for layer in enc.fusion.layers:
         out += [layer.norm1.weight, layer.norm1.bias, layer.self_attn.in_proj_weight, layer.self_attn.in_proj_bias,
@@ -58,7 +59,10 @@ class _EncoderTrainFn(torch.autograd.Function):
         desc = _lib.PfEmbedTrainDesc(prec, n_det, n_extra, 1 if training else 0, float(dropout_p), int(seed))
         key = (dev, prec, tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
         if state.get("key") != key:        # flat fp32 copy of the parameters + their MFMA fragments, once per weight update
-            raw = torch.cat([p.detach().reshape(-1).float() for p in params])
+            if len(params) == 1:           # flat mode: the leaf IS the raw layout
+                raw = params[0].detach()
+            else:
+                raw = torch.cat([p.detach().reshape(-1).float() for p in params])
             assert raw.numel() == L.pf_embed_train_raw_param_count()
             packed = torch.empty(L.pf_embed_train_packed_bytes(prec), dtype=torch.uint8, device=dev)
             _lib.check(L.pf_embed_train_pack(prec, raw.data_ptr(), packed.data_ptr(), _stream(dev)), "pf_embed_train_pack")
@@ -125,5 +129,6 @@ def encode_tokens(enc, strain: torch.Tensor, extra_tokens: Optional[torch.Tensor
         seed = _draw_seed()
     state = enc.__dict__.setdefault("_train_state", {})
     state["last_seed"] = seed if train else None      # (tests rebuild the dropout factors from it)
+    params = [enc._theta] if getattr(enc, "_theta", None) is not None else train_parameters(enc)
     return _EncoderTrainFn.apply(state, enc.precision, strain.shape[1], train, p, seed or 0, strain, extra_tokens, token_bias, q,
-                                 *train_parameters(enc))
+                                 *params)

@@ -108,6 +108,7 @@ class LeanStrainEncoder(nn.Module):
                  n_pool_queries: int = 8, n_energy_windows: int = 16, context_dim: int = 256,
                  dropout: float = 0.05, psd_bands: int = 0):
         super().__init__()
+        self.__dict__["_theta"] = None          # flat mode (flatten_parameters): the one leaf, registered as a Parameter
         self.n_detectors, self.n_energy_windows = n_detectors, n_energy_windows
         self.context_dim, self.psd_bands = context_dim, psd_bands
         convs = []
@@ -133,6 +134,88 @@ class LeanStrainEncoder(nn.Module):
             extra = 32
         self.out_proj = nn.Sequential(nn.Linear(n_pool_queries * d_model + 64 + extra, 512), nn.GELU(),
                                       nn.Linear(512, context_dim))
+
+    # ---- flat parameter storage (opt-in, like NSFPosteriorFlow.flatten_parameters) -------------------------------------
+    def _flat_slots(self):
+        """(module, attribute, state_dict name) of the parameters of the HIP training path, in its raw layout
+        (``_enc_train.train_parameters`` / pf_embed_train_* of include/pf_hip.h)"""
+        out = [(self.stem[i], n, f"stem.{i}.{n}") for i in (0, 2, 4, 6) for n in ("weight", "bias")]
+        for l, layer in enumerate(self.fusion.layers):
+            pre = f"fusion.layers.{l}."
+            out += [(layer.norm1, "weight", pre + "norm1.weight"), (layer.norm1, "bias", pre + "norm1.bias"),
+                    (layer.self_attn, "in_proj_weight", pre + "self_attn.in_proj_weight"),
+                    (layer.self_attn, "in_proj_bias", pre + "self_attn.in_proj_bias"),
+                    (layer.self_attn.out_proj, "weight", pre + "self_attn.out_proj.weight"),
+                    (layer.self_attn.out_proj, "bias", pre + "self_attn.out_proj.bias"),
+                    (layer.norm2, "weight", pre + "norm2.weight"), (layer.norm2, "bias", pre + "norm2.bias"),
+                    (layer.linear1, "weight", pre + "linear1.weight"), (layer.linear1, "bias", pre + "linear1.bias"),
+                    (layer.linear2, "weight", pre + "linear2.weight"), (layer.linear2, "bias", pre + "linear2.bias")]
+        return out + [(self.pool_attn, "in_proj_weight", "pool_attn.in_proj_weight"),
+                      (self.pool_attn, "in_proj_bias", "pool_attn.in_proj_bias")]
+
+    def flatten_parameters(self) -> "LeanStrainEncoder":
+        """Re-home the 58 parameters of the stem, the Transformer layers and the pool's input projection into ONE flat leaf
+        ``_theta`` (the raw layout pf_embed_train_pack reads and pf_embed_train_backward writes); ``weight`` / ``bias`` of
+        the sub-modules become views of it.  A training step then hands autograd one tensor instead of 58, skips the
+        per-step concatenation, and its flat gradient IS ``_theta.grad``; the optimiser steps one tensor.
+        ``state_dict()`` / ``load_state_dict()`` keep the reference's key names.  Call it before building the optimiser."""
+        if self.__dict__.get("_flat_shapes") is not None:
+            return self
+        slots = self._flat_slots()
+        params = [getattr(m, n) for m, n, _ in slots]
+        with torch.no_grad():
+            flat = torch.cat([q.detach().reshape(-1).float() for q in params])
+        self._flat_shapes = [tuple(q.shape) for q in params]
+        theta = nn.Parameter(flat, requires_grad=any(q.requires_grad for q in params))
+        for m, n, _ in slots:
+            del m._parameters[n]
+        self.__dict__.pop("_theta", None)
+        self.register_parameter("_theta", theta)
+        self._refresh_flat_views()
+        return self
+
+    def _refresh_flat_views(self):
+        off = 0
+        for (m, n, _), shp in zip(self._flat_slots(), self._flat_shapes):
+            k = math.prod(shp)
+            m.__dict__[n] = self._theta[off:off + k].view(shp)
+            off += k
+        self.__dict__.pop("_train_state", None)
+        self.__dict__.pop("_mixer_state", None)
+        self.__dict__.pop("_stem_state", None)
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        if self._theta is not None:
+            self._refresh_flat_views()
+        return out
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+        if self._theta is not None:        # flat mode: the reference's names, not "_theta"
+            destination.pop(prefix + "_theta", None)
+            for m, n, name in self._flat_slots():
+                v = getattr(m, n)
+                destination[prefix + name] = v if keep_vars else v.detach()
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        if self._theta is not None:        # flat mode: gather the reference-named tensors into the leaf (the child modules
+            with torch.no_grad():          # no longer own them and must not see the keys)
+                for m, n, name in self._flat_slots():
+                    src = state_dict.pop(prefix + name, None)
+                    view = getattr(m, n)
+                    if src is None:
+                        if strict:
+                            missing_keys.append(prefix + name)
+                        continue
+                    if tuple(src.shape) != tuple(view.shape):
+                        error_msgs.append(f"size mismatch for {prefix + name}: {tuple(src.shape)} vs {tuple(view.shape)}")
+                        continue
+                    view.copy_(src)
+            state_dict[prefix + "_theta"] = self._theta.detach()
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
+        if self._theta is not None:
+            state_dict.pop(prefix + "_theta", None)
 
     # --- HIP stem ------------------------------------------------------------------------------
     _allow_tensor_op_stem = False
@@ -438,6 +521,14 @@ class LeanNPE(nn.Module):
             raise ValueError(f"precision must be 'fp32' or 'bf16', got {precision!r}")
         self.encoder.precision = precision
         self.flow.precision = precision
+        return self
+
+    def flatten_parameters(self) -> "LeanNPE":
+        """One flat leaf for the flow and one for the encoder's HIP-trained parameters (``NSFPosteriorFlow.flatten_parameters``,
+        ``LeanStrainEncoder.flatten_parameters``): a training step's autograd, gradient clipping and AdamW then handle ~25
+        tensors instead of ~260.  ``state_dict`` keys are unchanged.  Call it before building the optimiser."""
+        self.flow.flatten_parameters()
+        self.encoder.flatten_parameters()
         return self
 
     def _full_context(self, context: torch.Tensor, rank: torch.Tensor) -> torch.Tensor:

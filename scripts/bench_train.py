@@ -25,7 +25,7 @@ ds = RemixDataset(tmp, seed=0)
 torch.manual_seed(0)
 model = npe.LeanNPE().to(dev).train()
 model.encoder.precision = prec; model.flow.precision = prec
-model.flow.flatten_parameters()
+model.flatten_parameters()
 opt = train.make_optimizer(model); sched = train.make_scheduler(opt, 10000)
 g = torch.Generator(device="cuda").manual_seed(0)
 

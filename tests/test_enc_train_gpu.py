@@ -167,3 +167,36 @@ def test_coherent_encoder_trains_through_the_hip_path(golden_encoder):
         rel = ((g - ww).abs().max() / ww.abs().max()).item()
         print(f"[coherent] {name}: {rel:.2e}")
         assert rel < 2e-3, (name, rel)
+
+
+def test_flat_parameter_mode_of_the_encoder():
+    """LeanStrainEncoder.flatten_parameters(): one leaf for the 46 HIP-trained tensors.  Same output, the leaf's gradient
+    equals the per-tensor gradients laid end to end, state_dict keys and values unchanged, loading works both ways."""
+    from posteriflow_amd import npe, _enc_train
+    torch.manual_seed(3)
+    a = npe.LeanStrainEncoder().cuda().train()
+    b = npe.LeanStrainEncoder().cuda().train()
+    b.load_state_dict(a.state_dict())
+    b.flatten_parameters()
+    assert set(a.state_dict()) == set(b.state_dict()) and all(torch.equal(v, b.state_dict()[k]) for k, v in a.state_dict().items())
+    assert len(list(b.parameters())) < 20 < len(list(a.parameters()))
+    for m in (a, b):
+        m.precision = "bf16"
+    strain = torch.randn(6, 3, 16384, device="cuda")
+    outs = []
+    for m in (a, b):
+        torch.manual_seed(11)                                  # the dropout seed is drawn from torch's CPU generator
+        y = m(strain)
+        y.square().mean().backward()
+        outs.append(y.detach())
+    assert torch.equal(outs[0], outs[1])
+    want = torch.cat([p.grad.reshape(-1) for p in _enc_train.train_parameters(a)])
+    got = b._theta.grad
+    assert got.shape == want.shape
+    assert (got - want).abs().max() <= 1e-6 * want.abs().max() + 1e-12      # (float atomics: the order of additions differs)
+    for (_, pa), (_, pb) in zip(sorted((n, p) for n, p in a.named_parameters() if n.startswith(("energy", "out_proj", "pool_q", "detector"))),
+                                sorted((n, p) for n, p in b.named_parameters() if n.startswith(("energy", "out_proj", "pool_q", "detector")))):
+        assert (pa.grad - pb.grad).abs().max() <= 1e-5 * pa.grad.abs().max() + 1e-12
+    c = npe.LeanStrainEncoder().cuda()
+    c.load_state_dict(b.state_dict())                          # flat -> plain
+    assert torch.equal(c.stem[0].weight, a.stem[0].weight)

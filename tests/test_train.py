@@ -177,7 +177,7 @@ def test_config4_training_step_at_per_gpu_size():
     ds = synthetic_dataset(dev, n_noise=256, n_events=256, seed=0)
     torch.manual_seed(0)
     model = LeanNPE().to(dev).train().set_precision("bf16")
-    model.flow.flatten_parameters()                 # the flow's parameters as one leaf (what bench.py's config-4 step uses)
+    model.flatten_parameters()                      # flow and encoder as one leaf each (what bench.py's config-4 step uses)
     opt = make_optimizer(model)
     sched = make_scheduler(opt, total_steps=1000, warmup_steps=2)
     g = torch.Generator(device=dev).manual_seed(0)
