@@ -87,6 +87,15 @@ typedef struct PfFlowDesc {
     int32_t reserved;          /* flags: PF_FLAG_*                             */
 } PfFlowDesc;
 
+/* ---- supported shapes ------------------------------------------------------
+ * Scheduled kernels (static weight streams, the numbers of bench.py): hidden_features in {64, 128, 192, 256},
+ * num_bins <= 16, features <= hidden_features / 16, num_blocks = 2.  Any other plain-conditioner shape with
+ * hidden_features % 16 == 0, <= 512, features <= 32, num_bins <= 32 whose workgroup image fits 160 KB of LDS (the reference
+ * also builds 12 x 384 x 24 heads, experiments/frozen_context_heads.py:159-163) is served by one generic kernel behind the
+ * SAME entry points: pf_flow_raw_param_count / packed_bytes / pack_map_len / build_pack_map / pack, pf_flow_forward,
+ * pf_flow_forward_reduce, pf_flow_inverse.  The training, incremental-inverse, large-batch and backward entry points
+ * return PF_ERR_UNSUPPORTED for such a shape. */
+
 /* ---- raw parameter layout -------------------------------------------------
  * One flat fp32 buffer, layer after layer, each layer in nflows state_dict
  * order (SURVEY.md 8a "state_dict layout"):

@@ -64,8 +64,9 @@ int layout_of(const PfFlowDesc* d, pf::FlowPlan& L) {
     if (!d) return fail(PF_ERR_BAD_ARG, "desc is null");
     const int rc = pf::make_plan(*d, L);
     if (rc != PF_OK)
-        return fail(rc, "unsupported flow shape (need D<=H/16, H in {64,128,192,256}, K<=16, num_blocks=2; in-layer context: C<=288, "
-                    "or <=576 in bf16 at H=256 -- wider contexts need PF_FLAG_HOIST_CTX, C<=1024 / 2048 in bf16)");
+        return fail(rc, "unsupported flow shape (scheduled kernels: D<=H/16, H in {64,128,192,256}, K<=16, num_blocks=2; in-layer "
+                    "context: C<=288, or <=576 in bf16 at H=256 -- wider contexts need PF_FLAG_HOIST_CTX, C<=1024 / 2048 in bf16; "
+                    "generic kernel: plain conditioner, H%16==0, H<=512, D<=32, K<=32, LDS image <= 160 KB)");
     if (!(d->tail_bound > 0.f)) return fail(PF_ERR_BAD_ARG, "tail_bound must be positive");
     if (d->min_bin_width * d->num_bins > 1.f || d->min_bin_height * d->num_bins > 1.f)
         return fail(PF_ERR_BAD_ARG, "minimal bin size too large for the number of bins");
@@ -190,6 +191,7 @@ int pf_flow_dropout_mask(const PfFlowDesc* desc, float dropout_p, uint64_t dropo
     pf::FlowPlan L;
     int rc = layout_of(desc, L);
     if (rc != PF_OK) return rc;
+    if (L.generic) return fail(PF_ERR_UNSUPPORTED, "the generic-shape kernel is an evaluation kernel: no dropout");
     if (batch < 0 || !(dropout_p >= 0.f && dropout_p < 1.f)) return fail(PF_ERR_BAD_ARG, "need batch >= 0 and dropout_p in [0, 1)");
     if (batch == 0) return PF_OK;
     if (!mask) return fail(PF_ERR_BAD_ARG, "mask is null");
@@ -576,7 +578,7 @@ namespace {
 int ctx_t_plan(const PfFlowDesc* desc, pf::FlowPlan& L) {
     const int rc = layout_of(desc, L);
     if (rc != PF_OK) return rc;
-    if (L.C <= 0 || L.C % 16 || L.NB != 2 || 3 * L.L > pf::kMaxPackEntries || (desc->reserved & PF_FLAG_MASKED_CONTEXT))
+    if (L.generic || L.C <= 0 || L.C % 16 || L.NB != 2 || 3 * L.L > pf::kMaxPackEntries || (desc->reserved & PF_FLAG_MASKED_CONTEXT))
         return fail(PF_ERR_UNSUPPORTED, "context gradient GEMM: plain conditioner, C % 16 == 0, at most 16 layers");
     return PF_OK;
 }
@@ -609,7 +611,7 @@ int64_t pf_flow_issued_flop_per_row(const PfFlowDesc* desc) {
     if (compute_layout_of(desc, L) != PF_OK) return -1;
     // every 1-KiB fragment of the stream is multiplied with each row once: bf16 16 units x 32 k (wide: 32 x 16) = 512 MAC,
     // fp32 16 x 16 = 256 MAC; the zero padding behind each wave's stream (kWindowPad) is never multiplied
-    const int64_t frags = L.wide ? L.fragsTotal : (int64_t)L.L * L.NF * L.NW;
+    const int64_t frags = (L.wide || L.generic) ? L.fragsTotal : (int64_t)L.L * L.NF * L.NW;
     return frags * (L.bf16 ? 1024 : 512);
 }
 

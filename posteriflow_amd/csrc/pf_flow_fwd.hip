@@ -31,6 +31,7 @@ size_t fwd_lds_bytes_host(const FlowPlan& L, int R) {
 
 static int rows_per_workgroup_dir(const FlowPlan& L, int64_t batch, bool inverse) {
     if (L.wide) return wide::kRowsPerWG;
+    if (L.generic) return 16;
     // A workgroup streams the whole weight set whatever its row count, so more rows per workgroup (R groups
     // of 16) amortise the stream -- but a launch costs ceil(workgroups / 256 CUs) rounds, and a round of
     // R = 1 / 2 / 3 groups takes 108 / 142 / 195 us (forward, measured): pick the R with the cheapest launch.
@@ -62,12 +63,16 @@ int rows_per_workgroup(const FlowPlan& L, int64_t batch) { return rows_per_workg
 // the kernel launch_flow_forward picks for (plan, batch), as rocprofv3 prints it
 void forward_kernel_name(const FlowPlan& L, int64_t batch, char* out, size_t n) {
     if (L.wide) { snprintf(out, n, "pf::flow_wide_kernel<%d, %d>", L.D, L.CKM); return; }
+    if (L.generic) { snprintf(out, n, "pf::flow_generic_kernel<%s, false>", L.bf16 ? "true" : "false"); return; }
     const int R = L.dense == 1 ? 1 : rows_per_workgroup(L, batch) / 16;
     snprintf(out, n, "pf::flow_kernel<%s, %d, %d, %d, %d, false>", L.bf16 ? "true" : "false", L.NT, R, L.CKM, L.dense);
 }
 
+int launch_flow_generic(const FwdParams& p, bool inverse, hipStream_t s);       // pf_flow_generic.hip
+
 int launch_flow_forward(const FwdParams& p_in, hipStream_t s) {
     if (p_in.batch == 0) return PF_OK;
+    if (p_in.plan.generic) return p_in.drop_thresh ? (int)PF_ERR_UNSUPPORTED : launch_flow_generic(p_in, false, s);
     if (p_in.plan.wide) {
         if (p_in.drop_thresh) return PF_ERR_UNSUPPORTED;   // the large-batch kernel is an evaluation kernel
         if (p_in.plan.D == 15) return launch_flow_wide_d15(p_in, s);
@@ -122,6 +127,7 @@ int launch_dropout_mask(const FlowPlan& L, uint32_t thresh, uint32_t seed, float
 
 int launch_flow_inverse(const FwdParams& p, hipStream_t s) {
     if (p.batch == 0) return PF_OK;
+    if (p.plan.generic) return launch_flow_generic(p, true, s);
     if (p.plan.wide) return PF_ERR_UNSUPPORTED;             // the large-batch layout is forward-only
     const int R = rows_per_workgroup_dir(p.plan, p.batch, true) / 16;
 #define PF_CASE(P, N) case N: return launch_flow_inverse_p##P##_nt##N(p, R, s);

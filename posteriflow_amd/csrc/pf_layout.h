@@ -100,6 +100,9 @@ struct FlowPlan {
                                 // pair up); 2: masked, KHS = HK + kPadH + 1 (bf16, NT = 16)
     int wide;                   // 1: the large-batch kernel's single common stream (pf_wide_layout.h); CKS in CKM
     int bwd;                    // 1: PF_FLAG_BWD -- bf16 A-fragments for the backward: transposed matrices (chain), forward matrices + biases (re-evaluation)
+    int generic;                // 1: a shape none of the scheduled kernels is built for (e.g. H = 384, K = 24): dense masked
+                                // matrices as plain [tile][k-step] fragment arrays in nflows unit order, pf_flow_generic.hip
+    int gKx, gKc, gKh, gTf;     // generic: k-steps of the x / context / hidden operands, tiles of the final layer
     int KHS, KOS, NF;
     int kH[kMaxTiles];          // active k-steps of tile t in a masked H x H GEMM
     int kO[kMaxTiles];          // active k-steps of feature f in the final layer
@@ -137,6 +140,18 @@ struct FlowPlan {
     PF_HD int fwd_layer_bias() const { return H + (C > 0 ? 3 * H : 0) + 4 * H + 16 * bwd_ntf(); }
     PF_HD int64_t fwd_region() const { return (int64_t)L * bwd_layer_frags(); }          // first forward fragment
 
+    // generic layout: per layer [Win: NT x gKx][Wc, Wg0, Wg1: NT x gKc each, if C > 0][W1_0, W2_0, W1_1, W2_1: NT x gKh]
+    // [Wf: gTf x gKh] fragments; after the fragments of ALL layers the fp32 biases, per layer
+    // [b_in H][bc, bg0, bg1: H each, if C > 0][b1_0, b2_0, b1_1, b2_1: H each][bf: 16 gTf]
+    PF_HD int gen_layer_frags() const { return NT * gKx + (C > 0 ? 3 * NT * gKc : 0) + 4 * NT * gKh + gTf * gKh; }
+    PF_HD int gen_layer_bias() const { return H + (C > 0 ? 3 * H : 0) + 4 * H + 16 * gTf; }
+    PF_HD int gen_xh() const { return (D + 15) / 16 * 16; }                  // bf16: x enters as hi | lo halves of this width
+    PF_HD int64_t gen_lds_bytes() const {
+        const int esz = bf16 ? 2 : 4;
+        return (int64_t)16 * ((int64_t)gKx * kstep * esz + 16 + (int64_t)gKc * kstep * esz + 16 + 2 * ((int64_t)gKh * kstep * esz + 16)
+                              + (int64_t)H * 4 + (int64_t)16 * gTf * 4 + 4 * 32 * 4) + 256;
+    }
+
     PF_HD int64_t bias_index(int layer, int tile) const {
         return ((int64_t)layer * NT + tile) * kBiasFloatsPerTile;
     }
@@ -168,15 +183,47 @@ inline void sorted_units(int D, int H, int* perm) {
             if (hid_degree(D, u) == deg) perm[n++] = u;
 }
 
+// Shapes outside the scheduled set (the reference also builds 12 x 384 x 24 heads, experiments/frozen_context_heads.py:159-163):
+// one generic kernel, plain conditioner, forward and D-pass inverse in both precisions.  H a multiple of 16 up to 512, D <= 32,
+// K <= 32, and the workgroup's LDS image within 160 KB.
+inline int make_generic_plan(const PfFlowDesc& d, FlowPlan& o) {
+    if (d.reserved & (PF_FLAG_MASKED_CONTEXT | PF_FLAG_WIDE | PF_FLAG_BWD)) return PF_ERR_UNSUPPORTED;
+    if (d.hidden_features < 16 || d.hidden_features > 512 || d.hidden_features % 16) return PF_ERR_UNSUPPORTED;
+    if (d.features < 1 || d.features > 32 || d.num_bins < 2 || d.num_bins > 32) return PF_ERR_UNSUPPORTED;
+    o = FlowPlan{};
+    o.generic = 1;
+    o.D = d.features; o.C = d.context_features; o.H = d.hidden_features;
+    o.K = d.num_bins; o.L = d.num_layers; o.M = 3 * d.num_bins - 1; o.NB = d.num_blocks;
+    o.bf16 = d.precision == PF_PREC_BF16;
+    o.NT = o.H / 16; o.NW = 8;
+    o.kstep = o.bf16 ? 32 : 16;
+    const int xw = o.bf16 ? 2 * o.gen_xh() : o.D;                       // bf16: hi | lo halves
+    o.gKx = (xw + o.kstep - 1) / o.kstep;
+    o.gKc = (o.C + o.kstep - 1) / o.kstep;
+    o.gKh = (o.H + o.kstep - 1) / o.kstep;
+    o.gTf = (o.D * o.M + 15) / 16;
+    o.CK = o.gKc; o.CKM = 0; o.HK = o.gKh; o.hoist = 0;
+    if (o.gen_lds_bytes() > 160 * 1024) return PF_ERR_UNSUPPORTED;
+    o.fragsPerWave = 0;
+    o.fragsTotal = (int64_t)o.L * o.gen_layer_frags();
+    o.weightBytes = o.fragsTotal * kFragBytes;
+    o.biasFloats = (int64_t)o.L * o.gen_layer_bias();
+    o.ctxFrags = 0; o.ctxBiasFloats = 0;
+    const int64_t ctxp = o.C > 0 ? ((int64_t)o.H * o.C + o.H) : 0;
+    o.rawPerLayer = (int64_t)o.H * o.D + o.H + ctxp + (int64_t)o.NB * (ctxp + 2 * ((int64_t)o.H * o.H + o.H))
+                  + (int64_t)o.D * o.M * o.H + (int64_t)o.D * o.M;
+    return PF_OK;
+}
+
 // returns 0 on success, PF_ERR_* otherwise
 inline int make_plan(const PfFlowDesc& d, FlowPlan& o) {
-    if (d.hidden_features != 64 && d.hidden_features != 128 && d.hidden_features != 192 &&
-        d.hidden_features != 256)
-        return PF_ERR_UNSUPPORTED;
-    if (d.features < 1 || d.features > d.hidden_features / 16) return PF_ERR_UNSUPPORTED;
-    if (d.num_bins < 2 || d.num_bins > 16) return PF_ERR_UNSUPPORTED;
     if (d.num_layers < 1 || d.context_features < 0 || d.num_blocks != 2) return PF_ERR_UNSUPPORTED;
     if (d.precision != PF_PREC_F32 && d.precision != PF_PREC_BF16) return PF_ERR_BAD_ARG;
+    o.generic = 0;
+    const bool scheduled_shape = (d.hidden_features == 64 || d.hidden_features == 128 || d.hidden_features == 192 ||
+                                  d.hidden_features == 256) &&
+                                 d.features >= 1 && d.features <= d.hidden_features / 16 && d.num_bins >= 2 && d.num_bins <= 16;
+    if (!scheduled_shape) return make_generic_plan(d, o);
     o.D = d.features; o.C = d.context_features; o.H = d.hidden_features;
     o.K = d.num_bins; o.L = d.num_layers; o.M = 3 * d.num_bins - 1; o.NB = d.num_blocks;
     o.bf16 = d.precision == PF_PREC_BF16;

@@ -17,6 +17,8 @@
 
 namespace pf {
 
+int64_t pack_map_len(const FlowPlan& L);
+
 struct RawOffsets {
     int64_t in_w, in_b, c_w, c_b;
     int64_t g_w[2], g_b[2], w0_w[2], w0_b[2], w1_w[2], w1_b[2];
@@ -282,7 +284,66 @@ static int build_bwd_pack_map(const FlowPlan& L, int32_t* map) {
     return idx == L.fragsTotal * 512 + L.biasFloats ? PF_OK : PF_ERR_BAD_ARG;
 }
 
+// generic plan (pf_layout.h): every matrix as [tile][k-step][lane][elements] fragments in nflows unit order, masks from the
+// degree rule, then the biases
+static int build_generic_pack_map(const FlowPlan& L, int32_t* map) {
+    const RawOffsets ro = raw_offsets(L);
+    const int per = L.bf16 ? 8 : 4, ks_w = L.kstep;
+    const int xh = L.gen_xh();
+    int64_t idx = 0;
+    // kind: 0 x input (initial layer), 1 context (unmasked), 2 hidden -> hidden, 3 hidden -> spline parameters
+    auto matrix = [&](int kind, int64_t w_off, int n_rows, int n_tiles, int nks, int64_t base) {
+        for (int t = 0; t < n_tiles; ++t)
+            for (int ks = 0; ks < nks; ++ks)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < per; ++e, ++idx) {
+                        const int row = 16 * t + (lane & 15), k = ks_w * ks + per * (lane >> 4) + e;
+                        int64_t src = -1;
+                        if (row < n_rows) {
+                            if (kind == 0) {
+                                const int d = L.bf16 ? (k < 2 * xh ? k % xh : L.D) : k;          // bf16: hi | lo halves of x
+                                if (d < L.D && hid_degree(L.D, row) >= d + 1) src = w_off + (int64_t)row * L.D + d;
+                            } else if (kind == 1) {
+                                if (k < L.C) src = w_off + (int64_t)row * L.C + k;
+                            } else if (kind == 2) {
+                                if (k < L.H && hid_degree(L.D, row) >= hid_degree(L.D, k)) src = w_off + (int64_t)row * L.H + k;
+                            } else {
+                                const int f = row / L.M;                                          // output unit row = f M + j
+                                if (k < L.H && f + 1 > hid_degree(L.D, k)) src = w_off + (int64_t)row * L.H + k;
+                            }
+                        }
+                        map[idx] = src < 0 ? -1 : (int32_t)(base + src);
+                    }
+    };
+    for (int l = 0; l < L.L; ++l) {
+        const int64_t base = (int64_t)l * ro.total;
+        matrix(0, ro.in_w, L.H, L.NT, L.gKx, base);
+        if (L.C > 0) {
+            matrix(1, ro.c_w, L.H, L.NT, L.gKc, base);
+            matrix(1, ro.g_w[0], L.H, L.NT, L.gKc, base);
+            matrix(1, ro.g_w[1], L.H, L.NT, L.gKc, base);
+        }
+        for (int b = 0; b < 2; ++b) {
+            matrix(2, ro.w0_w[b], L.H, L.NT, L.gKh, base);
+            matrix(2, ro.w1_w[b], L.H, L.NT, L.gKh, base);
+        }
+        matrix(3, ro.out_w, L.D * L.M, L.gTf, L.gKh, base);
+    }
+    for (int l = 0; l < L.L; ++l) {
+        const int64_t base = (int64_t)l * ro.total;
+        auto vec = [&](int64_t off, int n, int padded) {
+            for (int i = 0; i < padded; ++i, ++idx) map[idx] = i < n ? (int32_t)(base + off + i) : -1;
+        };
+        vec(ro.in_b, L.H, L.H);
+        if (L.C > 0) { vec(ro.c_b, L.H, L.H); vec(ro.g_b[0], L.H, L.H); vec(ro.g_b[1], L.H, L.H); }
+        for (int b = 0; b < 2; ++b) { vec(ro.w0_b[b], L.H, L.H); vec(ro.w1_b[b], L.H, L.H); }
+        vec(ro.out_b, L.D * L.M, 16 * L.gTf);
+    }
+    return idx == pack_map_len(L) ? PF_OK : PF_ERR_BAD_ARG;
+}
+
 int build_pack_map(const FlowPlan& L, int32_t* map) {
+    if (L.generic) return build_generic_pack_map(L, map);
     if (L.bwd) return build_bwd_pack_map(L, map);
     if (L.wide) return build_wide_pack_map(L, map);
     const RawOffsets ro = raw_offsets(L);

@@ -700,6 +700,11 @@ class NSFPosteriorFlow(nn.Module):
         need = torch.is_grad_enabled() and (
             any(t is not None and t.requires_grad for t in tensors)
             or any(p.requires_grad for p in self._autograd_parameters()))
+        if need and self._generic_shape():
+            raise NotImplementedError(
+                f"NSFPosteriorFlow(H={self.hidden_features}, D={self.features}, K={self.num_bins}): the generic-shape kernel "
+                "evaluates densities and samples; the backward kernels are built for H in {64, 128, 192, 256}, D <= H / 16, "
+                "K <= 16 -- call under torch.no_grad() or freeze the parameters")
         return need
 
     # ---- conditioner dropout (train mode) ---------------------------------------------
@@ -826,8 +831,14 @@ class NSFPosteriorFlow(nn.Module):
     # ---- incremental inverse: one masked conditioner evaluation per layer instead of D dense ones ----
     incremental_inverse: Optional[bool] = None      # None: on for the plain conditioner (both precisions); False: D-pass kernel
 
+    def _generic_shape(self) -> bool:
+        """a shape outside the scheduled kernels' set (e.g. the 12 x 384 x 24 head of experiments/frozen_context_heads.py:
+        159-163): evaluated by the generic kernel (csrc/pf_flow_generic.hip) -- forward and the D-pass inverse, no gradients"""
+        return not (self.hidden_features in (64, 128, 192, 256) and 1 <= self.features <= self.hidden_features // 16
+                    and 2 <= self.num_bins <= 16)
+
     def _use_incremental(self) -> bool:
-        if self.incremental_inverse is False or self.use_masked_context:
+        if self.incremental_inverse is False or self.use_masked_context or self._generic_shape():
             return False
         # features == 1: every hidden unit has degree 0 (one pass, nothing incremental about it): D-pass kernel
         return (self.hidden_features % 32 == 0 and 2 <= self.features <= min(16, self.hidden_features // 16))

@@ -121,3 +121,74 @@ def test_masked_context_variant_shapes(D, block, H, K, L):
         z, ld = flow(x.cuda(), ctx.cuda())
     assert (z.cpu().double() - z64).abs().max() < max(6 * (z32.double() - z64).abs().max().item(), 3e-5)
     assert (ld.cpu().double() - ld64).abs().max() < max(6 * (ld32.double() - ld64).abs().max().item(), 1e-4)
+
+
+# ---- shapes none of the scheduled kernels is built for: the generic kernel (csrc/pf_flow_generic.hip) -----------------------
+GENERIC = [  # D, C, H, K, L, tail, B, permute, seed
+    (11, 288, 384, 24, 12, 3.0, 100, False, 4001),     # FlowHead(12, 384, 24), experiments/frozen_context_heads.py:159-163
+    (17, 33, 256, 16, 2, 5.0, 37, True, 4002),         # D > H / 16
+    (6, 0, 48, 3, 3, 1.0, 16, False, 4003),            # H not a scheduled width, context-free
+    (8, 96, 256, 20, 3, 3.0, 257, True, 4004),         # K > 16
+    (1, 7, 64, 5, 2, 3.0, 15, False, 4005),            # would be scheduled ... D = 1 is; kept as a control of the same test
+    (32, 64, 512, 6, 2, 5.0, 33, False, 4006),         # the widest: H = 512, D = 32
+]
+
+
+@pytest.mark.parametrize("D,C,H,K,L,tb,B,permute,seed", GENERIC,
+                         ids=lambda v: str(v) if not isinstance(v, bool) else ("perm" if v else "id"))
+def test_generic_shape_matches_oracle(D, C, H, K, L, tb, B, permute, seed):
+    """forward (z, log-det, nll) in fp32 against the fp64 oracle at the CPU fp32 path's own distance, bf16 against the
+    same-rounding oracle; the D-pass inverse against the oracle's inverse and as a round trip; gradients are refused."""
+    ref, ref64, flow = make_pair(D, C, H, L, K, tb, seed=seed)
+    if permute:
+        order = list(range(D))
+        random.Random(seed).shuffle(order)
+        for m in (ref, ref64, flow):
+            m.set_autoregressive_order(order)
+    x, ctx = flow_inputs(B, D, C, tb, seed=seed + 1)
+    cg = None if ctx is None else ctx.cuda()
+    with torch.no_grad():
+        z64, ld64 = ref64(x.double(), None if ctx is None else ctx.double())
+        z32, ld32 = ref(x, ctx)
+        zg, ldg = flow(x.cuda(), cg)
+        nll = flow.compute_psd_aware_nll(x.cuda(), cg, None)
+        want_nll = ref64.compute_psd_aware_nll(x.double(), None if ctx is None else ctx.double(), torch.zeros_like(x).double())
+    for got, w32, w64 in ((zg.cpu(), z32, z64), (ldg.cpu(), ld32, ld64), (nll.cpu(), -(-ld32), want_nll)):
+        err = (got.double() - w64).abs()
+        scale = w64.abs().clamp_min(1.0)
+        if got is nll.cpu():
+            assert (err / scale).max() < 1e-4, (err / scale).max()
+            continue
+        cpu = (w32.double() - w64).abs()
+        assert (err / scale).max() < max(2e-5, 6 * (cpu / scale).max().item()), ((err / scale).max(), (cpu / scale).max())
+    # inverse: against the oracle's D-pass inverse of the SAME z, and the round trip
+    with torch.no_grad():
+        xb, ldi = flow.inverse(zg, cg)
+        xo, ldo = ref64.inverse(zg.cpu().double(), None if ctx is None else ctx.double())
+    assert (xb.cpu().double() - xo).abs().max() < 5e-4, (xb.cpu().double() - xo).abs().max()
+    assert ((ldi.cpu().double() - ldo).abs() / ldo.abs().clamp_min(1.0)).max() < 1e-3
+    inside = (x.abs() < 3.0).all(dim=1)
+    if inside.any():
+        assert (xb.cpu()[inside] - x[inside]).abs().max() < 5e-3
+    # grouped context (one context row per group of draws) == the expanded form
+    if ctx is not None and B % 2 == 0:
+        half = ctx[: B // 2].cuda()
+        zz = torch.randn(B, D, device="cuda")
+        with torch.no_grad():
+            a, _ = flow.inverse(zz, half.repeat_interleave(2, dim=0))
+            b, _ = flow.inverse(zz, half)
+        assert torch.equal(a, b)
+    # bf16 mode: the kernel against the oracle evaluated with the same operand rounding
+    from oracle import nflows_restated
+    flow.precision = "bf16"
+    with torch.no_grad():
+        zb, lb = flow(x.cuda(), cg)
+        with nflows_restated.gemm_emulation("bf16"):
+            ze, le = ref(x, ctx)
+    dz = (zb.cpu() - ze).abs()
+    dl = (lb.cpu() - le).abs() / le.abs().clamp_min(1.0)
+    assert dz.median() < 5e-3 and dl.median() < 1e-2, (dz.median(), dl.median())
+    flow.precision = "fp32"
+    if flow._generic_shape():
+        with pytest.raises(NotImplementedError):
+            flow(x.cuda().requires_grad_(True), cg)

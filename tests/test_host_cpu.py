@@ -224,10 +224,26 @@ def test_plan_sizes_and_unsupported_shapes(lib):
     assert 0.6 * dense_bf16 < packed < 0.9 * dense_bf16        # mask-aware stream is smaller than dense
     assert h.pf_flow_rows_per_workgroup(C_byref(d), 4096) == 16
     assert h.pf_flow_rows_per_workgroup(C_byref(d), 65536) == 32
-    for bad in (desc_of(lib, 17, 288, 256, 16, 8, "bf16"),     # D > H/16
-                desc_of(lib, 11, 288, 384, 16, 8, "bf16"),     # H not built
-                desc_of(lib, 11, 288, 256, 17, 8, "bf16"),     # K > 16
-                desc_of(lib, 11, 5000, 256, 16, 8, "bf16")):   # C too large
+    # shapes outside the scheduled kernels' set go to the generic kernel (pf_flow_generic.hip): dense masked fragment arrays
+    for D_, C_, H_, K_, L_ in ((17, 288, 256, 16, 8),          # D > H/16
+                               (11, 288, 384, 24, 12),         # FlowHead(12, 384, 24), experiments/frozen_context_heads.py:159-163
+                               (11, 288, 256, 17, 8),          # K > 16
+                               (5, 0, 48, 3, 2)):              # H not a scheduled width
+        for prec in ("bf16", "fp32"):
+            gd = desc_of(lib, D_, C_, H_, K_, L_, prec)
+            ks = 32 if prec == "bf16" else 16
+            nt, kx = H_ // 16, -(-(2 * (-(-D_ // 16) * 16) if prec == "bf16" else D_) // ks)
+            kc, kh, tf = -(-C_ // ks), -(-H_ // ks), -(-(D_ * (3 * K_ - 1)) // 16)
+            frags = nt * kx + (3 * nt * kc if C_ else 0) + 4 * nt * kh + tf * kh
+            bias = H_ + (3 * H_ if C_ else 0) + 4 * H_ + 16 * tf
+            assert h.pf_flow_packed_bytes(C_byref(gd)) == L_ * (frags * 1024 + bias * 4)
+            assert h.pf_flow_rows_per_workgroup(C_byref(gd), 4096) == 16
+            assert h.pf_flow_forward(C_byref(gd), None, None, None, None, None, 4, None, None, None, None, 0, None) == lib.PF_ERR_BAD_ARG
+    for bad in (desc_of(lib, 11, 5000, 256, 16, 8, "bf16"),    # C too large for the in-layer kernels and for the generic LDS image
+                desc_of(lib, 33, 0, 256, 8, 2, "bf16"),        # D > 32
+                desc_of(lib, 8, 0, 520, 8, 2, "bf16"),         # H > 512
+                desc_of(lib, 8, 0, 250, 8, 2, "bf16"),         # H % 16
+                desc_of(lib, 32, 288, 512, 32, 2, "fp32")):    # 32 x 95 parameters per row: LDS image > 160 KB
         assert h.pf_flow_packed_bytes(C_byref(bad)) == -1
         assert h.pf_flow_forward(C_byref(bad), None, None, None, None, None, 4, None, None, None, None, 0, None) == lib.PF_ERR_UNSUPPORTED
     # argument checks happen before any launch
@@ -352,3 +368,39 @@ def test_nflows_cross_check_script_skips_cleanly_without_nflows():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "compare_with_nflows.py")],
                          capture_output=True, text=True, timeout=120)
     assert out.returncode == 77 and "not importable" in out.stdout
+
+
+def test_generic_pack_map_is_the_masked_dense_matrices(lib):
+    """generic plan (H = 48, D = 5, K = 3, C = 7): every fragment element decodes to the masked weight it should hold"""
+    import numpy as np
+    h = lib.lib()
+    D_, C_, H_, K_, L_ = 5, 7, 48, 3, 2
+    M_ = 3 * K_ - 1
+    for prec, per, ks in (("bf16", 8, 32), ("fp32", 4, 16)):
+        d = desc_of(lib, D_, C_, H_, K_, L_, prec)
+        n = h.pf_flow_pack_map_len(C_byref(d))
+        m = np.zeros(n, dtype=np.int32)
+        assert h.pf_flow_build_pack_map(C_byref(d), m.ctypes.data_as(C.c_void_p)) == lib.PF_OK
+        raw_n = h.pf_flow_raw_param_count(C_byref(d))
+        per_layer = raw_n // L_
+        deg = lambda u: u % max(1, D_ - 1) + min(1, D_ - 1)
+        nt = H_ // 16
+        xh = -(-D_ // 16) * 16
+        kx = -(-(2 * xh if prec == "bf16" else D_) // ks)
+        # first matrix of layer 1: W_in [H, D]
+        frags_per_layer = nt * kx + 3 * nt * (-(-C_ // ks)) + 4 * nt * (-(-H_ // ks)) + (-(-(D_ * M_) // 16)) * (-(-H_ // ks))
+        base = 1 * frags_per_layer * 64 * per
+        for t in range(nt):
+            for s_ in range(kx):
+                for lane in range(64):
+                    for e in range(per):
+                        row, k = 16 * t + (lane & 15), ks * s_ + per * (lane >> 4) + e
+                        got = m[base + ((t * kx + s_) * 64 + lane) * per + e]
+                        dcol = (k % xh if k < 2 * xh else D_) if prec == "bf16" else k
+                        want = per_layer + row * D_ + dcol if (dcol < D_ and deg(row) >= dcol + 1) else -1
+                        assert got == want, (prec, t, s_, lane, e, got, want)
+        # the map references every unmasked weight of W_in exactly once (fp32) / twice (bf16 hi | lo)
+        win = m[base:base + nt * kx * 64 * per]
+        used = win[win >= 0] - per_layer
+        assert sorted(set(used.tolist())) == sorted(r * D_ + c for r in range(H_) for c in range(D_) if deg(r) >= c + 1)
+        assert len(used) == (2 if prec == "bf16" else 1) * len(set(used.tolist()))
