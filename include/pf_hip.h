@@ -68,6 +68,11 @@ extern "C" {
                               *  then fp32 biases per layer: b_in | bc, bg0, bg1 | b1_0, b2_0, b1_1, b2_1 | bf (padded to 16).
                               * bf16 precision, plain conditioner.  pf_flow_packed_bytes / pack_map_len / build_pack_map /
                               * pack take the flag; the forward, inverse and workspace entry points refuse it. */
+#define PF_FLAG_GENERIC 16    /* request the generic kernel's layout (plain [tile][k-step] fragment arrays of the dense masked
+                              * matrices, nflows unit order) for a shape the scheduled kernels would take: the fp32-mode
+                              * conditioner re-evaluation (pf_flow_reevaluate with an fp32 desc) reads this layout; forward and
+                              * inverse calls with such a desc run the generic kernel.  Shapes outside the scheduled set get it
+                              * without the flag. */
 
 /* Plain-old-data description of one NSFPosteriorFlow (flows.py:379-548).
  * conditioner: nflows MADE, num_blocks residual blocks with GLU context gate,
@@ -228,12 +233,14 @@ typedef struct PfFlowBwdChainArgs {
 } PfFlowBwdChainArgs;
 int pf_flow_backward_chain(const PfFlowDesc* desc, const PfFlowBwdChainArgs* args, void* stream);
 
-/* ---- backward: the conditioner re-evaluation in one launch (bf16 descs) -------------------------------------------
+/* ---- backward: the conditioner re-evaluation in one launch -------------------------------------------------------------
  * Recomputes, from the layer inputs pf_flow_forward_train kept, the activations of every layer's MADE that the chain and the
  * weight-gradient GEMMs read -- what autograd keeps alive for the reference under flows.py:615-617.  Grid = 16-row blocks x
  * layers (the layers are independent given their inputs); bf16 operands, x as hi + lo, fp32 accumulate: the arithmetic of the
  * bf16 forward kernel.  `packed` is the PF_FLAG_BWD stream (its forward region).  Plain conditioner, bf16 desc, H % 32 == 0.
- * Outputs fp32, nflows unit order; context-free flows pass ctx = t2s = gates = pc = NULL. */
+ * Outputs fp32, nflows unit order; context-free flows pass ctx = t2s = gates = pc = NULL.
+ * fp32 descs (the parity mode): the same function in exact-fp32 MFMA arithmetic by the generic kernel's conditioner
+ * (csrc/pf_flow_generic.hip); `packed` is then the packed buffer of the desc with PF_FLAG_GENERIC set, `compact` must be 0. */
 typedef struct PfFlowReevalArgs {
     int64_t batch;
     const void* packed;  /* PF_FLAG_BWD stream */

@@ -133,11 +133,12 @@ REEVAL_HIP = True      # tests: False keeps the tensor-op re-evaluation in bf16 
 COMPACT = True         # tests: False keeps fp32 activations / gradient vectors between the bf16 backward kernels
 
 
-def _reevaluate_hip(flow, U, ctx, drop=None, compact=False):
-    """bf16 mode: every layer's conditioner from its kept input in ONE launch (pf_flow_reevaluate, csrc/pf_flow_reeval.hip),
-    in the arithmetic of the bf16 forward kernel.  Returns (hs, t1s, t2s, gates, pc, h2, params): fp32 raw values, or with
-    ``compact`` bf16 tensors already in the form the backward uses them (hs = relu(h_j), t1s = relu(t1_j) . drop[j],
-    pc = relu(pc); params stay fp32)."""
+def _reevaluate_hip(flow, U, ctx, drop=None, compact=False, fp32=False):
+    """Every layer's conditioner from its kept input in ONE launch (pf_flow_reevaluate): bf16 mode in the arithmetic of the
+    bf16 forward kernel (csrc/pf_flow_reeval.hip); ``fp32``: exact-fp32 MFMA by the generic kernel's conditioner
+    (csrc/pf_flow_generic.hip, the PF_FLAG_GENERIC layout).  Returns (hs, t1s, t2s, gates, pc, h2, params): fp32 raw values, or
+    with ``compact`` (bf16 only) bf16 tensors already in the form the backward uses them (hs = relu(h_j), t1s = relu(t1_j) .
+    drop[j], pc = relu(pc); params stay fp32)."""
     Ln, B, D = U.shape
     H, dev = flow.hidden_features, U.device
     has_ctx = ctx is not None
@@ -146,7 +147,7 @@ def _reevaluate_hip(flow, U, ctx, drop=None, compact=False):
     HS, T1, H2 = new(2, Ln, B, H), new(2, Ln, B, H), new(Ln, B, H)
     params = torch.empty(Ln, B, D * (3 * flow.num_bins - 1), dtype=torch.float32, device=dev)
     T2 = G = PC = None
-    packed = flow.packed_weights(bwd=True)
+    packed = flow.packed_weights("fp32", generic=True) if fp32 else flow.packed_weights(bwd=True)
     a = _lib.PfFlowReevalArgs()
     a.batch, a.packed, a.U = B, packed.data_ptr(), U.data_ptr()
     a.hs, a.t1s, a.h2, a.params = HS.data_ptr(), T1.data_ptr(), H2.data_ptr(), params.data_ptr()
@@ -156,7 +157,7 @@ def _reevaluate_hip(flow, U, ctx, drop=None, compact=False):
     if drop is not None:
         a.drop = drop.data_ptr()
     a.compact = 1 if compact else 0
-    _lib.check(_lib.lib().pf_flow_reevaluate(flow._desc("bf16"), a, torch.cuda.current_stream(dev).cuda_stream),
+    _lib.check(_lib.lib().pf_flow_reevaluate(flow._desc("fp32" if fp32 else "bf16"), a, torch.cuda.current_stream(dev).cuda_stream),
                "pf_flow_reevaluate")
     return HS, T1, T2, G, PC, H2, params
 
@@ -191,12 +192,14 @@ def _flow_backward_batched(flow, U, ctx, g_z, g_lad, drop=None, nll=None):
 
     # 1. conditioners
     cmp = bf and REEVAL_HIP and COMPACT
-    hip_reeval = bf and REEVAL_HIP
+    # fp32 (parity) mode: the same launch in exact-fp32 MFMA arithmetic (the generic kernel's conditioner)
+    f32_hip = (not bf) and REEVAL_HIP and flow.precision != "bf16" and nb == 2 and U.is_contiguous() and (ctx is None or ctx.is_contiguous())
+    hip_reeval = (bf and REEVAL_HIP) or f32_hip
     if hip_reeval:
         try:
-            re = _reevaluate_hip(flow, U, ctx, drop, compact=cmp)
+            re = _reevaluate_hip(flow, U, ctx, drop, compact=cmp, fp32=f32_hip)
         except NotImplementedError:      # PF_ERR_UNSUPPORTED (e.g. a context too wide for the kernel's LDS image):
-            hip_reeval = cmp = False     # the tensor-op re-evaluation below, fp32 interface of the chain
+            hip_reeval = cmp = f32_hip = False     # the tensor-op re-evaluation below, fp32 interface of the chain
     if hip_reeval and cmp:   # bf16 activations in their backward form; bf16 gradient vectors; bf16 weight-gradient GEMMs
         HSk, T1k, T2k, Gk, pck, h_last, params = re
         relu_h, a1s = [HSk[j] for j in range(nb)], [T1k[j] for j in range(nb)]
@@ -204,11 +207,14 @@ def _flow_backward_batched(flow, U, ctx, g_z, g_lad, drop=None, nll=None):
         HSk, T1k, T2k, Gk, pck, h_last, params = re
         relu_h = [F.relu(HSk[j]) for j in range(nb)]
         a1s = [F.relu(T1k[j]) if drop is None else F.relu(T1k[j]) * drop[j] for j in range(nb)]
-    else:
-        W0, b0 = st(lambda n: n.initial_layer.weight) * m0, st(lambda n: n.initial_layer.bias)
-        Wf, bf_ = st(lambda n: n.final_layer.weight) * mf, st(lambda n: n.final_layer.bias)
+    if not bf or not hip_reeval:     # masked weights stacked over the layers: operands of the fp32 chain (transposed below) and of the
+        #            tensor-op re-evaluation
+        W0 = st(lambda n: n.initial_layer.weight) * m0
+        Wf = st(lambda n: n.final_layer.weight) * mf
         W1 = [st(lambda n: n.blocks[j].linear_layers[0].weight) * m1[j] for j in range(nb)]
         W2 = [st(lambda n: n.blocks[j].linear_layers[1].weight) * m2[j] for j in range(nb)]
+    if not hip_reeval:
+        b0, bf_ = st(lambda n: n.initial_layer.bias), st(lambda n: n.final_layer.bias)
         b1 = [st(lambda n: n.blocks[j].linear_layers[0].bias) for j in range(nb)]
         b2 = [st(lambda n: n.blocks[j].linear_layers[1].bias) for j in range(nb)]
         if has_ctx:       # batched over layers: one GEMM for all context projections

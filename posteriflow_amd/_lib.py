@@ -19,6 +19,7 @@ PF_FLAG_HOIST_CTX = 1
 PF_FLAG_MASKED_CONTEXT = 2
 PF_FLAG_WIDE = 4
 PF_FLAG_BWD = 8
+PF_FLAG_GENERIC = 16
 PF_REDUCE_SLOTS = 16          # include/pf_hip.h
 PF_EPI_PLAIN, PF_EPI_GELU, PF_EPI_RESID, PF_EPI_MUL = 0, 1, 2, 3
 PRECISIONS = {"fp32": PF_PREC_F32, "f32": PF_PREC_F32, "bf16": PF_PREC_BF16}

@@ -35,6 +35,7 @@ int rqs_backward(const PfFlowDesc& d, float deriv_const, const float* u, const f
                  const float* glad, int64_t n, float* gparams, float* gu, hipStream_t s);
 int launch_gather(bool bf16, const float* raw, const int32_t* map, void* out, int64_t n, hipStream_t s);
 int flow_backward_chain(const PfFlowDesc& d, float deriv_const, const PfFlowBwdChainArgs& a, hipStream_t s);
+int flow_reevaluate_generic(const FlowPlan& L, const PfFlowReevalArgs& a, const PfFlowDesc& d, hipStream_t s);
 int flow_reevaluate(const FlowPlan& P, const PfFlowReevalArgs& a, hipStream_t s);
 int64_t enc_train_raw_count();
 int64_t enc_train_packed_bytes(bool bf16);
@@ -267,8 +268,30 @@ int pf_flow_backward_chain(const PfFlowDesc* desc, const PfFlowBwdChainArgs* a, 
 
 int pf_flow_reevaluate(const PfFlowDesc* desc, const PfFlowReevalArgs* a, void* stream) {
     if (!desc || !a) return fail(PF_ERR_BAD_ARG, "null pointer");
-    if (desc->precision != PF_PREC_BF16 || (desc->reserved & (PF_FLAG_MASKED_CONTEXT | PF_FLAG_BWD)))
-        return fail(PF_ERR_UNSUPPORTED, "re-evaluation kernel: bf16 desc of a plain-conditioner flow (the flow's own desc)");
+    if (desc->reserved & (PF_FLAG_MASKED_CONTEXT | PF_FLAG_BWD))
+        return fail(PF_ERR_UNSUPPORTED, "re-evaluation kernel: plain-conditioner flow (the flow's own desc)");
+    if (desc->precision == PF_PREC_F32) {           // parity mode: the generic kernel's conditioner, exact-fp32 MFMA
+        PfFlowDesc g = *desc;
+        g.reserved = PF_FLAG_GENERIC;
+        pf::FlowPlan G;
+        const int rg = layout_of(&g, G);
+        if (rg != PF_OK) return rg;
+        if (a->compact) return fail(PF_ERR_BAD_ARG, "fp32 re-evaluation: compact must be 0");
+        if (a->batch < 0) return fail(PF_ERR_BAD_ARG, "negative batch");
+        if (a->batch == 0) return PF_OK;
+        if (!a->packed || !a->U || !a->hs || !a->t1s || !a->h2 || !a->params) return fail(PF_ERR_BAD_ARG, "null pointer");
+        const bool cx = G.C > 0;
+        if (cx != (a->ctx != nullptr) || cx != (a->t2s != nullptr) || cx != (a->gates != nullptr) || cx != (a->pc != nullptr))
+            return fail(PF_ERR_BAD_ARG, "ctx, t2s, gates and pc go together with context_features > 0");
+        const void* al[] = {a->packed, a->hs, a->t1s, a->t2s, a->gates, a->pc, a->h2, a->drop};
+        for (const void* q : al)
+            if (misaligned(q, 16)) return fail(PF_ERR_BAD_ARG, "stream / activation tensors must be 16-byte aligned");
+        if (G.H % 4) return fail(PF_ERR_UNSUPPORTED, "hidden_features % 4");
+        const int rc = pf::flow_reevaluate_generic(G, *a, *desc, static_cast<hipStream_t>(stream));
+        return rc == PF_OK ? rc : fail(rc, rc == PF_ERR_HIP ? hipGetErrorString(static_cast<hipError_t>(pf::g_hip_error)) : "unsupported shape");
+    }
+    if (desc->precision != PF_PREC_BF16)
+        return fail(PF_ERR_BAD_ARG, "bad precision");
     PfFlowDesc d = *desc;
     d.reserved = PF_FLAG_BWD;                       // the layout of the stream it reads
     pf::FlowPlan P;

@@ -91,8 +91,16 @@ __device__ __forceinline__ void rqs_generic(const float* par, float v, int K, co
     }
 }
 
-template <bool BF16, bool INV>
-__global__ __launch_bounds__(kGenWaves * 64) void flow_generic_kernel(const FwdParams p) {
+// conditioner re-evaluation (pf_flow_reevaluate, fp32 descs): where the conditioner's intermediate values go, fp32 [.., B, H]
+struct ReevalSink {
+    float* hs; float* t1s; float* t2s; float* gates; float* pc; float* h2; float* params;
+    const float* drop;         // [2][L][B][H] or null
+};
+
+// MODE 0: forward, 1: D-pass inverse, 2: one layer's conditioner per workgroup (grid.y = layer), everything written out
+template <bool BF16, int MODE>
+__global__ __launch_bounds__(kGenWaves * 64) void flow_generic_kernel(const FwdParams p, const ReevalSink sink) {
+    constexpr bool INV = MODE == 1, REEVAL = MODE == 2;
     constexpr bool FAST = BF16;
     constexpr int KSTEP = BF16 ? 32 : 16, ESZ = BF16 ? 2 : 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -218,10 +226,18 @@ __global__ __launch_bounds__(kGenWaves * 64) void flow_generic_kernel(const FwdP
         // h = W_in x + b (+ relu(Wc ctx + bc)); s_a = relu(h)
         for (int t = wave; t < NT; t += kGenWaves) {
             f32x4 v = mm(f_in, t, L.gKx, s_x, sx) + *reinterpret_cast<const f32x4*>(b_in + 16 * t + 4 * g);
+            f32x4 pcv = {0.f, 0.f, 0.f, 0.f};
             if (C > 0) {
-                const f32x4 pc = mm(f_c, t, L.gKc, s_ctx, sc) + *reinterpret_cast<const f32x4*>(b_c + 16 * t + 4 * g);
+                pcv = mm(f_c, t, L.gKc, s_ctx, sc) + *reinterpret_cast<const f32x4*>(b_c + 16 * t + 4 * g);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += fmaxf(pc[e], 0.f);
+                for (int e = 0; e < 4; ++e) v[e] += fmaxf(pcv[e], 0.f);
+            }
+            if constexpr (REEVAL) {
+                if (row0 + c < p.batch) {
+                    const size_t o = ((size_t)l * p.batch + row0 + c) * H + 16 * t + 4 * g;
+                    *reinterpret_cast<f32x4*>(sink.hs + o) = v;                                   // hs[0]: state before block 0
+                    if (C > 0) *reinterpret_cast<f32x4*>(sink.pc + o) = pcv;
+                }
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -235,23 +251,41 @@ __global__ __launch_bounds__(kGenWaves * 64) void flow_generic_kernel(const FwdP
             const gu32x4* f2 = f1 + (size_t)NT * L.gKh * 64;
             for (int t = wave; t < NT; t += kGenWaves) {                           // t1 = W1 relu(h) + b1; s_b = relu(t1)
                 const f32x4 v = mm(f1, t, L.gKh, s_a, sh) + *reinterpret_cast<const f32x4*>(b_blk + (2 * b) * H + 16 * t + 4 * g);
+                f32x4 df = {1.f, 1.f, 1.f, 1.f};
+                if constexpr (REEVAL) {
+                    if (row0 + c < p.batch) {
+                        const size_t o = (((size_t)b * L.L + l) * p.batch + row0 + c) * H + 16 * t + 4 * g;
+                        *reinterpret_cast<f32x4*>(sink.t1s + o) = v;
+                        if (sink.drop) df = *reinterpret_cast<const f32x4*>(sink.drop + o);
+                    }
+                }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) store_act(s_b, sh, c, 16 * t + 4 * g + e, fmaxf(v[e], 0.f));
+                for (int e = 0; e < 4; ++e) store_act(s_b, sh, c, 16 * t + 4 * g + e, fmaxf(v[e], 0.f) * df[e]);
             }
             __syncthreads();
             for (int t = wave; t < NT; t += kGenWaves) {                           // h += (W2 . + b2) . sigmoid(Wg ctx + bg)
                 f32x4 v = mm(f2, t, L.gKh, s_b, sh) + *reinterpret_cast<const f32x4*>(b_blk + (2 * b + 1) * H + 16 * t + 4 * g);
+                const bool live = REEVAL && row0 + c < p.batch;
+                const size_t o = (((size_t)b * L.L + l) * p.batch + row0 + c) * H + 16 * t + 4 * g;
                 if (C > 0) {
-                    const f32x4 gt = mm(b == 0 ? f_g0 : f_g1, t, L.gKc, s_ctx, sc) +
-                                     *reinterpret_cast<const f32x4*>((b == 0 ? b_g0 : b_g1) + 16 * t + 4 * g);
+                    f32x4 gt = mm(b == 0 ? f_g0 : f_g1, t, L.gKc, s_ctx, sc) +
+                               *reinterpret_cast<const f32x4*>((b == 0 ? b_g0 : b_g1) + 16 * t + 4 * g);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] *= pf_sigmoid<FAST>(gt[e]);
+                    for (int e = 0; e < 4; ++e) gt[e] = pf_sigmoid<FAST>(gt[e]);
+                    if (live) { *reinterpret_cast<f32x4*>(sink.t2s + o) = v; *reinterpret_cast<f32x4*>(sink.gates + o) = gt; }
+                    v = v * gt;
                 }
+                f32x4 hv4;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float hv = s_h[c * H + 16 * t + 4 * g + e] + v[e];
+                    hv4[e] = hv;
                     s_h[c * H + 16 * t + 4 * g + e] = hv;
                     store_act(s_a, sh, c, 16 * t + 4 * g + e, b == 0 ? fmaxf(hv, 0.f) : hv);   // the final layer takes h itself
+                }
+                if (live) {
+                    if (b == 0) *reinterpret_cast<f32x4*>(sink.hs + (((size_t)1 * L.L + l) * p.batch + row0 + c) * H + 16 * t + 4 * g) = hv4;
+                    else *reinterpret_cast<f32x4*>(sink.h2 + ((size_t)l * p.batch + row0 + c) * H + 16 * t + 4 * g) = hv4;
                 }
             }
             __syncthreads();
@@ -265,7 +299,21 @@ __global__ __launch_bounds__(kGenWaves * 64) void flow_generic_kernel(const FwdP
     };
 
     const int n_pairs = 16 * D;
-    if constexpr (!INV) {
+    if constexpr (REEVAL) {
+        const int l = blockIdx.y;
+        if (tid < 16 * 32) {
+            const int r = tid >> 5, d = tid & 31;
+            const int64_t row = row0 + r < p.batch ? row0 + r : p.batch - 1;
+            s_u[tid] = d < D ? p.x[((size_t)l * p.batch + row) * D + d] : 0.f;          // p.x = U[L][B][D]
+        }
+        __syncthreads();
+        conditioner(l);
+        const int DM = D * M;
+        for (int i = tid; i < 16 * DM; i += kGenWaves * 64) {
+            const int r = i / DM, k = i - r * DM;
+            if (row0 + r < p.batch) sink.params[((size_t)l * p.batch + row0 + r) * DM + k] = s_par[r * PS + k];
+        }
+    } else if constexpr (!INV) {
         for (int l = 0; l < L.L; ++l) {
             // ReversePermutation in front of every autoregressive layer (flows.py:459-529)
             if (tid < 16 * 32) { const int r = tid >> 5, d = tid & 31; s_u[tid] = d < D ? s_y[r * 32 + D - 1 - d] : 0.f; }
@@ -342,23 +390,35 @@ __global__ __launch_bounds__(kGenWaves * 64) void flow_generic_kernel(const FwdP
     }
 }
 
-template <bool BF16, bool INV>
-int launch_generic_t(const FwdParams& p, hipStream_t s) {
+template <bool BF16, int MODE>
+int launch_generic_t(const FwdParams& p, const ReevalSink& sink, hipStream_t s) {
     const size_t lds = (size_t)p.plan.gen_lds_bytes();
-    auto k = flow_generic_kernel<BF16, INV>;
+    auto k = flow_generic_kernel<BF16, MODE>;
     if (lds > 160 * 1024) return PF_ERR_UNSUPPORTED;
     if (lds > 64 * 1024 && !opt_in_lds(reinterpret_cast<const void*>(k), (int)lds)) return PF_ERR_HIP;
     const unsigned grid = (unsigned)((p.batch + 15) / 16);
     if (grid == 0) return PF_OK;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(kGenWaves * 64), lds, s, p);
+    hipLaunchKernelGGL(k, dim3(grid, MODE == 2 ? (unsigned)p.plan.L : 1u), dim3(kGenWaves * 64), lds, s, p, sink);
     return launch_status();
 }
 
 }  // namespace
 
 int launch_flow_generic(const FwdParams& p, bool inverse, hipStream_t s) {
-    if (p.plan.bf16) return inverse ? launch_generic_t<true, true>(p, s) : launch_generic_t<true, false>(p, s);
-    return inverse ? launch_generic_t<false, true>(p, s) : launch_generic_t<false, false>(p, s);
+    const ReevalSink none{};
+    if (p.plan.bf16) return inverse ? launch_generic_t<true, 1>(p, none, s) : launch_generic_t<true, 0>(p, none, s);
+    return inverse ? launch_generic_t<false, 1>(p, none, s) : launch_generic_t<false, 0>(p, none, s);
+}
+
+// fp32 conditioner re-evaluation of every layer (pf_flow_reevaluate with an fp32 desc): L = the generic plan of the desc
+int flow_reevaluate_generic(const FlowPlan& L, const PfFlowReevalArgs& a, const PfFlowDesc& d, hipStream_t s) {
+    if (L.bf16 || !L.generic) return PF_ERR_UNSUPPORTED;
+    FwdParams p{};
+    p.packed = static_cast<const char*>(a.packed);
+    p.x = a.U; p.ctx = a.ctx; p.batch = a.batch; p.ctx_rows = a.batch; p.plan = L;
+    p.tail_bound = d.tail_bound; p.min_w = d.min_bin_width; p.min_h = d.min_bin_height; p.min_d = d.min_derivative;
+    ReevalSink sink{a.hs, a.t1s, a.t2s, a.gates, a.pc, a.h2, a.params, a.drop};
+    return launch_generic_t<false, 2>(p, sink, s);
 }
 
 }  // namespace pf

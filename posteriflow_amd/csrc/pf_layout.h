@@ -188,6 +188,7 @@ inline void sorted_units(int D, int H, int* perm) {
 // K <= 32, and the workgroup's LDS image within 160 KB.
 inline int make_generic_plan(const PfFlowDesc& d, FlowPlan& o) {
     if (d.reserved & (PF_FLAG_MASKED_CONTEXT | PF_FLAG_WIDE | PF_FLAG_BWD)) return PF_ERR_UNSUPPORTED;
+    if (d.num_bins * 3 - 1 < 1 || d.num_layers < 1) return PF_ERR_UNSUPPORTED;
     if (d.hidden_features < 16 || d.hidden_features > 512 || d.hidden_features % 16) return PF_ERR_UNSUPPORTED;
     if (d.features < 1 || d.features > 32 || d.num_bins < 2 || d.num_bins > 32) return PF_ERR_UNSUPPORTED;
     o = FlowPlan{};
@@ -223,7 +224,7 @@ inline int make_plan(const PfFlowDesc& d, FlowPlan& o) {
     const bool scheduled_shape = (d.hidden_features == 64 || d.hidden_features == 128 || d.hidden_features == 192 ||
                                   d.hidden_features == 256) &&
                                  d.features >= 1 && d.features <= d.hidden_features / 16 && d.num_bins >= 2 && d.num_bins <= 16;
-    if (!scheduled_shape) return make_generic_plan(d, o);
+    if (!scheduled_shape || (d.reserved & PF_FLAG_GENERIC)) return make_generic_plan(d, o);
     o.D = d.features; o.C = d.context_features; o.H = d.hidden_features;
     o.K = d.num_bins; o.L = d.num_layers; o.M = 3 * d.num_bins - 1; o.NB = d.num_blocks;
     o.bf16 = d.precision == PF_PREC_BF16;

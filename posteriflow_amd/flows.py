@@ -540,8 +540,12 @@ class NSFPosteriorFlow(nn.Module):
         return env == "1" or batch >= self.wide_min_batch
 
     def _desc(self, precision: Optional[str] = None, inverse: bool = False, wide: bool = False,
-              bwd: bool = False) -> _lib.PfFlowDesc:
+              bwd: bool = False, generic: bool = False) -> _lib.PfFlowDesc:
         prec = _lib.PRECISIONS[precision or self.precision]
+        if generic:  # the generic kernel's layout for this shape (fp32-mode conditioner re-evaluation reads it)
+            return _lib.PfFlowDesc(self.features, self.context_features, self.hidden_features, self.num_bins,
+                                   self.num_layers, 2, float(self._tail_bound), _MIN_BIN, _MIN_BIN, _MIN_BIN,
+                                   prec, _lib.PF_FLAG_GENERIC)
         if bwd:     # packing only: the backward chain's transposed bf16 fragments (PF_FLAG_BWD)
             return _lib.PfFlowDesc(self.features, self.context_features, self.hidden_features, self.num_bins,
                                    self.num_layers, 2, float(self._tail_bound), _MIN_BIN, _MIN_BIN, _MIN_BIN,
@@ -597,9 +601,9 @@ class NSFPosteriorFlow(nn.Module):
         return dev
 
     def packed_weights(self, precision: Optional[str] = None, inverse: bool = False, wide: bool = False,
-                       bwd: bool = False) -> torch.Tensor:
+                       bwd: bool = False, generic: bool = False) -> torch.Tensor:
         """Packed (masked, fragment-ordered) weights, rebuilt when a parameter changed."""
-        desc = self._desc(precision, inverse, wide, bwd)
+        desc = self._desc(precision, inverse, wide, bwd, generic)
         ck = (desc.precision, desc.reserved)
         if self._frozen and ck in self._packed and self._packed[ck].buf is not None:
             return self._packed[ck].buf
