@@ -286,6 +286,7 @@ def extras(flow, dev, batch):
     out[f"flow_fwd_bwd_ms_2048_{flow.precision}"] = timed(fwd_bwd, 10) * 1e3
     out.update(config5_sampling(dev, flow.precision))
     out.update(config4_train_step(dev, flow.precision))
+    out.update(generic_head(dev, flow.precision))
     log("extras: " + ", ".join(f"{k}={v:.3g}" for k, v in out.items()))
     return out
 
@@ -314,6 +315,27 @@ def config5_sampling(dev, precision, n_rank=125_000, reps=3):
     torch.cuda.synchronize(dev)
     dt = (time.perf_counter() - t0) / reps
     return {"config5_draws_per_s": n_rank / dt, "config5_ms_per_125000_draws": dt * 1e3}
+
+
+def generic_head(dev, precision, batch=4096):
+    """A flow size outside the scheduled kernels' set -- FlowHead(12, 384, 24) of experiments/frozen_context_heads.py:159-163 --
+    through the generic kernel: log-density of 4096 rows."""
+    from posteriflow_amd import NSFPosteriorFlow
+    torch.manual_seed(0)
+    fh = NSFPosteriorFlow(11, 288, 384, 12, 24, 3.0, temperature_scale=1.0, use_masked_context=False).to(dev).eval()
+    for q in fh.parameters():
+        q.requires_grad_(False)
+    fh.precision = precision
+    x = torch.rand(batch, 11, device=dev) * 2 - 1
+    c = torch.randn(batch, 288, device=dev)
+    fh.compute_psd_aware_nll(x, c, None)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        fh.compute_psd_aware_nll(x, c, None)
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / 5
+    return {"generic_head_12x384x24_samples_per_s": batch / dt}
 
 
 def config4_train_step(dev, precision, events=1024, reps=5):
