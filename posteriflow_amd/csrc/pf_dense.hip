@@ -249,11 +249,6 @@ __global__ __launch_bounds__(256, TP <= 3 ? 2 : 1) void dense_strip_kernel(const
         // instructions: 192 -> 768 plain 183 us, with GELU + its derivative (two outputs) 438 us, for 17 us of MFMAs.
         const uint32_t thr = enc_drop_threshold(p.drop_p);
         const float dscale = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
-        const bool f32o = EPI == kEpiResid || !BF16 || p.out_f32;
-        const int oesz = f32o ? 4 : 2;
-        const int srow = PC * oesz + 16;                                 // staged row (bytes), 16-byte aligned
-        const int sbuf = 16 * srow;                                      // one output's 16 rows
-        constexpr int NOUT = EPI == kEpiGelu ? 2 : 1;
         const int pcol0 = pass * PC;
         f32x4 b4[TP];
 #pragma unroll
@@ -261,18 +256,99 @@ __global__ __launch_bounds__(256, TP <= 3 ? 2 : 1) void dense_strip_kernel(const
             b4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (p.bias && tile[i] < ntiles && blockIdx.y == 0) b4[i] = *reinterpret_cast<const f32x4*>(p.bias + tile[i] * 16 + 4 * g);
         }
+        if constexpr (EPI == kEpiResid || EPI == kEpiMul) {
+            // Epilogues with a second global operand (the residual stream / the gelu' factor): it is combined in the ROW phase,
+            // from whole-row 16-byte loads requested Q groups ahead.  (First version: 8-byte loads in the accumulator layout,
+            // each used the moment it was requested -- one exposed global round trip per 16-row group and pass: the FFN2 data
+            // gradient 192 -> 768 took 106 us per workgroup for 4.6 us of MFMAs, conv2's 28 us for 1 us.)
+            constexpr int OESZ = EPI == kEpiResid ? 4 : (BF16 ? 2 : 4);      // output (= operand) element size
+            constexpr int EPC = 16 / OESZ, CPROW = PC * OESZ / 16, NPC = (16 * CPROW + 255) / 256;
+            constexpr int Q = NPC >= 3 ? 2 : 3;                              // groups ahead (12 registers per group at NPC = 3)
+            constexpr int SROW = PC * 4 + 16;                                // staged rows are fp32
+            const char* auxb = EPI == kEpiResid ? reinterpret_cast<const char*>(p.resid) : reinterpret_cast<const char*>(p.mul);
+            u32x4 aux[Q][NPC];
+            auto fetch = [&](int cgx, u32x4 (&dst)[NPC]) {
+#pragma unroll
+                for (int np = 0; np < NPC; ++np) {
+                    const int idx = tid + 256 * np;
+                    const int r16 = idx / CPROW, ch = idx - r16 * CPROW;
+                    dst[np] = u32x4{0u, 0u, 0u, 0u};
+                    if (idx < 16 * CPROW) {
+                        const int64_t xo = s_xoff[16 * cgx + r16];
+                        const int col = pcol0 + ch * EPC;
+                        if (xo >= 0 && col < p.N) dst[np] = *reinterpret_cast<const u32x4*>(auxb + (xo + col) * OESZ);
+                    }
+                }
+            };
+#pragma unroll
+            for (int q = 0; q < Q; ++q) fetch(q, aux[q]);
+#pragma unroll
+            for (int cg = 0; cg < CG; ++cg) {
+                char* buf = stg + (cg & 1) * 16 * SROW;
+                const int row = 16 * cg + c;
+#pragma unroll
+                for (int i = 0; i < TP; ++i) {
+                    const int n0 = tile[i] * 16 + 4 * g;
+                    f32x4 v = acc[i][cg] + b4[i];
+                    if constexpr (EPI == kEpiResid) {
+                        if (p.drop_p > 0.f) {
+                            f32x4 dfac;
+                            enc_drop4(p.seed, p.site, (uint32_t)((m0 + row) * p.N + n0), thr, dscale, dfac);
+                            v = v * dfac;
+                        }
+                    }
+                    *reinterpret_cast<f32x4*>(buf + c * SROW + ((wave * TP + i) * 16 + 4 * g) * 4) = v;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+#pragma unroll
+                for (int np = 0; np < NPC; ++np) {
+                    const int idx = tid + 256 * np;
+                    const int r16 = idx / CPROW, ch = idx - r16 * CPROW;
+                    const int grow = 16 * cg + r16;
+                    if (idx >= 16 * CPROW) continue;
+                    const int64_t oo = s_ooff[grow];
+                    const int col = pcol0 + ch * EPC;
+                    if (oo < 0 || col >= p.N) continue;
+                    if (p.o_valid_per_seq > 0) {
+                        const int64_t m = m0 + grow;
+                        const int64_t pos = m - (m / p.rows_per_seq) * p.rows_per_seq;
+                        if (pos * p.ldo + col + EPC > p.o_valid_per_seq) continue;
+                    }
+                    const u32x4 a = aux[cg % Q][np];
+                    char* dst = reinterpret_cast<char*>(p.out) + (oo + col) * OESZ;
+                    if constexpr (OESZ == 4) {
+                        const f32x4 sv = *reinterpret_cast<const f32x4*>(buf + r16 * SROW + ch * 16);
+                        const f32x4 av = __builtin_bit_cast(f32x4, a);
+                        *reinterpret_cast<f32x4*>(dst) = EPI == kEpiResid ? av + sv : sv * av;
+                    } else {
+                        const f32x4 s0 = *reinterpret_cast<const f32x4*>(buf + r16 * SROW + ch * 32);
+                        const f32x4 s1 = *reinterpret_cast<const f32x4*>(buf + r16 * SROW + ch * 32 + 16);
+                        const bf16x8 mv = __builtin_bit_cast(bf16x8, a);
+                        bf16x8 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { o[e] = (__bf16)(s0[e] * (float)mv[e]); o[4 + e] = (__bf16)(s1[e] * (float)mv[4 + e]); }
+                        *reinterpret_cast<bf16x8*>(dst) = o;
+                    }
+                }
+                if (cg + Q < CG) fetch(cg + Q, aux[cg % Q]);
+            }
+        } else {
+        const bool f32o = !BF16 || p.out_f32;
+        const int oesz = f32o ? 4 : 2;
+        const int srow = PC * oesz + 16;                                 // staged row (bytes), 16-byte aligned
+        const int sbuf = 16 * srow;                                      // one output's 16 rows
+        constexpr int NOUT = EPI == kEpiGelu ? 2 : 1;
 #pragma unroll
         for (int cg = 0; cg < CG; ++cg) {
             char* buf = stg + (cg & 1) * NOUT * sbuf;
             const int row = 16 * cg + c;
-            const int64_t xo = s_xoff[row];
 #pragma unroll
             for (int i = 0; i < TP; ++i) {
                 const int n0 = tile[i] * 16 + 4 * g;
-                const bool live = tile[i] < ntiles && xo >= 0;
                 f32x4 v = acc[i][cg] + b4[i];
                 f32x4 dfac = {1.f, 1.f, 1.f, 1.f};
-                if constexpr (EPI == kEpiGelu || EPI == kEpiResid) {
+                if constexpr (EPI == kEpiGelu) {
                     if (p.drop_p > 0.f) {
                         enc_drop4(p.seed, p.site, (uint32_t)((m0 + row) * p.N + n0), thr, dscale, dfac);
                     }
@@ -285,20 +361,6 @@ __global__ __launch_bounds__(256, TP <= 3 ? 2 : 1) void dense_strip_kernel(const
                         if constexpr (BF16) gelu_fast_pair(v[e], ye, de);
                         else { ye = gelu_f32(v[e]); de = gelu_grad_f32(v[e]); }
                         v[e] = ye * dfac[e]; v2[e] = de * dfac[e];
-                    }
-                } else if constexpr (EPI == kEpiResid) {
-                    f32x4 r = {0.f, 0.f, 0.f, 0.f};
-                    if (live) r = *reinterpret_cast<const f32x4*>(p.resid + xo + n0);
-                    v = r + v * dfac;
-                } else if constexpr (EPI == kEpiMul) {
-                    if (live) {
-                        if constexpr (BF16) {
-                            const bf16x4 mv = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(p.mul) + xo + n0);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] *= (float)mv[e];
-                        } else {
-                            v = v * *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.mul) + xo + n0);
-                        }
                     }
                 }
                 char* dst = buf + c * srow + ((wave * TP + i) * 16 + 4 * g) * oesz;
@@ -353,6 +415,7 @@ __global__ __launch_bounds__(256, TP <= 3 ? 2 : 1) void dense_strip_kernel(const
                 }
             }
         }
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the last group's LDS reads, before the next pass
         __builtin_amdgcn_s_barrier();                                    // (or chunk) may touch LDS again
     }
@@ -360,7 +423,7 @@ __global__ __launch_bounds__(256, TP <= 3 ? 2 : 1) void dense_strip_kernel(const
 
 template <bool BF16, int EPI, int TP, int RD>
 static int launch_strip(const DenseArgs& a, hipStream_t s) {
-    const int oesz = (EPI == kEpiResid || !BF16 || a.out_f32) ? 4 : 2;
+    const int oesz = (EPI == kEpiResid || EPI == kEpiMul || !BF16 || a.out_f32) ? 4 : 2;      // staged element: fp32 for the two-operand epilogues
     const size_t stage = (size_t)2 * (EPI == kEpiGelu ? 2 : 1) * 16 * (4 * TP * 16 * oesz + 16);
     const size_t lds = 3 * 128 * sizeof(int64_t) + (size_t)128 * a.KC * (BF16 ? 2 : 4) + stage;
     auto k = dense_strip_kernel<BF16, EPI, TP, RD>;
@@ -399,12 +462,13 @@ int dense_nt(bool bf16, int epilogue, const DenseArgs& a0, hipStream_t s) {
     if (a0.N % 16 || a0.KC % 64 || a0.K % a0.KC || a0.KC <= 0 || a0.M < 0) return PF_ERR_BAD_ARG;
     if (a0.M == 0) return PF_OK;
     DenseArgs a = a0;
+    if (epilogue == kEpiMul && bf16 && a.out_f32) return PF_ERR_BAD_ARG;         // (operand and output share one type)
     if (a.k_splits > 1 && (epilogue != kEpiPlain || !(a.out_f32 || !bf16) || a.k_splits > a.K / a.KC)) return PF_ERR_BAD_ARG;
     // the strip image (128 rows x KC) + the epilogue's staging must fit 160 KiB of LDS: halve the chunk while it does not
     // (fp32 with KC = 256: 128 KiB of image alone)
     auto lds_of = [&](int kc) {
         const int tp = (a.N / 16) % 16 == 0 && (a.N / 16) % 12 != 0 ? 4 : 3;
-        const int oesz = (epilogue == kEpiResid || !bf16 || a.out_f32) ? 4 : 2;
+        const int oesz = (epilogue == kEpiResid || epilogue == kEpiMul || !bf16 || a.out_f32) ? 4 : 2;
         return (size_t)3 * 128 * 8 + (size_t)128 * kc * (bf16 ? 2 : 4) + (size_t)2 * (epilogue == kEpiGelu ? 2 : 1) * 16 * (4 * tp * 16 * oesz + 16);
     };
     while (lds_of(a.KC) > 160 * 1024 && a.KC % 128 == 0 && a.a_chunk_stride <= 0 && a.k_splits <= 1) a.KC /= 2;
