@@ -92,7 +92,8 @@ __global__ __launch_bounds__(256, TP <= 3 ? 2 : 1) void dense_strip_kernel(const
     int64_t* s_aoff = reinterpret_cast<int64_t*>(smem);                // [BM] element offset of the row in A, -1 beyond M
     int64_t* s_ooff = s_aoff + BM;                                      // [BM] element offset of the row in out
     int64_t* s_xoff = s_ooff + BM;                                      // [BM] ... in the auxiliary operands (dact / resid / mul)
-    char* img = smem + 3 * BM * sizeof(int64_t);
+    int32_t* s_vlim = reinterpret_cast<int32_t*>(s_xoff + BM);          // [BM] output elements of the row that exist (o_valid_per_seq)
+    char* img = smem + 3 * BM * sizeof(int64_t) + BM * sizeof(int32_t);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -143,15 +144,21 @@ __global__ __launch_bounds__(256, TP <= 3 ? 2 : 1) void dense_strip_kernel(const
     if (tid < BM) {
         const int64_t m = m0 + tid;
         int64_t ao = -1, oo = -1, xo = -1;
+        int32_t vl = 0x7fffffff;
         if (m < p.M) {
             const int64_t n = m / p.rows_per_seq, pos = m - n * p.rows_per_seq;
             ao = n * p.a_seq_stride + pos * p.lda;
             oo = n * p.o_seq_stride + pos * p.ldo;
             xo = n * (p.x_seq_stride ? p.x_seq_stride : p.o_seq_stride) + pos * p.ldo;
+            if (p.o_valid_per_seq > 0) {                         // (one division per row here, none per stored piece)
+                const int64_t left = p.o_valid_per_seq - pos * p.ldo;
+                vl = left < 0 ? 0 : (left > 0x7fffffff ? 0x7fffffff : (int32_t)left);
+            }
         }
         s_aoff[tid] = ao;
         s_ooff[tid] = oo;
         s_xoff[tid] = xo;
+        s_vlim[tid] = vl;
     }
     __syncthreads();
 
@@ -276,7 +283,8 @@ __global__ __launch_bounds__(256, TP <= 3 ? 2 : 1) void dense_strip_kernel(const
                     if (idx < 16 * CPROW) {
                         const int64_t xo = s_xoff[16 * cgx + r16];
                         const int col = pcol0 + ch * EPC;
-                        if (xo >= 0 && col < p.N) dst[np] = *reinterpret_cast<const u32x4*>(auxb + (xo + col) * OESZ);
+                        const bool ok = xo >= 0 && col < p.N && col + EPC <= s_vlim[16 * cgx + r16];   // (the operand ends where the output does)
+                        if (ok) dst[np] = *reinterpret_cast<const u32x4*>(auxb + (xo + col) * OESZ);
                     }
                 }
             };
@@ -309,12 +317,7 @@ __global__ __launch_bounds__(256, TP <= 3 ? 2 : 1) void dense_strip_kernel(const
                     if (idx >= 16 * CPROW) continue;
                     const int64_t oo = s_ooff[grow];
                     const int col = pcol0 + ch * EPC;
-                    if (oo < 0 || col >= p.N) continue;
-                    if (p.o_valid_per_seq > 0) {
-                        const int64_t m = m0 + grow;
-                        const int64_t pos = m - (m / p.rows_per_seq) * p.rows_per_seq;
-                        if (pos * p.ldo + col + EPC > p.o_valid_per_seq) continue;
-                    }
+                    if (oo < 0 || col >= p.N || col + EPC > s_vlim[grow]) continue;
                     const u32x4 a = aux[cg % Q][np];
                     char* dst = reinterpret_cast<char*>(p.out) + (oo + col) * OESZ;
                     if constexpr (OESZ == 4) {
@@ -390,12 +393,7 @@ __global__ __launch_bounds__(256, TP <= 3 ? 2 : 1) void dense_strip_kernel(const
                 const int grow = 16 * cg + r16;
                 const int64_t oo = s_ooff[grow];
                 const int col = pcol0 + ch * epc;
-                if (oo < 0 || col >= p.N) continue;
-                if (p.o_valid_per_seq > 0) {
-                    const int64_t m = m0 + grow;
-                    const int64_t pos = m - (m / p.rows_per_seq) * p.rows_per_seq;
-                    if (pos * p.ldo + col + epc > p.o_valid_per_seq) continue;
-                }
+                if (oo < 0 || col >= p.N || col + epc > s_vlim[grow]) continue;
                 const u32x4 val = *reinterpret_cast<const u32x4*>(buf + r16 * srow + ch * 16);
                 if constexpr (EPI == kEpiPlain) {
                     if (ksp > 1) {                                       // (fp32 output: host-checked)
@@ -425,7 +423,7 @@ template <bool BF16, int EPI, int TP, int RD>
 static int launch_strip(const DenseArgs& a, hipStream_t s) {
     const int oesz = (EPI == kEpiResid || EPI == kEpiMul || !BF16 || a.out_f32) ? 4 : 2;      // staged element: fp32 for the two-operand epilogues
     const size_t stage = (size_t)2 * (EPI == kEpiGelu ? 2 : 1) * 16 * (4 * TP * 16 * oesz + 16);
-    const size_t lds = 3 * 128 * sizeof(int64_t) + (size_t)128 * a.KC * (BF16 ? 2 : 4) + stage;
+    const size_t lds = 3 * 128 * sizeof(int64_t) + 128 * sizeof(int32_t) + (size_t)128 * a.KC * (BF16 ? 2 : 4) + stage;
     auto k = dense_strip_kernel<BF16, EPI, TP, RD>;
     if (lds > 160 * 1024) return PF_ERR_UNSUPPORTED;
     if (lds > 64 * 1024 && !opt_in_lds(reinterpret_cast<const void*>(k), (int)lds)) return PF_ERR_HIP;
@@ -469,9 +467,13 @@ int dense_nt(bool bf16, int epilogue, const DenseArgs& a0, hipStream_t s) {
     auto lds_of = [&](int kc) {
         const int tp = (a.N / 16) % 16 == 0 && (a.N / 16) % 12 != 0 ? 4 : 3;
         const int oesz = (epilogue == kEpiResid || epilogue == kEpiMul || !bf16 || a.out_f32) ? 4 : 2;
-        return (size_t)3 * 128 * 8 + (size_t)128 * kc * (bf16 ? 2 : 4) + (size_t)2 * (epilogue == kEpiGelu ? 2 : 1) * 16 * (4 * tp * 16 * oesz + 16);
+        return (size_t)3 * 128 * 8 + 128 * 4 + (size_t)128 * kc * (bf16 ? 2 : 4) + (size_t)2 * (epilogue == kEpiGelu ? 2 : 1) * 16 * (4 * tp * 16 * oesz + 16);
     };
     while (lds_of(a.KC) > 160 * 1024 && a.KC % 128 == 0 && a.a_chunk_stride <= 0 && a.k_splits <= 1) a.KC /= 2;
+    // two workgroups per CU where one pass covers the output (<= 12 tiles): a 128 x 256 image + staging is 90 KB = ONE
+    // workgroup of 4 waves per CU, whose staging, MFMA and store phases do not overlap with anything (conv2's data gradient:
+    // 720 us at KC = 256, 500 us at KC = 128)
+    if (a.N / 16 <= 12 && lds_of(a.KC) > 80 * 1024 && a.KC % 128 == 0 && a.a_chunk_stride <= 0 && a.k_splits <= 1) a.KC /= 2;
     switch (epilogue) {
     case kEpiPlain: return bf16 ? launch_strip_tp<true, kEpiPlain>(a, s) : launch_strip_tp<false, kEpiPlain>(a, s);
     case kEpiGelu: return bf16 ? launch_strip_tp<true, kEpiGelu>(a, s) : launch_strip_tp<false, kEpiGelu>(a, s);
