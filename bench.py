@@ -354,7 +354,8 @@ def config4_train_step(dev, precision, events=1024, reps=5):
     def step():
         idx = torch.randint(0, ds.n_events, (events,), device=dev, generator=g)
         strain, labels, nsig, _ = ds.batch(idx, generator=g)
-        return train.train_step(model, opt, sched, strain, labels, nsig)["loss"]        # row_cap="exact": the existing pairs
+        # row_cap="exact": the existing pairs; sync=False: the loss stays on the device (read once, after the timed steps)
+        return train.train_step(model, opt, sched, strain, labels, nsig, sync=False)["loss"]
 
     for _ in range(2):
         loss = step()
@@ -364,7 +365,7 @@ def config4_train_step(dev, precision, events=1024, reps=5):
         loss = step()
     torch.cuda.synchronize(dev)
     dt = (time.perf_counter() - t0) / reps
-    assert torch.isfinite(torch.as_tensor(loss)).all(), "training step produced a non-finite loss"
+    assert bool(torch.isfinite(torch.as_tensor(loss)).all()), "training step produced a non-finite loss"
     return {f"train_step_ms_{events}": dt * 1e3, f"train_events_per_s_{events}": events / dt}
 
 
