@@ -250,12 +250,23 @@ __global__ __launch_bounds__(256, BF16 ? 3 : 1) void attn_fwd_kernel(const AttnA
     const uint32_t thr = enc_drop_threshold(a.drop_p);
     const float dscale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
     const int ntile = (T + 15) >> 4;
+    // the next tile's global operands are requested before this tile's arithmetic (unconditionally, on a clamped tile: a
+    // conditional load would make the compiler drain the queue): requested at the top of their own tile they cost one exposed
+    // round trip per tile, three per wave
+    HeadFrag<BF16> qf_next;
+    {
+        const int q0 = 16 * (wave < ntile ? wave : ntile - 1) + c;
+        global_head_frag<BF16>(qf_next, a.qkv, (r0 + (q0 < T ? q0 : T - 1)) * (3 * kEncD) + kEncHd * h, true, g);
+    }
 #pragma unroll 1
     for (int qt = wave; qt < ntile; qt += 4) {
         const int q = 16 * qt + c;
         const bool qv = q < T;
-        HeadFrag<BF16> qf;
-        global_head_frag<BF16>(qf, a.qkv, (r0 + q) * (3 * kEncD) + kEncHd * h, qv, g);
+        HeadFrag<BF16> qf = qf_next;
+        {
+            const int qn = 16 * (qt + 4 < ntile ? qt + 4 : qt) + c;
+            global_head_frag<BF16>(qf_next, a.qkv, (r0 + (qn < T ? qn : T - 1)) * (3 * kEncD) + kEncHd * h, true, g);
+        }
         f32x4 s[12];
         float mx = -INFINITY;
 #pragma unroll
@@ -325,14 +336,24 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
     const float dscale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
     const int ntile = (T + 15) >> 4;
     const uint32_t idx_base = (uint32_t)((e * kEncHeads + h) * T) * (uint32_t)kEncMaxTokens;
+    HeadFrag<BF16> qf_next, dof_next, of_next;
+    float lse_next;
+    auto request = [&](int qt_) {                     // (clamped: always a valid row; rows beyond T are masked by qv below)
+        const int qq = 16 * qt_ + c;
+        const int64_t row = r0 + (qq < T ? qq : T - 1);
+        global_head_frag<BF16>(qf_next, a.qkv, row * (3 * kEncD) + kEncHd * h, true, g);
+        global_head_frag<BF16>(dof_next, a.dout, row * kEncD + kEncHd * h, true, g);
+        global_head_frag<BF16>(of_next, a.out, row * kEncD + kEncHd * h, true, g);
+        lse_next = a.lse[(e * kEncHeads + h) * T + (qq < T ? qq : T - 1)];
+    };
+    request(wave < ntile ? wave : ntile - 1);
 #pragma unroll 1
     for (int qt = wave; qt < ntile; qt += 4) {
         const int q = 16 * qt + c;
         const bool qv = q < T;
-        HeadFrag<BF16> qf, dof, of;
-        global_head_frag<BF16>(qf, a.qkv, (r0 + q) * (3 * kEncD) + kEncHd * h, qv, g);
-        global_head_frag<BF16>(dof, a.dout, (r0 + q) * kEncD + kEncHd * h, qv, g);
-        global_head_frag<BF16>(of, a.out, (r0 + q) * kEncD + kEncHd * h, qv, g);
+        HeadFrag<BF16> qf = qf_next, dof = dof_next, of = of_next;
+        const float lse_cur = lse_next;
+        request(qt + 4 < ntile ? qt + 4 : qt);
         // delta_q = dO[q] . O[q] over the head's 32 features: this lane's 8, then across the four lane groups
         float del_q = 0.f;
         if constexpr (BF16) {
@@ -345,7 +366,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
         }
         del_q += __shfl_xor(del_q, 16);
         del_q += __shfl_xor(del_q, 32);
-        const float lse_q = qv ? a.lse[(e * kEncHeads + h) * T + q] : 0.f;
+        const float lse_q = qv ? lse_cur : 0.f;
         f32x4 dq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll 2
         for (int kt = 0; kt < ntile; ++kt) {
@@ -408,13 +429,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
     const float dscale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
     const int ntile = (T + 15) >> 4;
     const uint32_t idx_base = (uint32_t)((e * kEncHeads + h) * T) * (uint32_t)kEncMaxTokens;
+    HeadFrag<BF16> kf_next, vf_next;
+    auto request = [&](int kt_) {
+        const int kk = 16 * kt_ + c;
+        const int64_t row = r0 + (kk < T ? kk : T - 1);
+        global_head_frag<BF16>(kf_next, a.qkv, row * (3 * kEncD) + kEncD + kEncHd * h, true, g);
+        global_head_frag<BF16>(vf_next, a.qkv, row * (3 * kEncD) + 2 * kEncD + kEncHd * h, true, g);
+    };
+    request(wave < ntile ? wave : ntile - 1);
 #pragma unroll 1
     for (int kt = wave; kt < ntile; kt += 4) {
         const int key = 16 * kt + c;
         const bool kv = key < T;
-        HeadFrag<BF16> kf, vf;
-        global_head_frag<BF16>(kf, a.qkv, (r0 + key) * (3 * kEncD) + kEncD + kEncHd * h, kv, g);
-        global_head_frag<BF16>(vf, a.qkv, (r0 + key) * (3 * kEncD) + 2 * kEncD + kEncHd * h, kv, g);
+        HeadFrag<BF16> kf = kf_next, vf = vf_next;
+        request(kt + 4 < ntile ? kt + 4 : kt);
         f32x4 dk[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
         f32x4 dv[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll 2
