@@ -57,7 +57,7 @@ class _EncoderTrainFn(torch.autograd.Function):
         b = strain.shape[0]
         n_extra = 0 if extra is None else extra.shape[1]
         desc = _lib.PfEmbedTrainDesc(prec, n_det, n_extra, 1 if training else 0, float(dropout_p), int(seed))
-        key = (dev, prec, tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
+        key = (_lib.param_epoch(), dev, prec, tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
         if state.get("key") != key:        # flat fp32 copy of the parameters + their MFMA fragments, once per weight update
             if len(params) == 1:           # flat mode: the leaf IS the raw layout
                 raw = params[0].detach()

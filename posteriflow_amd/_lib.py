@@ -201,3 +201,32 @@ def check(rc: int, what: str):
         if rc == PF_ERR_UNSUPPORTED:
             raise NotImplementedError(f"{what}: {msg}")
         raise PfError(f"{what}: HIP error: {msg}")
+
+
+# ---- parameter epoch -----------------------------------------------------------------------------------------------------
+# The packed-weight caches are keyed on the parameters' version counters.  torch's fused optimisers (AdamW(fused=True),
+# torch._fused_adamw_) update parameters WITHOUT bumping those counters (measured: leaf and view versions 0 -> 0 across
+# opt.step()), so a cache keyed on versions alone would keep serving the weights of before the step.  Every optimiser step
+# anywhere in the process therefore advances a global epoch that is part of every key.  Weights edited through ``.data`` or
+# ``torch.no_grad`` tricks that bypass version counting need ``invalidate_packed_caches()``.
+_PARAM_EPOCH = [0]
+
+
+def param_epoch() -> int:
+    return _PARAM_EPOCH[0]
+
+
+def invalidate_packed_caches() -> None:
+    """call after changing parameters in a way autograd's version counters do not see"""
+    _PARAM_EPOCH[0] += 1
+
+
+def _install_optimizer_hook() -> None:
+    try:
+        from torch.optim.optimizer import register_optimizer_step_post_hook
+        register_optimizer_step_post_hook(lambda opt, args, kwargs: invalidate_packed_caches())
+    except Exception:                                  # pragma: no cover -- torch without global optimiser hooks
+        pass
+
+
+_install_optimizer_hook()

@@ -430,10 +430,10 @@ class NSFPosteriorFlow(nn.Module):
         """(flat fp32 copy of the transform parameters in raw-layout order, key of the weights it was made from); in flat
         mode the leaf itself"""
         if self._theta is not None:
-            key = (dev, self._theta._version, self._theta.data_ptr())
+            key = (_lib.param_epoch(), dev, self._theta._version, self._theta.data_ptr())
             return self._theta.detach(), key
         params = self._ordered_parameters()
-        key = (dev, tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
+        key = (_lib.param_epoch(), dev, tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
         rk = self.__dict__.get("_raw_cache")          # one flat copy of the parameters serves every stream of a weight update
         if rk is not None and rk[0] == key:
             return rk[1], key
@@ -853,7 +853,7 @@ class NSFPosteriorFlow(nn.Module):
         parameter changed."""
         params = self._ordered_parameters()
         f32 = self.precision != "bf16"
-        key = (dev, f32, tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
+        key = (_lib.param_epoch(), dev, f32, tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
         st = self.__dict__.setdefault("_inc", {}).setdefault(self.precision, {})
         if st.get("key") == key:
             return st

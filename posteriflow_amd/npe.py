@@ -237,7 +237,7 @@ class LeanStrainEncoder(nn.Module):
         L = _lib.lib()
         prec = _lib.PRECISIONS[self.precision]
         params = self._stem_params()
-        key = (dev, prec, tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
+        key = (_lib.param_epoch(), dev, prec, tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
         st = self.__dict__.setdefault("_stem_state", {})
         if st.get("key") != key:
             if st.get("map_prec") != (dev, prec):
@@ -300,7 +300,7 @@ class LeanStrainEncoder(nn.Module):
         overwritten with the Transformer output."""
         L, dev = _lib.lib(), tok.device
         params = self._mixer_params()
-        key = (dev, tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
+        key = (_lib.param_epoch(), dev, tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
         st = self.__dict__.setdefault("_mixer_state", {})
         e = 192
         if st.get("key") != key:

@@ -12,6 +12,7 @@ The loss value comes from the HIP kernels; gradients flow through the interim te
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, Iterable, List, Optional
 
 import torch
@@ -22,8 +23,13 @@ from .npe import LeanNPE, batch_nll
 LR, WEIGHT_DECAY, WARMUP_STEPS, GRAD_CLIP = 3e-4, 1e-5, 500, 5.0      # train_lean_npe.py:185-188, 301, 366
 
 
-def make_optimizer(model: torch.nn.Module, lr: float = LR) -> torch.optim.Optimizer:
-    return torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=WEIGHT_DECAY)
+def make_optimizer(model: torch.nn.Module, lr: float = LR, fused: Optional[bool] = None) -> torch.optim.Optimizer:
+    """AdamW with the reference's hyper-parameters (train_lean_npe.py:301-311).  ``fused``: torch's single-launch
+    implementation (same update rule); default: on when every parameter lives on a GPU."""
+    params = list(model.parameters())
+    if fused is None:
+        fused = len(params) > 0 and all(p.is_cuda for p in params) and os.environ.get("PF_FUSED_ADAMW", "1") != "0"
+    return torch.optim.AdamW(params, lr=lr, weight_decay=WEIGHT_DECAY, fused=bool(fused))
 
 
 def lr_factor(step: int, total_steps: int, warmup_steps: int = WARMUP_STEPS) -> float:

@@ -157,7 +157,9 @@ def test_train_step_reduces_loss_gpu(precision):
     params = torch.stack([recipe.physical_params(8, seed=30 + r) for r in range(5)], dim=1).cuda()
     nsig = torch.tensor([1, 2, 1, 3, 1, 1, 2, 1]).cuda()
     losses = [train_step(model, opt, sched, strain, params, nsig)["loss"] for _ in range(8)]
-    assert all(math.isfinite(v) for v in losses) and losses[-1] < losses[0]
+    # (the trajectory of 8 events at lr 1e-3 is spiky and, with float atomics in the gradients, not bit-reproducible: 14.1 ->
+    # 9 .. 12 over the last steps in every run observed)
+    assert all(math.isfinite(v) for v in losses) and min(losses[-3:]) < losses[0] - 1.0, losses
     ck = checkpoint_dict(model, 0, losses[-1])
     assert set(ck) == {"model_state_dict", "epoch", "val_nll", "diagnostics", "args"}
     model.eval()
@@ -190,3 +192,42 @@ def test_config4_training_step_at_per_gpu_size():
         out.append(train_step(model, opt, sched, strain, labels, nsig, row_cap=2048))
     assert all(math.isfinite(o["loss"]) and math.isfinite(o["grad_norm"]) and o["grad_norm"] > 0 for o in out), out
     assert any(not torch.equal(b, p.detach()) for b, p in zip(before, list(model.parameters())[:4]))
+
+
+@pytest.mark.gpu
+def test_fused_optimizer_updates_reach_the_kernels():
+    """torch's fused AdamW updates parameters without bumping their version counters (leaf and views: 0 -> 0); the packed
+    weights are keyed on an optimiser-step epoch as well, so the step after a fused update evaluates the NEW weights: the
+    trajectory equals the unfused optimiser's, and an eval-mode call right after a step sees the update."""
+    from posteriflow_amd import npe, train
+    from posteriflow_amd.remix import synthetic_dataset
+    dev = torch.device("cuda")
+    ds = synthetic_dataset(dev, n_noise=64, n_events=64, seed=0)
+    traj = {}
+    for fused in (False, True):
+        torch.manual_seed(0)
+        model = npe.LeanNPE().to(dev).train().set_precision("fp32").flatten_parameters()
+        for l in model.encoder.fusion.layers:                          # (no dropout: the two runs must be comparable)
+            l.dropout.p = l.dropout1.p = l.dropout2.p = 0.0
+            l.self_attn.dropout = 0.0
+        opt = train.make_optimizer(model, lr=1e-4, fused=fused)
+        g = torch.Generator(device=dev).manual_seed(0)
+        losses = []
+        for it in range(3):
+            idx = torch.randint(0, ds.n_events, (8,), device=dev, generator=g)
+            strain, labels, nsig, _ = ds.batch(idx, generator=g)
+            losses.append(train.train_step(model, opt, None, strain, labels, nsig)["loss"])
+        rank0 = torch.zeros(8, dtype=torch.long, device=dev)
+        model.eval()
+        with torch.no_grad():
+            before = model.nll(strain, labels[:, 0], rank0).sum().item()
+        model.train()
+        train.train_step(model, opt, None, strain, labels, nsig)
+        model.eval()
+        with torch.no_grad():
+            after = model.nll(strain, labels[:, 0], rank0).sum().item()
+        assert abs(after - before) > 1e-4 * abs(before), (fused, before, after)      # the eval call saw the step
+        traj[fused] = losses
+    assert traj[False][0] == traj[True][0]
+    for a, b in zip(traj[False], traj[True]):          # same trajectory: the step after a fused update used the new weights
+        assert abs(a - b) < 2e-3 * abs(a), traj
