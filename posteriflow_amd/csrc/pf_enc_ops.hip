@@ -612,23 +612,21 @@ __global__ __launch_bounds__(256) void pool_kernel(const PoolArgs a) {
 // ---------------------------------------------------------------------------------------------------------------------
 // token assembly and small element-wise kernels
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void tok_assemble_kernel(const float* __restrict__ stem, const float* __restrict__ extra,
+__global__ __launch_bounds__(192) void tok_assemble_kernel(const float* __restrict__ stem, const float* __restrict__ extra,
                                                            const float* __restrict__ bias, int64_t B, int n_extra, int n_stem,
                                                            float* __restrict__ x0) {
+    // 4 token rows per workgroup (48 lanes x 16 bytes each), blockIdx.y strides over the events: the row / token / event
+    // indices are block-level integers, not three 64-bit divisions per element
     const int T = n_extra + n_stem;
-    const int64_t total = B * T * (kEncD / 4);
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int c4 = (int)(i % (kEncD / 4));
-        const int64_t row = i / (kEncD / 4);
-        const int t = (int)(row % T);
-        const int64_t e = row / T;
+    const int t = 4 * blockIdx.x + threadIdx.x / 48, c4 = 4 * (threadIdx.x % 48);
+    if (t >= T) return;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias && t >= n_extra) bv = *reinterpret_cast<const f32x4*>(bias + (int64_t)t * kEncD + c4);
+    for (int64_t e = blockIdx.y; e < B; e += gridDim.y) {
         f32x4 v;
-        if (t < n_extra) v = *reinterpret_cast<const f32x4*>(extra + (e * n_extra + t) * kEncD + 4 * c4);
-        else {
-            v = *reinterpret_cast<const f32x4*>(stem + (e * n_stem + (t - n_extra)) * kEncD + 4 * c4);
-            if (bias) v += *reinterpret_cast<const f32x4*>(bias + (int64_t)t * kEncD + 4 * c4);
-        }
-        *reinterpret_cast<f32x4*>(x0 + row * kEncD + 4 * c4) = v;
+        if (t < n_extra) v = *reinterpret_cast<const f32x4*>(extra + (e * n_extra + t) * kEncD + c4);
+        else v = *reinterpret_cast<const f32x4*>(stem + (e * n_stem + (t - n_extra)) * kEncD + c4) + bv;
+        *reinterpret_cast<f32x4*>(x0 + (e * T + t) * kEncD + c4) = v;
     }
 }
 
@@ -636,26 +634,25 @@ template <bool BF16>
 __global__ __launch_bounds__(192) void tok_backward_kernel(const float* __restrict__ dx0, const void* __restrict__ dact, int64_t B,
                                                            int n_extra, int n_det, void* __restrict__ gpad, int64_t gseq,
                                                            int64_t goff, float* __restrict__ dextra, float* __restrict__ dbias) {
+    // 4 tokens per workgroup, 48 lanes x 4 channels per token row (16-byte loads, 8-byte bf16 stores); blockIdx.y = a range of
+    // events; 4 events per iteration with the loads first.  (One channel per thread and one event at a time: 2-byte stores and 64
+    // dependent round trips per thread, 143 us for 288 MB.)
     const int T = n_extra + 61 * n_det;
-    const int t = blockIdx.x, cc = threadIdx.x;
+    const int t = 4 * blockIdx.x + threadIdx.x / 48, c4 = 4 * (threadIdx.x % 48);
+    if (t >= T) return;
     const int64_t per = (B + gridDim.y - 1) / gridDim.y;
     const int64_t e0 = (int64_t)blockIdx.y * per, e1 = e0 + per < B ? e0 + per : B;
-    float sum = 0.f;
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
     const int j = t - n_extra, d = j >= 0 ? j / 61 : 0, pp = j >= 0 ? j - 61 * d : 0;
-    // 8 events per iteration, loads first (one event at a time = 64 dependent round trips per thread: 142 us)
-    constexpr int U = 8;
+    constexpr int U = 4;
     for (int64_t eb = e0; eb < e1; eb += U) {
-        float v[U], da[U];
+        f32x4 v[U], da[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t e = eb + u < e1 ? eb + u : e1 - 1;
-            v[u] = dx0[(e * T + t) * kEncD + cc];
-            da[u] = 1.f;
-            if (t >= n_extra) {
-                const int64_t src = ((e * n_det + d) * 61 + pp) * kEncD + cc;
-                if constexpr (BF16) da[u] = (float)reinterpret_cast<const __bf16*>(dact)[src];
-                else da[u] = reinterpret_cast<const float*>(dact)[src];
-            }
+            v[u] = *reinterpret_cast<const f32x4*>(dx0 + (e * T + t) * kEncD + c4);
+            da[u] = f32x4{1.f, 1.f, 1.f, 1.f};
+            if (t >= n_extra) da[u] = load_act4<BF16>(dact, ((e * n_det + d) * 61 + pp) * kEncD + c4);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -663,16 +660,16 @@ __global__ __launch_bounds__(192) void tok_backward_kernel(const float* __restri
             if (e >= e1) break;
             sum += v[u];
             if (t < n_extra) {
-                if (dextra) dextra[(e * n_extra + t) * kEncD + cc] = v[u];
+                if (dextra) *reinterpret_cast<f32x4*>(dextra + (e * n_extra + t) * kEncD + c4) = v[u];
             } else {
-                const int64_t n = e * n_det + d;
-                const int64_t dst = n * gseq + goff + (int64_t)pp * kEncD + cc;
-                if constexpr (BF16) reinterpret_cast<__bf16*>(gpad)[dst] = (__bf16)(v[u] * da[u]);
-                else reinterpret_cast<float*>(gpad)[dst] = v[u] * da[u];
+                store_act4<BF16>(gpad, (e * n_det + d) * gseq + goff + (int64_t)pp * kEncD + c4, v[u] * da[u]);
             }
         }
     }
-    if (dbias && e0 < e1) atomicAdd(dbias + (int64_t)t * kEncD + cc, sum);
+    if (dbias && e0 < e1) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) atomicAdd(dbias + (int64_t)t * kEncD + c4 + k, sum[k]);
+    }
 }
 
 __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int64_t n4) {
@@ -749,19 +746,20 @@ int pool_backward(bool bf16, const PoolArgs& a, hipStream_t s) {
 int tok_assemble(const float* stem_tokens, const float* extra, const float* token_bias, int64_t B, int n_extra, int n_stem,
                  float* x0, hipStream_t s) {
     if (B <= 0) return PF_OK;
-    const int64_t total = B * (n_extra + n_stem) * (kEncD / 4);
-    hipLaunchKernelGGL(tok_assemble_kernel, dim3(grid_for(total, 256 * 4)), dim3(256), 0, s, stem_tokens, extra, token_bias, B, n_extra,
-                       n_stem, x0);
+    const int T = n_extra + n_stem;
+    hipLaunchKernelGGL(tok_assemble_kernel, dim3((unsigned)((T + 3) / 4), (unsigned)(B < 256 ? B : 256)), dim3(192), 0, s, stem_tokens, extra,
+                       token_bias, B, n_extra, n_stem, x0);
     return launch_status();
 }
 int tok_backward(bool bf16, const float* dx0, const void* dact, int64_t B, int n_extra, int n_det, void* gpad, int64_t gpad_seq_stride,
                  int64_t gpad_offset, float* dextra, float* dbias, hipStream_t s) {
     if (B <= 0) return PF_OK;
     const int T = n_extra + 61 * n_det;
-    const unsigned ny = (unsigned)(B < 16 ? B : 16);
-    if (bf16) hipLaunchKernelGGL(tok_backward_kernel<true>, dim3(T, ny), dim3(192), 0, s, dx0, dact, B, n_extra, n_det, gpad,
+    const unsigned ny = (unsigned)(B < 64 ? B : 64);
+    const dim3 grid((unsigned)((T + 3) / 4), ny);
+    if (bf16) hipLaunchKernelGGL(tok_backward_kernel<true>, grid, dim3(192), 0, s, dx0, dact, B, n_extra, n_det, gpad,
                                  gpad_seq_stride, gpad_offset, dextra, dbias);
-    else hipLaunchKernelGGL(tok_backward_kernel<false>, dim3(T, ny), dim3(192), 0, s, dx0, dact, B, n_extra, n_det, gpad,
+    else hipLaunchKernelGGL(tok_backward_kernel<false>, grid, dim3(192), 0, s, dx0, dact, B, n_extra, n_det, gpad,
                             gpad_seq_stride, gpad_offset, dextra, dbias);
     return launch_status();
 }

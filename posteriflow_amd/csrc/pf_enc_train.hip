@@ -222,20 +222,33 @@ __global__ __launch_bounds__(256) void drop_cast_kernel(const float* __restrict_
     typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
     const uint32_t thr = enc_drop_threshold(p);
     const float sc = p > 0.f ? 1.f / (1.f - p) : 1.f;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * i);
-        if (p > 0.f) {
-            f32x4 fac;
-            enc_drop4(seed, site, (uint32_t)(4 * i), thr, sc, fac);
-            v = v * fac;
-        }
-        if (bf16) {
-            bf16x4 o;
+    // 4 pieces per thread and iteration, loads first
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < n4; i0 += 4 * stride) {
+        f32x4 v[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
-            *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(dst) + 4 * i) = o;
-        } else {
-            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(dst) + 4 * i) = v;
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = i0 + u * stride;
+            v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (i < n4) v[u] = *reinterpret_cast<const f32x4*>(src + 4 * i);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = i0 + u * stride;
+            if (i >= n4) break;
+            if (p > 0.f) {
+                f32x4 fac;
+                enc_drop4(seed, site, (uint32_t)(4 * i), thr, sc, fac);
+                v[u] = v[u] * fac;
+            }
+            if (bf16) {
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[u][e];
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(dst) + 4 * i) = o;
+            } else {
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(dst) + 4 * i) = v[u];
+            }
         }
     }
 }
