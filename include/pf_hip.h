@@ -98,8 +98,10 @@ typedef struct PfFlowDesc {
  * hidden_features % 16 == 0, <= 512, features <= 32, num_bins <= 32 whose workgroup image fits 160 KB of LDS (the reference
  * also builds 12 x 384 x 24 heads, experiments/frozen_context_heads.py:159-163) is served by one generic kernel behind the
  * SAME entry points: pf_flow_raw_param_count / packed_bytes / pack_map_len / build_pack_map / pack, pf_flow_forward,
- * pf_flow_forward_reduce, pf_flow_inverse.  The training, incremental-inverse, large-batch and backward entry points
- * return PF_ERR_UNSUPPORTED for such a shape. */
+ * pf_flow_forward_reduce, pf_flow_forward_train (layer inputs; no dropout), pf_flow_inverse, and -- fp32 descs, features <= 16,
+ * hidden_features in {64, 128, 192, 256, 384, 512}, num_bins <= 32 -- pf_flow_reevaluate (PF_FLAG_GENERIC layout),
+ * pf_flow_backward_chain and pf_flow_rqs_backward.  The incremental-inverse, large-batch and bf16 backward entry points return
+ * PF_ERR_UNSUPPORTED for such a shape. */
 
 /* ---- raw parameter layout -------------------------------------------------
  * One flat fp32 buffer, layer after layer, each layer in nflows state_dict
@@ -416,6 +418,8 @@ typedef struct PfDenseArgs {
     int32_t out_f32;          /* PF_EPI_PLAIN: fp32 output in either precision */
     int64_t a_chunk_stride;   /* > 0: k-chunk c of every row starts at A + c * a_chunk_stride (+ the row's offset) instead of
                                * c * KC elements into the row: the reduction runs over K / KC separate [rows][KC] slabs */
+    int32_t a_slab_chunks;    /* > 1 (with a_chunk_stride): a slab holds this many consecutive chunks of KC -- chunk c starts at
+                               * (c / a_slab_chunks) a_chunk_stride + (c % a_slab_chunks) KC (slabs wider than the LDS image allows) */
     int32_t k_splits;         /* > 1 (PF_EPI_PLAIN, out_f32, K / KC chunks): the chunks are divided over k_splits workgroups per
                                * strip which ADD their partial sums into out with float atomics -- out must hold zeros (or the
                                * value to accumulate onto); for few-row, long-reduction products that would leave CUs idle */

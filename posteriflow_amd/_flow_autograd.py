@@ -188,12 +188,15 @@ def _flow_backward_batched(flow, U, ctx, g_z, g_lad, drop=None, nll=None):
                                    + [st(lambda n: n.blocks[j].context_layer.weight) for j in range(nb)], dim=1))
         return Wcat_[0]
     # bf16 mode: re-evaluation and chain are HIP kernels reading the packed PF_FLAG_BWD stream (one gather per weight update)
-    bf = flow.precision == "bf16" and H % 32 == 0 and nb == 2 and U.is_contiguous() and (ctx is None or ctx.is_contiguous())
+    generic = flow._generic_shape()      # shapes of the generic forward kernel: fp32 re-evaluation + fp32 chain in either precision
+    bf = (flow.precision == "bf16" and H % 32 == 0 and nb == 2 and U.is_contiguous() and (ctx is None or ctx.is_contiguous())
+          and not generic)
 
     # 1. conditioners
     cmp = bf and REEVAL_HIP and COMPACT
     # fp32 (parity) mode: the same launch in exact-fp32 MFMA arithmetic (the generic kernel's conditioner)
-    f32_hip = (not bf) and REEVAL_HIP and flow.precision != "bf16" and nb == 2 and U.is_contiguous() and (ctx is None or ctx.is_contiguous())
+    f32_hip = ((not bf) and REEVAL_HIP and (flow.precision != "bf16" or generic) and nb == 2 and U.is_contiguous()
+               and (ctx is None or ctx.is_contiguous()))
     hip_reeval = (bf and REEVAL_HIP) or f32_hip
     if hip_reeval:
         try:
@@ -353,7 +356,13 @@ def _flow_backward_batched(flow, U, ctx, g_z, g_lad, drop=None, nll=None):
                 nt = min(per_call, tiles - t0)
                 a2 = _lib.PfDenseArgs()
                 a2.A, a2.M, a2.rows_per_seq, a2.a_seq_stride, a2.lda = Gc.data_ptr(), B, B, 0, H
-                a2.K, a2.N, a2.KC, a2.a_chunk_stride = (1 + nb) * Ln * H, 16 * nt, H, B * H
+                # a slab = one (layer, j) of Gc, H wide; its LDS image (128 rows x KC) must fit: H = 384 in fp32 goes in 3 chunks
+                kc = H
+                while 128 * kc * (2 if cmp else 4) > 96 * 1024 and kc % 128 == 0:
+                    kc //= 2
+                if 128 * kc * (2 if cmp else 4) > 96 * 1024 and H % 3 == 0 and (H // 3) % 64 == 0:
+                    kc = H // 3
+                a2.K, a2.N, a2.KC, a2.a_chunk_stride, a2.a_slab_chunks = (1 + nb) * Ln * H, 16 * nt, kc, B * H, H // kc
                 a2.wfrags = wt.data_ptr() + t0 * nks_total * 64 * 16
                 a2.out, a2.o_seq_stride, a2.ldo, a2.out_f32 = g_ctx.data_ptr() + 4 * 16 * t0, 0, C, 1
                 a2.k_splits = splits

@@ -220,8 +220,8 @@ int pf_flow_rqs_backward(const PfFlowDesc* desc, const float* u, const float* pa
                          const float* grad_logabsdet, int64_t rows, float* grad_params, float* grad_u,
                          void* stream) {
     if (!desc) return fail(PF_ERR_BAD_ARG, "desc is null");
-    if (desc->features < 1 || desc->num_bins < 2 || desc->num_bins > 16)
-        return fail(PF_ERR_UNSUPPORTED, "need features >= 1 and 2 <= num_bins <= 16");
+    if (desc->features < 1 || desc->num_bins < 2 || desc->num_bins > 32)
+        return fail(PF_ERR_UNSUPPORTED, "need features >= 1 and 2 <= num_bins <= 32");
     if (!(desc->tail_bound > 0.f)) return fail(PF_ERR_BAD_ARG, "tail_bound must be positive");
     if (rows < 0) return fail(PF_ERR_BAD_ARG, "negative rows");
     if (rows == 0) return PF_OK;
@@ -236,9 +236,12 @@ int pf_flow_rqs_backward(const PfFlowDesc* desc, const float* u, const float* pa
 int pf_flow_backward_chain(const PfFlowDesc* desc, const PfFlowBwdChainArgs* a, void* stream) {
     if (!desc || !a) return fail(PF_ERR_BAD_ARG, "null pointer");
     const int D = desc->features, H = desc->hidden_features, K = desc->num_bins;
-    if (H % 64 || H < 64 || H > 256 || D < 1 || D > 16 || K < 2 || K > 16 || desc->num_blocks != 2 || desc->num_layers < 1 ||
+    const bool f32d = desc->precision == PF_PREC_F32;
+    const bool h_ok = H == 64 || H == 128 || H == 192 || H == 256 || (f32d && (H == 384 || H == 512));
+    if (!h_ok || D < 1 || D > 16 || K < 2 || K > (f32d ? 32 : 16) || desc->num_blocks != 2 || desc->num_layers < 1 ||
         (desc->reserved & PF_FLAG_MASKED_CONTEXT))
-        return fail(PF_ERR_UNSUPPORTED, "backward chain: plain conditioner, H in {64,128,192,256}, D <= 16, K <= 16, 2 blocks");
+        return fail(PF_ERR_UNSUPPORTED, "backward chain: plain conditioner, 2 blocks, D <= 16; bf16: H in {64,128,192,256}, K <= 16; "
+                    "fp32: also H = 384, 512 and K <= 32");
     if (!(desc->tail_bound > 0.f)) return fail(PF_ERR_BAD_ARG, "tail_bound must be positive");
     if (a->batch < 0) return fail(PF_ERR_BAD_ARG, "negative batch");
     if (a->batch == 0) return PF_OK;
@@ -601,7 +604,7 @@ namespace {
 int ctx_t_plan(const PfFlowDesc* desc, pf::FlowPlan& L) {
     const int rc = layout_of(desc, L);
     if (rc != PF_OK) return rc;
-    if (L.generic || L.C <= 0 || L.C % 16 || L.NB != 2 || 3 * L.L > pf::kMaxPackEntries || (desc->reserved & PF_FLAG_MASKED_CONTEXT))
+    if (L.C <= 0 || L.C % 16 || L.NB != 2 || 3 * L.L > pf::kMaxPackEntries || (desc->reserved & PF_FLAG_MASKED_CONTEXT))
         return fail(PF_ERR_UNSUPPORTED, "context gradient GEMM: plain conditioner, C % 16 == 0, at most 16 layers");
     return PF_OK;
 }

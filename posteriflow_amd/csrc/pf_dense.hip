@@ -168,7 +168,11 @@ __global__ __launch_bounds__(256, TP <= 3 ? 2 : 1) void dense_strip_kernel(const
     auto stage = [&](int ch, auto rb_tag) {
         constexpr int RB = decltype(rb_tag)::value;
         constexpr int U = BF16 ? 4 : 8;                         // slots per thread and sweep (KC <= 256)
-        const int64_t k0 = (int64_t)ch * (p.a_chunk_stride > 0 ? p.a_chunk_stride : (int64_t)p.KC);
+        int64_t k0 = (int64_t)ch * p.KC;
+        if (p.a_chunk_stride > 0) {
+            const int sc = p.a_slab_chunks > 1 ? p.a_slab_chunks : 1;
+            k0 = (int64_t)(ch / sc) * p.a_chunk_stride + (int64_t)(ch % sc) * p.KC;
+        }
 #pragma unroll 1
         for (int rr0 = 0; rr0 < BM / 32; rr0 += RB) {
             u32x4 v[RB][U];

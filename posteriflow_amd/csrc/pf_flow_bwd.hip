@@ -40,12 +40,13 @@ struct RqsBwdArgs {
     RqsConsts c;
 };
 
+template <int MAXB>
 __global__ __launch_bounds__(256) void rqs_backward_kernel(RqsBwdArgs a) {
     const int64_t idx = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
     if (idx >= a.n * a.D) return;
     const int64_t row = idx / a.D;
     const int P = 3 * a.c.K - 1;
-    a.gu[idx] = rqs_backward_pair(a.params + idx * P, a.gparams + idx * P, a.u[idx], a.gy[idx], a.glad[row], a.c);
+    a.gu[idx] = rqs_backward_pair<MAXB>(a.params + idx * P, a.gparams + idx * P, a.u[idx], a.gy[idx], a.glad[row], a.c);
 }
 }  // namespace
 
@@ -54,7 +55,8 @@ int rqs_backward(const PfFlowDesc& d, float deriv_const, const float* u, const f
     RqsBwdArgs a{u, params, gy, glad, gparams, gu, n, d.features,
                  RqsConsts{d.num_bins, d.tail_bound, d.min_bin_width, d.min_bin_height, d.min_derivative, deriv_const}};
     const int64_t pairs = n * d.features;
-    rqs_backward_kernel<<<dim3(static_cast<unsigned>((pairs + 255) / 256)), dim3(256), 0, s>>>(a);
+    if (d.num_bins <= 16) rqs_backward_kernel<16><<<dim3(static_cast<unsigned>((pairs + 255) / 256)), dim3(256), 0, s>>>(a);
+    else rqs_backward_kernel<32><<<dim3(static_cast<unsigned>((pairs + 255) / 256)), dim3(256), 0, s>>>(a);
     return launch_status();
 }
 }  // namespace pf

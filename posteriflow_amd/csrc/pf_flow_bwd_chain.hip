@@ -64,7 +64,7 @@ struct ChainArgs {
 #ifndef PF_CHAIN_ABLATE
 #define PF_CHAIN_ABLATE 0      // timing experiments (side builds): 1 no spline backward, 2 no MFMA, 4 no gradient stores, 8 no activation loads
 #endif
-template <int TPW, bool BF, int NW>
+template <int TPW, bool BF, int NW, int KMAX = 16>
 __global__ __launch_bounds__(NW * 64) void flow_bwd_chain_kernel(const ChainArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(NW * 64) void flow_bwd_chain_kernel(const ChainArgs
             float* par = s_gp + r * PMS + f * M;
             if constexpr (PF_CHAIN_ABLATE & 1) s_gu[r * 16 + f] = s_gy[r * 16 + f] + par[0];
             else
-            s_gu[r * 16 + f] = rqs_backward_pair(par, par, A.U[((size_t)l * B + row) * D + f], s_gy[r * 16 + f],
+            s_gu[r * 16 + f] = rqs_backward_pair<KMAX>(par, par, A.U[((size_t)l * B + row) * D + f], s_gy[r * 16 + f],
                                                  A.g_nll ? -A.g_nll[row] : A.g_lad[row], p.c);
         }
         __syncthreads();
@@ -434,6 +434,7 @@ int flow_backward_chain(const PfFlowDesc& d, float deriv_const, const PfFlowBwdC
     p.B = a.batch;
     const bool bf = d.precision == PF_PREC_BF16;
     const int nw = p.H % 128 == 0 ? 8 : 4;
+    const bool wide_k = d.num_bins > 16;           // fp32 only: spline backward with a 32-bin capacity
     const size_t lds = ((size_t)16 * (p.PM + 4) + 2 * 16 * (p.H + 4) + 256 + 256 + nw * 256) * sizeof(float)
                      + (bf ? (size_t)16 * (32 * ((p.D * p.M + 31) / 32) + 8) * 2 : 0);
     const unsigned grid = (unsigned)((a.batch + 15) / 16);
@@ -444,12 +445,28 @@ int flow_backward_chain(const PfFlowDesc& d, float deriv_const, const PfFlowBwdC
         hipLaunchKernelGGL(kern, dim3(grid), dim3(nw * 64), lds, s, p);
         return launch_status();
     };
-    switch (p.H) {
-    case 64: return bf ? launch(flow_bwd_chain_kernel<1, true, 4>) : launch(flow_bwd_chain_kernel<1, false, 4>);
-    case 128: return bf ? launch(flow_bwd_chain_kernel<1, true, 8>) : launch(flow_bwd_chain_kernel<1, false, 8>);
-    case 192: return bf ? launch(flow_bwd_chain_kernel<3, true, 4>) : launch(flow_bwd_chain_kernel<3, false, 4>);
-    case 256: return bf ? launch(flow_bwd_chain_kernel<2, true, 8>) : launch(flow_bwd_chain_kernel<2, false, 8>);
+    if (lds > 160 * 1024) return PF_ERR_UNSUPPORTED;
+    if (bf) {
+        if (wide_k) return PF_ERR_UNSUPPORTED;
+        switch (p.H) {
+        case 64: return launch(flow_bwd_chain_kernel<1, true, 4>);
+        case 128: return launch(flow_bwd_chain_kernel<1, true, 8>);
+        case 192: return launch(flow_bwd_chain_kernel<3, true, 4>);
+        case 256: return launch(flow_bwd_chain_kernel<2, true, 8>);
+        }
+        return PF_ERR_UNSUPPORTED;
     }
+    // fp32: also the widths and bin counts beyond the scheduled kernels' set (the generic forward's shapes with D <= 16)
+#define PF_CHAIN_F32(TPW_, NW_) (wide_k ? launch(flow_bwd_chain_kernel<TPW_, false, NW_, 32>) : launch(flow_bwd_chain_kernel<TPW_, false, NW_, 16>))
+    switch (p.H) {
+    case 64: return PF_CHAIN_F32(1, 4);
+    case 128: return PF_CHAIN_F32(1, 8);
+    case 192: return PF_CHAIN_F32(3, 4);
+    case 256: return PF_CHAIN_F32(2, 8);
+    case 384: return PF_CHAIN_F32(3, 8);
+    case 512: return PF_CHAIN_F32(4, 8);
+    }
+#undef PF_CHAIN_F32
     return PF_ERR_UNSUPPORTED;
 }
 

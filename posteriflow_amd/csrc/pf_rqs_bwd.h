@@ -8,7 +8,7 @@
 
 namespace pf {
 
-constexpr int kRqsMaxBins = 16;
+constexpr int kRqsMaxBins = 16;      // the scheduled kernels' bin capacity (register arrays); the wide variant below takes 32
 
 struct RqsConsts {
     int K;
@@ -20,6 +20,7 @@ __device__ __forceinline__ float rqs_sigmoid_f(float v) { return 1.f / (1.f + ex
 
 // One (row, feature) pair: par = its 3K-1 raw parameters (nflows order), gp receives dL/d(raw parameters) (may alias
 // par: every parameter is read before the first write), returns the direct part of dL/du.
+template <int MAXB = kRqsMaxBins>
 __device__ __forceinline__ float rqs_backward_pair(const float* par, float* gp, float x, float gy, float gl, const RqsConsts& a) {
     const int K = a.K, P = 3 * K - 1;
     const float tb = a.tb;
@@ -27,10 +28,10 @@ __device__ __forceinline__ float rqs_backward_pair(const float* par, float* gp, 
         for (int i = 0; i < P; ++i) gp[i] = 0.f;
         return gy;
     }
-    float sw[kRqsMaxBins], sh[kRqsMaxBins], ud[kRqsMaxBins];
+    float sw[MAXB], sh[MAXB], ud[MAXB];
     float mw = -INFINITY, mh = -INFINITY;
 #pragma unroll
-    for (int i = 0; i < kRqsMaxBins; ++i) {
+    for (int i = 0; i < MAXB; ++i) {
         sw[i] = i < K ? par[i] : -INFINITY;
         sh[i] = i < K ? par[K + i] : -INFINITY;
         ud[i] = i < K - 1 ? par[2 * K + i] : 0.f;
@@ -38,13 +39,13 @@ __device__ __forceinline__ float rqs_backward_pair(const float* par, float* gp, 
     }
     float tw = 0.f, th_ = 0.f;
 #pragma unroll
-    for (int i = 0; i < kRqsMaxBins; ++i) {
+    for (int i = 0; i < MAXB; ++i) {
         sw[i] = i < K ? expf(sw[i] - mw) : 0.f; tw += sw[i];
         sh[i] = i < K ? expf(sh[i] - mh) : 0.f; th_ += sh[i];
     }
     const float cw = 1.f - a.min_w * static_cast<float>(K), ch = 1.f - a.min_h * static_cast<float>(K);
 #pragma unroll
-    for (int i = 0; i < kRqsMaxBins; ++i) { sw[i] /= tw; sh[i] /= th_; }      // softmax probabilities
+    for (int i = 0; i < MAXB; ++i) { sw[i] /= tw; sh[i] /= th_; }      // softmax probabilities
 
     // bin search, as the forward does it (right knot of the last bin carries the 1e-6 of searchsorted)
     const float span = 2.f * tb;
@@ -53,7 +54,7 @@ __device__ __forceinline__ float rqs_backward_pair(const float* par, float* gp, 
     int b = 0;
     bool prev_ge = true;
 #pragma unroll
-    for (int i = 0; i < kRqsMaxBins; ++i) {
+    for (int i = 0; i < MAXB; ++i) {
         if (i < K) {
             cumw += a.min_w + cw * sw[i];
             cumh += a.min_h + ch * sh[i];
@@ -100,9 +101,9 @@ __device__ __forceinline__ float rqs_backward_pair(const float* par, float* gp, 
     // knots -> softmax probabilities: kx_j = span * sum_{i<j} (min + c s_i) - tb for 1 <= j <= K-1
     const bool right_free = b + 1 <= K - 1;                    // knot b+1 is interior
     float dot_w = 0.f, dot_h = 0.f;
-    float gsw[kRqsMaxBins], gsh[kRqsMaxBins];
+    float gsw[MAXB], gsh[MAXB];
 #pragma unroll
-    for (int i = 0; i < kRqsMaxBins; ++i) {
+    for (int i = 0; i < MAXB; ++i) {
         const float below = i < b ? 1.f : 0.f;                 // i < b  (knot b; b = 0 -> never)
         const float upto = (i <= b && right_free) ? 1.f : 0.f; // i < b+1 (knot b+1)
         gsw[i] = span * cw * (below * g_kxb + upto * g_kxb1);
@@ -111,7 +112,7 @@ __device__ __forceinline__ float rqs_backward_pair(const float* par, float* gp, 
         dot_h += sh[i] * gsh[i];
     }
 #pragma unroll
-    for (int i = 0; i < kRqsMaxBins; ++i) {
+    for (int i = 0; i < MAXB; ++i) {
         if (i < K) {
             gp[i] = sw[i] * (gsw[i] - dot_w);
             gp[K + i] = sh[i] * (gsh[i] - dot_h);

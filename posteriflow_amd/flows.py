@@ -704,12 +704,18 @@ class NSFPosteriorFlow(nn.Module):
         need = torch.is_grad_enabled() and (
             any(t is not None and t.requires_grad for t in tensors)
             or any(p.requires_grad for p in self._autograd_parameters()))
-        if need and self._generic_shape():
+        if need and self._generic_shape() and not self._generic_trainable():
             raise NotImplementedError(
                 f"NSFPosteriorFlow(H={self.hidden_features}, D={self.features}, K={self.num_bins}): the generic-shape kernel "
-                "evaluates densities and samples; the backward kernels are built for H in {64, 128, 192, 256}, D <= H / 16, "
-                "K <= 16 -- call under torch.no_grad() or freeze the parameters")
+                "evaluates densities and samples for this shape; its backward (fp32 data-gradient chain) needs "
+                "H in {64, 128, 192, 256, 384, 512}, D <= 16, K <= 32, a plain conditioner and no conditioner dropout -- call "
+                "under torch.no_grad() or freeze the parameters")
         return need
+
+    def _generic_trainable(self) -> bool:
+        """generic shapes the fp32 backward chain covers (csrc/pf_flow_bwd_chain.hip: H = 384 / 512 and K <= 32 in fp32)"""
+        return (self.hidden_features in (64, 128, 192, 256, 384, 512) and self.features <= 16 and self.num_bins <= 32
+                and not self.use_masked_context and not (self.dropout and self.dropout > 0.0))
 
     # ---- conditioner dropout (train mode) ---------------------------------------------
     # nflows drops relu(W0 relu(h) + b0) inside every residual block while the module is in train mode (upstream

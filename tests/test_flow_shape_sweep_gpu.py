@@ -189,6 +189,45 @@ def test_generic_shape_matches_oracle(D, C, H, K, L, tb, B, permute, seed):
     dl = (lb.cpu() - le).abs() / le.abs().clamp_min(1.0)
     assert dz.median() < 5e-3 and dl.median() < 1e-2, (dz.median(), dl.median())
     flow.precision = "fp32"
-    if flow._generic_shape():
+    if flow._generic_shape() and not flow._generic_trainable():       # D > 16 or a width the backward chain is not built for
         with pytest.raises(NotImplementedError):
             flow(x.cuda().requires_grad_(True), cg)
+
+
+@pytest.mark.parametrize("D,C,H,K,L,tb,precision", [(11, 288, 384, 24, 3, 3.0, "fp32"), (8, 96, 256, 20, 2, 3.0, "fp32"),
+                                                    (6, 0, 512, 6, 2, 5.0, "fp32"), (11, 288, 384, 24, 2, 3.0, "bf16")])
+def test_generic_shape_gradients_match_oracle_autograd(D, C, H, K, L, tb, precision):
+    """Training of the shapes the generic forward kernel serves (H = 384 / 512, K <= 32, D <= 16): generic forward with the
+    layer inputs kept -> fp32 re-evaluation by the generic kernel's conditioner -> fp32 chain (32-bin spline backward) ->
+    transposed GEMMs.  Gradients of x, context, log sigma and every parameter tensor against autograd through the oracle."""
+    ref, _, flow = make_pair(D, C, H, L, K, tb, seed=5000 + H + K)
+    flow.precision = precision
+    B = 80
+    x, ctx = flow_inputs(B, D, C, tb, seed=77)
+    g = torch.Generator().manual_seed(4)
+    w, ls = torch.rand(B, generator=g) + 0.5, torch.randn(B, D, generator=g) * 0.2
+    xr = x.clone().requires_grad_(True)
+    cr = ctx.clone().requires_grad_(True) if C else None
+    lr = ls.clone().requires_grad_(True)
+    (ref.compute_psd_aware_nll(xr, cr, lr) * w).sum().backward()
+    xg = x.cuda().requires_grad_(True)
+    cg = ctx.cuda().requires_grad_(True) if C else None
+    lg = ls.cuda().requires_grad_(True)
+    (flow.compute_psd_aware_nll(xg, cg, lg) * w.cuda()).sum().backward()
+    if precision == "fp32":
+        rel = lambda a, b: ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
+        tol = 3e-4
+        assert rel(xg.grad.cpu(), xr.grad) < tol and rel(lg.grad.cpu(), lr.grad) < 1e-4
+        if C:
+            assert rel(cg.grad.cpu(), cr.grad) < tol
+    else:       # bf16 forward (generic kernel, bf16 operands) + fp32 backward on its trajectory: direction, not digits
+        rel = lambda a, b: 1.0 - torch.nn.functional.cosine_similarity(a.flatten().double(), b.flatten().double(), dim=0).item()
+        tol = 5e-2
+        assert rel(xg.grad.cpu(), xr.grad) < tol
+    ref_params = dict(ref.named_parameters())
+    n_checked = 0
+    for name, p in flow.named_parameters():
+        if name.startswith("transform.") and p.grad is not None:
+            assert rel(p.grad.cpu(), ref_params[name].grad) < tol, (name, rel(p.grad.cpu(), ref_params[name].grad))
+            n_checked += 1
+    assert n_checked == L * (18 if C else 12)

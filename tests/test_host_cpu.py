@@ -404,3 +404,24 @@ def test_generic_pack_map_is_the_masked_dense_matrices(lib):
         used = win[win >= 0] - per_layer
         assert sorted(set(used.tolist())) == sorted(r * D_ + c for r in range(H_) for c in range(D_) if deg(r) >= c + 1)
         assert len(used) == (2 if prec == "bf16" else 1) * len(set(used.tolist()))
+
+
+def test_ctypes_structs_match_the_header(lib, tmp_path):
+    """every ctypes.Structure of posteriflow_amd/_lib.py has the size its C declaration in include/pf_hip.h has (a field added
+    on one side only would shift every later argument silently)"""
+    import shutil, subprocess
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        pytest.skip("no C compiler")
+    names = ["PfFlowDesc", "PfFlowBwdChainArgs", "PfFlowReevalArgs", "PfEmbedTrainDesc", "PfDenseArgs", "PfDenseTnArgs", "PfLnArgs",
+             "PfAttnArgs", "PfPoolArgs"]
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "pf_hip.h"\nint main(void) {\n'
+                   + "".join(f'  printf("{n} %zu\\n", sizeof({n}));\n' for n in names) + "  return 0;\n}\n")
+    exe = tmp_path / "sz"
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    subprocess.run([cc, "-I", inc, str(src), "-o", str(exe)], check=True, capture_output=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    sizes = dict(line.split() for line in out.strip().splitlines())
+    for n in names:
+        assert C.sizeof(getattr(lib, n)) == int(sizes[n]), (n, C.sizeof(getattr(lib, n)), sizes[n])
