@@ -101,7 +101,11 @@ typedef struct PfFlowDesc {
  * pf_flow_forward_reduce, pf_flow_forward_train (layer inputs; no dropout), pf_flow_inverse, and -- fp32 descs, features <= 16,
  * hidden_features in {64, 128, 192, 256, 384, 512}, num_bins <= 32 -- pf_flow_reevaluate (PF_FLAG_GENERIC layout),
  * pf_flow_backward_chain and pf_flow_rqs_backward.  The incremental-inverse, large-batch and bf16 backward entry points return
- * PF_ERR_UNSUPPORTED for such a shape. */
+ * PF_ERR_UNSUPPORTED for such a shape.
+ * Masked-context conditioner (PF_FLAG_MASKED_CONTEXT): forward / inverse on the scheduled kernels (context projections
+ * hoisted) or the generic kernel; backward through the SAME fp32 entry points in their additive form -- pf_flow_reevaluate
+ * (fp32 desc, PF_FLAG_GENERIC | PF_FLAG_MASKED_CONTEXT layout; gates = NULL) and pf_flow_backward_chain (fp32 desc with the
+ * flag; t2s = gates = NULL, Gc[l][1 + j] = dL/d(block j's context projection) = Gt1[j][l]). */
 
 /* ---- raw parameter layout -------------------------------------------------
  * One flat fp32 buffer, layer after layer, each layer in nflows state_dict
@@ -217,7 +221,8 @@ typedef struct PfFlowBwdChainArgs {
     float* Gh0;          /* [L][B][H]  dL/d(initial layer output) */
     float* Gt1;          /* [2][L][B][H] */
     float* Gt2;          /* [2][L][B][H] */
-    float* Gc;           /* [L][3][B][H]  dL/d(context projections): context_layer, gate of block 0, of block 1; or NULL */
+    float* Gc;           /* [L][3][B][H]  dL/d(context projections): context_layer, gate of block 0, of block 1 (masked-context
+                          * descs: the additive projection of block 0, of block 1); or NULL */
     float* g_x;          /* [B][D]  dL/d(x[:, ar_perm]) */
     const float* drop;   /* [2][L][B][H] dropout factors of the forward (pf_flow_dropout_mask), or NULL:
                           * gt1 = (W2^T gt2) . drop . [t1 > 0] */

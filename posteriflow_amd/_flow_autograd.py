@@ -152,8 +152,11 @@ def _reevaluate_hip(flow, U, ctx, drop=None, compact=False, fp32=False):
     a.batch, a.packed, a.U = B, packed.data_ptr(), U.data_ptr()
     a.hs, a.t1s, a.h2, a.params = HS.data_ptr(), T1.data_ptr(), H2.data_ptr(), params.data_ptr()
     if has_ctx:
-        T2, G, PC = new(2, Ln, B, H), new(2, Ln, B, H), new(Ln, B, H)
-        a.ctx, a.t2s, a.gates, a.pc = ctx.data_ptr(), T2.data_ptr(), G.data_ptr(), PC.data_ptr()
+        T2, PC = new(2, Ln, B, H), new(Ln, B, H)
+        a.ctx, a.t2s, a.pc = ctx.data_ptr(), T2.data_ptr(), PC.data_ptr()
+        if not flow.use_masked_context:          # GLU gates (the masked-context conditioner adds its projections instead)
+            G = new(2, Ln, B, H)
+            a.gates = G.data_ptr()
     if drop is not None:
         a.drop = drop.data_ptr()
     a.compact = 1 if compact else 0
@@ -184,18 +187,20 @@ def _flow_backward_batched(flow, U, ctx, g_z, g_lad, drop=None, nll=None):
 
     def wcat():      # [L, 1 + nb, H, C] context weights stacked (tensor-op re-evaluation / library fallback only)
         if not Wcat_:
-            Wcat_.append(torch.cat([st(lambda n: n.context_layer.weight)]
-                                   + [st(lambda n: n.blocks[j].context_layer.weight) for j in range(nb)], dim=1))
+            cw = lambda m: m.masked_weight() if hasattr(m, "masked_weight") else m.weight
+            Wcat_.append(torch.cat([st(lambda n: cw(n.context_layer))]
+                                   + [st(lambda n: cw(n.blocks[j].context_layer)) for j in range(nb)], dim=1))
         return Wcat_[0]
     # bf16 mode: re-evaluation and chain are HIP kernels reading the packed PF_FLAG_BWD stream (one gather per weight update)
     generic = flow._generic_shape()      # shapes of the generic forward kernel: fp32 re-evaluation + fp32 chain in either precision
+    additive = bool(flow.use_masked_context) and has_ctx     # masked-context conditioner (flows.py:225-234): same, fp32 kernels
     bf = (flow.precision == "bf16" and H % 32 == 0 and nb == 2 and U.is_contiguous() and (ctx is None or ctx.is_contiguous())
-          and not generic)
+          and not generic and not additive)
 
     # 1. conditioners
     cmp = bf and REEVAL_HIP and COMPACT
     # fp32 (parity) mode: the same launch in exact-fp32 MFMA arithmetic (the generic kernel's conditioner)
-    f32_hip = ((not bf) and REEVAL_HIP and (flow.precision != "bf16" or generic) and nb == 2 and U.is_contiguous()
+    f32_hip = ((not bf) and REEVAL_HIP and (flow.precision != "bf16" or generic or additive) and nb == 2 and U.is_contiguous()
                and (ctx is None or ctx.is_contiguous()))
     hip_reeval = (bf and REEVAL_HIP) or f32_hip
     if hip_reeval:
@@ -226,22 +231,24 @@ def _flow_backward_batched(flow, U, ctx, g_z, g_lad, drop=None, nll=None):
             proj = torch.addmm(bcat.reshape(-1), ctx, wcat().reshape(-1, C).t())
             proj = proj.view(B, Ln, 1 + nb, H).permute(1, 2, 0, 3)                   # [L, 1+nb, B, H]
             pc = proj[:, 0]
-            gates = [torch.sigmoid(proj[:, 1 + j]) for j in range(nb)]
+            gates = [None if additive else torch.sigmoid(proj[:, 1 + j]) for j in range(nb)]
         h = torch.baddbmm(b0[:, None, :], U, W0.transpose(1, 2))
         if has_ctx:
             h = h + F.relu(pc)
         hs, t1s, t2s, a1s = [h], [], [], []
         for j in range(nb):
             t1 = torch.baddbmm(b1[j][:, None, :], F.relu(h), W1[j].transpose(1, 2))
+            if additive:
+                t1 = t1 + proj[:, 1 + j]
             a1 = F.relu(t1) if drop is None else F.relu(t1) * drop[j]                 # the second linear's input
             t2 = torch.baddbmm(b2[j][:, None, :], a1, W2[j].transpose(1, 2))
-            h = h + (t2 * gates[j] if has_ctx else t2)
+            h = h + (t2 * gates[j] if (has_ctx and not additive) else t2)
             hs.append(h), t1s.append(t1), t2s.append(t2), a1s.append(a1)
         params = torch.baddbmm(bf_[:, None, :], h, Wf.transpose(1, 2))                # [L, B, D(3K-1)]
         h_last, relu_h = hs[nb], [F.relu(hs[j]) for j in range(nb)]
         HSk, T1k = torch.stack(hs[:nb]), torch.stack(t1s)
         if has_ctx:
-            T2k, Gk, pck = torch.stack(t2s), torch.stack(gates), pc.contiguous()
+            T2k, Gk, pck = torch.stack(t2s), (None if additive else torch.stack(gates)), pc.contiguous()
 
     # 2. the chain, last layer first: ONE launch (pf_flow_backward_chain, csrc/pf_flow_bwd_chain.hip) instead of ~25
     #    small ones per layer -- spline backward, the transposed masked GEMMs on MFMA, the gate / ReLU algebra
@@ -291,7 +298,9 @@ def _flow_backward_batched(flow, U, ctx, g_z, g_lad, drop=None, nll=None):
     if has_ctx:
         Gc = torch.empty(Ln, 1 + nb, B, H, dtype=gdt, device=U.device)
         keep += [T2k, Gk, pck, Gc]
-        a.t2s, a.gates, a.pc, a.Gc = T2k.data_ptr(), Gk.data_ptr(), pck.data_ptr(), Gc.data_ptr()
+        a.pc, a.Gc = pck.data_ptr(), Gc.data_ptr()
+        if not additive:
+            a.t2s, a.gates = T2k.data_ptr(), Gk.data_ptr()
     _lib.check(_lib.lib().pf_flow_backward_chain(flow._desc("bf16" if bf else "fp32"), a,
                                                  torch.cuda.current_stream(U.device).cuda_stream), "pf_flow_backward_chain")
     g_x = gx_perm[:, flow._ar_inv_perm]              # the kernel returns dL/d x[:, ar_perm]
@@ -341,7 +350,8 @@ def _flow_backward_batched(flow, U, ctx, g_z, g_lad, drop=None, nll=None):
         ctxa = F.pad(ctx.to(adt), (0, Cp - C)) if (Cp != C or ctx.dtype != adt) else ctx
         keep2.append(ctxa)
         for j in range(1 + nb):
-            tn(Gc, j * B * H, (1 + nb) * B * H, H, ctxa, 0, Cp, H, Cp, lay["Wc"][j], lay["bc"][j], C, n2_cols=C)
+            tn(Gc, j * B * H, (1 + nb) * B * H, H, ctxa, 0, Cp, H, Cp, lay["Wc"][j], lay["bc"][j], C, n2_cols=C,
+               masked=additive and not flow.full_context)
         wt = flow.packed_ctx_transposed("bf16" if cmp else "fp32")
         if wt is not None:
             # few rows, long reduction: B / 128 strips x ceil(tiles / 12) calls would leave most CUs idle (2048 rows: 32
@@ -402,7 +412,12 @@ def flow_backward(flow, U, ctx, g_z, g_lad, drop_seed=None, nll=None):
 
 
 def _fast(flow) -> bool:
-    return not bool(getattr(flow, "use_masked_context", False))
+    """the HIP backward (re-evaluation + chain + split GEMMs) covers this flow; otherwise autograd over ``flow_forward``"""
+    if not bool(getattr(flow, "use_masked_context", False)):
+        return True
+    # masked-context conditioner: the fp32 re-evaluation and chain kernels carry its additive form
+    return (REEVAL_HIP and flow.features <= 16 and flow.hidden_features in (64, 128, 192, 256, 384, 512)
+            and flow.num_bins <= 32)
 
 
 def _layer_inputs(flow, x):

@@ -239,9 +239,9 @@ int pf_flow_backward_chain(const PfFlowDesc* desc, const PfFlowBwdChainArgs* a, 
     const bool f32d = desc->precision == PF_PREC_F32;
     const bool h_ok = H == 64 || H == 128 || H == 192 || H == 256 || (f32d && (H == 384 || H == 512));
     if (!h_ok || D < 1 || D > 16 || K < 2 || K > (f32d ? 32 : 16) || desc->num_blocks != 2 || desc->num_layers < 1 ||
-        (desc->reserved & PF_FLAG_MASKED_CONTEXT))
-        return fail(PF_ERR_UNSUPPORTED, "backward chain: plain conditioner, 2 blocks, D <= 16; bf16: H in {64,128,192,256}, K <= 16; "
-                    "fp32: also H = 384, 512 and K <= 32");
+        ((desc->reserved & PF_FLAG_MASKED_CONTEXT) && !f32d))
+        return fail(PF_ERR_UNSUPPORTED, "backward chain: 2 blocks, D <= 16; bf16: plain conditioner, H in {64,128,192,256}, K <= 16; "
+                    "fp32: also H = 384, 512, K <= 32 and the masked-context conditioner");
     if (!(desc->tail_bound > 0.f)) return fail(PF_ERR_BAD_ARG, "tail_bound must be positive");
     if (a->batch < 0) return fail(PF_ERR_BAD_ARG, "negative batch");
     if (a->batch == 0) return PF_OK;
@@ -257,9 +257,9 @@ int pf_flow_backward_chain(const PfFlowDesc* desc, const PfFlowBwdChainArgs* a, 
     if (a->gp_ld && (int)a->gp_ld < D * (3 * K - 1)) return fail(PF_ERR_BAD_ARG, "gp_ld is shorter than a row of Gp");
     if (a->g_nll ? (!a->nll_z || a->g_z || a->g_lad) : (!a->g_z || !a->g_lad))
         return fail(PF_ERR_BAD_ARG, "pass either (g_z, g_lad) or (g_nll, nll_z[, log_sigma])");
-    const bool ctx = a->gates != nullptr;
-    if (ctx != (a->t2s != nullptr) || ctx != (a->pc != nullptr) || ctx != (a->Gc != nullptr))
-        return fail(PF_ERR_BAD_ARG, "t2s, gates, pc and Gc go together (all NULL for a context-free flow)");
+    const bool ctx = a->pc != nullptr, glu = ctx && !(desc->reserved & PF_FLAG_MASKED_CONTEXT);
+    if (glu != (a->t2s != nullptr) || glu != (a->gates != nullptr) || ctx != (a->Gc != nullptr))
+        return fail(PF_ERR_BAD_ARG, "pc and Gc (and t2s, gates for the plain conditioner) go together (all NULL for a context-free flow)");
     const void* al[] = {bf ? nullptr : a->WfT, bf ? nullptr : a->W2T, bf ? nullptr : a->W1T, bf ? nullptr : a->W0T, bf ? a->packed : nullptr,
                         a->hs, a->t1s, a->t2s, a->gates, a->pc, a->Gh0, a->Gt1, a->Gt2, a->Gc, a->drop};
     for (const void* q : al)
@@ -271,11 +271,11 @@ int pf_flow_backward_chain(const PfFlowDesc* desc, const PfFlowBwdChainArgs* a, 
 
 int pf_flow_reevaluate(const PfFlowDesc* desc, const PfFlowReevalArgs* a, void* stream) {
     if (!desc || !a) return fail(PF_ERR_BAD_ARG, "null pointer");
-    if (desc->reserved & (PF_FLAG_MASKED_CONTEXT | PF_FLAG_BWD))
-        return fail(PF_ERR_UNSUPPORTED, "re-evaluation kernel: plain-conditioner flow (the flow's own desc)");
+    if ((desc->reserved & PF_FLAG_BWD) || ((desc->reserved & PF_FLAG_MASKED_CONTEXT) && desc->precision != PF_PREC_F32))
+        return fail(PF_ERR_UNSUPPORTED, "re-evaluation kernel: the flow's own desc; the masked-context conditioner in fp32 only");
     if (desc->precision == PF_PREC_F32) {           // parity mode: the generic kernel's conditioner, exact-fp32 MFMA
         PfFlowDesc g = *desc;
-        g.reserved = PF_FLAG_GENERIC;
+        g.reserved = PF_FLAG_GENERIC | (desc->reserved & PF_FLAG_MASKED_CONTEXT);
         pf::FlowPlan G;
         const int rg = layout_of(&g, G);
         if (rg != PF_OK) return rg;
@@ -283,9 +283,9 @@ int pf_flow_reevaluate(const PfFlowDesc* desc, const PfFlowReevalArgs* a, void* 
         if (a->batch < 0) return fail(PF_ERR_BAD_ARG, "negative batch");
         if (a->batch == 0) return PF_OK;
         if (!a->packed || !a->U || !a->hs || !a->t1s || !a->h2 || !a->params) return fail(PF_ERR_BAD_ARG, "null pointer");
-        const bool cx = G.C > 0;
-        if (cx != (a->ctx != nullptr) || cx != (a->t2s != nullptr) || cx != (a->gates != nullptr) || cx != (a->pc != nullptr))
-            return fail(PF_ERR_BAD_ARG, "ctx, t2s, gates and pc go together with context_features > 0");
+        const bool cx = G.C > 0, glu = cx && !G.additive;
+        if (cx != (a->ctx != nullptr) || cx != (a->t2s != nullptr) || glu != (a->gates != nullptr) || cx != (a->pc != nullptr))
+            return fail(PF_ERR_BAD_ARG, "ctx, t2s, pc (and gates, for the plain conditioner) go together with context_features > 0");
         const void* al[] = {a->packed, a->hs, a->t1s, a->t2s, a->gates, a->pc, a->h2, a->drop};
         for (const void* q : al)
             if (misaligned(q, 16)) return fail(PF_ERR_BAD_ARG, "stream / activation tensors must be 16-byte aligned");
@@ -604,7 +604,7 @@ namespace {
 int ctx_t_plan(const PfFlowDesc* desc, pf::FlowPlan& L) {
     const int rc = layout_of(desc, L);
     if (rc != PF_OK) return rc;
-    if (L.C <= 0 || L.C % 16 || L.NB != 2 || 3 * L.L > pf::kMaxPackEntries || (desc->reserved & PF_FLAG_MASKED_CONTEXT))
+    if (L.C <= 0 || L.C % 16 || L.NB != 2 || 3 * L.L > pf::kMaxPackEntries)
         return fail(PF_ERR_UNSUPPORTED, "context gradient GEMM: plain conditioner, C % 16 == 0, at most 16 layers");
     return PF_OK;
 }

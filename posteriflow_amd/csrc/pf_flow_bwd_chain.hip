@@ -56,6 +56,8 @@ struct ChainArgs {
     RqsConsts c;
     int D, H, L, M, PM;       // M = 3K-1, PM = D*M padded to 16
     int64_t B;
+    int additive;             // masked-context conditioner (flows.py:186-234): t1 = W1 relu(h) + b1 + context_layer(ctx), no gate, no
+                              // ReversePermutation; Gc[3 l + 1 + j] = dL/d(that projection) = gt1_j
 };
 
 // NW waves per workgroup, TPW = H / (16 NW) unit tiles per wave; BF: bf16 operands from the PF_FLAG_BWD stream.
@@ -90,7 +92,9 @@ __global__ __launch_bounds__(NW * 64) void flow_bwd_chain_kernel(const ChainArgs
     const int64_t my_row = row0 + c < B ? row0 + c : B - 1;   // clamped (stores are guarded)
     const bool live = row0 + c < B;
     const PfFlowBwdChainArgs& A = p.a;
-    const bool has_ctx = A.gates != nullptr;
+    const bool additive = p.additive != 0;
+    const bool has_ctx = A.pc != nullptr;                     // (gates / t2s only exist for the GLU conditioner)
+    const bool glu = has_ctx && !additive;
 
     for (int s = tid; s < 256; s += NW * 64) {
         const int r = s >> 4, d = s & 15;
@@ -292,7 +296,7 @@ __global__ __launch_bounds__(NW * 64) void flow_bwd_chain_kernel(const ChainArgs
         // ---- gh = Wf^T Gp ----------------------------------------------------------------------------------------
         f32x4 gh[TPW], acc[TPW];
         f32x4 gate_n[TPW], t2_n[TPW];                        // block operands, requested one GEMM ahead of their use
-        if (has_ctx) {
+        if (glu) {
 #pragma unroll
             for (int i = 0; i < TPW; ++i) { gate_n[i] = ld4(A.gates, 1 * L + l, wave + NW * i); t2_n[i] = ld4(A.t2s, 1 * L + l, wave + NW * i); }
         }
@@ -304,7 +308,7 @@ __global__ __launch_bounds__(NW * 64) void flow_bwd_chain_kernel(const ChainArgs
             for (int i = 0; i < TPW; ++i) {
                 const int t = wave + NW * i;
                 f32x4 gt2 = gh[i];
-                if (has_ctx) {
+                if (glu) {
                     const f32x4 gate = gate_n[i], t2 = t2_n[i];
                     f32x4 gc;
 #pragma unroll
@@ -342,7 +346,7 @@ __global__ __launch_bounds__(NW * 64) void flow_bwd_chain_kernel(const ChainArgs
             if (has_ctx) {                                   // the next block's gate / t2 (block 0 after block 1), or the context layer's pc
 #pragma unroll
                 for (int i = 0; i < TPW; ++i) {
-                    if (j == 1) { gate_n[i] = ld4(A.gates, l, wave + NW * i); t2_n[i] = ld4(A.t2s, l, wave + NW * i); }
+                    if (j == 1) { if (glu) { gate_n[i] = ld4(A.gates, l, wave + NW * i); t2_n[i] = ld4(A.t2s, l, wave + NW * i); } }
                     else gate_n[i] = ld4(A.pc, l, wave + NW * i);
                 }
             }
@@ -355,6 +359,7 @@ __global__ __launch_bounds__(NW * 64) void flow_bwd_chain_kernel(const ChainArgs
 #pragma unroll
                 for (int e = 0; e < 4; ++e) gt1[e] = acc[i][e] * t1[i][e];        // t1 holds [t1 > 0] (. dropout factor)
                 st4(A.Gt1, j * L + l, t, gt1);
+                if (additive && has_ctx) st4(A.Gc, 3 * l + 1 + j, t, gt1);       // t1 = ... + context_layer(ctx): same gradient
                 to_lds(1, t, gt1);
             }
             __syncthreads();
@@ -412,7 +417,7 @@ __global__ __launch_bounds__(NW * 64) void flow_bwd_chain_kernel(const ChainArgs
                 v = s_gu[r * 16 + d];
 #pragma unroll
                 for (int w = 0; w < NW; ++w) v += s_part[(w * 16 + r) * 16 + d];
-                s_gy[r * 16 + (D - 1 - d)] = v;              // through this layer's ReversePermutation
+                s_gy[r * 16 + (additive ? d : D - 1 - d)] = v;  // through this layer's ReversePermutation (none: masked-context)
             }
         }
         __syncthreads();
@@ -432,7 +437,9 @@ int flow_backward_chain(const PfFlowDesc& d, float deriv_const, const PfFlowBwdC
     p.D = d.features; p.H = d.hidden_features; p.L = d.num_layers; p.M = 3 * d.num_bins - 1;
     p.PM = (p.D * p.M + 15) / 16 * 16;
     p.B = a.batch;
+    p.additive = (d.reserved & PF_FLAG_MASKED_CONTEXT) ? 1 : 0;
     const bool bf = d.precision == PF_PREC_BF16;
+    if (bf && p.additive) return PF_ERR_UNSUPPORTED;       // (the PF_FLAG_BWD stream is the GLU conditioner's)
     const int nw = p.H % 128 == 0 ? 8 : 4;
     const bool wide_k = d.num_bins > 16;           // fp32 only: spline backward with a 32-bin capacity
     const size_t lds = ((size_t)16 * (p.PM + 4) + 2 * 16 * (p.H + 4) + 256 + 256 + nw * 256) * sizeof(float)

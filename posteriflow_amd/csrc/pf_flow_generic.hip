@@ -106,6 +106,8 @@ __global__ __launch_bounds__(kGenWaves * 64) void flow_generic_kernel(const FwdP
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const FlowPlan& L = p.plan;
     const int D = L.D, H = L.H, K = L.K, M = L.M, C = L.C, NT = L.NT;
+    const bool additive = L.additive != 0;       // masked-context conditioner: additive context inside the blocks, no gates,
+                                                 // no ReversePermutation between the layers
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, c = lane & 15;
@@ -250,7 +252,9 @@ __global__ __launch_bounds__(kGenWaves * 64) void flow_generic_kernel(const FwdP
             const gu32x4* f1 = f_blk + (size_t)(2 * b) * NT * L.gKh * 64;
             const gu32x4* f2 = f1 + (size_t)NT * L.gKh * 64;
             for (int t = wave; t < NT; t += kGenWaves) {                           // t1 = W1 relu(h) + b1; s_b = relu(t1)
-                const f32x4 v = mm(f1, t, L.gKh, s_a, sh) + *reinterpret_cast<const f32x4*>(b_blk + (2 * b) * H + 16 * t + 4 * g);
+                f32x4 v = mm(f1, t, L.gKh, s_a, sh) + *reinterpret_cast<const f32x4*>(b_blk + (2 * b) * H + 16 * t + 4 * g);
+                if (additive)          // t1 = W1 relu(h) + b1 + context_layer(ctx)   (flows.py:225-234)
+                    v = v + mm(b == 0 ? f_g0 : f_g1, t, L.gKc, s_ctx, sc) + *reinterpret_cast<const f32x4*>((b == 0 ? b_g0 : b_g1) + 16 * t + 4 * g);
                 f32x4 df = {1.f, 1.f, 1.f, 1.f};
                 if constexpr (REEVAL) {
                     if (row0 + c < p.batch) {
@@ -267,7 +271,9 @@ __global__ __launch_bounds__(kGenWaves * 64) void flow_generic_kernel(const FwdP
                 f32x4 v = mm(f2, t, L.gKh, s_b, sh) + *reinterpret_cast<const f32x4*>(b_blk + (2 * b + 1) * H + 16 * t + 4 * g);
                 const bool live = REEVAL && row0 + c < p.batch;
                 const size_t o = (((size_t)b * L.L + l) * p.batch + row0 + c) * H + 16 * t + 4 * g;
-                if (C > 0) {
+                if (additive) {
+                    if (live) *reinterpret_cast<f32x4*>(sink.t2s + o) = v;
+                } else if (C > 0) {
                     f32x4 gt = mm(b == 0 ? f_g0 : f_g1, t, L.gKc, s_ctx, sc) +
                                *reinterpret_cast<const f32x4*>((b == 0 ? b_g0 : b_g1) + 16 * t + 4 * g);
 #pragma unroll
@@ -316,7 +322,7 @@ __global__ __launch_bounds__(kGenWaves * 64) void flow_generic_kernel(const FwdP
     } else if constexpr (!INV) {
         for (int l = 0; l < L.L; ++l) {
             // ReversePermutation in front of every autoregressive layer (flows.py:459-529)
-            if (tid < 16 * 32) { const int r = tid >> 5, d = tid & 31; s_u[tid] = d < D ? s_y[r * 32 + D - 1 - d] : 0.f; }
+            if (tid < 16 * 32) { const int r = tid >> 5, d = tid & 31; s_u[tid] = d < D ? s_y[r * 32 + (additive ? d : D - 1 - d)] : 0.f; }
             __syncthreads();
             if (p.u_save && tid < n_pairs) {
                 const int r = tid / D, d = tid - r * D;
@@ -375,7 +381,7 @@ __global__ __launch_bounds__(kGenWaves * 64) void flow_generic_kernel(const FwdP
             }
             if (tid < 16) { float a = s_acc[tid]; for (int f = 0; f < D; ++f) a += s_ld[tid * 32 + f]; s_acc[tid] = a; }
             // undo the ReversePermutation that preceded this layer
-            if (tid < 16 * 32) { const int r = tid >> 5, d = tid & 31; s_y[tid] = d < D ? s_u[r * 32 + D - 1 - d] : 0.f; }
+            if (tid < 16 * 32) { const int r = tid >> 5, d = tid & 31; s_y[tid] = d < D ? s_u[r * 32 + (additive ? d : D - 1 - d)] : 0.f; }
             __syncthreads();
         }
         if (tid < 16 && row0 + tid < p.batch) {

@@ -187,7 +187,7 @@ inline void sorted_units(int D, int H, int* perm) {
 // one generic kernel, plain conditioner, forward and D-pass inverse in both precisions.  H a multiple of 16 up to 512, D <= 32,
 // K <= 32, and the workgroup's LDS image within 160 KB.
 inline int make_generic_plan(const PfFlowDesc& d, FlowPlan& o) {
-    if (d.reserved & (PF_FLAG_MASKED_CONTEXT | PF_FLAG_WIDE | PF_FLAG_BWD)) return PF_ERR_UNSUPPORTED;
+    if (d.reserved & (PF_FLAG_WIDE | PF_FLAG_BWD)) return PF_ERR_UNSUPPORTED;
     if (d.num_bins * 3 - 1 < 1 || d.num_layers < 1) return PF_ERR_UNSUPPORTED;
     if (d.hidden_features < 16 || d.hidden_features > 512 || d.hidden_features % 16) return PF_ERR_UNSUPPORTED;
     if (d.features < 1 || d.features > 32 || d.num_bins < 2 || d.num_bins > 32) return PF_ERR_UNSUPPORTED;
@@ -204,6 +204,7 @@ inline int make_generic_plan(const PfFlowDesc& d, FlowPlan& o) {
     o.gKh = (o.H + o.kstep - 1) / o.kstep;
     o.gTf = (o.D * o.M + 15) / 16;
     o.CK = o.gKc; o.CKM = 0; o.HK = o.gKh; o.hoist = 0;
+    o.additive = (d.reserved & PF_FLAG_MASKED_CONTEXT) && o.C > 0 ? 1 : 0;     // masked-context conditioner (flows.py:186-234)
     if (o.gen_lds_bytes() > 160 * 1024) return PF_ERR_UNSUPPORTED;
     o.fragsPerWave = 0;
     o.fragsTotal = (int64_t)o.L * o.gen_layer_frags();

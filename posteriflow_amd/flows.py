@@ -245,6 +245,7 @@ class NSFPosteriorFlow(nn.Module):
         # MaskedContextLinear's full_context (flows.py:145): MADEWithMaskedContext never passes it (flows.py:268), so every
         # flow the reference builds has the all-ones context mask; the per-position mask is reachable here as a keyword
         full_context = bool(kwargs.pop("full_context", True))
+        self.full_context = full_context
         mblocks = (self.n_context_blocks, self.context_block_dim, full_context) if self.use_masked_context else None
         for _ in range(num_layers):
             if not self.use_masked_context:                              # flows.py:459-460
@@ -397,7 +398,8 @@ class NSFPosteriorFlow(nn.Module):
             parts = []
             for mod, name in self._param_slots()[:len(self._raw_layout()["shapes"])]:
                 t = getattr(mod, name)
-                if name == "weight" and isinstance(mod, _MaskedLinear):
+                if name == "weight" and (isinstance(mod, _MaskedLinear)
+                                         or (isinstance(mod, _MaskedContextLinear) and not mod.full_context)):
                     parts.append(mod.mask.detach().reshape(-1).float())
                 else:
                     parts.append(torch.ones(t.numel(), dtype=torch.float32, device=t.device))
@@ -409,6 +411,8 @@ class NSFPosteriorFlow(nn.Module):
     def packed_ctx_transposed(self, precision: str):
         """all layers' context weights transposed, as pf_dense_nt fragments (pf_flow_pack_ctx_transposed): the weight
         operand of the context gradient; None where the packed form is not built (C % 16, masked-context, L > 16)"""
+        if self.use_masked_context and not self.full_context:
+            return None                      # (the packing call reads the raw weights; this variant's context mask is not in them)
         desc = self._desc(precision)
         L = _lib.lib()
         nbytes = L.pf_flow_ctx_transposed_bytes(desc)
@@ -545,7 +549,7 @@ class NSFPosteriorFlow(nn.Module):
         if generic:  # the generic kernel's layout for this shape (fp32-mode conditioner re-evaluation reads it)
             return _lib.PfFlowDesc(self.features, self.context_features, self.hidden_features, self.num_bins,
                                    self.num_layers, 2, float(self._tail_bound), _MIN_BIN, _MIN_BIN, _MIN_BIN,
-                                   prec, _lib.PF_FLAG_GENERIC)
+                                   prec, _lib.PF_FLAG_GENERIC | (_lib.PF_FLAG_MASKED_CONTEXT if self.use_masked_context else 0))
         if bwd:     # packing only: the backward chain's transposed bf16 fragments (PF_FLAG_BWD)
             return _lib.PfFlowDesc(self.features, self.context_features, self.hidden_features, self.num_bins,
                                    self.num_layers, 2, float(self._tail_bound), _MIN_BIN, _MIN_BIN, _MIN_BIN,
@@ -715,7 +719,7 @@ class NSFPosteriorFlow(nn.Module):
     def _generic_trainable(self) -> bool:
         """generic shapes the fp32 backward chain covers (csrc/pf_flow_bwd_chain.hip: H = 384 / 512 and K <= 32 in fp32)"""
         return (self.hidden_features in (64, 128, 192, 256, 384, 512) and self.features <= 16 and self.num_bins <= 32
-                and not self.use_masked_context and not (self.dropout and self.dropout > 0.0))
+                and not (self.dropout and self.dropout > 0.0))
 
     # ---- conditioner dropout (train mode) ---------------------------------------------
     # nflows drops relu(W0 relu(h) + b0) inside every residual block while the module is in train mode (upstream

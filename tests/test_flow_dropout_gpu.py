@@ -308,8 +308,8 @@ def test_dropout_backward_in_bf16_mode_follows_the_fp32_mode():
 
 
 def test_masked_context_flow_trains_with_dropout():
-    """the reference's own masked-context block drops at the same place (flows.py:232); its backward here is autograd over
-    device tensor ops (_flow_autograd.flow_forward) with the forward's factors"""
+    """the reference's own masked-context block drops at the same place (flows.py:232); its backward is the fp32 re-evaluation
+    + chain kernels in their additive form, reading the forward's factors"""
     from posteriflow_amd._flow_autograd import dropout_mask
     D, C, H, L, K, tb, B, p = 11, 264, 256, 2, 16, 5.0, 64, 0.2
     ref, ref64, flow = _pair(D, C, H, L, K, tb, p, masked=True)

@@ -231,3 +231,68 @@ def test_generic_shape_gradients_match_oracle_autograd(D, C, H, K, L, tb, precis
             assert rel(p.grad.cpu(), ref_params[name].grad) < tol, (name, rel(p.grad.cpu(), ref_params[name].grad))
             n_checked += 1
     assert n_checked == L * (18 if C else 12)
+
+
+@pytest.mark.parametrize("D,block,H,K,L,full,prec", [(4, 5, 64, 8, 2, True, "fp32"), (12, 3, 192, 13, 2, True, "fp32"),
+                                                    (11, 24, 256, 16, 3, True, "bf16"), (15, 20, 256, 16, 2, False, "fp32"),
+                                                    (7, 16, 128, 16, 3, False, "bf16"), (6, 8, 384, 24, 2, True, "fp32")])
+def test_masked_context_gradients_on_the_hip_backward(D, block, H, K, L, full, prec):
+    """backward of the reference's masked-context conditioner (flows.py:186-234: additive projections inside the blocks, no gates,
+    no ReversePermutation) on the fp32 re-evaluation + chain kernels: every gradient against the fp32 oracle's autograd, and the
+    kernels are the ones that ran (no tensor-op forward replay)."""
+    from helpers import oracle_state_for_product
+    from oracle.flow_ref import NSFPosteriorFlowRef
+    from posteriflow_amd import NSFPosteriorFlow, _flow_autograd as fa
+    C, tb, B = D * block, 4.0, 150
+    torch.manual_seed(D + H)
+    ref = NSFPosteriorFlowRef(D, C, H, L, K, tb, temperature_scale=1.0, use_masked_context=True, full_context=full)
+    with torch.no_grad():
+        for t in ref.transform._transforms:
+            if hasattr(t, "autoregressive_net"):
+                for blk in t.autoregressive_net.blocks:
+                    blk.linear_layers[1].weight.mul_(40.0 if prec == "fp32" else 8.0)
+    flow = NSFPosteriorFlow(D, C, H, L, K, tb, temperature_scale=1.0, full_context=full)
+    flow.load_state_dict(oracle_state_for_product(ref))
+    flow = flow.cuda()
+    flow.precision = prec
+    assert flow.use_masked_context and fa._fast(flow)
+    order = list(range(D))
+    random.Random(D).shuffle(order)
+    for f in (ref, flow):
+        f.set_autoregressive_order(order)
+    x, ctx = flow_inputs(B, D, C, tb, seed=D)
+    g = torch.Generator().manual_seed(4)
+    w, ls = torch.rand(B, generator=g) + 0.5, torch.randn(B, D, generator=g) * 0.2
+    xr, cr, lr = x.clone().requires_grad_(True), ctx.clone().requires_grad_(True), ls.clone().requires_grad_(True)
+    (ref.compute_psd_aware_nll(xr, cr, lr) * w).sum().backward()
+    xg, cg, lg = (t.cuda().requires_grad_(True) for t in (x, ctx, ls))
+    calls = []
+    orig = fa.flow_forward
+    fa.flow_forward = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        (flow.compute_psd_aware_nll(xg, cg, lg) * w.cuda()).sum().backward()
+    finally:
+        fa.flow_forward = orig
+    assert not calls                                            # the tensor-op replay did not run
+    if prec == "fp32":
+        tol = 5e-4
+        relg = lambda a, b: ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
+    else:
+        # bf16: z and the layer inputs come from the bf16 forward kernel, the gradient is the fp32 one AT those inputs.  A pair
+        # that the bf16 conditioner puts in the neighbouring bin has a different log-det gradient (the spline is C1, the
+        # derivative of its log-slope jumps at a knot), so a few rows differ by O(1) while the rest agree to bf16 accuracy:
+        # (parameter gradients sum over the rows, so every element carries some of it): error relative to the gradient's norm
+        tol = 0.25
+        relg = lambda a, b: ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
+    assert relg(xg.grad.cpu(), xr.grad) < tol and relg(cg.grad.cpu(), cr.grad) < tol and relg(lg.grad.cpu(), lr.grad) < tol
+    ref_params = dict(ref.named_parameters())
+    n = 0
+    for name, prm in flow.named_parameters():
+        if name.startswith("transform."):
+            assert prm.grad is not None, name
+            assert relg(prm.grad.cpu(), ref_params[name].grad) < tol, name
+            if "context_layer.weight" in name and not full:      # the per-position context mask holds in the gradient
+                mod = flow.get_submodule(name.rsplit(".", 1)[0])
+                assert (prm.grad * (1 - mod.mask)).abs().max() == 0
+            n += 1
+    assert n > 0
