@@ -287,6 +287,7 @@ def extras(flow, dev, batch):
     out.update(config5_sampling(dev, flow.precision))
     out.update(config4_train_step(dev, flow.precision))
     out.update(generic_head(dev, flow.precision))
+    out.update(coherent_geometry(dev))
     log("extras: " + ", ".join(f"{k}={v:.3g}" for k, v in out.items()))
     return out
 
@@ -336,6 +337,22 @@ def generic_head(dev, precision, batch=4096):
     torch.cuda.synchronize(dev)
     dt = (time.perf_counter() - t0) / 5
     return {"generic_head_12x384x24_samples_per_s": batch / dt}
+
+
+def coherent_geometry(dev, events=1024):
+    """CoherentEncoder's frequency-domain geometry features (coherent_encoder.py:79-116: 3 rfft + 3 irfft of 16 384 samples
+    per event + band reductions) by pf_geom_features: events per second."""
+    from posteriflow_amd import npe
+    enc = npe.CoherentEncoder(context_dim=256, psd_bands=16).to(dev).eval()
+    x = torch.randn(events, 3, 16384, device=dev)
+    with torch.no_grad():
+        enc._geometry_rel(x)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            enc._geometry_rel(x)
+        torch.cuda.synchronize(dev)
+    return {"coherent_geometry_events_per_s": events * 5 / (time.perf_counter() - t0)}
 
 
 def config4_train_step(dev, precision, events=1024, reps=5):

@@ -12,6 +12,7 @@
  *   pf_flow_pack      the per-call `weight * mask` of nflows MaskedLinear, done once
  *   pf_embed_fusion_forward  LeanStrainEncoder fusion transformer + pool attention  lean_npe.py:226-229
  *   pf_remix_forward  RemixDataset.__getitem__ (algebra)      experiments/remix_data.py:218-299
+ *   pf_geom_features  CoherentEncoder._geometry_rel           src/ahsd/models/coherent_encoder.py:79-116
  *   pf_embed_train_forward / _backward  LeanStrainEncoder._compute_feats under autograd (training)  lean_npe.py:199-233,
  *                     experiments/train_lean_npe.py:363-364
  *   pf_embed_stem_forward  LeanStrainEncoder stem + energy windows  src/ahsd/models/lean_npe.py:207-217
@@ -481,6 +482,31 @@ typedef struct PfPoolArgs {     /* 8 learned queries per head over the tokens of
 } PfPoolArgs;
 int pf_enc_pool_forward(int32_t precision, const PfPoolArgs* args, void* stream);
 int pf_enc_pool_backward(int32_t precision, const PfPoolArgs* args, void* stream);
+
+/* ---- coherent encoder: frequency-domain geometry features ------------------------------------------------
+ * CoherentEncoder._geometry_rel (src/ahsd/models/coherent_encoder.py:79-116) for a batch of events: rfft (ortho) of every
+ * detector's 16 384 sanitised samples, kept bins [band_lo, band_lo + nf); per detector n_bands log band energies
+ * log(mean_band |X|^2 + 1e-8); per detector pair (i < j, lexicographic) and band the power-weighted coherence
+ * (|g| + 1e-8, Re g / |g|, Im g / |g|), g = sum X_i conj X_j / (sum |X_i| |X_j| + 1e-8) with |X| = sqrt(|X|^2 + 1e-12); the
+ * peak of |irfft(X_i conj X_j on the band)| over the lags -maxlag .. maxlag as (lag / maxlag, max / (mean + 1e-8)); and
+ * log(sum |X_i|^2 + 1e-8) - log(sum |X_j|^2 + 1e-8).  Row layout of rel = the reference's torch.cat order:
+ * [n_det][n_bands] energies, then per pair [n_bands] |g| | [n_bands] cos | [n_bands] sin | lag | sharpness | log ratio.
+ * Both transforms run in LDS (csrc/pf_geom.hip); fp32.  Limits: n_det <= 8, n_bands <= 16, 1 <= band_lo, band_lo + nf <= 4096,
+ * 1 <= maxlag <= 127; band b = kept bins [band_edge[b], band_edge[b+1]) (non-decreasing, within [0, nf]).
+ * twiddle: device copy of the table pf_geom_twiddles writes (host memory, 8192 x (cos, sin) of -2 pi m / 16384).
+ * spec / etot: caller-owned workspaces. */
+typedef struct PfGeomArgs {
+    const float* clean;        /* [batch][n_det][16384] */
+    int64_t batch;
+    int32_t n_det, band_lo, nf, n_bands, maxlag;
+    int32_t band_edge[17];
+    const float* twiddle;      /* [8192][2] */
+    float* spec;               /* [batch][n_det][nf][2] workspace: band spectra */
+    float* etot;               /* [batch][n_det] workspace: total band power */
+    float* rel;                /* [batch][n_det n_bands + npairs (3 n_bands + 3)] */
+} PfGeomArgs;
+int pf_geom_twiddles(float* host_table);
+int pf_geom_features(const PfGeomArgs* args, void* stream);
 
 /* ---- training-example remix ------------------------------------------
  * The deterministic half of RemixDataset.__getitem__ (experiments/remix_data.py:218-299) for a

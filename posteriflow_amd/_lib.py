@@ -79,6 +79,12 @@ class PfPoolArgs(C.Structure):
                 ("dpooled", C.c_void_p), ("dkv", C.c_void_p), ("dq", C.c_void_p)]
 
 
+class PfGeomArgs(C.Structure):
+    _fields_ = [("clean", C.c_void_p), ("batch", C.c_int64), ("n_det", C.c_int32), ("band_lo", C.c_int32), ("nf", C.c_int32),
+                ("n_bands", C.c_int32), ("maxlag", C.c_int32), ("band_edge", C.c_int32 * 17), ("twiddle", C.c_void_p),
+                ("spec", C.c_void_p), ("etot", C.c_void_p), ("rel", C.c_void_p)]
+
+
 class PfFlowDesc(C.Structure):
     _fields_ = [
         ("features", C.c_int32), ("context_features", C.c_int32),
@@ -162,6 +168,8 @@ SYMBOLS = {
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                    C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                    C.c_void_p]),
+    "pf_geom_twiddles": (C.c_int, [C.c_void_p]),
+    "pf_geom_features": (C.c_int, [C.POINTER(PfGeomArgs), C.c_void_p]),
     "pf_last_error": (C.c_char_p, []),
     "pf_version": (C.c_char_p, []),
     "pf_flow_rows_per_workgroup": (C.c_int32, [_P, C.c_int64]),

@@ -53,6 +53,8 @@ int enc_train_backward(const PfEmbedTrainDesc* desc, const void* packed, const f
 
 namespace pf {
 thread_local int g_hip_error = 0;
+void geom_twiddles(float* table);
+int geom_features(const PfGeomArgs& a, hipStream_t st);
 }
 
 namespace {
@@ -647,4 +649,26 @@ int32_t pf_flow_rows_per_workgroup(const PfFlowDesc* desc, int64_t batch) {
     return pf::rows_per_workgroup(L, batch);
 }
 
+int pf_geom_twiddles(float* host_table) {
+    if (!host_table) return fail(PF_ERR_BAD_ARG, "null pointer");
+    pf::geom_twiddles(host_table);
+    return PF_OK;
+}
+
+int pf_geom_features(const PfGeomArgs* a, void* stream) {
+    if (!a || !a->clean || !a->twiddle || !a->spec || !a->etot || !a->rel) return fail(PF_ERR_BAD_ARG, "null pointer");
+    if (a->batch < 0) return fail(PF_ERR_BAD_ARG, "negative batch");
+    if (misaligned(a->clean, 16) || misaligned(a->twiddle, 8) || misaligned(a->spec, 8))
+        return fail(PF_ERR_BAD_ARG, "clean must be 16-byte, twiddle / spec 8-byte aligned");
+    if (a->n_det < 1 || a->n_det > 8 || a->n_bands < 1 || a->n_bands > 16 || a->band_lo < 1 || a->nf < 1 ||
+        a->band_lo + a->nf > 4096 || a->maxlag < 1 || a->maxlag > 127)
+        return fail(PF_ERR_UNSUPPORTED, "geometry features: n_det <= 8, n_bands <= 16, 1 <= band_lo, band_lo + nf <= 4096, maxlag <= 127");
+    if (a->band_edge[0] < 0 || a->band_edge[a->n_bands] > a->nf) return fail(PF_ERR_BAD_ARG, "band edges outside the kept bins");
+    for (int b = 0; b < a->n_bands; ++b)
+        if (a->band_edge[b] > a->band_edge[b + 1]) return fail(PF_ERR_BAD_ARG, "band edges must be non-decreasing");
+    if (a->batch == 0) return PF_OK;
+    if (a->batch * (int64_t)a->n_det * (a->n_det > 1 ? (a->n_det - 1) : 1) > 0x7fffffffLL) return fail(PF_ERR_UNSUPPORTED, "batch too large for one launch");
+    const int rc = pf::geom_features(*a, static_cast<hipStream_t>(stream));
+    return rc == PF_OK ? rc : fail(rc, hipGetErrorString(static_cast<hipError_t>(pf::g_hip_error)));
+}
 }  // extern "C"

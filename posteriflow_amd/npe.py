@@ -451,8 +451,51 @@ class CoherentEncoder(LeanStrainEncoder):
                                       nn.Linear(geom_hidden, geom_hidden), nn.GELU())
         self.geom_to_tokens = nn.Linear(geom_hidden, self.n_geom_tokens * self.d_model)
 
+    def _geometry_plan(self):
+        """band b as a contiguous range of the kept bins (geomspace bands are intervals), or None when they are not"""
+        plan = self.__dict__.get("_geom_plan")
+        if plan is None:
+            m = self.Bsum.detach().cpu().numpy() > 0
+            edges, ok = [0], self.K <= 16 and m.sum(0).max() <= 1
+            for k in range(self.K):
+                idx = np.flatnonzero(m[k])
+                lo, hi = (int(idx[0]), int(idx[-1]) + 1) if idx.size else (edges[-1], edges[-1])
+                ok = ok and lo == edges[-1] and hi - lo == idx.size
+                edges.append(hi)
+            ok = (ok and edges[-1] == self.Nf and _T_LEN == 16384 and self.band_lo >= 1 and self.band_lo + self.Nf <= 4096
+                  and 1 <= self.maxlag <= 127 and self.n_detectors <= 8)
+            plan = self.__dict__["_geom_plan"] = (edges if ok else False)
+        return plan or None
+
+    def _geometry_rel_hip(self, clean, edges):
+        """the same features by pf_geom_features (csrc/pf_geom.hip): both transforms in LDS, one launch per stage"""
+        from . import _lib
+        b, dev = clean.shape[0], clean.device
+        tw = self.__dict__.get("_geom_twiddle")
+        if tw is None or tw.device != dev:
+            host = torch.empty(8192, 2, dtype=torch.float32)
+            _lib.check(_lib.lib().pf_geom_twiddles(host.data_ptr()), "pf_geom_twiddles")
+            tw = self.__dict__["_geom_twiddle"] = host.to(dev)
+        x = clean.float().contiguous()
+        a = _lib.PfGeomArgs()
+        a.clean, a.batch, a.n_det = x.data_ptr(), b, self.n_detectors
+        a.band_lo, a.nf, a.n_bands, a.maxlag = self.band_lo, self.Nf, self.K, self.maxlag
+        for i, e in enumerate(edges):
+            a.band_edge[i] = e
+        spec = torch.empty(b, self.n_detectors, self.Nf, 2, dtype=torch.float32, device=dev)
+        etot = torch.empty(b, self.n_detectors, dtype=torch.float32, device=dev)
+        rel = torch.empty(b, self.n_detectors * self.K + len(self.pairs) * (3 * self.K + 3), dtype=torch.float32, device=dev)
+        a.twiddle, a.spec, a.etot, a.rel = tw.data_ptr(), spec.data_ptr(), etot.data_ptr(), rel.data_ptr()
+        _lib.check(_lib.lib().pf_geom_features(a, torch.cuda.current_stream(dev).cuda_stream), "pf_geom_features")
+        return rel
+
     def _geometry_rel(self, clean):
         b = clean.shape[0]
+        if clean.is_cuda and not (torch.is_grad_enabled() and clean.requires_grad):
+            # (the strain is data: no caller differentiates the features with respect to it; if one does, the tensor ops below)
+            edges = self._geometry_plan()
+            if edges is not None:
+                return self._geometry_rel_hip(clean, edges)
         spec = torch.fft.rfft(clean.float().contiguous(), norm="ortho", dim=-1)
         spec = spec[..., self.band_lo: self.band_lo + self.Nf]
         re, im = spec.real, spec.imag

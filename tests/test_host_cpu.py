@@ -414,7 +414,7 @@ def test_ctypes_structs_match_the_header(lib, tmp_path):
     if cc is None:
         pytest.skip("no C compiler")
     names = ["PfFlowDesc", "PfFlowBwdChainArgs", "PfFlowReevalArgs", "PfEmbedTrainDesc", "PfDenseArgs", "PfDenseTnArgs", "PfLnArgs",
-             "PfAttnArgs", "PfPoolArgs"]
+             "PfAttnArgs", "PfPoolArgs", "PfGeomArgs"]
     src = tmp_path / "sz.c"
     src.write_text('#include <stdio.h>\n#include "pf_hip.h"\nint main(void) {\n'
                    + "".join(f'  printf("{n} %zu\\n", sizeof({n}));\n' for n in names) + "  return 0;\n}\n")
