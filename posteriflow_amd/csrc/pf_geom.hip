@@ -60,13 +60,22 @@ __device__ void fft_dif(c32* s, const c32* __restrict__ tw, int tid) {
 #pragma unroll 1
     for (int ls = 13; ls >= 7; ls -= 2) {                  // stages of size 2^ls and 2^(ls-1) in one pass
         const int q = 1 << (ls - 2);
-#pragma unroll 2
-        for (int gi = tid; gi < kN / 4; gi += kThreads) {
+        // the pass's 16 twiddles of this thread in one batch: one L2 round trip per pass instead of one per butterfly group
+        constexpr int kIt = kN / 4 / kThreads;
+        c32 w1s[kIt], w2s[kIt];
+#pragma unroll
+        for (int it = 0; it < kIt; ++it) {
+            const int j = (tid + it * kThreads) & (q - 1);
+            w1s[it] = tw[j << (14 - ls)];                  // W_s^j;  W_s^(j+q) = -i W_s^j
+            w2s[it] = tw[j << (15 - ls)];                  // W_(s/2)^j
+        }
+#pragma unroll
+        for (int it = 0; it < kIt; ++it) {
+            const int gi = tid + it * kThreads;
             const int j = gi & (q - 1), base = (gi >> (ls - 2)) << ls;
             const int i0 = base + j;
             const c32 a0 = s[slot(i0)], a1 = s[slot(i0 + q)], a2 = s[slot(i0 + 2 * q)], a3 = s[slot(i0 + 3 * q)];
-            const c32 w1 = tw[j << (14 - ls)];             // W_s^j;  W_s^(j+q) = -i W_s^j
-            const c32 w2 = tw[j << (15 - ls)];             // W_(s/2)^j
+            const c32 w1 = w1s[it], w2 = w2s[it];
             const c32 b0 = a0 + a2, b2 = cmul(a0 - a2, w1), b1 = a1 + a3, b3 = mul_neg_i(cmul(a1 - a3, w1));
             s[slot(i0)] = b0 + b1;
             s[slot(i0 + q)] = cmul(b0 - b1, w2);
@@ -117,10 +126,14 @@ __global__ __launch_bounds__(kThreads) void geom_spectrum_kernel(const GeomParam
     const int64_t seq = blockIdx.x;
     const c32* const tw = reinterpret_cast<const c32*>(A.twiddle);
     const float4* x4 = reinterpret_cast<const float4*>(A.clean + seq * kT);
-    for (int i = tid; i < kT / 4; i += kThreads) {
-        const float4 v = x4[i];
-        s[slot(2 * i)] = c32{v.x, v.y};
-        s[slot(2 * i + 1)] = c32{v.z, v.w};
+    float4 xv[kT / 4 / kThreads];                               // all 16 loads of the thread in flight together
+#pragma unroll
+    for (int it = 0; it < kT / 4 / kThreads; ++it) xv[it] = x4[tid + it * kThreads];
+#pragma unroll
+    for (int it = 0; it < kT / 4 / kThreads; ++it) {
+        const int i = tid + it * kThreads;
+        s[slot(2 * i)] = c32{xv[it].x, xv[it].y};
+        s[slot(2 * i + 1)] = c32{xv[it].z, xv[it].w};
     }
     __syncthreads();
     fft_dif(s, tw, tid);
@@ -177,15 +190,55 @@ __global__ __launch_bounds__(kThreads) void geom_pair_kernel(const GeomParams p)
     const c32* const tw = reinterpret_cast<const c32*>(A.twiddle);
     const c32* const Si = reinterpret_cast<const c32*>(A.spec) + (ev_i * A.n_det + di) * A.nf;
     const c32* const Sj = reinterpret_cast<const c32*>(A.spec) + (ev_i * A.n_det + dj) * A.nf;
+    // cross spectrum of this thread's bins (kk = tid + 256 it) in registers; a copy + |X_i| |X_j| through LDS for the band sums
+    // (the bands are 22 .. 893 bins long: summing them from global memory by 16 threads per band was 56 dependent L2
+    // round trips for the last band -- 40 % of this kernel)
+    constexpr int kIt = kN / 2 / kThreads;
+    c32 F[kIt], wv[kIt];
+    float* const fr = reinterpret_cast<float*>(smem);             // [3][4096]: Re F | Im F | |X_i| |X_j| (before the transform's array is built)
+    {
+        c32 av[kIt], bv[kIt];
+#pragma unroll
+        for (int it = 0; it < kIt; ++it) {
+            const int kk = tid + it * kThreads, kc = kk < A.nf ? kk : A.nf - 1;
+            av[it] = Si[kc]; bv[it] = Sj[kc]; wv[it] = tw[A.band_lo + kc];
+        }
+#pragma unroll
+        for (int it = 0; it < kIt; ++it) {
+            const int kk = tid + it * kThreads;
+            const c32 a = av[it], b = bv[it];
+            F[it] = c32{a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y};     // X_i conj(X_j)
+            fr[kk] = F[it].x;
+            fr[4096 + kk] = F[it].y;
+            fr[8192 + kk] = sqrtf(a.x * a.x + a.y * a.y + 1e-12f) * sqrtf(b.x * b.x + b.y * b.y + 1e-12f);
+        }
+    }
+    __syncthreads();
+    {
+        const int b = tid >> 4, r = tid & 15;
+        float sr = 0.f, si = 0.f, sd = 0.f;
+        if (b < A.n_bands)
+            for (int kk = A.band_edge[b] + r; kk < A.band_edge[b + 1]; kk += 16) { sr += fr[kk]; si += fr[4096 + kk]; sd += fr[8192 + kk]; }
+        sr = row16_sum(sr); si = row16_sum(si); sd = row16_sum(sd);
+        if (b < A.n_bands && r == 0) {
+            const float den = sd + 1e-8f, gr = sr / den, gi = si / den, gm = sqrtf(gr * gr + gi * gi) + 1e-8f;
+            float* o = A.rel + ev_i * p.rel_dim + A.n_det * A.n_bands + pr * (3 * A.n_bands + 3);
+            o[b] = gm;
+            o[A.n_bands + b] = gr / gm;
+            o[2 * A.n_bands + b] = gi / gm;
+        }
+    }
+    __syncthreads();
     for (int i = tid; i < kSlots; i += kThreads) s[i] = c32{0.f, 0.f};
     __syncthreads();
-    for (int kk = tid; kk < A.nf; kk += kThreads) {
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) {
+        const int kk = tid + it * kThreads;
+        if (kk >= A.nf) continue;
         const int k = A.band_lo + kk;
-        const c32 a = Si[kk], b = Sj[kk];
-        const c32 F = {a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y};     // X_i conj(X_j)
-        const c32 w = tw[k];                                                // e^{-2 pi i k / T}
-        s[slot(k)] = cmul(c32{F.x, -F.y}, c32{1.f + w.y, -w.x});           // conj(F) (1 - i w)
-        s[slot(kN - k)] = cmul(F, c32{1.f - w.y, -w.x});                   // F (1 - i conj w)
+        const c32 w = wv[it];                                               // e^{-2 pi i k / T}
+        s[slot(k)] = cmul(c32{F[it].x, -F[it].y}, c32{1.f + w.y, -w.x});   // conj(F) (1 - i w)
+        s[slot(kN - k)] = cmul(F[it], c32{1.f - w.y, -w.x});               // F (1 - i conj w)
     }
     __syncthreads();
     fft_dif(s, tw, tid);
@@ -218,23 +271,6 @@ __global__ __launch_bounds__(kThreads) void geom_pair_kernel(const GeomParams p)
             o[1] = best / (sum / (float)nl + 1e-8f);
             o[2] = logf(A.etot[ev_i * A.n_det + di] + 1e-8f) - logf(A.etot[ev_i * A.n_det + dj] + 1e-8f);
         }
-    }
-    const int b = tid >> 4, r = tid & 15;
-    float sr = 0.f, si = 0.f, sd = 0.f;
-    if (b < A.n_bands)
-        for (int kk = A.band_edge[b] + r; kk < A.band_edge[b + 1]; kk += 16) {
-            const c32 a = Si[kk], c = Sj[kk];
-            sr += a.x * c.x + a.y * c.y;
-            si += a.y * c.x - a.x * c.y;
-            sd += sqrtf(a.x * a.x + a.y * a.y + 1e-12f) * sqrtf(c.x * c.x + c.y * c.y + 1e-12f);
-        }
-    sr = row16_sum(sr); si = row16_sum(si); sd = row16_sum(sd);
-    if (b < A.n_bands && r == 0) {
-        const float den = sd + 1e-8f, gr = sr / den, gi = si / den, gm = sqrtf(gr * gr + gi * gi) + 1e-8f;
-        float* o = A.rel + ev_i * p.rel_dim + A.n_det * A.n_bands + pr * (3 * A.n_bands + 3);
-        o[b] = gm;
-        o[A.n_bands + b] = gr / gm;
-        o[2 * A.n_bands + b] = gi / gm;
     }
 }
 }  // namespace
