@@ -24,7 +24,8 @@
 //   order is permuted to the accumulator layout (slot 8g+j <- key 32s+4g+j | 32s+16+4g+j-4) and V^T is
 //   read from LDS in the same order.  Each head's output goes through LDS once into the out-projection,
 //   which accumulates over heads in registers; the FFN hidden layer goes through LDS in 4 chunks of 192
-//   and never exists in full.  LDS: 73 728 (normalised tokens) + 73 728 (Q|K|V^T|O or hidden chunk) + 6 144.
+//   and never exists in full.  Two heads are in flight per iteration (24 (head, query tile) units = 3 per wave; O goes over
+//   the Q tile its wave consumed).  LDS: 73 728 (normalised tokens) + 74 752 (2 x (Q/O|K|V^T) or hidden chunk) + 6 144.
 // bf16 operands, fp32 accumulation, fp32 LayerNorm / softmax / GELU (erf) / residual.
 #include <hip/hip_runtime.h>
 
@@ -49,7 +50,9 @@ constexpr int kE = 192, kHeads = 6, kHd = 32, kFF = 768, kLayers = 3, kPoolQ = 8
 constexpr int kTok = 192, kTT = 12;                   // padded tokens, token tiles
 constexpr int kXS = 384, kQS = 64, kVS = 400;           // LDS byte strides: [tok][192], [tok][32] (XOR-swizzled), V^T [32][192]
 constexpr int kBuf = kTok * kXS;                       // 73 728
-constexpr int kLds = 2 * kBuf + 4 * kTok * 8;         // + per-wave token statistics
+constexpr int kHeadSet = 2 * kTok * kQS + kHd * kVS;   // one head's Q (later O) | K | V^T: 37 376
+constexpr int kBufB = 2 * kHeadSet > kBuf ? 2 * kHeadSet : kBuf;       // two heads in flight / an FFN hidden chunk: 74 752
+constexpr int kLds = kBuf + kBufB + 4 * kTok * 8;     // + per-wave token statistics
 constexpr int kFrag = 1024;
 
 // ---- packed parameter block --------------------------------------------------------------------
@@ -103,12 +106,14 @@ __device__ __forceinline__ int qoff(int row, int byte) {
 __global__ __launch_bounds__(512) void fusion_kernel(FusionParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const xn = smem;                       // normalised tokens, bf16 [192][384 B]
-    char* const hb = smem + kBuf;                // FFN hidden chunk, bf16 [192][384 B]   (aliases the four below)
-    char* const qb = smem + kBuf;                // Q  [192][64 B]
-    char* const kb = qb + kTok * kQS;            // K  [192][64 B]
-    char* const vt = kb + kTok * kQS;            // V^T [32][400 B]
-    char* const ob = vt + kHd * kVS;             // O  [192][64 B]
-    float2* const stats = reinterpret_cast<float2*>(smem + 2 * kBuf);   // [4 waves][192 tokens] (sum, sum of squares)
+    char* const hb = smem + kBuf;                // FFN hidden chunk, bf16 [192][384 B]   (aliases the head sets below)
+    // two heads are in flight at a time (24 (head, query tile) units = 3 per wave; with one head the 12 tiles left
+    // half the waves idle for a third of the attention phase): head slot hs at hb + hs * kHeadSet holds
+    // Q [192][64 B] -- overwritten tile by tile with O by the wave that consumed the tile -- | K [192][64 B] | V^T [32][400 B]
+    char* const qb = smem + kBuf;
+    char* const kb = qb + kTok * kQS;
+    char* const vt = kb + kTok * kQS;
+    float2* const stats = reinterpret_cast<float2*>(smem + kBuf + kBufB);   // [4 waves][192 tokens] (sum, sum of squares)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
     const int T = p.T;
     float* const Xg = p.x + static_cast<int64_t>(blockIdx.x) * T * kE;
@@ -253,17 +258,19 @@ __global__ __launch_bounds__(512) void fusion_kernel(FusionParams p) {
     };
     // one (head, 16-query tile): softmax(K Q^T) V with keys >= T masked; result O^T tiles (2 x f32x4).
     // exp(s - m) = exp2(s log2e - m log2e): one packed fma + a bare v_exp_f32 per score.
-    auto attend = [&](int qt, f32x4 (&o)[2]) {
+    // mask_from: first key tile that can hold padded keys (compile time: 11 when T > 176, else 0) -- selects instead of a
+    // uniform branch per tile, so that one call is one basic block and the scheduler can run the MFMAs of one (head, query
+    // tile) unit under the softmax of another
+    auto attend = [&](auto mask_from, const char* qb, const char* kb, const char* vt, int qt, f32x4 (&o)[2]) {
         const bf16x8 qf = bq(qb, qt);
         f32x4 s[kTT];
         float m = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < kTT; ++kt) {
             s[kt] = mfma(bq(kb, kt), qf, f32x4{0.f, 0.f, 0.f, 0.f});
-            if (16 * kt + 16 > T) {                 // (uniform) only the tiles that hold padded keys
+            if (kt >= decltype(mask_from)::value) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (16 * kt + 4 * g + e >= T) s[kt][e] = -INFINITY;
+                for (int e = 0; e < 4; ++e) s[kt][e] = 16 * kt + 4 * g + e >= T ? -INFINITY : s[kt][e];
             }
             m = fmaxf(fmaxf(m, fmaxf(s[kt][0], s[kt][1])), fmaxf(s[kt][2], s[kt][3]));
         }
@@ -305,7 +312,7 @@ __global__ __launch_bounds__(512) void fusion_kernel(FusionParams p) {
     auto put_qk = [&](char* buf, int dt, int tt, f32x4 v) {
         *reinterpret_cast<bf16x4*>(buf + tt * (16 * kQS) + qw[dt]) = to_bf16(v);
     };
-    auto put_vt = [&](int dt, int tt, f32x4 v) {
+    auto put_vt = [&](char* vt, int dt, int tt, f32x4 v) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
             *reinterpret_cast<__bf16*>(vt + (16 * dt + 4 * g + e) * kVS + (16 * tt + c) * 2) = (__bf16)v[e];
@@ -317,27 +324,36 @@ __global__ __launch_bounds__(512) void fusion_kernel(FusionParams p) {
         // ================= self-attention block =================
         stage_tokens(vec + kLn1g, vec + kLn1b);
         add_bias(vec + kBo);
-        for (int h = 0; h < kHeads; ++h) {
-            {   // Q | K | V of head h: this wave's 3 of the 6 tiles x its 6 token tiles
+        for (int hp = 0; hp < kHeads / 2; ++hp) {
+            {   // Q | K | V of heads 2 hp, 2 hp + 1: this wave's 3 of a head's 6 tiles x its 3 token tiles, the two heads' 12
+                // k-steps as ONE pipelined sequence (the weight fragments of a step are requested one step ahead, across the
+                // head boundary too)
                 f32x4 t[3][3];
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) t[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                // tile index in the 36-tile in_proj: Q 2h,2h+1 | K 12+2h,12+2h+1 | V 24+2h,24+2h+1
-                int tile[3];
-                tile[0] = fb2 == 0 ? 2 * h : 12 + 2 * h + 1;
-                tile[1] = fb2 == 0 ? 2 * h + 1 : 24 + 2 * h;
-                tile[2] = fb2 == 0 ? 12 + 2 * h : 24 + 2 * h + 1;
+                auto tile_of = [&](int hs, int i) {
+                    // tile index in the 36-tile in_proj: Q 2h,2h+1 | K 12+2h,12+2h+1 | V 24+2h,24+2h+1
+                    const int h = 2 * hp + hs;
+                    return i == 0 ? (fb2 == 0 ? 2 * h : 12 + 2 * h + 1) : i == 1 ? (fb2 == 0 ? 2 * h + 1 : 24 + 2 * h)
+                                                                                  : (fb2 == 0 ? 12 + 2 * h : 24 + 2 * h + 1);
+                };
+                bf16x8 a[2][3];
                 if constexpr (!(kAbl & 8)) {
-                    bf16x8 a[2][3];
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) a[0][i] = afrag(lw + kWqkv, tile[i], 6, 0);
+                    for (int i = 0; i < 3; ++i) a[0][i] = afrag(lw + kWqkv, tile_of(0, i), 6, 0);
+                }
 #pragma unroll
-                    for (int ks = 0; ks < 6; ++ks) {
-                        if (ks + 1 < 6) {
+                for (int step = 0; step < 12; ++step) {
+                    const int hs = step / 6, ks = step % 6;
+                    if (ks == 0) {
 #pragma unroll
-                            for (int i = 0; i < 3; ++i) a[(ks + 1) & 1][i] = afrag(lw + kWqkv, tile[i], 6, ks + 1);
+                        for (int i = 0; i < 3; ++i)
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) t[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                    if constexpr (!(kAbl & 8)) {
+                        if (step + 1 < 12) {
+#pragma unroll
+                            for (int i = 0; i < 3; ++i)
+                                a[(step + 1) & 1][i] = afrag(lw + kWqkv, tile_of((step + 1) / 6, i), 6, (step + 1) % 6);
                         }
                         __builtin_amdgcn_sched_barrier(0);          // (see dense)
                         bf16x8 b[3];
@@ -346,40 +362,53 @@ __global__ __launch_bounds__(512) void fusion_kernel(FusionParams p) {
 #pragma unroll
                         for (int i = 0; i < 3; ++i)
 #pragma unroll
-                            for (int j = 0; j < 3; ++j) t[i][j] = mfma(a[ks & 1][i], b[j], t[i][j]);
+                            for (int j = 0; j < 3; ++j) t[i][j] = mfma(a[step & 1][i], b[j], t[i][j]);
                     }
-                }
+                    if (ks == 5) {
+                        char* const q_ = qb + hs * kHeadSet;
+                        char* const k_ = kb + hs * kHeadSet;
+                        char* const v_ = vt + hs * kHeadSet;
 #pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(vec + kBqkv + 16 * tile[i] + 4 * g);
+                        for (int i = 0; i < 3; ++i) {
+                            const f32x4 b4 = *reinterpret_cast<const f32x4*>(vec + kBqkv + 16 * tile_of(hs, i) + 4 * g);
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        const int tt = 3 * tb4 + j;
-                        const f32x4 v = t[i][j] + b4;
-                        if (fb2 == 0) {
-                            if (i == 0) put_qk(qb, 0, tt, v * kQScale);
-                            else if (i == 1) put_qk(qb, 1, tt, v * kQScale);
-                            else put_qk(kb, 0, tt, v);
-                        } else {
-                            if (i == 0) put_qk(kb, 1, tt, v);
-                            else put_vt(i - 1, tt, v);
+                            for (int j = 0; j < 3; ++j) {
+                                const int tt = 3 * tb4 + j;
+                                const f32x4 v = t[i][j] + b4;
+                                if (fb2 == 0) {
+                                    if (i == 0) put_qk(q_, 0, tt, v * kQScale);
+                                    else if (i == 1) put_qk(q_, 1, tt, v * kQScale);
+                                    else put_qk(k_, 0, tt, v);
+                                } else {
+                                    if (i == 0) put_qk(k_, 1, tt, v);
+                                    else put_vt(v_, i - 1, tt, v);
+                                }
+                            }
                         }
                     }
                 }
             }
             __syncthreads();
-            for (int qt = w; qt < kTT; qt += 8) {
-                f32x4 o[2];
-                if constexpr (kAbl & 2) { o[0] = o[1] = f32x4{0.f, 0.f, 0.f, 0.f}; } else
-                attend(qt, o);
-                put_qk(ob, 0, qt, o[0]);
-                put_qk(ob, 1, qt, o[1]);
-            }
+            auto units = [&](auto mask_from) {              // 24 (head slot, query tile) units: 3 per wave
+#pragma unroll 1
+                for (int it = 0; it < 2 * kTT / 8; ++it) {
+                    const int u = w + 8 * it;
+                    const int hs = u >= kTT ? 1 : 0, qt = u - hs * kTT;
+                    char* const q_ = qb + hs * kHeadSet;
+                    f32x4 o[2];
+                    if constexpr (kAbl & 2) { o[0] = o[1] = f32x4{0.f, 0.f, 0.f, 0.f}; } else
+                    attend(mask_from, q_, kb + hs * kHeadSet, vt + hs * kHeadSet, qt, o);
+                    put_qk(q_, 0, qt, o[0]);                 // O over the Q tile this wave alone has read
+                    put_qk(q_, 1, qt, o[1]);
+                }
+            };
+            if (T > 16 * (kTT - 1)) units(ic<kTT - 1>{}); else units(ic<0>{});
             __syncthreads();
-            // out-projection straight into the residual: k-step h of Wo against this head's O
-            dense(X, kHT * th, lw + kWo, 3 * fblk, 6, h, ic<1>{}, [&](int tt, int) { return bq(ob, tt); });
+            // out-projection straight into the residual: k-steps 2 hp, 2 hp + 1 of Wo against the two heads' O
+            dense(X, kHT * th, lw + kWo, 3 * fblk, 6, 2 * hp, ic<2>{},
+                  [&](int tt, int ks) { return bq(qb + ks * kHeadSet, tt); });
+            __syncthreads();                                   // O lives where the next pair's Q goes
         }
-        __syncthreads();                                   // ob / hb alias: all out-projections done
         // ================= feed-forward block =================
         stage_tokens(vec + kLn2g, vec + kLn2b);
         add_bias(vec + kB2);
@@ -451,7 +480,7 @@ __global__ __launch_bounds__(512) void fusion_kernel(FusionParams p) {
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
                     if (fb2 == 0) put_qk(kb, i, 3 * tb4 + j, t[i][j] + b4);
-                    else put_vt(i, 3 * tb4 + j, t[i][j] + b4);
+                    else put_vt(vt, i, 3 * tb4 + j, t[i][j] + b4);
                 }
             }
             // the head's 8 queries (rows 8..15 of the tile are zero)
@@ -464,7 +493,7 @@ __global__ __launch_bounds__(512) void fusion_kernel(FusionParams p) {
         __syncthreads();
         if (w == 0) {
             f32x4 o[2];
-            attend(0, o);
+            attend(ic<0>{}, qb, kb, vt, 0, o);
             if (c < kPoolQ) {
                 float* dst = p.pooled + (static_cast<int64_t>(blockIdx.x) * kPoolQ + c) * kE + kHd * h + 4 * g;
                 *reinterpret_cast<f32x4*>(dst) = o[0];
