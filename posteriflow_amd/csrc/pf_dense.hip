@@ -127,6 +127,8 @@ __global__ __launch_bounds__(256, TP <= 3 ? 2 : 1) void dense_strip_kernel(const
     const int ksp = p.k_splits > 1 ? p.k_splits : 1;
     const int cps = (nchunks + ksp - 1) / ksp;
     const int ch_lo = (int)blockIdx.y * cps, ch_hi = ch_lo + cps < nchunks ? ch_lo + cps : nchunks;
+    if (ch_lo >= nchunks) return;      // (the launcher sizes grid.y to the non-empty splits; an empty one would prefetch weight
+                                       // fragments from beyond the stream: 25 splits of 30 chunks = 15 of 2, ten empty)
     f_kk = ch_lo * nks;
     u32x4 ring[RD][TP];
     auto fetch = [&](u32x4 (&dst)[TP]) {
@@ -433,7 +435,10 @@ static int launch_strip(const DenseArgs& a, hipStream_t s) {
     if (lds > 64 * 1024 && !opt_in_lds(reinterpret_cast<const void*>(k), (int)lds)) return PF_ERR_HIP;
     const unsigned grid = (unsigned)((a.M + 127) / 128);
     if (grid == 0) return PF_OK;
-    hipLaunchKernelGGL(k, dim3(grid, a.k_splits > 1 ? a.k_splits : 1), dim3(256), lds, s, a);
+    // splits: ceil(nchunks / k_splits) chunks each -- only the splits that own a chunk are launched
+    const int nchunks = a.K / a.KC, ksp = a.k_splits > 1 ? a.k_splits : 1, cps = (nchunks + ksp - 1) / ksp;
+    const unsigned ny = (unsigned)((nchunks + cps - 1) / cps);
+    hipLaunchKernelGGL(k, dim3(grid, ny), dim3(256), lds, s, a);
     return launch_status();
 }
 

@@ -12,7 +12,10 @@ opt = train.make_optimizer(model); sched = train.make_scheduler(opt, 2000, warmu
 g = torch.Generator(device=dev).manual_seed(0)
 losses = []
 t0 = time.perf_counter()
+RAGGED = [1, 7, 33, 100, 183, 256, 333, 500] if os.environ.get("PF_SOAK_RAGGED") else None      # event counts cycled step by step
 for it in range(steps):
+    if RAGGED:
+        events = RAGGED[it % len(RAGGED)]
     idx = torch.randint(0, ds.n_events, (events,), device=dev, generator=g)
     strain, labels, nsig, _ = ds.batch(idx, generator=g)
     out = train.train_step(model, opt, sched, strain, labels, nsig, sync=(it % 20 == 19))

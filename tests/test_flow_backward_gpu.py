@@ -343,3 +343,32 @@ def test_flat_parameter_mode_gives_the_same_gradients_and_state_dict(precision):
     fresh.load_state_dict(flat.state_dict())                           # back into a per-parameter flow
     assert torch.equal(fresh._ar_transforms[0].autoregressive_net.initial_layer.weight.detach(),
                        flat._ar_transforms[0].autoregressive_net.initial_layer.weight.detach())
+
+
+@pytest.mark.parametrize("precision,B", [("bf16", 517), ("fp32", 517), ("bf16", 1100), ("fp32", 300)])
+def test_context_gradient_split_reduction_on_ragged_batches(precision, B):
+    """dL/dcontext = the 3 L slabs of Gc against the transposed context weights, divided over `splits` workgroups per row strip
+    (pf_dense_nt k_splits).  At LeanNPE's flow (L = 10: 30 chunks) a ragged batch of ~500 rows asks for 25 splits = 15 of 2
+    chunks and ten EMPTY ones, which used to prefetch weight fragments from beyond the stream (a GPU memory fault in a soak
+    run; the launcher now starts the non-empty splits only).  Against the library-GEMM route on the same Gc."""
+    from helpers import make_pair, flow_inputs
+    D, C, H, L, K, tb = 11, 288, 256, 10, 16, 5.0
+    _, _, flow = make_pair(D, C, H, L, K, tb, scale=10.0)
+    flow.precision = precision
+    x, ctx = flow_inputs(B, D, C, tb, seed=3)
+    w = torch.rand(B, generator=torch.Generator().manual_seed(5)) + 0.5
+
+    def grad_ctx():
+        c = ctx.cuda().requires_grad_(True)
+        (flow.compute_psd_aware_nll(x.cuda(), c, None) * w.cuda()).sum().backward()
+        return c.grad.clone()
+    got = grad_ctx()
+    orig = flow.packed_ctx_transposed
+    flow.packed_ctx_transposed = lambda prec: None              # no packed weights: flat Gc @ Wc by the library
+    try:
+        want = grad_ctx()
+    finally:
+        flow.packed_ctx_transposed = orig
+    assert torch.isfinite(got).all()
+    err = ((got - want).abs().max() / want.abs().max()).item()
+    assert err < (2e-2 if precision == "bf16" else 2e-5), err
