@@ -1,0 +1,83 @@
+"""Size fuzz: the entry points at random (ragged) batch sizes -- nothing may fault, and what a row gets must not depend on the
+batch it travels in (log-density, inverse, per-row gradients; encoder context per event).  python scripts/fuzz_sizes.py [seed] [n]"""
+import os, random, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from posteriflow_amd import NSFPosteriorFlow, npe
+
+seed, n = (int(sys.argv[1]) if len(sys.argv) > 1 else 0), (int(sys.argv[2]) if len(sys.argv) > 2 else 40)
+rnd = random.Random(seed)
+dev = torch.device("cuda")
+fails = 0
+
+
+def report(ok, what):
+    global fails
+    fails += 0 if ok else 1
+    print(("ok   " if ok else "FAIL ") + what, flush=True)
+
+
+def rel(a, b):
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
+
+
+for D, C, H, L, K in [(11, 288, 256, 10, 16), (15, 288, 256, 8, 16), (4, 40, 64, 3, 8), (12, 288, 384, 4, 24)]:
+    torch.manual_seed(seed)
+    flow = NSFPosteriorFlow(D, C, H, L, K, 5.0, temperature_scale=1.0, use_masked_context=False).to(dev)
+    with torch.no_grad():
+        for t in flow._ar_transforms:
+            t.autoregressive_net.final_layer.weight.mul_(10.0)
+    sizes = [1, 2, 15, 16, 17, 127, 129, 500, 517, 1100, 4095, 4097] + [rnd.randint(1, 6000) for _ in range(n // 4)] + [20479, 20481, 33333]
+    g = torch.Generator(device=dev).manual_seed(seed)
+    X = torch.rand(max(sizes), D, device=dev, generator=g) * 2 - 1
+    Cx = torch.randn(max(sizes), C, device=dev, generator=g)
+    for prec in ("bf16", "fp32"):
+        flow.precision = prec
+        flow.eval()
+        with torch.no_grad():
+            ref_nll = flow.compute_psd_aware_nll(X[:16], Cx[:16], None)
+            zr = torch.randn(16, D, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+            ref_x, _ = flow.inverse(zr, Cx[:16])
+        xs, cs = X[:16].clone().requires_grad_(True), Cx[:16].clone().requires_grad_(True)
+        flow.train()
+        flow.compute_psd_aware_nll(xs, cs, None).sum().backward()
+        ref_gx, ref_gc = xs.grad.clone(), cs.grad.clone()
+        flow.zero_grad(set_to_none=True)
+        for B in sizes:
+            if prec == "fp32" and B > 6000:
+                continue
+            flow.eval()
+            with torch.no_grad():
+                nll = flow.compute_psd_aware_nll(X[:B], Cx[:B], None)
+                m = min(B, 16)
+                ok = bool(torch.isfinite(nll).all()) and rel(nll[:m], ref_nll[:m]) < (3e-2 if prec == "bf16" else 1e-5)
+                zz = torch.cat([zr, torch.randn(max(B - 16, 0), D, device=dev)])[:B]
+                xi, _ = flow.inverse(zz, Cx[:B])
+                ok = ok and bool(torch.isfinite(xi).all()) and rel(xi[:m], ref_x[:m]) < (5e-2 if prec == "bf16" else 1e-4)
+            if B <= 6000:
+                flow.train()
+                xs, cs = X[:B].clone().requires_grad_(True), Cx[:B].clone().requires_grad_(True)
+                flow.compute_psd_aware_nll(xs, cs, None).sum().backward()
+                pg = [p.grad for p in flow.parameters() if p.grad is not None]
+                ok = ok and all(bool(torch.isfinite(t).all()) for t in pg + [xs.grad, cs.grad])
+                tol = 5e-2 if prec == "bf16" else 2e-5
+                ok = ok and rel(xs.grad[:m], ref_gx[:m]) < tol and rel(cs.grad[:m], ref_gc[:m]) < tol
+                flow.zero_grad(set_to_none=True)
+            if not ok or B in (sizes[0], sizes[-1]):
+                report(ok, f"flow D{D} C{C} H{H} L{L} K{K} {prec} B={B}")
+    del flow
+
+torch.manual_seed(seed)
+enc = npe.LeanStrainEncoder(context_dim=256).to(dev).eval()
+S = torch.randn(300, 3, 16384, device=dev)
+for prec in ("bf16", "fp32"):
+    enc.precision = prec
+    with torch.no_grad():
+        ref = enc(S[:3])
+        for E in [1, 2, 3, 5, 17, 64, 100, 255, 300]:
+            out = enc(S[:E])
+            m = min(E, 3)
+            ok = bool(torch.isfinite(out).all()) and rel(out[:m], ref[:m]) < (2e-2 if prec == "bf16" else 1e-4)
+            report(ok, f"encoder {prec} events={E}")
+print(f"{fails} failures")
+sys.exit(1 if fails else 0)

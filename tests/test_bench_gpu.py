@@ -91,3 +91,14 @@ def test_gpus_flag_nccl_world2():
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8192 and d["config"]["parallelism"] == "dp2"
     assert d["scaling"] == "weak" and 50.0 < d["config"]["global_mean_nll"] < 500.0
     assert d["value"] > 2e7                                   # two GPUs: more than one GPU's 4e7 / 2
+
+
+@pytest.mark.gpu
+def test_size_fuzz_script():
+    """scripts/fuzz_sizes.py: forward / inverse / backward of four flow shapes and the encoder at ragged batch sizes (1 .. 33 333):
+    no fault, every row independent of the batch it travels in (a ragged ~500-row batch once sent a split GEMM out of bounds)"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_sizes.py"), "1", "16"], cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "0 failures" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
