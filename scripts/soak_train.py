@@ -7,7 +7,7 @@ steps, events = int(sys.argv[1]) if len(sys.argv) > 1 else 200, int(sys.argv[2])
 dev = torch.device("cuda")
 ds = synthetic_dataset(dev, n_noise=256, n_events=512, seed=0)
 torch.manual_seed(0)
-model = npe.LeanNPE().to(dev).train().set_precision("bf16").flatten_parameters()
+model = npe.LeanNPE().to(dev).train().set_precision(os.environ.get("PF_SOAK_PREC", "bf16")).flatten_parameters()
 opt = train.make_optimizer(model); sched = train.make_scheduler(opt, 2000, warmup_steps=20) if "warmup_steps" in train.make_scheduler.__code__.co_varnames else train.make_scheduler(opt, 2000)
 g = torch.Generator(device=dev).manual_seed(0)
 losses = []
