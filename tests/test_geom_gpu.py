@@ -68,6 +68,7 @@ def check(enc, geom, clean, tol=2e-5):
     other[lag_cols] = False
     # everything but the arg-max: fp32 transforms and sums against float64
     err = np.abs(got[:, other] - want[:, other]) / np.maximum(np.abs(want[:, other]), 1.0)
+    print(f"\n[geometry features] max err vs float64 {err.max():.2e} (bound {tol:.0e})")
     assert err.max() < tol, (err.max(), np.unravel_index(err.argmax(), err.shape))
     for p, col in enumerate(lag_cols):          # the lag: identical unless float64 itself has a near tie on the window
         a = windows[p]
