@@ -453,10 +453,14 @@ class FlowNLL(torch.autograd.Function):
             gl = None
             if log_sigma is not None and ctx_.needs_input_grad[3]:
                 gl = g_nll[:, None] * (1.0 - (z * torch.exp(-log_sigma)).square())
-            gx, gc, gp = flow_backward(flow, U, context, None, None, ctx_.drop_seed, nll=(g_nll, z, log_sigma))
-            return (None, gx if ctx_.needs_input_grad[1] else None,
-                    gc if (context is not None and ctx_.needs_input_grad[2]) else None, gl,
-                    *[g if p.requires_grad else None for g, p in zip(gp, params)])
+            try:
+                gx, gc, gp = flow_backward(flow, U, context, None, None, ctx_.drop_seed, nll=(g_nll, z, log_sigma))
+                return (None, gx if ctx_.needs_input_grad[1] else None,
+                        gc if (context is not None and ctx_.needs_input_grad[2]) else None, gl,
+                        *[g if p.requires_grad else None for g, p in zip(gp, params)])
+            except NotImplementedError:      # PF_ERR_UNSUPPORTED from a backward kernel (e.g. D = 16, K = 32 at H = 512: the chain's
+                if not flow.use_masked_context:      # LDS image): the masked-context conditioner still has the replay below
+                    raise
         with torch.enable_grad():
             xs = x.detach().requires_grad_(x.requires_grad)
             cs = None if context is None else context.detach().requires_grad_(context.requires_grad)
@@ -502,10 +506,14 @@ class FlowForward(torch.autograd.Function):
         if U is not None:
             gz = torch.zeros_like(x) if gz is None else gz
             gld = torch.zeros(x.shape[0], device=x.device) if gld is None else gld
-            gx, gc, gp = flow_backward(flow, U, context, gz, gld, ctx_.drop_seed)
-            return (None, gx if ctx_.needs_input_grad[1] else None,
-                    gc if (context is not None and ctx_.needs_input_grad[2]) else None,
-                    *[g if p.requires_grad else None for g, p in zip(gp, params)])
+            try:
+                gx, gc, gp = flow_backward(flow, U, context, gz, gld, ctx_.drop_seed)
+                return (None, gx if ctx_.needs_input_grad[1] else None,
+                        gc if (context is not None and ctx_.needs_input_grad[2]) else None,
+                        *[g if p.requires_grad else None for g, p in zip(gp, params)])
+            except NotImplementedError:      # (see FlowNLL.backward)
+                if not flow.use_masked_context:
+                    raise
         with torch.enable_grad():
             xs = x.detach().requires_grad_(x.requires_grad)
             cs = None if context is None else context.detach().requires_grad_(context.requires_grad)

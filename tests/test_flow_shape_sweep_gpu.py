@@ -296,3 +296,4 @@ def test_masked_context_gradients_on_the_hip_backward(D, block, H, K, L, full, p
                 assert (prm.grad * (1 - mod.mask)).abs().max() == 0
             n += 1
     assert n > 0
+
