@@ -504,6 +504,8 @@ typedef struct PfGeomArgs {
     float* spec;               /* [batch][n_det][nf][2] workspace: band spectra */
     float* etot;               /* [batch][n_det] workspace: total band power */
     float* rel;                /* [batch][n_det n_bands + npairs (3 n_bands + 3)] */
+    int32_t sanitize;          /* 1: `clean` is the RAW strain; the samples are sanitised on load as lean_npe.py:207 does
+                                * (nan -> 0, +-inf -> +-100, clamp to +-100), saving the caller a pass over the strain */
 } PfGeomArgs;
 int pf_geom_twiddles(float* host_table);
 int pf_geom_features(const PfGeomArgs* args, void* stream);

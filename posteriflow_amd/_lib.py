@@ -82,7 +82,7 @@ class PfPoolArgs(C.Structure):
 class PfGeomArgs(C.Structure):
     _fields_ = [("clean", C.c_void_p), ("batch", C.c_int64), ("n_det", C.c_int32), ("band_lo", C.c_int32), ("nf", C.c_int32),
                 ("n_bands", C.c_int32), ("maxlag", C.c_int32), ("band_edge", C.c_int32 * 17), ("twiddle", C.c_void_p),
-                ("spec", C.c_void_p), ("etot", C.c_void_p), ("rel", C.c_void_p)]
+                ("spec", C.c_void_p), ("etot", C.c_void_p), ("rel", C.c_void_p), ("sanitize", C.c_int32)]
 
 
 class PfFlowDesc(C.Structure):

@@ -132,6 +132,10 @@ __global__ __launch_bounds__(kThreads) void geom_spectrum_kernel(const GeomParam
 #pragma unroll
     for (int it = 0; it < kT / 4 / kThreads; ++it) {
         const int i = tid + it * kThreads;
+        if (A.sanitize) {                                       // lean_npe.py:207
+            auto san = [](float x) { x = (x != x) ? 0.f : x; return fminf(fmaxf(x, -100.f), 100.f); };
+            xv[it] = float4{san(xv[it].x), san(xv[it].y), san(xv[it].z), san(xv[it].w)};
+        }
         s[slot(2 * i)] = c32{xv[it].x, xv[it].y};
         s[slot(2 * i + 1)] = c32{xv[it].z, xv[it].w};
     }

@@ -467,8 +467,9 @@ class CoherentEncoder(LeanStrainEncoder):
             plan = self.__dict__["_geom_plan"] = (edges if ok else False)
         return plan or None
 
-    def _geometry_rel_hip(self, clean, edges):
-        """the same features by pf_geom_features (csrc/pf_geom.hip): both transforms in LDS, one launch per stage"""
+    def _geometry_rel_hip(self, clean, edges, sanitize=False):
+        """the same features by pf_geom_features (csrc/pf_geom.hip): both transforms in LDS, one launch per stage;
+        ``sanitize``: ``clean`` is the raw strain, sanitised inside the kernel (LN:207)"""
         from . import _lib
         b, dev = clean.shape[0], clean.device
         tw = self.__dict__.get("_geom_twiddle")
@@ -486,6 +487,7 @@ class CoherentEncoder(LeanStrainEncoder):
         etot = torch.empty(b, self.n_detectors, dtype=torch.float32, device=dev)
         rel = torch.empty(b, self.n_detectors * self.K + len(self.pairs) * (3 * self.K + 3), dtype=torch.float32, device=dev)
         a.twiddle, a.spec, a.etot, a.rel = tw.data_ptr(), spec.data_ptr(), etot.data_ptr(), rel.data_ptr()
+        a.sanitize = 1 if sanitize else 0
         _lib.check(_lib.lib().pf_geom_features(a, torch.cuda.current_stream(dev).cuda_stream), "pf_geom_features")
         return rel
 
@@ -522,8 +524,13 @@ class CoherentEncoder(LeanStrainEncoder):
     def forward(self, strain, asd_bands=None):
         if strain.shape[0] == 0:
             return self._empty(strain)
-        clean = self._sanitize(strain)
-        rel = self._geometry_rel(clean)                      # FFT features stay fp32
+        edges = self._geometry_plan() if (strain.is_cuda and not (torch.is_grad_enabled() and strain.requires_grad)) else None
+        if edges is not None:      # GPU: both consumers sanitise the raw strain on load (no extra pass over it)
+            clean = strain
+            rel = self._geometry_rel_hip(strain, edges, sanitize=True)
+        else:
+            clean = self._sanitize(strain)
+            rel = self._geometry_rel(clean)                  # FFT features stay fp32
         with self._autocast(strain.device):
             g = self.geom_mlp(rel)
             gtok = self.geom_to_tokens(g).reshape(-1, self.n_geom_tokens, self.d_model)

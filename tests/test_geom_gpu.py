@@ -115,9 +115,13 @@ def test_geometry_features_match_the_reference_golden():
     clean = lean_ref.sanitize_strain(recipe.strain_batch(4, 3, seed=9))
     got = check(enc, geom, clean, tol=1e-4)       # (cos, sin) of a weak band coherence amplify the fp32 rounding of the sums
     np.testing.assert_allclose(got, gold["coh_rel"], rtol=1e-4, atol=2e-5)
+    raw = recipe.strain_batch(4, 3, seed=9).cuda()                 # event 1 holds nan / +-inf / out-of-range samples
+    assert not torch.isfinite(raw).all()
     with torch.no_grad():
-        rel = enc._geometry_rel(enc._sanitize(recipe.strain_batch(4, 3, seed=9).cuda()))
+        rel = enc._geometry_rel(enc._sanitize(raw))
+        rel_raw = enc._geometry_rel_hip(raw, enc._geometry_plan(), sanitize=True)      # sanitised on load inside the kernel
     np.testing.assert_allclose(rel.cpu().numpy(), gold["coh_rel"], rtol=1e-4, atol=2e-5)
+    assert torch.equal(rel, rel_raw)
 
 
 def test_spectrum_workspace_is_the_ortho_rfft():
