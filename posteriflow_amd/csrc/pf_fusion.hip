@@ -36,12 +36,18 @@
 #include "../../include/pf_hip.h"
 #include "pf_math.h"
 
+#ifndef PF_FUSION_WAVES
+#define PF_FUSION_WAVES 8       // 8: two waves per SIMD, 256 registers each (the build); 4: one per SIMD with 512 registers and a
+#endif                          // deeper weight pipeline (experiment)
 #ifndef PF_FUSION_ABLATE
 #define PF_FUSION_ABLATE 0      // timing experiments only: 1 no GELU, 2 no attention, 4 no dense matmuls, 8 no QKV projection, 16 no LN
 #endif
 namespace pf {
 namespace {
 constexpr int kAbl = PF_FUSION_ABLATE;
+constexpr int kWaves = PF_FUSION_WAVES, kThreads = 64 * kWaves;
+constexpr int kDepth = kWaves == 4 ? 4 : 2;            // weight fragments of kDepth - 1 k-steps in flight ahead of the MFMAs
+static_assert(kWaves == 8 || kWaves == 4, "4 feature blocks x 1 or 2 token halves");
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -103,7 +109,7 @@ __device__ __forceinline__ int qoff(int row, int byte) {
     return row * kQS + ((((byte >> 4) ^ ((4 - ((row >> 2) & 3)) & 3)) << 4) | (byte & 15));
 }
 
-__global__ __launch_bounds__(512) void fusion_kernel(FusionParams p) {
+__global__ __launch_bounds__(kThreads) void fusion_kernel(FusionParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const xn = smem;                       // normalised tokens, bf16 [192][384 B]
     char* const hb = smem + kBuf;                // FFN hidden chunk, bf16 [192][384 B]   (aliases the head sets below)
@@ -134,7 +140,8 @@ __global__ __launch_bounds__(512) void fusion_kernel(FusionParams p) {
     // ---- the fp32 residual stream lives in registers for the whole kernel: X[i][j] = features
     // 16 (3 w + i) + 4 g .. +3 of token 16 j + c (the MFMA accumulator layout of this wave's block), so
     // that the out-projection and the second FFN matmul accumulate straight into it
-    constexpr int kHT = kTT / 2;                 // token tiles per wave
+    constexpr int kHT = kTT / (kWaves / 4);      // token tiles per wave
+    constexpr int kQT = kTT / (kWaves / 2);      // token tiles per wave in the per-head projections
     f32x4 X[3][kHT];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -235,14 +242,18 @@ __global__ __launch_bounds__(512) void fusion_kernel(FusionParams p) {
         if constexpr (kAbl & 4) return;
         // weight fragments (L2 latency) double-buffered in registers: those of k-step ks+1 are issued before
         // the MFMAs of k-step ks; activation fragments (LDS latency) are loaded per k-step
-        bf16x8 a[2][3];
+        bf16x8 a[kDepth][3];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) a[0][i] = afrag(wbase, ft0 + i, ksteps, ks0);
+        for (int d = 0; d < kDepth - 1; ++d)
+            if (d < KS) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) a[d][i] = afrag(wbase, ft0 + i, ksteps, ks0 + d);
+            }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            if (ks + 1 < KS) {
+            if (ks + kDepth - 1 < KS) {
 #pragma unroll
-                for (int i = 0; i < 3; ++i) a[(ks + 1) & 1][i] = afrag(wbase, ft0 + i, ksteps, ks0 + ks + 1);
+                for (int i = 0; i < 3; ++i) a[(ks + kDepth - 1) % kDepth][i] = afrag(wbase, ft0 + i, ksteps, ks0 + ks + kDepth - 1);
             }
             // keep the next k-step's weight loads ahead of this k-step's MFMAs: under register pressure the scheduler
             // sinks them to ~6 MFMAs before their use and every k-step then waits out an L2 round trip
@@ -253,7 +264,7 @@ __global__ __launch_bounds__(512) void fusion_kernel(FusionParams p) {
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = mfma(a[ks & 1][i], b[j], acc[i][j]);
+                for (int j = 0; j < NT; ++j) acc[i][j] = mfma(a[ks % kDepth][i], b[j], acc[i][j]);
         }
     };
     // one (head, 16-query tile): softmax(K Q^T) V with keys >= T masked; result O^T tiles (2 x f32x4).
@@ -328,7 +339,7 @@ __global__ __launch_bounds__(512) void fusion_kernel(FusionParams p) {
             {   // Q | K | V of heads 2 hp, 2 hp + 1: this wave's 3 of a head's 6 tiles x its 3 token tiles, the two heads' 12
                 // k-steps as ONE pipelined sequence (the weight fragments of a step are requested one step ahead, across the
                 // head boundary too)
-                f32x4 t[3][3];
+                f32x4 t[3][kQT];
                 auto tile_of = [&](int hs, int i) {
                     // tile index in the 36-tile in_proj: Q 2h,2h+1 | K 12+2h,12+2h+1 | V 24+2h,24+2h+1
                     const int h = 2 * hp + hs;
@@ -347,7 +358,7 @@ __global__ __launch_bounds__(512) void fusion_kernel(FusionParams p) {
 #pragma unroll
                         for (int i = 0; i < 3; ++i)
 #pragma unroll
-                            for (int j = 0; j < 3; ++j) t[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                            for (int j = 0; j < kQT; ++j) t[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                     }
                     if constexpr (!(kAbl & 8)) {
                         if (step + 1 < 12) {
@@ -356,13 +367,13 @@ __global__ __launch_bounds__(512) void fusion_kernel(FusionParams p) {
                                 a[(step + 1) & 1][i] = afrag(lw + kWqkv, tile_of((step + 1) / 6, i), 6, (step + 1) % 6);
                         }
                         __builtin_amdgcn_sched_barrier(0);          // (see dense)
-                        bf16x8 b[3];
+                        bf16x8 b[kQT];
 #pragma unroll
-                        for (int j = 0; j < 3; ++j) b[j] = bx(xn, 3 * tb4 + j, ks);
+                        for (int j = 0; j < kQT; ++j) b[j] = bx(xn, kQT * tb4 + j, ks);
 #pragma unroll
                         for (int i = 0; i < 3; ++i)
 #pragma unroll
-                            for (int j = 0; j < 3; ++j) t[i][j] = mfma(a[step & 1][i], b[j], t[i][j]);
+                            for (int j = 0; j < kQT; ++j) t[i][j] = mfma(a[step & 1][i], b[j], t[i][j]);
                     }
                     if (ks == 5) {
                         char* const q_ = qb + hs * kHeadSet;
@@ -372,8 +383,8 @@ __global__ __launch_bounds__(512) void fusion_kernel(FusionParams p) {
                         for (int i = 0; i < 3; ++i) {
                             const f32x4 b4 = *reinterpret_cast<const f32x4*>(vec + kBqkv + 16 * tile_of(hs, i) + 4 * g);
 #pragma unroll
-                            for (int j = 0; j < 3; ++j) {
-                                const int tt = 3 * tb4 + j;
+                            for (int j = 0; j < kQT; ++j) {
+                                const int tt = kQT * tb4 + j;
                                 const f32x4 v = t[i][j] + b4;
                                 if (fb2 == 0) {
                                     if (i == 0) put_qk(q_, 0, tt, v * kQScale);
@@ -391,8 +402,8 @@ __global__ __launch_bounds__(512) void fusion_kernel(FusionParams p) {
             __syncthreads();
             auto units = [&](auto mask_from) {              // 24 (head slot, query tile) units: 3 per wave
 #pragma unroll 1
-                for (int it = 0; it < 2 * kTT / 8; ++it) {
-                    const int u = w + 8 * it;
+                for (int it = 0; it < 2 * kTT / kWaves; ++it) {
+                    const int u = w + kWaves * it;
                     const int hs = u >= kTT ? 1 : 0, qt = u - hs * kTT;
                     char* const q_ = qb + hs * kHeadSet;
                     f32x4 o[2];
@@ -450,11 +461,11 @@ __global__ __launch_bounds__(512) void fusion_kernel(FusionParams p) {
     const float* bkv = reinterpret_cast<const float*>(p.packed + kPoolB);
     for (int h = 0; h < kHeads; ++h) {
         {   // K | V of head h: 2 tiles per wave x 6 token tiles (tile space: K 0..11 | V 12..23)
-            f32x4 t[2][3];
+            f32x4 t[2][kQT];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 3; ++j) t[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < kQT; ++j) t[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             const int tile0 = (fb2 == 0 ? 0 : 12) + 2 * h;
             // all 12 weight fragments of the head in one batch (the residual registers are free here): one L2 round
             // trip per head instead of one per k-step
@@ -466,25 +477,25 @@ __global__ __launch_bounds__(512) void fusion_kernel(FusionParams p) {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ks = 0; ks < 6; ++ks) {
-                bf16x8 b[3];
+                bf16x8 b[kQT];
 #pragma unroll
-                for (int j = 0; j < 3; ++j) b[j] = bx(xn, 3 * tb4 + j, ks);
+                for (int j = 0; j < kQT; ++j) b[j] = bx(xn, kQT * tb4 + j, ks);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) t[i][j] = mfma(a[ks][i], b[j], t[i][j]);
+                    for (int j = 0; j < kQT; ++j) t[i][j] = mfma(a[ks][i], b[j], t[i][j]);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const f32x4 b4 = *reinterpret_cast<const f32x4*>(bkv + 16 * (tile0 + i) + 4 * g);
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    if (fb2 == 0) put_qk(kb, i, 3 * tb4 + j, t[i][j] + b4);
-                    else put_vt(vt, i, 3 * tb4 + j, t[i][j] + b4);
+                for (int j = 0; j < kQT; ++j) {
+                    if (fb2 == 0) put_qk(kb, i, kQT * tb4 + j, t[i][j] + b4);
+                    else put_vt(vt, i, kQT * tb4 + j, t[i][j] + b4);
                 }
             }
             // the head's 8 queries (rows 8..15 of the tile are zero)
-            for (int i = tid; i < 16 * kHd; i += 512) {
+            for (int i = tid; i < 16 * kHd; i += kThreads) {
                 const int q = i >> 5, d = i & 31;
                 const float v = q < kPoolQ ? p.pool_q[q * kE + kHd * h + d] : 0.f;
                 *reinterpret_cast<__bf16*>(qb + qoff(q, d * 2)) = (__bf16)v;
@@ -558,7 +569,7 @@ int fusion_forward(const char* packed, float* tokens, int n_tokens, const float*
         configured = true;
     }
     FusionParams p{packed, tokens, tok_bias, pool_q, pooled, n_tokens};
-    fusion_kernel<<<dim3(static_cast<unsigned>(n_events)), dim3(512), kLds, s>>>(p);
+    fusion_kernel<<<dim3(static_cast<unsigned>(n_events)), dim3(kThreads), kLds, s>>>(p);
     return launch_status();
 }
 }  // namespace pf
