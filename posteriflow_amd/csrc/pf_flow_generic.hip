@@ -132,9 +132,10 @@ __global__ __launch_bounds__(kGenWaves * 64) void flow_generic_kernel(const FwdP
         else reinterpret_cast<float*>(base + r * stride)[k] = v;
     };
     // out^T[16 t + 4 g + e][row c] = sum_k W[16 t + r][k] act[row][k]: fragments [tile][k-step][lane], B rows from LDS
-    auto mm = [&](const gu32x4* fr, int tile, int nks, const char* act, int stride) -> f32x4 {
+    // nks_row: k-steps per tile row in the fragment array; nks <= nks_row: the k-steps evaluated (sorted plans skip the rest)
+    auto mm = [&](const gu32x4* fr, int tile, int nks_row, int nks, const char* act, int stride) -> f32x4 {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        const gu32x4* a = fr + (size_t)tile * nks * 64 + lane;
+        const gu32x4* a = fr + (size_t)tile * nks_row * 64 + lane;
         const char* brow = act + c * stride + g * 16;
         int ks = 0;
         for (; ks + 4 <= nks; ks += 4) {                      // four fragment loads in flight
@@ -165,6 +166,28 @@ __global__ __launch_bounds__(kGenWaves * 64) void flow_generic_kernel(const FwdP
             }
         }
         return acc;
+    };
+    // sorted plans (hidden units in degree order, csrc/pf_pack.hip): unit p has degree deg_at(p); the units of degree <= d are the
+    // first cnt_le(d) positions.  A hidden -> hidden tile needs the columns of degree <= its largest row degree (nflows mask
+    // deg_out >= deg_in), an output tile those of degree <= its last feature index (deg_out = f + 1 > deg_in)
+    auto cnt_le = [&](int d) {
+        if (d >= D - 1) return H;
+        if (d <= 0) return 0;
+        const int full = H / (D - 1), rem = H % (D - 1);
+        return full * d + (rem < d ? rem : d);
+    };
+    auto ksteps_of = [&](int cols) { const int n = (cols + KSTEP - 1) / KSTEP; return n < L.gKh ? n : L.gKh; };
+    auto kmax_hidden = [&](int t) {
+        if (!L.gsorted) return L.gKh;
+        int d = 1;
+        while (d < D - 1 && cnt_le(d) <= 16 * t + 15) ++d;
+        return ksteps_of(cnt_le(d));
+    };
+    auto kmax_out = [&](int t) {
+        if (!L.gsorted) return L.gKh;
+        int f = (16 * t + 15) / M;
+        if (f > D - 1) f = D - 1;
+        return ksteps_of(cnt_le(f));
     };
 
     // ---- context rows (once), zero padding of every operand image ---------------------------------------------------------
@@ -227,10 +250,10 @@ __global__ __launch_bounds__(kGenWaves * 64) void flow_generic_kernel(const FwdP
         __syncthreads();
         // h = W_in x + b (+ relu(Wc ctx + bc)); s_a = relu(h)
         for (int t = wave; t < NT; t += kGenWaves) {
-            f32x4 v = mm(f_in, t, L.gKx, s_x, sx) + *reinterpret_cast<const f32x4*>(b_in + 16 * t + 4 * g);
+            f32x4 v = mm(f_in, t, L.gKx, L.gKx, s_x, sx) + *reinterpret_cast<const f32x4*>(b_in + 16 * t + 4 * g);
             f32x4 pcv = {0.f, 0.f, 0.f, 0.f};
             if (C > 0) {
-                pcv = mm(f_c, t, L.gKc, s_ctx, sc) + *reinterpret_cast<const f32x4*>(b_c + 16 * t + 4 * g);
+                pcv = mm(f_c, t, L.gKc, L.gKc, s_ctx, sc) + *reinterpret_cast<const f32x4*>(b_c + 16 * t + 4 * g);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] += fmaxf(pcv[e], 0.f);
             }
@@ -252,9 +275,10 @@ __global__ __launch_bounds__(kGenWaves * 64) void flow_generic_kernel(const FwdP
             const gu32x4* f1 = f_blk + (size_t)(2 * b) * NT * L.gKh * 64;
             const gu32x4* f2 = f1 + (size_t)NT * L.gKh * 64;
             for (int t = wave; t < NT; t += kGenWaves) {                           // t1 = W1 relu(h) + b1; s_b = relu(t1)
-                f32x4 v = mm(f1, t, L.gKh, s_a, sh) + *reinterpret_cast<const f32x4*>(b_blk + (2 * b) * H + 16 * t + 4 * g);
+                const int kh = kmax_hidden(t);
+                f32x4 v = mm(f1, t, L.gKh, kh, s_a, sh) + *reinterpret_cast<const f32x4*>(b_blk + (2 * b) * H + 16 * t + 4 * g);
                 if (additive)          // t1 = W1 relu(h) + b1 + context_layer(ctx)   (flows.py:225-234)
-                    v = v + mm(b == 0 ? f_g0 : f_g1, t, L.gKc, s_ctx, sc) + *reinterpret_cast<const f32x4*>((b == 0 ? b_g0 : b_g1) + 16 * t + 4 * g);
+                    v = v + mm(b == 0 ? f_g0 : f_g1, t, L.gKc, L.gKc, s_ctx, sc) + *reinterpret_cast<const f32x4*>((b == 0 ? b_g0 : b_g1) + 16 * t + 4 * g);
                 f32x4 df = {1.f, 1.f, 1.f, 1.f};
                 if constexpr (REEVAL) {
                     if (row0 + c < p.batch) {
@@ -268,13 +292,13 @@ __global__ __launch_bounds__(kGenWaves * 64) void flow_generic_kernel(const FwdP
             }
             __syncthreads();
             for (int t = wave; t < NT; t += kGenWaves) {                           // h += (W2 . + b2) . sigmoid(Wg ctx + bg)
-                f32x4 v = mm(f2, t, L.gKh, s_b, sh) + *reinterpret_cast<const f32x4*>(b_blk + (2 * b + 1) * H + 16 * t + 4 * g);
+                f32x4 v = mm(f2, t, L.gKh, kmax_hidden(t), s_b, sh) + *reinterpret_cast<const f32x4*>(b_blk + (2 * b + 1) * H + 16 * t + 4 * g);
                 const bool live = REEVAL && row0 + c < p.batch;
                 const size_t o = (((size_t)b * L.L + l) * p.batch + row0 + c) * H + 16 * t + 4 * g;
                 if (additive) {
                     if (live) *reinterpret_cast<f32x4*>(sink.t2s + o) = v;
                 } else if (C > 0) {
-                    f32x4 gt = mm(b == 0 ? f_g0 : f_g1, t, L.gKc, s_ctx, sc) +
+                    f32x4 gt = mm(b == 0 ? f_g0 : f_g1, t, L.gKc, L.gKc, s_ctx, sc) +
                                *reinterpret_cast<const f32x4*>((b == 0 ? b_g0 : b_g1) + 16 * t + 4 * g);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) gt[e] = pf_sigmoid<FAST>(gt[e]);
@@ -297,7 +321,7 @@ __global__ __launch_bounds__(kGenWaves * 64) void flow_generic_kernel(const FwdP
             __syncthreads();
         }
         for (int t = wave; t < L.gTf; t += kGenWaves) {
-            const f32x4 v = mm(f_out, t, L.gKh, s_a, sh) + *reinterpret_cast<const f32x4*>(b_out + 16 * t + 4 * g);
+            const f32x4 v = mm(f_out, t, L.gKh, kmax_out(t), s_a, sh) + *reinterpret_cast<const f32x4*>(b_out + 16 * t + 4 * g);
 #pragma unroll
             for (int e = 0; e < 4; ++e) s_par[c * PS + 16 * t + 4 * g + e] = v[e];
         }

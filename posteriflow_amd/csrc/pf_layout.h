@@ -103,6 +103,9 @@ struct FlowPlan {
     int generic;                // 1: a shape none of the scheduled kernels is built for (e.g. H = 384, K = 24): dense masked
                                 // matrices as plain [tile][k-step] fragment arrays in nflows unit order, pf_flow_generic.hip
     int gKx, gKc, gKh, gTf;     // generic: k-steps of the x / context / hidden operands, tiles of the final layer
+    int gsorted;                // generic: hidden units stored in degree order (sorted_units): the masked matrices are then block
+                                // lower-triangular and the kernel skips the k-steps beyond a tile's last non-zero column.  0 for
+                                // the PF_FLAG_GENERIC layout the re-evaluation reads (its outputs are in nflows unit order)
     int KHS, KOS, NF;
     int kH[kMaxTiles];          // active k-steps of tile t in a masked H x H GEMM
     int kO[kMaxTiles];          // active k-steps of feature f in the final layer
@@ -205,6 +208,7 @@ inline int make_generic_plan(const PfFlowDesc& d, FlowPlan& o) {
     o.gTf = (o.D * o.M + 15) / 16;
     o.CK = o.gKc; o.CKM = 0; o.HK = o.gKh; o.hoist = 0;
     o.additive = (d.reserved & PF_FLAG_MASKED_CONTEXT) && o.C > 0 ? 1 : 0;     // masked-context conditioner (flows.py:186-234)
+    o.gsorted = ((d.reserved & PF_FLAG_GENERIC) || o.D < 2) ? 0 : 1;
     if (o.gen_lds_bytes() > 160 * 1024) return PF_ERR_UNSUPPORTED;
     o.fragsPerWave = 0;
     o.fragsTotal = (int64_t)o.L * o.gen_layer_frags();

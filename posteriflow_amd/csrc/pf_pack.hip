@@ -291,6 +291,11 @@ static int build_generic_pack_map(const FlowPlan& L, int32_t* map) {
     const int per = L.bf16 ? 8 : 4, ks_w = L.kstep;
     const int xh = L.gen_xh();
     int64_t idx = 0;
+    // position p of the hidden dimension holds nflows unit unit_of[p]: degree order when the plan is sorted (the masks are then
+    // block lower-triangular, csrc/pf_flow_generic.hip skips the zero k-steps), identity otherwise
+    int unit_of[512];
+    if (L.gsorted) sorted_units(L.D, L.H, unit_of);
+    else for (int u = 0; u < L.H; ++u) unit_of[u] = u;
     // kind: 0 x input (initial layer), 1 context (unmasked), 2 hidden -> hidden, 3 hidden -> spline parameters
     auto matrix = [&](int kind, int64_t w_off, int n_rows, int n_tiles, int nks, int64_t base) {
         for (int t = 0; t < n_tiles; ++t)
@@ -300,16 +305,17 @@ static int build_generic_pack_map(const FlowPlan& L, int32_t* map) {
                         const int row = 16 * t + (lane & 15), k = ks_w * ks + per * (lane >> 4) + e;
                         int64_t src = -1;
                         if (row < n_rows) {
+                            const int ur = kind == 3 ? row : unit_of[row];                        // hidden output unit of this row
                             if (kind == 0) {
                                 const int d = L.bf16 ? (k < 2 * xh ? k % xh : L.D) : k;          // bf16: hi | lo halves of x
-                                if (d < L.D && hid_degree(L.D, row) >= d + 1) src = w_off + (int64_t)row * L.D + d;
+                                if (d < L.D && hid_degree(L.D, ur) >= d + 1) src = w_off + (int64_t)ur * L.D + d;
                             } else if (kind == 1) {
-                                if (k < L.C) src = w_off + (int64_t)row * L.C + k;
+                                if (k < L.C) src = w_off + (int64_t)ur * L.C + k;
                             } else if (kind == 2) {
-                                if (k < L.H && hid_degree(L.D, row) >= hid_degree(L.D, k)) src = w_off + (int64_t)row * L.H + k;
+                                if (k < L.H && hid_degree(L.D, ur) >= hid_degree(L.D, unit_of[k])) src = w_off + (int64_t)ur * L.H + unit_of[k];
                             } else {
                                 const int f = row / L.M;                                          // output unit row = f M + j
-                                if (k < L.H && f + 1 > hid_degree(L.D, k)) src = w_off + (int64_t)row * L.H + k;
+                                if (k < L.H && f + 1 > hid_degree(L.D, unit_of[k])) src = w_off + (int64_t)row * L.H + unit_of[k];
                             }
                         }
                         map[idx] = src < 0 ? -1 : (int32_t)(base + src);
@@ -331,13 +337,13 @@ static int build_generic_pack_map(const FlowPlan& L, int32_t* map) {
     }
     for (int l = 0; l < L.L; ++l) {
         const int64_t base = (int64_t)l * ro.total;
-        auto vec = [&](int64_t off, int n, int padded) {
-            for (int i = 0; i < padded; ++i, ++idx) map[idx] = i < n ? (int32_t)(base + off + i) : -1;
+        auto vec = [&](int64_t off, int n, int padded, bool hidden) {
+            for (int i = 0; i < padded; ++i, ++idx) map[idx] = i < n ? (int32_t)(base + off + (hidden ? unit_of[i] : i)) : -1;
         };
-        vec(ro.in_b, L.H, L.H);
-        if (L.C > 0) { vec(ro.c_b, L.H, L.H); vec(ro.g_b[0], L.H, L.H); vec(ro.g_b[1], L.H, L.H); }
-        for (int b = 0; b < 2; ++b) { vec(ro.w0_b[b], L.H, L.H); vec(ro.w1_b[b], L.H, L.H); }
-        vec(ro.out_b, L.D * L.M, 16 * L.gTf);
+        vec(ro.in_b, L.H, L.H, true);
+        if (L.C > 0) { vec(ro.c_b, L.H, L.H, true); vec(ro.g_b[0], L.H, L.H, true); vec(ro.g_b[1], L.H, L.H, true); }
+        for (int b = 0; b < 2; ++b) { vec(ro.w0_b[b], L.H, L.H, true); vec(ro.w1_b[b], L.H, L.H, true); }
+        vec(ro.out_b, L.D * L.M, 16 * L.gTf, false);
     }
     return idx == pack_map_len(L) ? PF_OK : PF_ERR_BAD_ARG;
 }

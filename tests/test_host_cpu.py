@@ -384,6 +384,7 @@ def test_generic_pack_map_is_the_masked_dense_matrices(lib):
         raw_n = h.pf_flow_raw_param_count(C_byref(d))
         per_layer = raw_n // L_
         deg = lambda u: u % max(1, D_ - 1) + min(1, D_ - 1)
+        unit_of = sorted(range(H_), key=lambda u: (deg(u), u))        # the plan stores the hidden units in degree order
         nt = H_ // 16
         xh = -(-D_ // 16) * 16
         kx = -(-(2 * xh if prec == "bf16" else D_) // ks)
@@ -397,13 +398,34 @@ def test_generic_pack_map_is_the_masked_dense_matrices(lib):
                         row, k = 16 * t + (lane & 15), ks * s_ + per * (lane >> 4) + e
                         got = m[base + ((t * kx + s_) * 64 + lane) * per + e]
                         dcol = (k % xh if k < 2 * xh else D_) if prec == "bf16" else k
-                        want = per_layer + row * D_ + dcol if (dcol < D_ and deg(row) >= dcol + 1) else -1
+                        u = unit_of[row]
+                        want = per_layer + u * D_ + dcol if (dcol < D_ and deg(u) >= dcol + 1) else -1
                         assert got == want, (prec, t, s_, lane, e, got, want)
         # the map references every unmasked weight of W_in exactly once (fp32) / twice (bf16 hi | lo)
         win = m[base:base + nt * kx * 64 * per]
         used = win[win >= 0] - per_layer
         assert sorted(set(used.tolist())) == sorted(r * D_ + c for r in range(H_) for c in range(D_) if deg(r) >= c + 1)
         assert len(used) == (2 if prec == "bf16" else 1) * len(set(used.tolist()))
+        # a hidden -> hidden matrix (W1 of block 0): position (row, k) holds weight (unit_of[row], unit_of[k]) where the mask allows,
+        # and the non-zero columns of a tile form a prefix (what lets the kernel skip the k-steps behind it)
+        kh, kc = -(-H_ // ks), -(-C_ // ks)
+        hbase = base + (nt * kx + 3 * nt * kc) * 64 * per
+        w1_off = per_layer + H_ * D_ + H_ + 2 * (H_ * C_ + H_)          # raw layout: in | ctx | block 0: ctx | W0 ...
+        for t in range(nt):
+            last = -1
+            for s_ in range(kh):
+                blk = m[hbase + (t * kh + s_) * 64 * per: hbase + (t * kh + s_ + 1) * 64 * per]
+                if (blk >= 0).any():
+                    assert last == s_ - 1, (prec, t, s_)
+                    last = s_
+                for lane in range(0, 64, 7):
+                    for e in range(per):
+                        row, k = 16 * t + (lane & 15), ks * s_ + per * (lane >> 4) + e
+                        got = blk[lane * per + e]
+                        if k < H_ and deg(unit_of[row]) >= deg(unit_of[k]):
+                            assert got == w1_off + unit_of[row] * H_ + unit_of[k], (prec, t, s_, lane, e)
+                        else:
+                            assert got == -1
 
 
 def test_ctypes_structs_match_the_header(lib, tmp_path):
