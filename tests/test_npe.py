@@ -202,3 +202,21 @@ def test_encoder_and_npe_with_an_empty_batch(precision):
         strain = torch.empty(0, 3, 16384, device="cuda")
         nll = model.nll(strain, torch.empty(0, 11, device="cuda"), torch.empty(0, dtype=torch.long, device="cuda"), context=ctx)
         assert nll.shape == (0,)
+
+
+def test_coherent_geometry_plan_is_the_band_membership():
+    """the HIP geometry kernel takes the 16 log-spaced bands (coherent_encoder.py:60-66) as contiguous ranges of the kept rfft
+    bins: the plan derived from the Bsum buffer partitions [0, Nf), agrees with the membership matrix, and refuses a
+    membership that is not a partition into intervals (tensor ops then)"""
+    enc = npe.CoherentEncoder(context_dim=256, psd_bands=16)
+    edges = enc._geometry_plan()
+    assert edges is not None and len(edges) == 17 and edges[0] == 0 and edges[-1] == enc.Nf == 4016
+    assert [enc.band_lo, enc.maxlag] == [80, 122]
+    m = enc.Bsum.numpy()
+    for b in range(16):
+        want = np.zeros(enc.Nf, np.float32)
+        want[edges[b]:edges[b + 1]] = 1.0
+        assert np.array_equal(m[b], want) and edges[b + 1] - edges[b] == int(enc.bcount[b])
+    enc2 = npe.CoherentEncoder(context_dim=256, psd_bands=16)
+    enc2.Bsum[3, 10] = 1.0                                    # bin 10 in two bands: not a partition
+    assert enc2._geometry_plan() is None
