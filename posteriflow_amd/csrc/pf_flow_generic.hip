@@ -119,13 +119,15 @@ __global__ __launch_bounds__(kGenWaves * 64) void flow_generic_kernel(const FwdP
     char* s_ctx = s_x + 16 * sx;
     char* s_a = s_ctx + 16 * sc;
     char* s_b = s_a + 16 * sh;
-    float* s_h = reinterpret_cast<float*>(s_b + 16 * sh);          // [16][H]
-    float* s_par = s_h + 16 * H;                                    // [16][16 gTf]
-    float* s_u = s_par + 16 * 16 * L.gTf;                           // [16][32] input of the current layer's conditioner
+    // rows of the fp32 images are padded by 16 bytes: with H (and 16 gTf) a multiple of 64 floats the 16 rows of a tile sat on
+    // the same banks (PMC: 76 % of the LDS-active cycles were bank conflicts)
+    const int HS = H + 4, PS = 16 * L.gTf + 4;
+    float* s_h = reinterpret_cast<float*>(s_b + 16 * sh);          // [16][H + 4]
+    float* s_par = s_h + 16 * HS;                                   // [16][16 gTf + 4]
+    float* s_u = s_par + 16 * PS;                                   // [16][32] input of the current layer's conditioner
     float* s_y = s_u + 16 * 32;                                     // [16][32] the layer's other side (forward: output)
     float* s_ld = s_y + 16 * 32;                                    // [16][32] per-(row, feature) log-dets of a layer
     float* s_acc = s_ld + 16 * 32;                                  // [16] accumulated log-det, [16..32) bad flags
-    const int PS = 16 * L.gTf;
 
     auto store_act = [&](char* base, int stride, int r, int k, float v) {
         if constexpr (BF16) reinterpret_cast<__bf16*>(base + r * stride)[k] = (__bf16)v;
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(kGenWaves * 64) void flow_generic_kernel(const FwdP
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                s_h[c * H + 16 * t + 4 * g + e] = v[e];
+                s_h[c * HS + 16 * t + 4 * g + e] = v[e];
                 store_act(s_a, sh, c, 16 * t + 4 * g + e, fmaxf(v[e], 0.f));
             }
         }
@@ -308,9 +310,9 @@ __global__ __launch_bounds__(kGenWaves * 64) void flow_generic_kernel(const FwdP
                 f32x4 hv4;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float hv = s_h[c * H + 16 * t + 4 * g + e] + v[e];
+                    const float hv = s_h[c * HS + 16 * t + 4 * g + e] + v[e];
                     hv4[e] = hv;
-                    s_h[c * H + 16 * t + 4 * g + e] = hv;
+                    s_h[c * HS + 16 * t + 4 * g + e] = hv;
                     store_act(s_a, sh, c, 16 * t + 4 * g + e, b == 0 ? fmaxf(hv, 0.f) : hv);   // the final layer takes h itself
                 }
                 if (live) {

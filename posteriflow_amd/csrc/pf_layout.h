@@ -152,7 +152,7 @@ struct FlowPlan {
     PF_HD int64_t gen_lds_bytes() const {
         const int esz = bf16 ? 2 : 4;
         return (int64_t)16 * ((int64_t)gKx * kstep * esz + 16 + (int64_t)gKc * kstep * esz + 16 + 2 * ((int64_t)gKh * kstep * esz + 16)
-                              + (int64_t)H * 4 + (int64_t)16 * gTf * 4 + 4 * 32 * 4) + 256;
+                              + (int64_t)(H + 4) * 4 + (int64_t)(16 * gTf + 4) * 4 + 4 * 32 * 4) + 256;
     }
 
     PF_HD int64_t bias_index(int layer, int tile) const {
