@@ -447,3 +447,39 @@ def test_ctypes_structs_match_the_header(lib, tmp_path):
     sizes = dict(line.split() for line in out.strip().splitlines())
     for n in names:
         assert C.sizeof(getattr(lib, n)) == int(sizes[n]), (n, C.sizeof(getattr(lib, n)), sizes[n])
+
+
+def test_geometry_entry_point_argument_checks_and_twiddles(lib):
+    """pf_geom_twiddles is host code (the table of e^{-2 pi i m / 16384} in double precision, rounded once); pf_geom_features
+    validates before it launches: null pointers / misalignment -> BAD_ARG, shapes outside the kernel -> UNSUPPORTED,
+    an empty batch -> OK without touching the GPU"""
+    import numpy as np
+    h = lib.lib()
+    tw = np.zeros((8192, 2), np.float32)
+    assert h.pf_geom_twiddles(tw.ctypes.data_as(C.c_void_p)) == lib.PF_OK
+    m = np.arange(8192, dtype=np.float64)
+    assert np.array_equal(tw[:, 0], np.cos(-2 * np.pi * m / 16384).astype(np.float32))
+    assert np.array_equal(tw[:, 1], np.sin(-2 * np.pi * m / 16384).astype(np.float32))
+    assert h.pf_geom_twiddles(None) == lib.PF_ERR_BAD_ARG
+    buf = np.zeros(64, np.float32)                              # stands in for device memory: nothing is launched below
+    ptr = buf.ctypes.data_as(C.c_void_p).value
+    a = lib.PfGeomArgs()
+    a.clean = a.twiddle = a.spec = a.etot = a.rel = ptr
+    a.batch, a.n_det, a.band_lo, a.nf, a.n_bands, a.maxlag = 0, 3, 80, 4016, 16, 122
+    edges = np.linspace(0, 4016, 17).astype(int)
+    for i, e in enumerate(edges):
+        a.band_edge[i] = int(e)
+    assert h.pf_geom_features(C.byref(a), None) == lib.PF_OK                       # empty batch
+    for field, bad in (("maxlag", 128), ("n_bands", 17), ("n_det", 9), ("band_lo", 0), ("nf", 4096)):
+        old = getattr(a, field)
+        setattr(a, field, bad)
+        assert h.pf_geom_features(C.byref(a), None) == lib.PF_ERR_UNSUPPORTED, field
+        setattr(a, field, old)
+    a.band_edge[5] = a.band_edge[4] - 1                                              # decreasing edges
+    assert h.pf_geom_features(C.byref(a), None) == lib.PF_ERR_BAD_ARG
+    a.band_edge[5] = int(edges[5])
+    a.rel = None
+    assert h.pf_geom_features(C.byref(a), None) == lib.PF_ERR_BAD_ARG
+    a.rel, a.clean = ptr, ptr + 4                                                    # misaligned strain
+    assert h.pf_geom_features(C.byref(a), None) == lib.PF_ERR_BAD_ARG
+    assert b"aligned" in h.pf_last_error()
