@@ -483,3 +483,34 @@ def test_geometry_entry_point_argument_checks_and_twiddles(lib):
     a.rel, a.clean = ptr, ptr + 4                                                    # misaligned strain
     assert h.pf_geom_features(C.byref(a), None) == lib.PF_ERR_BAD_ARG
     assert b"aligned" in h.pf_last_error()
+
+
+def test_generic_layout_with_the_explicit_flag_stays_in_nflows_unit_order(lib):
+    """PF_FLAG_GENERIC (the layout the fp32 conditioner re-evaluation reads: its outputs feed the backward in nflows unit order)
+    is NOT degree-sorted: row r of W_in is hidden unit r, and the two layouts have the same size"""
+    import numpy as np
+    h = lib.lib()
+    D_, C_, H_, K_, L_ = 5, 7, 48, 3, 1
+    deg = lambda u: u % max(1, D_ - 1) + min(1, D_ - 1)
+    maps = {}
+    for flags in (0, lib.PF_FLAG_GENERIC):
+        d = desc_of(lib, D_, C_, H_, K_, L_, "fp32", flags)
+        n = h.pf_flow_pack_map_len(C_byref(d))
+        m = np.zeros(n, dtype=np.int32)
+        assert h.pf_flow_build_pack_map(C_byref(d), m.ctypes.data_as(C.c_void_p)) == lib.PF_OK
+        maps[flags] = m
+    assert maps[0].shape == maps[lib.PF_FLAG_GENERIC].shape
+    per, ks, nt, kx = 4, 16, H_ // 16, 1
+    unit_of = sorted(range(H_), key=lambda u: (deg(u), u))
+    for flags, order in ((0, unit_of), (lib.PF_FLAG_GENERIC, list(range(H_)))):
+        m = maps[flags]
+        for t in range(nt):
+            for lane in range(64):
+                for e in range(per):
+                    row, k = 16 * t + (lane & 15), per * (lane >> 4) + e
+                    got = m[((t * kx) * 64 + lane) * per + e]
+                    u = order[row]
+                    assert got == (u * D_ + k if (k < D_ and deg(u) >= k + 1) else -1), (flags, t, lane, e)
+    # same multiset of source weights either way
+    a, b = maps[0], maps[lib.PF_FLAG_GENERIC]
+    assert sorted(a[a >= 0].tolist()) == sorted(b[b >= 0].tolist())
