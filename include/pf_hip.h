@@ -72,8 +72,10 @@ extern "C" {
 #define PF_FLAG_GENERIC 16    /* request the generic kernel's layout (plain [tile][k-step] fragment arrays of the dense masked
                               * matrices, nflows unit order) for a shape the scheduled kernels would take: the fp32-mode
                               * conditioner re-evaluation (pf_flow_reevaluate with an fp32 desc) reads this layout; forward and
-                              * inverse calls with such a desc run the generic kernel.  Shapes outside the scheduled set get it
-                              * without the flag. */
+                              * inverse calls with such a desc run the generic kernel.  Shapes outside the scheduled set get the
+                              * generic kernel without the flag, and then with the hidden units stored in autoregressive-degree
+                              * order (block lower-triangular masks: the kernel skips the zero k-steps); a packed buffer belongs to
+                              * the desc it was packed for (same flags). */
 
 /* Plain-old-data description of one NSFPosteriorFlow (flows.py:379-548).
  * conditioner: nflows MADE, num_blocks residual blocks with GLU context gate,

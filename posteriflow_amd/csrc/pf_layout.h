@@ -101,7 +101,7 @@ struct FlowPlan {
     int wide;                   // 1: the large-batch kernel's single common stream (pf_wide_layout.h); CKS in CKM
     int bwd;                    // 1: PF_FLAG_BWD -- bf16 A-fragments for the backward: transposed matrices (chain), forward matrices + biases (re-evaluation)
     int generic;                // 1: a shape none of the scheduled kernels is built for (e.g. H = 384, K = 24): dense masked
-                                // matrices as plain [tile][k-step] fragment arrays in nflows unit order, pf_flow_generic.hip
+                                // matrices as plain [tile][k-step] fragment arrays (unit order: see gsorted), pf_flow_generic.hip
     int gKx, gKc, gKh, gTf;     // generic: k-steps of the x / context / hidden operands, tiles of the final layer
     int gsorted;                // generic: hidden units stored in degree order (sorted_units): the masked matrices are then block
                                 // lower-triangular and the kernel skips the k-steps beyond a tile's last non-zero column.  0 for
