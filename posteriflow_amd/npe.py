@@ -631,7 +631,7 @@ def _side_stream(device) -> "torch.cuda.Stream":
     return _SIDE_STREAMS[i]
 
 
-def batch_nll(model: LeanNPE, strain, params, nsig, asd_bands=None, row_cap=None):
+def batch_nll(model: LeanNPE, strain, params, nsig, asd_bands=None, row_cap=None, reduction: str = "mean"):
     """Mean per-signal NLL of a batch of events with up to ``max_signals`` signals each
     (experiments/train_lean_npe.py:108-127), as ONE flow call over all (event, rank) pairs with a
     0/1 weight for rank < nsig, instead of looping over ranks with a boolean-index host sync per rank
@@ -647,7 +647,20 @@ def batch_nll(model: LeanNPE, strain, params, nsig, asd_bands=None, row_cap=None
     ``row_cap="exact"``: what the reference's loop evaluates -- exactly the existing pairs and nothing else.  Their indices
     come from ONE ``nonzero`` on the [B, max_signals] mask (one host sync on data the remix kernel produced, taken BEFORE
     the encoder is queued so that nothing waits behind it; the reference syncs once per rank); the flow then runs on
-    ~1.8 rows per event instead of 5, forward and backward."""
+    ~1.8 rows per event instead of 5, forward and backward.
+
+    ``reduction``: "mean" (default) is the reference's scalar ``sum nll / sum nsig`` over THIS call's events.  "sum"
+    returns the pair ``(sum nll, number of pairs)`` (two 0-dim tensors, the count without a graph) -- what a data-parallel
+    step needs: the reference's loss over the GLOBAL batch is ``sum_ranks(sum nll) / sum_ranks(count)``, which is not the
+    mean of the ranks' local means when the ranks hold different numbers of signals (``train.train_step``)."""
+    if reduction not in ("mean", "sum"):
+        raise ValueError(f"reduction must be 'mean' or 'sum', got {reduction!r}")
+
+    def _out(total, count):
+        if reduction == "sum":
+            return total, count.detach().to(total.dtype)
+        return total / count.to(total.dtype).clamp_min(1)
+
     b, r_max = params.shape[0], params.shape[1]
     ranks = torch.arange(r_max, device=nsig.device)[None, :].expand(b, r_max)
     keep = (ranks < nsig[:, None]).reshape(-1)
@@ -657,23 +670,28 @@ def batch_nll(model: LeanNPE, strain, params, nsig, asd_bands=None, row_cap=None
         # The encoder is queued FIRST; the pair indices are resolved on a side stream that waits only for what was queued
         # before this call (the remix kernel), so the host sync of nonzero() returns while the encoder is running and
         # the GPU never idles behind it (in program order "nonzero, then encode" the GPU waited ~0.4 ms for the host).
-        main = torch.cuda.current_stream(strain.device)
-        entry = torch.cuda.Event()
-        entry.record(main)
-        context = model.encode(strain, asd_bands)
-        side = _side_stream(strain.device)
-        side.wait_event(entry)
-        with torch.cuda.stream(side):
-            idx = torch.nonzero(keep).squeeze(1)                 # (host sync on `side`: the number of pairs is a shape)
-        keep.record_stream(side)
-        main.wait_stream(side)
-        idx.record_stream(main)
+        if keep.is_cuda:
+            main = torch.cuda.current_stream(strain.device)
+            entry = torch.cuda.Event()
+            entry.record(main)
+            context = model.encode(strain, asd_bands)
+            side = _side_stream(strain.device)
+            side.wait_event(entry)
+            with torch.cuda.stream(side):
+                idx = torch.nonzero(keep).squeeze(1)             # (host sync on `side`: the number of pairs is a shape)
+            keep.record_stream(side)
+            main.wait_stream(side)
+            idx.record_stream(main)
+        else:                                                    # (host tensors: the stand-in models of the CPU tests)
+            context = model.encode(strain, asd_bands)
+            idx = torch.nonzero(keep).squeeze(1)
+        count = torch.full((), float(idx.numel()), device=context.device)
         if idx.numel() == 0:
-            return context.sum() * 0.0
+            return _out(context.sum() * 0.0, count)
         event = torch.div(idx, r_max, rounding_mode="floor")
         nll = model.nll(None, params.reshape(b * r_max, -1)[idx], ranks.reshape(-1)[idx],
                         context=torch.index_select(context, 0, event))  # (backward: one index_add, not a sort)
-        return nll.mean()
+        return _out(nll.sum(), count) if reduction == "sum" else nll.mean()
     context = model.encode(strain, asd_bands)
     # rows of absent ranks are all-zero labels (remix_data.py:229): give them a valid stand-in (rank 0 of
     # the same event) so that the unused rows stay finite; their weight is 0
@@ -685,6 +703,6 @@ def batch_nll(model: LeanNPE, strain, params, nsig, asd_bands=None, row_cap=None
         event = order // r_max
         nll = model.nll(None, rows[order], rank_flat[order], context=context[event])
         kept = keep[order]
-        return torch.where(kept, nll, torch.zeros_like(nll)).sum() / kept.sum().clamp_min(1)
+        return _out(torch.where(kept, nll, torch.zeros_like(nll)).sum(), kept.sum())
     nll = model.nll(None, rows, rank_flat, context=context.repeat_interleave(r_max, dim=0))
-    return torch.where(keep, nll, torch.zeros_like(nll)).sum() / keep.sum().clamp_min(1)
+    return _out(torch.where(keep, nll, torch.zeros_like(nll)).sum(), keep.sum())

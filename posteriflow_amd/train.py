@@ -4,11 +4,14 @@ Mirrors ``experiments/train_lean_npe.py``: optimiser AdamW(lr 3e-4, weight_decay
 LambdaLR linear warm-up (500 steps) then cosine decay to 1 % (:305-311), per step
 ``batch_nll -> zero_grad -> backward -> clip_grad_norm_(5.0) -> opt.step -> sched.step`` (:363-368),
 checkpoint dictionary keys (:424-427).  Added for one-process-per-GPU data parallelism (the
-reference is single-device): the gradients are all-reduced (mean) in a few flat buckets over
-RCCL/xGMI before clipping, and the reported loss is the global per-signal mean.
+reference is single-device): every rank back-propagates ``sum nll / N`` with N the GLOBAL number of
+(event, rank) pairs (one 16-byte all-reduce queued before the backward), the gradients are all-reduced
+(SUM) in a few flat buckets over RCCL/xGMI before clipping -- so the reduced gradient IS the gradient of
+the reference's loss ``sum nll / sum nsig`` (train_lean_npe.py:108-127) over the concatenated batch,
+whatever the ranks' signal counts are -- and the reported loss is that global per-signal mean.
 
-The loss value comes from the HIP kernels; gradients flow through the interim tensor-op backward
-(``_flow_autograd.py``)."""
+Loss and gradients both come from the HIP kernels: the flow's backward is ``_flow_autograd.py`` (re-evaluation,
+chain kernel, hand-written transposed GEMMs), the encoder's is ``_enc_train.py``."""
 from __future__ import annotations
 
 import math
@@ -43,8 +46,9 @@ def make_scheduler(opt, total_steps: int, warmup_steps: int = WARMUP_STEPS):
     return torch.optim.lr_scheduler.LambdaLR(opt, lambda s: lr_factor(s, total_steps, warmup_steps))
 
 
-def allreduce_gradients(params: Iterable[torch.nn.Parameter], bucket_bytes: int = 16 << 20, group=None) -> None:
-    """Mean of the gradients over ranks, in flat fp32 buckets.  ~8.9 M parameters = 35 MB fp32:
+def allreduce_gradients(params: Iterable[torch.nn.Parameter], bucket_bytes: int = 16 << 20, group=None,
+                        average: bool = True) -> None:
+    """Mean (``average=False``: sum) of the gradients over ranks, in flat fp32 buckets.  ~8.9 M parameters = 35 MB fp32:
     3 buckets of <= 16 MB; ring all-reduce moves 2 (N-1)/N x 35 MB per GPU over one xGMI link
     direction (~153 GB/s) ~ 0.4 ms per step."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
@@ -60,7 +64,8 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], bucket_bytes: int 
             return
         flat = torch.cat([g.reshape(-1) for g in bucket])
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-        flat.div_(world)
+        if average:
+            flat.div_(world)
         off = 0
         for g in bucket:
             n = g.numel()
@@ -83,7 +88,8 @@ class OverlappedGradReducer:
     its bucket, so nothing is concatenated or copied back); buckets are filled in reverse parameter order -- roughly
     the order in which backward produces gradients -- and a post-accumulate hook marks a bucket ready the moment its
     last gradient has been accumulated, while autograd is still working on the earlier layers.  ``finish()`` waits
-    for the outstanding reductions and scales by 1 / world.  35 MB of fp32 gradients = 4 buckets of ~9 MB: a ring
+    for the outstanding reductions and scales by 1 / world (``finish(average=False)``: leaves the sum -- the form
+    ``train_step`` uses, whose local losses are already divided by the global signal count).  35 MB of fp32 gradients = 4 buckets of ~9 MB: a ring
     all-reduce of one bucket is ~0.1 ms per link direction, hidden behind the backward of the encoder.
 
     Contract -- ONE ``backward()`` per ``zero()``:
@@ -123,11 +129,11 @@ class OverlappedGradReducer:
 
     def _close(self, plist, size):
         p0 = plist[0]
-        flat = torch.zeros(size, dtype=torch.float32, device=p0.device)
+        flat = torch.zeros(size, dtype=p0.dtype, device=p0.device)      # (fp32 in production; the CPU tests use fp64)
         off = 0
         for p in plist:
-            if p.dtype != torch.float32:
-                raise TypeError("OverlappedGradReducer expects fp32 parameters")
+            if p.dtype != p0.dtype or not p.dtype.is_floating_point:
+                raise TypeError("OverlappedGradReducer expects floating-point parameters of one dtype")
             p.grad = flat[off:off + p.numel()].view_as(p)
             off += p.numel()
         self.buckets.append({"flat": flat, "params": plist, "pending": len(plist), "work": None, "launched": False})
@@ -165,13 +171,13 @@ class OverlappedGradReducer:
             b["pending"], b["work"], b["launched"] = len(b["params"]), None, False
             off = 0
             for p in b["params"]:                      # someone may have set .grad to None (zero_grad(set_to_none=True))
-                if p.grad is None or p.grad.data_ptr() != b["flat"].data_ptr() + 4 * off:
+                if p.grad is None or p.grad.data_ptr() != b["flat"].data_ptr() + b["flat"].element_size() * off:
                     p.grad = b["flat"][off:off + p.numel()].view_as(p)
                 off += p.numel()
 
-    def finish(self):
+    def finish(self, average: bool = True):
         """after backward(): reduce -- in bucket order -- the buckets that are not out yet (parameters without a gradient
-        this step), wait, take the mean"""
+        this step), wait, take the mean (``average=False``: keep the sum over ranks)"""
         for b in self.buckets[self._next:]:
             self._launch(b)
         self._next = len(self.buckets)
@@ -179,7 +185,7 @@ class OverlappedGradReducer:
             if b["work"] is not None:
                 b["work"].wait()
                 b["work"] = None
-            if self.world > 1:
+            if self.world > 1 and average:
                 b["flat"].div_(self.world)
 
     def close(self):
@@ -188,36 +194,45 @@ class OverlappedGradReducer:
         self._hooks = []
 
 
+def _world(group=None) -> int:
+    return dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+
+
 def train_step(model: LeanNPE, opt, sched, strain, params, nsig, asd_bands=None, group=None,
                reducer: Optional[OverlappedGradReducer] = None, row_cap="exact", sync: bool = True) -> Dict[str, float]:
-    """One optimisation step on this rank's shard of the batch.  With a ``reducer`` the gradient all-reduce overlaps
-    the backward pass (one backward per step: the reducer's contract); without one (single rank, or the simple path) it
-    runs after it.  ``row_cap`` (``batch_nll``): "exact" (default: the existing (event, rank) pairs, one host sync per step), an int
+    """One optimisation step on this rank's shard of the batch; on N ranks the parameters move exactly as the reference's
+    single-process step on the concatenated batch would move them (loss ``sum nll / sum nsig`` over ALL ranks' events: each
+    rank back-propagates its ``sum nll`` divided by the global pair count and the gradients are SUMMED).  With a
+    ``reducer`` the gradient all-reduce overlaps the backward pass (one backward per step: the reducer's contract);
+    without one (single rank, or the simple path) it runs after it.  ``row_cap`` (``batch_nll``): "exact" (default: the existing (event, rank) pairs, one host sync per step), an int
     (static bound, no sync) or None (all max_signals rows per event).  ``sync=False`` returns the loss and the gradient norm
     as 0-dim device tensors instead of Python floats: the reference reads ``loss.item()`` every step
     (train_lean_npe.py:368), which makes the host wait for the whole step before it queues the next one (~1 ms of idle GPU
     per 13 ms step here); a loop that logs every k-th step converts only then."""
-    loss = batch_nll(model, strain, params, nsig, asd_bands, row_cap=row_cap)
+    total, count = batch_nll(model, strain, params, nsig, asd_bands, row_cap=row_cap, reduction="sum")
+    # the reference's loss over the GLOBAL batch: sum_ranks(sum nll) / sum_ranks(pairs).  The global count is needed
+    # before the backward (it scales every gradient), the global sum only for the log: both in one 16-byte all-reduce
+    # queued here, in float64 (sums of ~1e3 terms of ~1e1 nats)
+    red = torch.stack([total.detach().double(), count.double()])
+    if _world(group) > 1:
+        dist.all_reduce(red, group=group)
+    n_global = red[1].clamp_min(1.0)
+    loss = total / n_global.to(total.dtype)
     if reducer is not None:
         reducer.zero()
         loss.backward()
-        reducer.finish()
+        reducer.finish(average=False)
     else:
         opt.zero_grad(set_to_none=True)
         loss.backward()
-        allreduce_gradients(model.parameters(), group=group)
+        allreduce_gradients(model.parameters(), group=group, average=False)
     gn = torch.nn.utils.clip_grad_norm_(model.parameters(), GRAD_CLIP)
     opt.step()
     if sched is not None:
         sched.step()
-    # global per-signal mean of the loss (weights: signals per rank)
-    n_sig = nsig.sum().to(torch.float64)
-    red = torch.stack([loss.detach().double() * n_sig, n_sig])
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(red, group=group)
     if not sync:
-        return {"loss": red[0] / red[1], "grad_norm": gn}
-    return {"loss": (red[0] / red[1]).item(), "grad_norm": float(gn)}
+        return {"loss": red[0] / n_global, "grad_norm": gn}
+    return {"loss": (red[0] / n_global).item(), "grad_norm": float(gn)}
 
 
 def checkpoint_dict(model: LeanNPE, epoch: int, val_nll: float, diagnostics: Optional[dict] = None,

@@ -98,6 +98,113 @@ def test_gradient_allreduce_gloo_world2(tmp_path):
     assert out.stdout.count("ok") == 2
 
 
+DP_WORKER = r"""
+# Data-parallel train_step against the reference's single-process loss sum(nll) / sum(nsig) over the CONCATENATED batch
+# (experiments/train_lean_npe.py:108-127), with ranks that hold DIFFERENT numbers of (event, rank) pairs.
+import os, sys, copy, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+backend = sys.argv[2]
+from posteriflow_amd.train import OverlappedGradReducer, train_step
+from posteriflow_amd.npe import batch_nll
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+if backend == "nccl":
+    torch.cuda.set_device(int(os.environ["LOCAL_RANK"]))
+dev = torch.device("cuda" if backend == "nccl" else "cpu")
+dist.init_process_group(backend, rank=rank, world_size=world)
+torch.set_default_dtype(torch.float64)
+
+class Toy(torch.nn.Module):
+    # the (encode, nll) interface batch_nll drives; smooth, every parameter reached by every row
+    def __init__(self):
+        super().__init__()
+        self.enc = torch.nn.Linear(24, 8)
+        self.rank_embed = torch.nn.Embedding(5, 3)
+        self.head = torch.nn.Linear(8 + 3 + 4, 1)
+    def encode(self, strain, asd_bands=None):
+        return torch.tanh(self.enc(strain))
+    def nll(self, strain, params, rank, context=None, asd_bands=None):
+        h = torch.cat([context, self.rank_embed(rank), params], dim=1)
+        return torch.nn.functional.softplus(self.head(h)).squeeze(1) + (params ** 2).sum(1)
+
+torch.manual_seed(0)
+model0 = Toy().to(dev)
+B = 12                                           # per rank
+strain = torch.randn(world * B, 24, device=dev)
+params = torch.randn(world * B, 5, 4, device=dev)
+nsig = torch.tensor([1, 1, 2, 1, 1, 1, 1, 2, 1, 1, 1, 1] + [5, 4, 5, 3, 5, 5, 4, 5, 5, 2, 5, 5], device=dev)   # 14 vs 53 pairs
+assert int(nsig[:B].sum()) != int(nsig[B:].sum())
+lo, hi = rank * B, rank * B + B
+
+def reference_gradient(model):
+    # what one process does on the whole batch: the reference's per-rank loop
+    ctx = model.encode(strain)
+    tot, cnt = 0.0, 0
+    for r in range(5):
+        m = nsig > r
+        if m.any():
+            rr = torch.full((int(m.sum()),), r, dtype=torch.long, device=dev)
+            tot = tot + model.nll(None, params[m, r], rr, context=ctx[m]).sum()
+            cnt += int(m.sum())
+    loss = tot / cnt
+    return loss.detach(), torch.autograd.grad(loss, list(model.parameters()))
+
+class NoStep:                                    # the gradients are what is compared: no parameter update
+    def zero_grad(self, set_to_none=True):
+        for p in self.params: p.grad = None
+    def step(self): pass
+
+for row_cap in ("exact", None, 56):                # 56: a static cap above both ranks' pair counts (14, 53)
+    for use_reducer in (False, True):
+        model = copy.deepcopy(model0)
+        want_loss, want = reference_gradient(model)
+        opt = NoStep(); opt.params = list(model.parameters())
+        red = OverlappedGradReducer(model.parameters(), n_buckets=2) if use_reducer else None
+        out = train_step(model, opt, None, strain[lo:hi], params[lo:hi], nsig[lo:hi], reducer=red, row_cap=row_cap)
+        # clip_grad_norm_(5.0) ran inside the step: undo nothing unless it clipped
+        gn = torch.sqrt(sum((w ** 2).sum() for w in want))
+        scale = min(1.0, 5.0 / (float(gn) + 1e-6))
+        assert abs(out["loss"] - float(want_loss)) < 1e-9, (row_cap, use_reducer, out["loss"], float(want_loss))
+        assert abs(out["grad_norm"] - float(gn)) < 1e-6 * float(gn)
+        for (name, p), w in zip(model.named_parameters(), want):
+            err = (p.grad - scale * w).abs().max().item()
+            assert err < 1e-6 * max(1.0, w.abs().max().item()), (row_cap, use_reducer, name, err)
+        # the mean of the ranks' LOCAL means is a different gradient on this data: the test can see the difference
+        local = batch_nll(copy.deepcopy(model0), strain[lo:hi], params[lo:hi], nsig[lo:hi], row_cap=row_cap)
+        both = torch.stack([local.detach()]); dist.all_reduce(both)
+        assert abs(float(both[0]) / world - float(want_loss)) > 1e-3
+        if red is not None: red.close()
+dist.destroy_process_group()
+print("ok", rank)
+"""
+
+
+def test_data_parallel_step_is_the_global_batch_gradient_gloo_world2(tmp_path):
+    """ranks with different signal counts; every reduced gradient = the single-process gradient of
+    sum nll / sum nsig over the concatenated batch (1e-6), through both reducers and every row_cap mode."""
+    script = tmp_path / "dp.py"
+    script.write_text(DP_WORKER)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29541", str(script), ROOT, "gloo"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert out.stdout.count("ok") == 2
+
+
+@pytest.mark.gpu
+def test_data_parallel_step_is_the_global_batch_gradient_nccl_world2(tmp_path):
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    script = tmp_path / "dp.py"
+    script.write_text(DP_WORKER)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29543", str(script), ROOT, "nccl"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert out.stdout.count("ok") == 2
+
+
 NCCL_WORKER = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
