@@ -316,6 +316,14 @@ int pf_flow_inverse(const PfFlowDesc* desc, const void* packed,
  * z, x, logdet, fail_flags, ar_inv_perm, ctx_rows as in pf_flow_inverse. */
 int pf_pack_bf16_frags(const float* src, int32_t n_rows, int32_t k, void* out, void* stream);
 int64_t pf_flow_inc_layer_bytes(const PfFlowDesc* desc);
+/* ctx_proj above, made on the GPU: out[r][n] = sum_c ctx[r][c] W[n][c] + bias[n] (fp32, row-major [rows][n_units]) for
+ * W [n_units][context_features] packed by pf_dense_pack_matrix(precision, W, 0, context_features, n_units, K) with K =
+ * context_features rounded up to 32 (bf16) / 16 (fp32) and zero columns beyond.  PF_PREC_BF16: context and weights enter the
+ * MFMA as bf16 (the forward kernel's operand rounding), fp32 accumulation.  The kernel is the hoisted-projection GEMM of
+ * the D-pass inverse (csrc/pf_flow_ctx.hip) with a row-major epilogue; replaces the three context_layer calls nflows makes
+ * per MADE pass (reference call site src/ahsd/models/flows.py:637). */
+int pf_flow_ctx_project_rows(int32_t precision, const void* wfrags, const float* bias, const float* ctx, int64_t rows,
+                             int32_t context_features, int32_t n_units, float* out, void* stream);
 int pf_flow_inverse_inc(const PfFlowDesc* desc, const int32_t* units_upto_degree, const void* packed,
                         const float* ctx_proj, int64_t ctx_rows, const float* z, const int32_t* ar_inv_perm,
                         int64_t batch, float* x, float* logdet, uint32_t* fail_flags, void* stream);
@@ -381,6 +389,9 @@ typedef struct PfEmbedTrainDesc {
     int32_t n_extra_tokens;   /* tokens prepended per event (CoherentEncoder: 4), n_extra + 61 n_det <= 192 */
     int32_t training;         /* 1: dropout active */
     float dropout_p;
+    int32_t forward_only;     /* 1: no backward will follow (a no-grad call): the workspace holds ONE layer's activations (the
+                                 layers reuse them) and none of the backward's temporaries -- ~5.5 MB per 3-detector event in
+                                 fp32 instead of ~16 MB; pf_embed_train_backward refuses such a desc */
     uint64_t dropout_seed;
 } PfEmbedTrainDesc;
 int64_t pf_embed_train_raw_param_count(void);

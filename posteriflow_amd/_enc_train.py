@@ -16,6 +16,7 @@ import torch
 from . import _lib
 
 D_MODEL, N_POOL_Q, TOK_PER_DET = 192, 8, 61
+FWD_ONLY_CHUNK = 1024      # events per launch group of a no-grad call (workspace ~5.5 MB per 3-detector event in fp32)
 
 
 def train_parameters(enc) -> List[torch.nn.Parameter]:
@@ -51,12 +52,12 @@ def _draw_seed() -> int:
 
 class _EncoderTrainFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, state, precision, n_det, training, dropout_p, seed, strain, extra, token_bias, pool_q, *params):
+    def forward(ctx, state, precision, n_det, training, dropout_p, seed, fwd_only, strain, extra, token_bias, pool_q, *params):
         L, dev = _lib.lib(), strain.device
         prec = _lib.PRECISIONS[precision]
         b = strain.shape[0]
         n_extra = 0 if extra is None else extra.shape[1]
-        desc = _lib.PfEmbedTrainDesc(prec, n_det, n_extra, 1 if training else 0, float(dropout_p), int(seed))
+        desc = _lib.PfEmbedTrainDesc(prec, n_det, n_extra, 1 if training else 0, float(dropout_p), 1 if fwd_only else 0, int(seed))
         key = (_lib.param_epoch(), dev, prec, tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
         if state.get("key") != key:        # flat fp32 copy of the parameters + their MFMA fragments, once per weight update
             if len(params) == 1:           # flat mode: the leaf IS the raw layout
@@ -82,17 +83,22 @@ class _EncoderTrainFn(torch.autograd.Function):
                                             0 if ex is None else ex.data_ptr(), 0 if tb is None else tb.data_ptr(), q.data_ptr(), b,
                                             pooled.data_ptr(), log_energy.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)),
                    "pf_embed_train_forward")
+        log_energy = log_energy.reshape(b, n_det, 16)
+        if fwd_only:                          # no backward will follow: nothing is kept (the workspace dies here)
+            ctx.held = None
+            return pooled, log_energy
         ctx.desc, ctx.b, ctx.n_extra, ctx.n_det = desc, b, n_extra, n_det
         ctx.shapes = [p.shape for p in params]
         ctx.has_tb = token_bias is not None
         ctx.held = (raw, packed, ws, q)       # plain attributes: none of them is an input or output of this Function
-        log_energy = log_energy.reshape(b, n_det, 16)
         ctx.mark_non_differentiable(log_energy)
         return pooled, log_energy
 
     @staticmethod
     def backward(ctx, g_pooled, _g_log_energy):
         L = _lib.lib()
+        if ctx.held is None:
+            raise RuntimeError("the strain embedding's forward ran forward-only (no input required a gradient when it was called)")
         raw, packed, ws, q = ctx.held
         dev = raw.device
         gp = g_pooled.contiguous().float()
@@ -111,7 +117,7 @@ class _EncoderTrainFn(torch.autograd.Function):
             n = math.prod(shp)
             grads.append(g_raw[off:off + n].view(shp))
             off += n
-        return (None, None, None, None, None, None, None, g_extra, g_tb, g_q, *grads)
+        return (None, None, None, None, None, None, None, None, g_extra, g_tb, g_q, *grads)
 
 
 def encode_tokens(enc, strain: torch.Tensor, extra_tokens: Optional[torch.Tensor], token_bias: Optional[torch.Tensor],
@@ -119,10 +125,8 @@ def encode_tokens(enc, strain: torch.Tensor, extra_tokens: Optional[torch.Tensor
     """(pooled [B, 8, 192] before pool_attn.out_proj, log_energy [B, D, 16]) through the HIP training path."""
     if strain.device.type != "cuda":
         raise _lib.PfError(f"the strain embedding runs on the MI355X only (input on {strain.device}); no CPU fallback")
-    e = D_MODEL
-    w, bias = enc.pool_attn.in_proj_weight, enc.pool_attn.in_proj_bias
     with torch.autocast("cuda", enabled=False):
-        q = (enc.pool_queries.float() @ w[:e].float().t() + bias[:e].float()) * (1.0 / math.sqrt(32.0))
+        q = enc._pool_queries_projected()
     p = float(enc.fusion.layers[0].dropout.p)
     train = bool(training and p > 0.0)
     if train and seed is None:
@@ -130,5 +134,24 @@ def encode_tokens(enc, strain: torch.Tensor, extra_tokens: Optional[torch.Tensor
     state = enc.__dict__.setdefault("_train_state", {})
     state["last_seed"] = seed if train else None      # (tests rebuild the dropout factors from it)
     params = [enc._theta] if getattr(enc, "_theta", None) is not None else train_parameters(enc)
-    return _EncoderTrainFn.apply(state, enc.precision, strain.shape[1], train, p, seed or 0, strain, extra_tokens, token_bias, q,
-                                 *params)
+    if strain.requires_grad and torch.is_grad_enabled():
+        # the backward has no d/d strain (the strain is data in every reference caller): refuse rather than hand autograd a
+        # silent zero through the stem
+        raise NotImplementedError("the HIP strain embedding does not differentiate with respect to the strain; detach it")
+    diff = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (extra_tokens, token_bias, q, *params))
+    if diff:
+        return _EncoderTrainFn.apply(state, enc.precision, strain.shape[1], train, p, seed or 0, False, strain, extra_tokens,
+                                     token_bias, q, *params)
+    # No gradient will be asked for (torch.no_grad(), or frozen parameters): the forward-only workspace (one layer's
+    # activations, none of the backward's temporaries), in chunks of FWD_ONLY_CHUNK events so that a 4096-event fp32 call
+    # needs ~5.6 GB of workspace instead of ~65 GB.  Dropout indices are per call: a train()-mode no-grad call over several
+    # chunks reuses the factors per chunk, which is as random as nn.Dropout's fresh draw.
+    outs = []
+    for lo in range(0, strain.shape[0], FWD_ONLY_CHUNK):
+        hi = min(strain.shape[0], lo + FWD_ONLY_CHUNK)
+        with torch.no_grad():
+            outs.append(_EncoderTrainFn.apply(state, enc.precision, strain.shape[1], train, p, (seed or 0) + lo, True, strain[lo:hi],
+                                              None if extra_tokens is None else extra_tokens[lo:hi], token_bias, q, *params))
+    if len(outs) == 1:
+        return outs[0]
+    return torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])

@@ -1,33 +1,44 @@
 """Backward of the flow.  The FORWARD value of every differentiable call comes from the HIP kernel
-(``pf_flow_forward_train``), which also keeps the input of every layer's conditioner.
+(``pf_flow_forward_train``), which also keeps the input of every layer's conditioner (``U [L, B, D]``).
 
-Plain conditioner (what LeanNPE uses): ``flow_backward`` --
-  1. re-evaluates the ten conditioners from the kept inputs, *batched over layers* (they are independent
-     given their inputs): one GEMM for all context projections, ``baddbmm`` over the layer dimension for
-     the masked linears;
-  2. walks the layer chain backwards in ONE HIP launch (``pf_flow_backward_chain``, pf_flow_bwd_chain.hip): the
-     hand-derived spline backward, the transposed masked GEMMs on fp32 MFMA and the gate / ReLU algebra of every
-     layer, last first (it replaced ~25 small launches per layer);
-  3. forms every weight gradient with batched GEMMs over the layer dimension and the context gradient
-     with one GEMM.
-GEMMs go to the vendor library through torch (plain library GEMMs); nothing runs on the CPU and nothing
-imports the oracle.
+``flow_backward`` (both conditioner flavours, every precision) is three groups of HIP launches, no library GEMM:
+  1. ``pf_flow_reevaluate``: the conditioners of all layers re-evaluated from the kept inputs in one launch
+     (bf16: ``flow_reeval_kernel`` on the packed ``PF_FLAG_BWD`` stream; fp32, generic shapes and the masked-context
+     conditioner: the generic kernel's conditioner, ``PF_FLAG_GENERIC`` layout);
+  2. ``pf_flow_backward_chain``: the layer chain walked backwards in ONE launch -- the hand-derived spline backward, the
+     transposed masked GEMMs on MFMA and the gate / ReLU algebra (additive form for the masked-context conditioner);
+  3. ``pf_dense_tn``: every weight / bias gradient by the hand-written transposed GEMM, batched over layers, accumulated
+     into ONE flat fp32 buffer in ``state_dict`` order; ``pf_dense_nt``: the context gradient by the strip GEMM over the
+     transposed context weights.
+Nothing runs on the CPU and nothing imports the oracle.
 
-Masked-context conditioner (flows.py:112-360, not used by LeanNPE): ``backward`` re-evaluates the
-chain with device tensor ops under autograd (``flow_forward`` below) and differentiates that.
-
-The tensor-op evaluation follows nflows (MADE with GLU-gated residual blocks, rational-quadratic
-spline with linear tails, ReversePermutation before every layer) and is written sync-free: no boolean
-indexing, the tail branch is a ``torch.where`` over a computation done on clamped inputs so that the
-unselected branch is always finite (no NaN gradients)."""
+``flow_forward`` below is the same chain written with device tensor ops under autograd (nflows' MADE with GLU-gated
+residual blocks, rational-quadratic spline with linear tails, ReversePermutation before every layer; sync-free: no
+boolean indexing, the tail branch is a ``torch.where`` over a computation on clamped inputs so that the unselected branch
+is finite).  It is NOT on the default path: it is the replay used only for masked-context flows outside the HIP
+backward's shapes (``_fast``: D > 16 or H not in the instantiated set), and taking it is logged once."""
 from __future__ import annotations
 
+import logging
 import math
 
 import torch
 import torch.nn.functional as F
 
 from . import _lib
+
+_log = logging.getLogger(__name__)
+_replay_logged = False
+
+
+def _note_replay(flow, why: str) -> None:
+    """the tensor-op replay is taken: say so once per process"""
+    global _replay_logged
+    if not _replay_logged:
+        _replay_logged = True
+        _log.warning("posteriflow_amd: flow backward by autograd replay over device tensor ops (%s; D=%d, H=%d, K=%d, "
+                     "masked_context=%s) -- the HIP backward does not cover this shape", why, flow.features,
+                     flow.hidden_features, flow.num_bins, bool(getattr(flow, "use_masked_context", False)))
 
 _MIN = 1e-3            # nflows DEFAULT_MIN_BIN_WIDTH / HEIGHT / DERIVATIVE
 
@@ -461,6 +472,9 @@ class FlowNLL(torch.autograd.Function):
             except NotImplementedError:      # PF_ERR_UNSUPPORTED from a backward kernel (e.g. D = 16, K = 32 at H = 512: the chain's
                 if not flow.use_masked_context:      # LDS image): the masked-context conditioner still has the replay below
                     raise
+                _note_replay(flow, "PF_ERR_UNSUPPORTED from a backward kernel")
+        else:
+            _note_replay(flow, "shape outside the HIP backward's set")
         with torch.enable_grad():
             xs = x.detach().requires_grad_(x.requires_grad)
             cs = None if context is None else context.detach().requires_grad_(context.requires_grad)
@@ -514,6 +528,9 @@ class FlowForward(torch.autograd.Function):
             except NotImplementedError:      # (see FlowNLL.backward)
                 if not flow.use_masked_context:
                     raise
+                _note_replay(flow, "PF_ERR_UNSUPPORTED from a backward kernel")
+        else:
+            _note_replay(flow, "shape outside the HIP backward's set")
         with torch.enable_grad():
             xs = x.detach().requires_grad_(x.requires_grad)
             cs = None if context is None else context.detach().requires_grad_(context.requires_grad)

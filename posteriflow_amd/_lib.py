@@ -42,7 +42,7 @@ class PfFlowReevalArgs(C.Structure):
 class PfEmbedTrainDesc(C.Structure):
     """include/pf_hip.h PfEmbedTrainDesc"""
     _fields_ = [("precision", C.c_int32), ("n_detectors", C.c_int32), ("n_extra_tokens", C.c_int32), ("training", C.c_int32),
-                ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64)]
+                ("dropout_p", C.c_float), ("forward_only", C.c_int32), ("dropout_seed", C.c_uint64)]
 
 
 class PfDenseArgs(C.Structure):
@@ -129,6 +129,8 @@ SYMBOLS = {
                                   C.c_void_p, C.c_int64, C.c_void_p]),
     "pf_pack_bf16_frags": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "pf_flow_inc_layer_bytes": (C.c_int64, [_P]),
+    "pf_flow_ctx_project_rows": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                           C.c_void_p, C.c_void_p]),
     "pf_flow_inverse_inc": (C.c_int, [_P, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                       C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pf_embed_stem_raw_param_count": (C.c_int64, []),

@@ -40,6 +40,8 @@ int flow_reevaluate(const FlowPlan& P, const PfFlowReevalArgs& a, hipStream_t s)
 int64_t enc_train_raw_count();
 int64_t enc_train_packed_bytes(bool bf16);
 int enc_train_pack(bool bf16, const float* raw, void* packed, hipStream_t s);
+int ctx_project_rows(bool bf16, const void* wfrags, const float* bias, const float* ctx, int64_t rows, int C, int n_units,
+                     float* out, hipStream_t s);
 int64_t enc_train_workspace_bytes(const PfEmbedTrainDesc* desc, int64_t n_events);
 int enc_train_forward(const PfEmbedTrainDesc* desc, const void* packed, const float* raw, const float* strain,
                       const float* extra_tokens, const float* token_bias, const float* pool_q, int64_t n_events, float* pooled,
@@ -566,10 +568,22 @@ int pf_dense_nt(int32_t precision, int32_t epilogue, const PfDenseArgs* a, void*
     if (a->M > 0 && (!a->A || !a->wfrags || !a->out || a->rows_per_seq <= 0)) return fail(PF_ERR_BAD_ARG, "pf_dense_nt: null pointer");
     if ((epilogue == PF_EPI_RESID && !a->resid) || (epilogue == PF_EPI_MUL && !a->mul))
         return fail(PF_ERR_BAD_ARG, "pf_dense_nt: the epilogue's operand is null");
+    if (epilogue < PF_EPI_PLAIN || epilogue > PF_EPI_MUL) return fail(PF_ERR_BAD_ARG, "pf_dense_nt: unknown epilogue");
+    // every global access of the kernels is a 16-byte piece (8 bytes for the accumulator-layout loads of an operand): check
+    // each pointer and stride against the element size of the array it addresses -- the output, resid and dact arrays are
+    // fp32 for the residual / multiply epilogues, in fp32 mode and with out_f32
     const int esz = precision == PF_PREC_BF16 ? 2 : 4;
-    if (misaligned(a->A, 16) || misaligned(a->wfrags, 16) || misaligned(a->out, 16) || (a->lda * esz) % 16 || (a->a_seq_stride * esz) % 16 ||
-        (a->ldo * esz) % 8 || a->N % 16)
+    const int oesz = (epilogue == PF_EPI_RESID || epilogue == PF_EPI_MUL || precision != PF_PREC_BF16 || a->out_f32) ? 4 : 2;
+    const int64_t xss = a->x_seq_stride ? a->x_seq_stride : a->o_seq_stride;
+    if (misaligned(a->A, 16) || misaligned(a->wfrags, 16) || (a->lda * (int64_t)esz) % 16 || (a->a_seq_stride * esz) % 16 ||
+        (a->a_chunk_stride * esz) % 16 || a->N % 16)
         return fail(PF_ERR_BAD_ARG, "pf_dense_nt: rows of A must start on 16-byte boundaries, N % 16 == 0");
+    if (misaligned(a->out, 16) || (a->ldo * (int64_t)oesz) % 16 || (a->o_seq_stride * oesz) % 16)
+        return fail(PF_ERR_BAD_ARG, "pf_dense_nt: rows of out must start on 16-byte boundaries (in its own element size)");
+    if (misaligned(a->bias, 4) || (epilogue == PF_EPI_RESID && (misaligned(a->resid, 16) || (xss * 4) % 16)) ||
+        (epilogue == PF_EPI_MUL && (misaligned(a->mul, 16) || (xss * esz) % 16)) ||
+        (epilogue == PF_EPI_GELU && a->dact && (misaligned(a->dact, 16) || (xss * oesz) % 16)))
+        return fail(PF_ERR_BAD_ARG, "pf_dense_nt: the epilogue's operand (resid / mul / dact) must be 16-byte aligned with 16-byte row starts");
     return finish(pf::dense_nt(precision == PF_PREC_BF16, epilogue, *a, static_cast<hipStream_t>(stream)),
                   "pf_dense_nt: KC too large for LDS, or a chunked reduction with N > 256");
 }
@@ -632,6 +646,19 @@ int pf_flow_pack_ctx_transposed(const PfFlowDesc* desc, const float* raw, void* 
             e.nks_total = 3 * L.L * (L.H / kstep); e.ks_off = (3 * l + j) * (L.H / kstep);
         }
     return finish(pf::dense_pack(L.bf16 != 0, raw, tab, out, static_cast<hipStream_t>(stream)), "");
+}
+
+int pf_flow_ctx_project_rows(int32_t precision, const void* wfrags, const float* bias, const float* ctx, int64_t rows,
+                             int32_t context_features, int32_t n_units, float* out, void* stream) {
+    if (!prec2(precision)) return fail(PF_ERR_BAD_ARG, "pf_flow_ctx_project_rows: bad precision");
+    if (rows < 0 || context_features <= 0 || n_units <= 0 || n_units % 16)
+        return fail(PF_ERR_BAD_ARG, "pf_flow_ctx_project_rows: rows >= 0, context_features > 0, n_units a positive multiple of 16");
+    if (rows == 0) return PF_OK;
+    if (!wfrags || !bias || !ctx || !out) return fail(PF_ERR_BAD_ARG, "pf_flow_ctx_project_rows: null pointer");
+    if (misaligned(wfrags, 16) || misaligned(bias, 16) || misaligned(out, 16) || misaligned(ctx, 4))
+        return fail(PF_ERR_BAD_ARG, "pf_flow_ctx_project_rows: wfrags / bias / out must be 16-byte aligned");
+    return finish(pf::ctx_project_rows(precision == PF_PREC_BF16, wfrags, bias, ctx, rows, context_features, n_units, out,
+                                       static_cast<hipStream_t>(stream)), "context width beyond the LDS tile (<= 1280 bf16 / 640 fp32)");
 }
 
 int64_t pf_flow_issued_flop_per_row(const PfFlowDesc* desc) {

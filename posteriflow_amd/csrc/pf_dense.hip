@@ -455,14 +455,18 @@ static int launch_strip_rd(const DenseArgs& a, hipStream_t s) {
     }
 }
 
+// Tiles per wave and pass (TP) of a strip launch -- ONE rule for the launcher and for dense_nt's LDS budget (they once
+// differed for a chunked reduction over 13..15 tiles).  A chunked reduction keeps its accumulators across chunks: one pass
+// over all tiles (<= 16); otherwise 3 tiles per wave and pass, 4 where that divides the tile count evenly.
+static int strip_tiles_per_pass(int ntiles, int nchunks) {
+    return ((nchunks > 1 && ntiles > 12) || (nchunks == 1 && ntiles % 16 == 0 && ntiles % 12 != 0)) ? 4 : 3;
+}
+
 template <bool BF16, int EPI>
 static int launch_strip_tp(const DenseArgs& a, hipStream_t s) {
     const int ntiles = a.N / 16, nchunks = a.K / a.KC;
-    // a chunked reduction keeps its accumulators across chunks: one pass over all tiles (<= 16); otherwise 3 tiles per
-    // wave and pass, 4 where that divides the tile count evenly
     if (nchunks > 1 && ntiles > 16) return PF_ERR_UNSUPPORTED;
-    const bool four = (nchunks > 1 && ntiles > 12) || (nchunks == 1 && ntiles % 16 == 0 && ntiles % 12 != 0);
-    return four ? launch_strip_rd<BF16, EPI, 4>(a, s) : launch_strip_rd<BF16, EPI, 3>(a, s);
+    return strip_tiles_per_pass(ntiles, nchunks) == 4 ? launch_strip_rd<BF16, EPI, 4>(a, s) : launch_strip_rd<BF16, EPI, 3>(a, s);
 }
 
 int dense_nt(bool bf16, int epilogue, const DenseArgs& a0, hipStream_t s) {
@@ -474,7 +478,7 @@ int dense_nt(bool bf16, int epilogue, const DenseArgs& a0, hipStream_t s) {
     // the strip image (128 rows x KC) + the epilogue's staging must fit 160 KiB of LDS: halve the chunk while it does not
     // (fp32 with KC = 256: 128 KiB of image alone)
     auto lds_of = [&](int kc) {
-        const int tp = (a.N / 16) % 16 == 0 && (a.N / 16) % 12 != 0 ? 4 : 3;
+        const int tp = strip_tiles_per_pass(a.N / 16, a.K / kc);
         const int oesz = (epilogue == kEpiResid || epilogue == kEpiMul || !bf16 || a.out_f32) ? 4 : 2;
         return (size_t)3 * 128 * 8 + 128 * 4 + (size_t)128 * kc * (bf16 ? 2 : 4) + (size_t)2 * (epilogue == kEpiGelu ? 2 : 1) * 16 * (4 * tp * 16 * oesz + 16);
     };
@@ -858,8 +862,9 @@ int dense_tn(bool bf16, const DenseTnArgs& a0, hipStream_t s) {
         // narrow gradients against wide (overlapping-window) inputs = the convolutions' weight gradients: a tile as wide as
         // the im2col row, so that the 4-8x redundant window reads happen once (conv2: 64 x 512 outputs, 600 us with
         // 128 x 128 tiles of which half the rows were empty and the input was read four times)
-        if (const char* e = getenv("PF_TN_CFG")) {       // tuning runs only (scripts/time_tn_flow.py)
-            switch (atoi(e)) {
+        static const int forced_cfg = [] { const char* e = getenv("PF_TN_CFG"); return e ? atoi(e) : -1; }();   // tuning runs only
+        if (forced_cfg >= 0) {                           // (scripts/time_tn_flow.py; read once per process)
+            switch (forced_cfg) {
             case 0: return launch_tn_bf16<1, 4, 2, 1>(a, s);
             case 1: return launch_tn_bf16<2, 2, 2, 2>(a, s);
             case 2: return launch_tn_bf16<2, 2, 4, 4>(a, s);

@@ -532,7 +532,8 @@ static int stem_forward_t(const char* packed, const float* strain, int64_t n_seq
     // bf16: conv1 inside conv2's staging (2.56 -> 2.13 ms per 12 288 sequences, tokens bit-identical to the
     // 4-launch path; $PF_STEM_UNFUSED keeps that path testable).  fp32: the fused image + signal need 84 KB of LDS =
     // one workgroup per CU and measured slower (9.4 -> 10.4 ms), so the parity mode keeps four launches.
-    if (BF16 && !std::getenv("PF_STEM_UNFUSED")) {
+    static const bool unfused = std::getenv("PF_STEM_UNFUSED") != nullptr;       // (read once per process)
+    if (BF16 && !unfused) {
         set(1, strain, act1);
         p.wfrags0 = reinterpret_cast<const u32x4*>(packed + w_off[0]);
         p.bias0 = reinterpret_cast<const float*>(packed + b_off[0]);

@@ -115,7 +115,7 @@ struct Ws {
     // backward temporaries
     int64_t dxa, dxb, g192a[kEncLayers], g192b[kEncLayers], g768[kEncLayers], dqkv[kEncLayers], dkv, dy, gpad[4], g1, conv_dw, total;
 };
-struct Dims { int64_t B, N, R; int T, D, n_extra; bool bf16; int esz; };
+struct Dims { int64_t B, N, R; int T, D, n_extra; bool bf16; int esz; bool fwd_only; };
 constexpr int kGpadRows[4] = {0, 514, 128, 64};                // rows per sequence of the padded gradient images of conv2..4
 constexpr int kGpadOff[4] = {0, 3, 1, 1};                      // kw / s - 1 leading zero rows
 constexpr int kDxRows[4] = {0, 511, 127, 63};                  // ceil(lin / s): rows of the transposed-convolution GEMM
@@ -131,6 +131,9 @@ Ws ws_layout(const Dims& d) {
     w.stem_tok = take(d.N * kTok * kEncD * 4);
     for (int l = 0; l < kEncLayers; ++l) {
         auto& L = w.L[l];
+        // forward-only: the layers share one set of buffers.  Safe in the forward's order: a layer's input x is last read
+        // by the out-projection's residual epilogue (-> xmid), FFN2 then writes the next layer's input over it
+        if (d.fwd_only && l > 0) { L = w.L[0]; continue; }
         L.x = take(d.R * kEncD * 4); L.mean1 = take(d.R * 4); L.rstd1 = take(d.R * 4);
         L.y1 = take(d.R * kEncD * e); L.qkv = take(d.R * 3 * kEncD * e); L.lse = take(d.B * kEncHeads * d.T * 4);
         L.o = take(d.R * kEncD * e); L.xmid = take(d.R * kEncD * 4); L.mean2 = take(d.R * 4); L.rstd2 = take(d.R * 4);
@@ -139,6 +142,7 @@ Ws ws_layout(const Dims& d) {
     w.x3 = take(d.R * kEncD * 4);
     w.x3a = d.bf16 ? take(d.R * kEncD * e) : w.x3;
     w.kv = take(d.R * 2 * kEncD * e);
+    if (d.fwd_only) { w.total = o; return w; }             // none of the backward's temporaries
     w.dxa = take(d.R * kEncD * 4); w.dxb = take(d.R * kEncD * 4);
     for (int l = 0; l < kEncLayers; ++l) {       // per layer: the weight-gradient GEMMs read them on a second stream while
         w.g192a[l] = take(d.R * kEncD * e); w.g192b[l] = take(d.R * kEncD * e);      // the chain moves on to the layer below
@@ -163,6 +167,7 @@ int dims_of(const PfEmbedTrainDesc* desc, int64_t n_events, Dims& d) {
     if (d.T > kEncMaxTokens) return PF_ERR_UNSUPPORTED;
     d.N = d.B * d.D; d.R = d.B * d.T;
     d.bf16 = desc->precision == PF_PREC_BF16; d.esz = d.bf16 ? 2 : 4;
+    d.fwd_only = desc->forward_only != 0;
     return PF_OK;
 }
 
@@ -339,6 +344,7 @@ int enc_train_backward(const PfEmbedTrainDesc* desc, const void* packed, const f
                        float* grad_token_bias, float* grad_pool_q, hipStream_t s) {
     Dims d;
     PF_TRY(dims_of(desc, n_events, d));
+    if (d.fwd_only) return PF_ERR_BAD_ARG;                  // the forward kept one layer's activations only
     const RawLayout r = raw_layout();
     if (hipMemsetAsync(grad_raw, 0, (size_t)r.total * 4, s) != hipSuccess) return hip_failed(hipGetLastError());
     if (grad_pool_q && hipMemsetAsync(grad_pool_q, 0, kEncPoolQ * kEncD * 4, s) != hipSuccess) return hip_failed(hipGetLastError());
@@ -367,6 +373,11 @@ int enc_train_backward(const PfEmbedTrainDesc* desc, const void* packed, const f
         return tn(side);
     };
 
+    float* conv_tmp[4];
+    // Everything between the fork above and the join below runs as one unit whose every exit is followed by the join: a
+    // failure half-way must not return while side-stream kernels still read the workspace and write grad_raw (the caller
+    // would release both to an allocator that orders reuse on ITS stream only)
+    auto chain = [&]() -> int {
     // ---- pool ----------------------------------------------------------------------------------------------------------
     PoolArgs po{};
     po.kv = ws + w.kv; po.q = pool_q; po.B = d.B; po.T = d.T; po.dpooled = grad_pooled; po.dkv = ws + w.dkv;
@@ -428,7 +439,6 @@ int enc_train_backward(const PfEmbedTrainDesc* desc, const void* packed, const f
             return hip_failed(hipGetLastError());
     PF_TRY(tok_backward(d.bf16, dxa, ws + w.dact[3], d.B, d.n_extra, d.D, ws + w.gpad[3], (int64_t)kGpadRows[3] * kEncD,
                         (int64_t)kGpadOff[3] * kEncD, grad_extra, grad_token_bias, s));
-    float* conv_tmp[4];
     {
         float* t0 = reinterpret_cast<float*>(ws + w.conv_dw);
         int64_t off = 0;
@@ -467,7 +477,14 @@ int enc_train_backward(const PfEmbedTrainDesc* desc, const void* packed, const f
         a.mul = ws + w.dact[l - 1];
         PF_TRY(dense_nt(d.bf16, kEpiMul, a, s));
     }
-    if (side != s) PF_TRY(g_side.order(side, s));       // join: the caller's stream continues after the last weight gradient
+    return PF_OK;
+    };
+    int rc = chain();
+    if (side != s) {                                    // join: the caller's stream continues after the last weight gradient
+        const int jrc = g_side.order(side, s);
+        if (rc == PF_OK) rc = jrc;
+    }
+    if (rc != PF_OK) return rc;
     for (int l = 0; l < 4; ++l) {
         const Conv& c = kConv[l];
         hipLaunchKernelGGL(conv_dw_permute_kernel, dim3((unsigned)((c.cout * c.cin * c.kw + 1023) / 1024)), dim3(256), 0, s, conv_tmp[l],

@@ -32,6 +32,7 @@ struct CtxParams {
     int64_t rows;
     int C, CK, NT, tiles, tiles_per_wave;
     int additive;           // 1: block projections are plain affine terms (masked-context conditioner)
+    int rowmajor;           // 1: out = raw affine values, fp32 row-major [rows][16 tiles] (the incremental inverse's operand)
 };
 
 constexpr int kCtxRowGroups = 4;   // 64 context rows per workgroup
@@ -136,6 +137,15 @@ __global__ __launch_bounds__(256) void ctx_project_kernel(const CtxParams p) {
         }
         if (kc != n_chunks - 1) return;
         const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + (size_t)u * 16 + 4 * g);
+        if (p.rowmajor) {          // lane (g, column cc) holds units 16 u + 4 g .. + 3 of context row 16 rg + cc: one 16-byte store
+#pragma unroll
+            for (int rg = 0; rg < kCtxRowGroups; ++rg) {
+                const int64_t row = row0 + 16 * rg + (lane & 15);
+                if (row < p.rows)
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + row * ((int64_t)p.tiles * 16) + (size_t)u * 16 + 4 * g) = acc[rg] + b;
+            }
+            return;
+        }
         const bool is_first = ((u / p.NT) % 3) == 0;
         const bool is_gate = !is_first && !p.additive;
 #pragma unroll
@@ -172,6 +182,8 @@ int64_t ctx_project_bytes(const FlowPlan& L, int64_t ctx_rows) {
     return blocks * 64 * 3 * L.L * L.H * 4;
 }
 
+static int launch_ctx(const CtxParams& p_in, bool bf16, hipStream_t s);
+
 int launch_ctx_project(const FlowPlan& L, const char* packed, const float* ctx, int64_t ctx_rows,
                        void* out, hipStream_t s) {
     CtxParams p{};
@@ -179,14 +191,35 @@ int launch_ctx_project(const FlowPlan& L, const char* packed, const float* ctx, 
     p.bias = reinterpret_cast<const float*>(packed + L.ctx_bias_offset());
     p.ctx = ctx; p.out = out; p.rows = ctx_rows;
     p.C = L.C; p.CK = L.CK; p.NT = L.NT; p.tiles = 3 * L.L * L.NT; p.additive = L.additive;
+    return launch_ctx(p, L.bf16 != 0, s);
+}
+
+// out[r][n] = sum_c ctx[r][c] W[n][c] + bias[n], fp32 row-major: the same kernel over any matrix packed as plain MFMA
+// A-fragments [n_units / 16 tiles][k-steps][64 lanes] (pf_dense_pack_matrix) -- the per-context-row projections the
+// incremental inverse reads (pf_flow_inverse_inc: [ctx_rows][L][3][H] raw affine values)
+int ctx_project_rows(bool bf16, const void* wfrags, const float* bias, const float* ctx, int64_t rows, int C, int n_units,
+                     float* out, hipStream_t s) {
+    if (rows == 0) return PF_OK;
+    const int kw = bf16 ? 32 : 16;
+    CtxParams p{};
+    p.frags = reinterpret_cast<const u32x4*>(wfrags);
+    p.bias = bias; p.ctx = ctx; p.out = out; p.rows = rows;
+    p.C = C; p.CK = (C + kw - 1) / kw; p.NT = 1; p.tiles = n_units / 16; p.additive = 1; p.rowmajor = 1;
+    if ((size_t)p.CK * kCtxRowGroups * kFragBytes > 160 * 1024) return PF_ERR_UNSUPPORTED;
+    return launch_ctx(p, bf16, s);
+}
+
+static int launch_ctx(const CtxParams& p_in, bool bf16, hipStream_t s) {
+    CtxParams p = p_in;
+    const int64_t ctx_rows = p.rows;
     const unsigned row_blocks = (unsigned)((ctx_rows + 63) / 64);
     // enough workgroups to fill the chip when there are few row blocks
     int tpw = 12;
     while (tpw > 2 && (int64_t)row_blocks * ((p.tiles + 4 * tpw - 1) / (4 * tpw)) < 1024) tpw >>= 1;
     p.tiles_per_wave = tpw;
     const unsigned chunks = (unsigned)((p.tiles + 4 * tpw - 1) / (4 * tpw));
-    const size_t lds = (size_t)L.CK * kCtxRowGroups * kFragBytes;
-    if (L.bf16) {
+    const size_t lds = (size_t)p.CK * kCtxRowGroups * kFragBytes;
+    if (bf16) {
         auto k = ctx_project_kernel<true>;
         if (lds > 64 * 1024 && !opt_in_lds(reinterpret_cast<const void*>(k), (int)lds)) return PF_ERR_HIP;
         hipLaunchKernelGGL(k, dim3(row_blocks, chunks), dim3(256), lds, s, p);

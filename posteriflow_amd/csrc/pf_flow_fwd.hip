@@ -80,7 +80,8 @@ int launch_flow_forward(const FwdParams& p_in, hipStream_t s) {
         return PF_ERR_UNSUPPORTED;
     }
     FwdParams p = p_in;
-    if (const char* a = getenv("PF_ABLATE")) p.ablate = atoi(a);   // only honoured by -DPF_ABLATE_BUILD builds
+    static const int ablate = [] { const char* a = getenv("PF_ABLATE"); return a ? atoi(a) : 0; }();   // (read once per process;
+    if (ablate) p.ablate = ablate;                                                                  // -DPF_ABLATE_BUILD builds only)
     const int R = rows_per_workgroup(p.plan, p.batch) / 16;
 #define PF_CASE(P, N) case N: return p.drop_thresh ? launch_flow_train_p##P##_nt##N(p, R, s) : launch_flow_forward_p##P##_nt##N(p, R, s);
     if (p.plan.bf16) {

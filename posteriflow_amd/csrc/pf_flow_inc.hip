@@ -553,9 +553,8 @@ int flow_inverse_inc(const PfFlowDesc& d, float deriv_const, const int32_t* u1, 
     for (int i = 1; i < p.D; ++i) max_tiles = std::max(max_tiles, (u1[i] + 15) / 16 - u1[i - 1] / 16);
     if (max_tiles > 8) return PF_ERR_UNSUPPORTED;
     int threads = max_tiles <= 4 ? 256 : 512;
-    if (const char* ft = std::getenv("PF_INC_THREADS")) {
-        if (std::atoi(ft) == 512) threads = 512;
-    }
+    static const bool force512 = [] { const char* ft = std::getenv("PF_INC_THREADS"); return ft && std::atoi(ft) == 512; }();
+    if (force512) threads = 512;                     // (tuning knob, read once per process)
     const size_t lds = 5 * 16 * (size_t)(f32 ? kActStrideF32 : kActStride) + 16 * 64 + 16 * (16 + 16 + kParS + 2) * 4;
     using Kern = void (*)(const IncParams);
     static const Kern kerns[8] = {

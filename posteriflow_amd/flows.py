@@ -324,6 +324,31 @@ class NSFPosteriorFlow(nn.Module):
             off += n
         self.__dict__.pop("_ordered_cache", None)
 
+    _DEVICE_CACHES = ("_raw_cache", "_ordered_cache", "_raw_mask_cache", "_ctxT", "_plan_cache", "_inc", "_packed", "_workspace",
+                      "_perm_i32")
+
+    def __deepcopy__(self, memo):
+        """``copy.deepcopy`` (EMA copies, snapshots).  In flat mode the sub-modules hold non-leaf VIEWS of ``_theta`` in their
+        ``__dict__`` and torch refuses to deep-copy tensors with a grad_fn: the views are dropped for the copy and rebuilt on
+        both sides.  Packed weights, workspaces and the other device-side caches are not copied (the copy packs its own)."""
+        import copy
+        flat = self._theta is not None
+        for mod, name in (self._param_slots() if flat else []):
+            mod.__dict__.pop(name, None)
+        try:
+            new = self.__class__.__new__(self.__class__)
+            memo[id(self)] = new
+            for k, v in self.__dict__.items():
+                if k not in self._DEVICE_CACHES:
+                    new.__dict__[k] = copy.deepcopy(v, memo)
+        finally:
+            if flat:
+                self._refresh_views()
+        new.__dict__.update(_packed={}, _workspace=None, _perm_i32=None, _frozen=False)
+        if flat:
+            new._refresh_views()
+        return new
+
     def _slot_names(self):
         """nflows state_dict names of the transform parameters (relative to this module), raw-layout order"""
         names = []
@@ -777,7 +802,7 @@ class NSFPosteriorFlow(nn.Module):
         return z, logdet, nll
 
     def _nll(self, x, context, log_sigma):
-        """nll[B]; differentiable (interim tensor-op backward, _flow_autograd.py) when grad is needed."""
+        """nll[B]; differentiable: the HIP backward of _flow_autograd.py (re-evaluation, chain, transposed GEMMs)."""
         if self._needs_grad(x, context, log_sigma):
             from ._flow_autograd import FlowNLL
             dev, x, context = self._check_inputs(x, context, "NSFPosteriorFlow.compute_psd_aware_nll")
@@ -925,10 +950,20 @@ class NSFPosteriorFlow(nn.Module):
                 if self.context_features > 0:
                     wc.append(torch.stack([net.context_layer.weight[perm]] + [b.context_layer.weight[perm] for b in net.blocks]))
                     bc.append(torch.stack([net.context_layer.bias[perm]] + [b.context_layer.bias[perm] for b in net.blocks]))
-            st.update(key=key, buf=buf, u1=u1,
-                      wcat=((lambda w: w if f32 else w.to(torch.bfloat16).float())(
-                          torch.stack(wc).reshape(-1, self.context_features).float()).contiguous() if wc else None),
-                      bcat=torch.stack(bc).reshape(-1).float().contiguous() if bc else None)
+            wfrags = bcat = None
+            if wc:       # every layer's three context matrices as ONE packed GEMM operand [L * 3 * H][C] (sorted-unit rows)
+                prec = _lib.PRECISIONS[self.precision]
+                C_ = self.context_features
+                kpad = -(-C_ // (16 if f32 else 32)) * (16 if f32 else 32)
+                wcat = torch.zeros(len(wc) * 3 * H, kpad, dtype=torch.float32, device=dev)
+                wcat[:, :C_] = torch.stack(wc).reshape(-1, C_).float()
+                nbytes = _lib.lib().pf_dense_frag_bytes(prec, wcat.shape[0], kpad)
+                wfrags = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                _lib.check(_lib.lib().pf_dense_pack_matrix(prec, wcat.data_ptr(), 0, kpad, wcat.shape[0], kpad, wfrags.data_ptr(),
+                                                           torch.cuda.current_stream(dev).cuda_stream), "pf_dense_pack_matrix")
+                bcat = torch.stack(bc).reshape(-1).float().contiguous()
+                st["_wcat_keep"] = wcat          # (the pack kernel is asynchronous)
+            st.update(key=key, buf=buf, u1=u1, wfrags=wfrags, bcat=bcat)
         return st
 
     def _inverse_call(self, z, context, ctx_rows):
@@ -942,13 +977,16 @@ class NSFPosteriorFlow(nn.Module):
         if self._use_incremental():
             st = self._inc_state(dev)
             proj = None
-            if st["wcat"] is not None:
-                with torch.no_grad():
-                    # [ctx_rows, L * 3 * H]: one GEMM for every layer's three context projections, with the operand
-                    # rounding of the bf16 forward kernel (context and weights to bf16, fp32 accumulation) so that
-                    # forward(inverse(z)) sees the same conditioner
-                    cx = context.float() if self.precision != "bf16" else context.to(torch.bfloat16).float()
-                    proj = torch.addmm(st["bcat"], cx, st["wcat"].t()).contiguous()
+            if st["wfrags"] is not None:
+                # [ctx_rows, L * 3 * H]: one GEMM for every layer's three context projections (pf_flow_ctx_project_rows: the
+                # hoisted-projection kernel with a row-major epilogue), with the operand rounding of the bf16 forward kernel
+                # (context and weights to bf16, fp32 accumulation) so that forward(inverse(z)) sees the same conditioner
+                cx = context.float().contiguous()
+                proj = torch.empty(cx.shape[0], st["bcat"].numel(), dtype=torch.float32, device=dev)
+                _lib.check(_lib.lib().pf_flow_ctx_project_rows(
+                    _lib.PRECISIONS[self.precision], st["wfrags"].data_ptr(), st["bcat"].data_ptr(), cx.data_ptr(), cx.shape[0],
+                    self.context_features, st["bcat"].numel(), proj.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
+                    "pf_flow_ctx_project_rows")
             rc = _lib.lib().pf_flow_inverse_inc(
                 self._desc(self.precision, inverse=True), st["u1"], st["buf"].data_ptr(), _dev_ptr(proj), ctx_rows,
                 z.data_ptr(), _dev_ptr(inv_perm), B, x.data_ptr(), logdet.data_ptr(), flags.data_ptr(),

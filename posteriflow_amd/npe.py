@@ -180,15 +180,37 @@ class LeanStrainEncoder(nn.Module):
             k = math.prod(shp)
             m.__dict__[n] = self._theta[off:off + k].view(shp)
             off += k
-        self.__dict__.pop("_train_state", None)
-        self.__dict__.pop("_mixer_state", None)
-        self.__dict__.pop("_stem_state", None)
+        for k in ("_train_state", "_mixer_state", "_stem_state", "_dense_state"):
+            self.__dict__.pop(k, None)
 
     def _apply(self, fn, *args, **kwargs):
         out = super()._apply(fn, *args, **kwargs)
         if self._theta is not None:
             self._refresh_flat_views()
         return out
+
+    _DEVICE_CACHES = ("_train_state", "_mixer_state", "_stem_state", "_dense_state", "_geom_twiddle")
+
+    def __deepcopy__(self, memo):
+        """``copy.deepcopy`` (EMA copies, snapshots): in flat mode the sub-modules' weight views of ``_theta`` (non-leaf
+        tensors, which torch refuses to deep-copy) are dropped for the copy and rebuilt on both sides; packed fragments and
+        the other device-side caches are not copied"""
+        import copy
+        flat = self._theta is not None
+        for m, n, _ in (self._flat_slots() if flat else []):
+            m.__dict__.pop(n, None)
+        try:
+            new = self.__class__.__new__(self.__class__)
+            memo[id(self)] = new
+            for k, v in self.__dict__.items():
+                if k not in self._DEVICE_CACHES:
+                    new.__dict__[k] = copy.deepcopy(v, memo)
+        finally:
+            if flat:
+                self._refresh_flat_views()
+        if flat:
+            new._refresh_flat_views()
+        return new
 
     def _save_to_state_dict(self, destination, prefix, keep_vars):
         super()._save_to_state_dict(destination, prefix, keep_vars)
@@ -294,6 +316,37 @@ class LeanStrainEncoder(nn.Module):
                 and a.linear1.out_features == 768 and self.pool_queries.shape == (8, 192)
                 and self.pool_attn.num_heads == 6 and self.fusion.norm is None)
 
+    # --- [B, .]-sized dense layers on the hand-written GEMMs (``_dense``: pf_dense_nt / pf_dense_tn, fp32 operands) ---------
+    def _dstate(self) -> dict:
+        return self.__dict__.setdefault("_dense_state", {})
+
+    def _seq(self, name: str, x):
+        """``getattr(self, name)(x)`` for an nn.Sequential / nn.Linear member, its Linears on the HIP GEMMs (host tensors,
+        which only the CPU wiring tests feed, go through the module itself)"""
+        mod = getattr(self, name)
+        if x.device.type != "cuda":
+            return mod(x)
+        from . import _dense
+        if isinstance(mod, nn.Linear):
+            return _dense.linear(x.float(), mod.weight, mod.bias, self._dstate(), name)
+        return _dense.sequential(mod, x.float(), self._dstate(), name)
+
+    def _pool_out(self, pooled):
+        m = self.pool_attn.out_proj
+        if pooled.device.type != "cuda":
+            return m(pooled)
+        from . import _dense
+        return _dense.linear(pooled.float(), m.weight, m.bias, self._dstate(), "pool_attn.out_proj")
+
+    def _pool_queries_projected(self):
+        """the 8 learned queries through the pool's query projection, scaled by 1 / sqrt(head dim) (LN:228-233: what
+        nn.MultiheadAttention does with ``query = pool_queries``)"""
+        from . import _dense
+        e = self.pool_queries.shape[1]
+        w, bias = self.pool_attn.in_proj_weight, self.pool_attn.in_proj_bias
+        q = _dense.linear(self.pool_queries.float(), w[:e], bias[:e], self._dstate(), "pool_attn.q")
+        return q * (1.0 / math.sqrt(e // self.pool_attn.num_heads))
+
     def _mix_hip(self, tok, token_bias=None):
         """[B, 8 * 192] pooled features from tokens [B, T, 192] (T <= 192): one pf_embed_fusion_forward call
         (token_bias add + 3 Transformer layers + pool attention) and the pool's out-projection.  ``tok`` is
@@ -314,15 +367,14 @@ class LeanStrainEncoder(nn.Module):
             st["key"] = key
         b, t, _ = tok.shape
         assert tok.dtype == torch.float32 and tok.is_contiguous()
-        w, bias = self.pool_attn.in_proj_weight, self.pool_attn.in_proj_bias
         with torch.autocast("cuda", enabled=False):
-            q = ((self.pool_queries.float() @ w[:e].float().t() + bias[:e].float()) * (1.0 / math.sqrt(32.0))).contiguous()
+            q = self._pool_queries_projected().contiguous()
         pooled = torch.empty(b, 8, e, dtype=torch.float32, device=dev)
         tb = None if token_bias is None else token_bias.float().contiguous()
         _lib.check(L.pf_embed_fusion_forward(st["packed"].data_ptr(), tok.data_ptr(), t, 0 if tb is None else tb.data_ptr(),
                                              q.data_ptr(), b, pooled.data_ptr(),
                                              torch.cuda.current_stream(dev).cuda_stream), "pf_embed_fusion_forward")
-        return self.pool_attn.out_proj(pooled).reshape(b, -1)
+        return self._pool_out(pooled).reshape(b, -1)
 
     def _compute_feats(self, strain, asd_bands=None, extra_tokens=None):
         """[B, 8*d_model + 64 (+32)] pre-projection features and the sanitised strain (LN:199-243).
@@ -359,7 +411,7 @@ class LeanStrainEncoder(nn.Module):
                 tok_bias = torch.cat([tok_bias.new_zeros(n_extra, e), tok_bias], dim=0)
             pooled, log_energy = _enc_train.encode_tokens(self, strain, None if extra_tokens is None else extra_tokens.float(),
                                                             tok_bias, training=self.training)
-            pooled = self.pool_attn.out_proj(pooled)
+            pooled = self._pool_out(pooled)
         else:
             tok, log_energy = self._stem_hip(strain)       # sanitises in-kernel
             n_tok, e = tok.shape[1], tok.shape[2]
@@ -370,12 +422,12 @@ class LeanStrainEncoder(nn.Module):
                 tok = torch.cat([extra_tokens.float(), tok], dim=1)
                 tok_bias = torch.cat([tok_bias.new_zeros(n_extra, e), tok_bias.float()], dim=0)
             pooled = self._mix_hip(tok.contiguous(), tok_bias)
-        energy = self.energy_mlp(log_energy.reshape(b, -1))
+        energy = self._seq("energy_mlp", log_energy.reshape(b, -1))
         parts = [pooled.reshape(b, -1), energy]
         if self.psd_bands > 0:
             if asd_bands is None:
                 asd_bands = strain.new_zeros(b, self.n_detectors, self.psd_bands)
-            parts.append(self.noise_mlp(asd_bands.reshape(b, -1)))
+            parts.append(self._seq("noise_mlp", asd_bands.reshape(b, -1)))
         return torch.cat(parts, dim=1), clean
 
     def _compute_feats_tensor_ops(self, strain, asd_bands=None, extra_tokens=None):
@@ -418,7 +470,7 @@ class LeanStrainEncoder(nn.Module):
             return self._empty(strain)
         with self._autocast(strain.device):
             feats, _ = self._compute_feats(strain, asd_bands)
-            return self.out_proj(feats).float()
+            return self._seq("out_proj", feats).float()
 
 
 _SR, _T_LEN, _F_LO, _F_HI = 4096, 16384, 20.0, 1024.0
@@ -532,10 +584,10 @@ class CoherentEncoder(LeanStrainEncoder):
             clean = self._sanitize(strain)
             rel = self._geometry_rel(clean)                  # FFT features stay fp32
         with self._autocast(strain.device):
-            g = self.geom_mlp(rel)
-            gtok = self.geom_to_tokens(g).reshape(-1, self.n_geom_tokens, self.d_model)
+            g = self._seq("geom_mlp", rel)
+            gtok = self._seq("geom_to_tokens", g).reshape(-1, self.n_geom_tokens, self.d_model)
             feats, _ = self._compute_feats(clean, asd_bands, extra_tokens=gtok)
-            return self.out_proj(feats).float()
+            return self._seq("out_proj", feats).float()
 
 
 class LeanNPE(nn.Module):
@@ -584,9 +636,9 @@ class LeanNPE(nn.Module):
     def _full_context(self, context: torch.Tensor, rank: torch.Tensor) -> torch.Tensor:
         w = self.rank_embed.weight
         if w.requires_grad and torch.is_grad_enabled():
-            # the same rows as rank_embed(rank), as a one-hot product: its backward is one small GEMM instead of the
-            # embedding's sort-and-segment-reduce (about 20 launches for 5 x 32 numbers)
-            emb = F.one_hot(rank, w.shape[0]).to(w.dtype) @ w
+            # the same rows as rank_embed(rank), as a row gather: its backward is one index_add (float atomics into 5 x 32
+            # numbers) instead of the embedding's sort-and-segment-reduce (about 20 launches)
+            emb = torch.index_select(w, 0, rank)
         else:
             emb = self.rank_embed(rank)
         return torch.cat([context, emb], dim=1)

@@ -514,3 +514,27 @@ def test_generic_layout_with_the_explicit_flag_stays_in_nflows_unit_order(lib):
     # same multiset of source weights either way
     a, b = maps[0], maps[lib.PF_FLAG_GENERIC]
     assert sorted(a[a >= 0].tolist()) == sorted(b[b >= 0].tolist())
+
+
+def test_embedding_forward_only_workspace_and_argument_checks(lib):
+    """a no-grad call of the training-path embedding asks for the forward-only workspace (one layer's activations,
+    no backward temporaries); the backward refuses such a desc.  Host arithmetic only: nothing is launched."""
+    h = lib.lib()
+    sizes = {}
+    for prec in (lib.PF_PREC_F32, lib.PF_PREC_BF16):
+        for fwd_only in (0, 1):
+            d = lib.PfEmbedTrainDesc(prec, 3, 0, 0, 0.05, fwd_only, 0)
+            sizes[prec, fwd_only] = h.pf_embed_train_workspace_bytes(C.byref(d), 1024)
+            assert sizes[prec, fwd_only] > 0
+    # fp32, 1024 three-detector events: ~16 GB with the backward's buffers, < 6 GB without
+    assert sizes[lib.PF_PREC_F32, 1] < 0.4 * sizes[lib.PF_PREC_F32, 0]
+    assert sizes[lib.PF_PREC_F32, 1] < 6 * 2 ** 30 < sizes[lib.PF_PREC_F32, 0]
+    assert sizes[lib.PF_PREC_BF16, 1] < 0.45 * sizes[lib.PF_PREC_BF16, 0]
+    # the backward of a forward-only desc is a caller error (non-null dummies: validation runs before any launch)
+    import numpy as np
+    buf = np.zeros(4096, np.float32)
+    ptr = buf.ctypes.data_as(C.c_void_p).value
+    ptr = (ptr + 255) // 256 * 256
+    d = lib.PfEmbedTrainDesc(lib.PF_PREC_F32, 3, 0, 0, 0.05, 1, 0)
+    rc = h.pf_embed_train_backward(C.byref(d), ptr, ptr, ptr, ptr, 0, ptr, 1 << 40, ptr, None, None, None, None)
+    assert rc == lib.PF_ERR_BAD_ARG

@@ -55,6 +55,30 @@ def test_coherent_encoder_golden_cpu(golden_encoder):
     np.testing.assert_allclose(ctx.numpy(), golden_encoder["coh_ctx"], rtol=1e-4, atol=2e-5)
 
 
+def test_deepcopy_of_flattened_modules():
+    """copy.deepcopy (EMA copies, snapshots) of a model whose parameters were flattened -- the sub-modules hold
+    non-leaf views of the flat leaf, which torch refuses to deep-copy"""
+    import copy
+    from posteriflow_amd import LeanNPE, NSFPosteriorFlow
+    flow = NSFPosteriorFlow(11, 288, 64, 2, 8, 5.0, use_masked_context=False).flatten_parameters()
+    twin = copy.deepcopy(flow)
+    assert twin._theta is not flow._theta and torch.equal(twin._theta, flow._theta)
+    net = twin._ar_transforms[0].autoregressive_net
+    assert net.initial_layer.weight.data_ptr() == twin._theta.data_ptr()            # the copy's views are views of ITS leaf
+    with torch.no_grad():
+        twin._theta.add_(1.0)
+    assert not torch.equal(twin._theta, flow._theta)
+    assert set(twin.state_dict()) == set(flow.state_dict())
+    model = LeanNPE(flow_layers=2, flow_hidden=64).flatten_parameters()
+    ema = copy.deepcopy(model)
+    assert ema.encoder._theta is not model.encoder._theta
+    assert ema.encoder.stem[0].weight.data_ptr() == ema.encoder._theta.data_ptr()
+    assert model.encoder.stem[0].weight.data_ptr() == model.encoder._theta.data_ptr()   # the original keeps its views
+    a, b = model.state_dict(), ema.state_dict()
+    assert a.keys() == b.keys() and all(torch.equal(a[k], b[k]) for k in a)
+    copy.deepcopy(LeanNPE(flow_layers=2, flow_hidden=64))                              # not flattened: unchanged behaviour
+
+
 def test_state_dict_layout_matches_reference_names():
     m = npe.LeanNPE(flow_layers=2)
     keys = set(m.state_dict())
