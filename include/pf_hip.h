@@ -420,8 +420,8 @@ typedef struct PfDenseArgs {
     int64_t rows_per_seq;     /* = M for a plain matrix */
     int64_t a_seq_stride;
     int32_t lda;
-    int32_t K, N, KC;         /* reduction length, output units (multiple of 16), k-chunk staged in LDS (divides K, multiple of 64;
-                               * K / KC > 1 needs N <= 256) */
+    int32_t K, N, KC;         /* reduction length, output units (multiple of 16), k-chunk staged in LDS (divides K, multiple of 64,
+                               * <= 256 after the library's own halving for LDS; K / KC > 1 needs N <= 256) */
     const void* wfrags;       /* W as MFMA A-fragments: pf_dense_pack_matrix */
     const float* bias;        /* [N] or NULL */
     void* out;                /* row m at out + seq * o_seq_stride + pos * ldo */
@@ -442,6 +442,11 @@ typedef struct PfDenseArgs {
     int32_t k_splits;         /* > 1 (PF_EPI_PLAIN, out_f32, K / KC chunks): the chunks are divided over k_splits workgroups per
                                * strip which ADD their partial sums into out with float atomics -- out must hold zeros (or the
                                * value to accumulate onto); for few-row, long-reduction products that would leave CUs idle */
+    int32_t n_group;          /* PF_EPI_PLAIN without dropout / o_valid_per_seq: the N output units are divided into groups of
+                               * n_group (a multiple of 16; <= 256 when K / KC > 1) handled by separate workgroups of ONE launch,
+                               * which lifts the N <= 256 limit of a chunked reduction and fills the chip when there are few
+                               * rows -- deterministic (no atomics), at the price of staging the rows once per group.
+                               * 0: chosen by the library (no grouping when the strips alone fill the chip) */
 } PfDenseArgs;
 typedef struct PfDenseTnArgs {  /* dW[n1][n2] += sum_m G[m][n1] A[m][n2],  db[n1] += sum_m G[m][n1]  (float atomics) */
     const void* G; int64_t g_seq_stride; int32_t ldg;

@@ -10,11 +10,11 @@ context projections of the incremental inverse run through the same two kernels 
   update;
 * weight / bias gradient: ``pf_dense_tn`` (``dW += G^T x``, ``db += sum G``, float atomics into zeroed fp32 buffers).
 
-Shapes the kernels do not take directly are zero-padded here: the reduction length to a multiple of 64 (the k-chunk staged in
-LDS), the output width to a multiple of 64 (it is the reduction length of the data gradient); a reduction that needs several
-chunks is limited to 256 output units per launch, so wider outputs go out in column groups.  Few rows with a long reduction
-(``out_proj``: 1600 -> 512 at 1024 rows = 8 strips) are split over workgroups (``k_splits``: partial sums added into an
-output that already holds the bias).
+Shapes the kernels do not take directly are zero-padded here: the reduction length to a multiple of 64 that splits into few
+k-chunks (the chunk staged in LDS), the output width likewise (it is the reduction length of the data gradient).  One launch
+per GEMM: the strip kernel divides wide outputs and few-row problems into column groups over its grid (``n_group``, chosen by
+the library), so the forward is deterministic -- no split reduction, no atomics (``out_proj``: 1600 -> 512 at 1024 rows = 8
+strips x 8 column groups).
 
 Activations (GELU) stay elementwise tensor ops between the linears.  Everything here is device work; the module raises off
 the GPU."""
@@ -27,8 +27,8 @@ import torch
 
 from . import _lib
 
-_KC_MAX = {_lib.PF_PREC_F32: 192, _lib.PF_PREC_BF16: 384}      # k-chunk (128 rows x KC operands in LDS, + staging, <= 160 KB)
-_NG = 256                                                       # output units per launch of a chunked reduction
+_KC_MAX = {_lib.PF_PREC_F32: 192, _lib.PF_PREC_BF16: 256}      # k-chunk: the strip kernel stages <= 256 operands per row, and
+#                                                                 128 rows x KC fp32 + the epilogue's staging must fit 160 KB
 
 
 def _ceil(v: int, m: int) -> int:
@@ -48,6 +48,17 @@ def _kc(kp: int, prec: int) -> int:
     return best
 
 
+def _padded(k: int, prec: int) -> int:
+    """reduction length the operands are zero-padded to: a multiple of 64 that splits into few k-chunks (a chunk costs a
+    staging pass and two barriers, a padded column a wasted multiply: 1600 -> 1728 = 9 x 192 rather than 25 x 64)"""
+    best, best_cost = None, None
+    for kp in range(_ceil(k, 64), _ceil(k, 64) + 256, 64):
+        cost = kp + 32 * (kp // _kc(kp, prec))
+        if best is None or cost < best_cost:
+            best, best_cost = kp, cost
+    return best
+
+
 def _pad_cols(t: torch.Tensor, width: int, dtype) -> torch.Tensor:
     """[M, width] contiguous copy of t [M, k <= width] in ``dtype``, zero-filled on the right (no copy when nothing changes)"""
     if t.shape[1] == width and t.dtype == dtype and t.is_contiguous():
@@ -60,13 +71,13 @@ def _pad_cols(t: torch.Tensor, width: int, dtype) -> torch.Tensor:
 
 
 class _Packed:
-    """MFMA fragments of one weight matrix [N, K] (zero-padded to [Np, Kp]): forward groups of <= 256 output units and the
+    """MFMA fragments of one weight matrix [N, K] (zero-padded to [Np, Kp]): the plain form for the forward and the
     transposed form for the data gradient, rebuilt when the weight changes."""
 
-    def __init__(self, weight: torch.Tensor, prec: int, want_transposed: bool):
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], prec: int, want_transposed: bool):
         L, dev = _lib.lib(), weight.device
         n, k = weight.shape
-        self.n, self.k, self.np_, self.kp = n, k, _ceil(n, 64), _ceil(k, 64)
+        self.n, self.k, self.np_, self.kp = n, k, _padded(n, prec), _padded(k, prec)
         self.prec = prec
         wp = torch.zeros(self.np_, self.kp, dtype=torch.float32, device=dev)
         wp[:n, :k] = weight.detach().float()
@@ -82,59 +93,36 @@ class _Packed:
             _lib.check(L.pf_dense_pack_matrix(prec, src.data_ptr(), mode, ld, N, K, out.data_ptr(), s), "pf_dense_pack_matrix")
             return out
 
-        # forward: out[:, g0:g0+ng] = x_p W_p[g0:g0+ng]^T -- one group when the reduction is a single chunk
-        gw = self.np_ if self.kp == self.kc_f else _NG
-        self.fwd = [(g0, min(gw, self.np_ - g0), pack(wp[g0:], 0, self.kp, min(gw, self.np_ - g0), self.kp))
-                    for g0 in range(0, self.np_, gw)]
-        # data gradient: dX[:, g0:g0+ng] = G_p (W_p[:, g0:g0+ng]): the packed matrix is W_p^T restricted to those columns
-        self.bwd = None
-        if want_transposed:
-            gw = self.kp if self.np_ == self.kc_t else _NG
-            self.bwd = [(g0, min(gw, self.kp - g0), pack(wp[:, g0:], 1, self.kp, min(gw, self.kp - g0), self.np_))
-                        for g0 in range(0, self.kp, gw)]
+        self.fwd = pack(wp, 0, self.kp, self.np_, self.kp)                       # W_p   [Np][Kp]: forward
+        self.bwd = pack(wp, 1, self.kp, self.kp, self.np_) if want_transposed else None   # W_p^T [Kp][Np]: dX = G W
         self._keep = wp     # (pack kernels are asynchronous: the padded copy must outlive them; it is small)
+        self.bias = None
+        if bias is not None:
+            self.bias = torch.zeros(self.np_, dtype=torch.float32, device=dev)
+            self.bias[:n] = bias.detach().float()
 
 
-def _packed(state: Dict, name: str, weight: torch.Tensor, prec: int, want_transposed: bool) -> _Packed:
-    key = (_lib.param_epoch(), weight.device, prec, weight._version, weight.data_ptr(), tuple(weight.shape))
+def _packed(state: Dict, name: str, weight: torch.Tensor, bias: Optional[torch.Tensor], prec: int,
+            want_transposed: bool) -> _Packed:
+    key = (_lib.param_epoch(), weight.device, prec, weight._version, weight.data_ptr(), tuple(weight.shape),
+           None if bias is None else (bias._version, bias.data_ptr()))
     ent = state.get(name)
     if ent is None or ent[0] != key or (want_transposed and ent[1].bwd is None):
-        ent = (key, _Packed(weight, prec, want_transposed))
+        ent = (key, _Packed(weight, bias, prec, want_transposed))
         state[name] = ent
     return ent[1]
 
 
-def _nt(prec: int, a_t: torch.Tensor, K: int, kc: int, frags: torch.Tensor, N: int, bias_ptr: int, out: torch.Tensor,
-        col0: int, k_splits: int) -> None:
-    """out[:, col0:col0+N] (fp32, row stride out.shape[1]) (+)= a_t[:, :K] . W^T (+ bias)"""
-    a = _lib.PfDenseArgs()
-    M = a_t.shape[0]
-    a.A, a.M, a.rows_per_seq, a.a_seq_stride, a.lda = a_t.data_ptr(), M, max(M, 1), 0, a_t.shape[1]
-    a.K, a.N, a.KC = K, N, kc
-    a.wfrags, a.bias = frags.data_ptr(), bias_ptr
-    a.out, a.o_seq_stride, a.ldo = out.data_ptr() + 4 * col0, 0, out.shape[1]
-    a.out_f32, a.k_splits = 1, k_splits
-    _lib.check(_lib.lib().pf_dense_nt(prec, _lib.PF_EPI_PLAIN, C.byref(a), _stream(a_t.device)), "pf_dense_nt")
-
-
-def _splits(m: int, n_groups: int, nchunks: int) -> int:
-    """workgroups along the reduction: enough to reach ~one round of the chip when the strips alone do not"""
-    strips = -(-m // 128) * n_groups
-    if nchunks <= 1 or strips >= 128:
-        return 1
-    return max(1, min(nchunks, 256 // strips))
-
-
-def _gemm(prec: int, a_t: torch.Tensor, groups, K: int, kc: int, n_out: int, bias: Optional[torch.Tensor]) -> torch.Tensor:
-    """[M, n_out] fp32 = a_t . W^T (+ bias) over the packed column groups"""
+def _gemm(prec: int, a_t: torch.Tensor, frags: torch.Tensor, K: int, kc: int, n_out: int, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """[M, n_out] fp32 = a_t[:, :K] . W^T (+ bias): one pf_dense_nt launch"""
     M, dev = a_t.shape[0], a_t.device
-    ks = _splits(M, len(groups), K // kc)
-    if ks > 1:          # partial sums are ADDED into the output: it starts as the bias (or zero)
-        out = torch.zeros(M, n_out, dtype=torch.float32, device=dev) if bias is None else bias.expand(M, n_out).contiguous()
-    else:
-        out = torch.empty(M, n_out, dtype=torch.float32, device=dev)
-    for g0, ng, frags in groups:
-        _nt(prec, a_t, K, kc, frags, ng, 0 if (bias is None or ks > 1) else bias.data_ptr() + 4 * g0, out, g0, ks)
+    out = torch.empty(M, n_out, dtype=torch.float32, device=dev)
+    a = _lib.PfDenseArgs()
+    a.A, a.M, a.rows_per_seq, a.a_seq_stride, a.lda = a_t.data_ptr(), M, max(M, 1), 0, a_t.shape[1]
+    a.K, a.N, a.KC = K, n_out, kc
+    a.wfrags, a.bias = frags.data_ptr(), 0 if bias is None else bias.data_ptr()
+    a.out, a.o_seq_stride, a.ldo, a.out_f32 = out.data_ptr(), 0, n_out, 1
+    _lib.check(_lib.lib().pf_dense_nt(prec, _lib.PF_EPI_PLAIN, C.byref(a), _stream(dev)), "pf_dense_nt")
     return out
 
 
@@ -142,14 +130,10 @@ class _LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, state, name, prec):
         need_bwd = any(ctx.needs_input_grad[:3])
-        pk = _packed(state, name, weight, prec, need_bwd)
+        pk = _packed(state, name, weight, bias, prec, need_bwd)
         adt = torch.bfloat16 if prec == _lib.PF_PREC_BF16 else torch.float32
         xp = _pad_cols(x.detach(), pk.kp, adt)
-        bp = None
-        if bias is not None:
-            bp = torch.zeros(pk.np_, dtype=torch.float32, device=x.device)
-            bp[: pk.n] = bias.detach().float()
-        out = _gemm(prec, xp, pk.fwd, pk.kp, pk.kc_f, pk.np_, bp)
+        out = _gemm(prec, xp, pk.fwd, pk.kp, pk.kc_f, pk.np_, pk.bias)
         ctx.pk, ctx.has_bias, ctx.adt, ctx.prec = pk, bias is not None, adt, prec
         ctx.save_for_backward(xp)
         return out[:, : pk.n] if pk.n != pk.np_ else out

@@ -51,7 +51,7 @@ class PfDenseArgs(C.Structure):
                 ("out", C.c_void_p), ("o_seq_stride", C.c_int64), ("ldo", C.c_int32), ("o_valid_per_seq", C.c_int64),
                 ("x_seq_stride", C.c_int64), ("dact", C.c_void_p), ("resid", C.c_void_p), ("mul", C.c_void_p),
                 ("drop_p", C.c_float), ("seed", C.c_uint32), ("site", C.c_uint32), ("out_f32", C.c_int32),
-                ("a_chunk_stride", C.c_int64), ("a_slab_chunks", C.c_int32), ("k_splits", C.c_int32)]
+                ("a_chunk_stride", C.c_int64), ("a_slab_chunks", C.c_int32), ("k_splits", C.c_int32), ("n_group", C.c_int32)]
 
 
 class PfDenseTnArgs(C.Structure):

@@ -85,9 +85,21 @@ int dense_pack(bool bf16, const float* raw, const DensePackTable& tab, void* pac
 // one-KiB loads in flight.  (First version: one k-step ahead = 24 MFMAs = 0.16 us of cover for a ~1 us L2 round trip; the
 // QKV projection of 187 K rows took 180 us against 17 us of MFMA time and 58 us of HBM time.)
 template <bool BF16, int EPI, int TP, int RD>
-__global__ __launch_bounds__(256, TP <= 3 ? 2 : 1) void dense_strip_kernel(const DenseArgs p) {
+__global__ __launch_bounds__(256, TP <= 3 ? 2 : 1) void dense_strip_kernel(const DenseArgs p_in) {
     constexpr int BM = 128, CG = 8;
     constexpr int KSTEP = BF16 ? 32 : 16, ESZ = BF16 ? 2 : 4, EPC = 16 / ESZ;
+    DenseArgs p = p_in;
+    if constexpr (EPI == kEpiPlain) {
+        // column groups (grid.z): this workgroup owns output units [col0, col0 + n_group) -- their fragments are a
+        // contiguous run of tiles, their bias and output columns an offset; everything below sees a narrower matrix
+        if (p.n_group > 0) {
+            const int col0 = (int)blockIdx.z * p.n_group;
+            p.wfrags = reinterpret_cast<const u32x4*>(p.wfrags) + (size_t)(col0 >> 4) * (p.K / KSTEP) * 64;
+            if (p.bias) p.bias += col0;
+            p.out = reinterpret_cast<char*>(p.out) + (size_t)col0 * ((!BF16 || p.out_f32) ? 4 : 2);
+            p.N = p.N - col0 < p.n_group ? p.N - col0 : p.n_group;
+        }
+    }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int64_t* s_aoff = reinterpret_cast<int64_t*>(smem);                // [BM] element offset of the row in A, -1 beyond M
     int64_t* s_ooff = s_aoff + BM;                                      // [BM] element offset of the row in out
@@ -438,7 +450,8 @@ static int launch_strip(const DenseArgs& a, hipStream_t s) {
     // splits: ceil(nchunks / k_splits) chunks each -- only the splits that own a chunk are launched
     const int nchunks = a.K / a.KC, ksp = a.k_splits > 1 ? a.k_splits : 1, cps = (nchunks + ksp - 1) / ksp;
     const unsigned ny = (unsigned)((nchunks + cps - 1) / cps);
-    hipLaunchKernelGGL(k, dim3(grid, ny), dim3(256), lds, s, a);
+    const unsigned nz = a.n_group > 0 ? (unsigned)((a.N + a.n_group - 1) / a.n_group) : 1u;
+    hipLaunchKernelGGL(k, dim3(grid, ny, nz), dim3(256), lds, s, a);
     return launch_status();
 }
 
@@ -464,7 +477,7 @@ static int strip_tiles_per_pass(int ntiles, int nchunks) {
 
 template <bool BF16, int EPI>
 static int launch_strip_tp(const DenseArgs& a, hipStream_t s) {
-    const int ntiles = a.N / 16, nchunks = a.K / a.KC;
+    const int ntiles = (a.n_group > 0 ? a.n_group : a.N) / 16, nchunks = a.K / a.KC;      // tiles ONE workgroup owns
     if (nchunks > 1 && ntiles > 16) return PF_ERR_UNSUPPORTED;
     return strip_tiles_per_pass(ntiles, nchunks) == 4 ? launch_strip_rd<BF16, EPI, 4>(a, s) : launch_strip_rd<BF16, EPI, 3>(a, s);
 }
@@ -475,10 +488,26 @@ int dense_nt(bool bf16, int epilogue, const DenseArgs& a0, hipStream_t s) {
     DenseArgs a = a0;
     if (epilogue == kEpiMul && bf16 && a.out_f32) return PF_ERR_BAD_ARG;         // (operand and output share one type)
     if (a.k_splits > 1 && (epilogue != kEpiPlain || !(a.out_f32 || !bf16) || a.k_splits > a.K / a.KC)) return PF_ERR_BAD_ARG;
+    // column groups (n_group): one launch, grid.z groups of output units -- plain epilogue only
+    const bool groupable = epilogue == kEpiPlain && !(a.drop_p > 0.f) && a.o_valid_per_seq <= 0 && a.k_splits <= 1 && !a.dact;
+    if (a.n_group < 0 || a.n_group % 16 || (a.n_group > 0 && !groupable)) return PF_ERR_BAD_ARG;
+    if (a.n_group >= a.N) a.n_group = 0;
+    if (a.n_group == 0 && groupable) {
+        // chosen here: few strips are grouped until ~3/4 of the CUs have a workgroup (the rows are staged once per group, so
+        // not beyond that); when the strips alone fill the chip nothing is grouped
+        const int64_t strips = (a.M + 127) / 128;
+        const int cand[4] = {256, 192, 128, 64};
+        for (int i = 0; i < 4 && strips < 192; ++i) {
+            if (cand[i] >= a.N) continue;
+            a.n_group = cand[i];
+            if (strips * ((a.N + cand[i] - 1) / cand[i]) >= 192) break;
+        }
+    }
+    auto n_eff = [&] { return a.n_group > 0 ? a.n_group : a.N; };                 // output units ONE workgroup owns
     // the strip image (128 rows x KC) + the epilogue's staging must fit 160 KiB of LDS: halve the chunk while it does not
     // (fp32 with KC = 256: 128 KiB of image alone)
     auto lds_of = [&](int kc) {
-        const int tp = strip_tiles_per_pass(a.N / 16, a.K / kc);
+        const int tp = strip_tiles_per_pass(n_eff() / 16, a.K / kc);
         const int oesz = (epilogue == kEpiResid || epilogue == kEpiMul || !bf16 || a.out_f32) ? 4 : 2;
         return (size_t)3 * 128 * 8 + 128 * 4 + (size_t)128 * kc * (bf16 ? 2 : 4) + (size_t)2 * (epilogue == kEpiGelu ? 2 : 1) * 16 * (4 * tp * 16 * oesz + 16);
     };
@@ -486,7 +515,13 @@ int dense_nt(bool bf16, int epilogue, const DenseArgs& a0, hipStream_t s) {
     // two workgroups per CU where one pass covers the output (<= 12 tiles): a 128 x 256 image + staging is 90 KB = ONE
     // workgroup of 4 waves per CU, whose staging, MFMA and store phases do not overlap with anything (conv2's data gradient:
     // 720 us at KC = 256, 500 us at KC = 128)
-    if (a.N / 16 <= 12 && lds_of(a.KC) > 80 * 1024 && a.KC % 128 == 0 && a.a_chunk_stride <= 0 && a.k_splits <= 1) a.KC /= 2;
+    if (n_eff() / 16 <= 12 && lds_of(a.KC) > 80 * 1024 && a.KC % 128 == 0 && a.a_chunk_stride <= 0 && a.k_splits <= 1) a.KC /= 2;
+    if (a.KC > 256) return PF_ERR_UNSUPPORTED;                                    // the staging sweeps cover 256 operands per row
+    // a chunked reduction keeps its accumulators across chunks: at most 256 units per workgroup
+    if (a.K / a.KC > 1 && n_eff() > 256) {
+        if (!groupable) return PF_ERR_UNSUPPORTED;
+        a.n_group = 256;
+    }
     switch (epilogue) {
     case kEpiPlain: return bf16 ? launch_strip_tp<true, kEpiPlain>(a, s) : launch_strip_tp<false, kEpiPlain>(a, s);
     case kEpiGelu: return bf16 ? launch_strip_tp<true, kEpiGelu>(a, s) : launch_strip_tp<false, kEpiGelu>(a, s);
