@@ -547,6 +547,13 @@ int pf_remix_forward(const void* noise_pool, int64_t n_noise, const void* signal
                      int64_t n_fill, int64_t batch, float* strain, float* sig_sum, float* net_snr,
                      void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- measurement aid (not part of the path) ------------------------------------
+ * The compute-free read that bounds the 16-row flow kernel: `workgroups` workgroups of 8 waves each read the SAME `bytes`
+ * of `buf` (16-byte loads, every wave its own contiguous eighth, `in_flight` = 2 | 4 | 8 | 16 one-KiB loads outstanding per
+ * wave, an xor per load) and write one word each to sink[workgroups].  bench.py times it over the packed weight stream of
+ * the flow it benchmarks, on the box it runs on: `roofline.ceiling` (csrc/pf_diag.hip). */
+int pf_diag_stream_ingest(const void* buf, int64_t bytes, int32_t workgroups, int32_t in_flight, uint32_t* sink, void* stream);
+
 /* ---- introspection ------------------------------------------------------------ */
 const char* pf_last_error(void);
 const char* pf_version(void);

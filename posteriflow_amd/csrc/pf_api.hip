@@ -42,6 +42,7 @@ int64_t enc_train_packed_bytes(bool bf16);
 int enc_train_pack(bool bf16, const float* raw, void* packed, hipStream_t s);
 int ctx_project_rows(bool bf16, const void* wfrags, const float* bias, const float* ctx, int64_t rows, int C, int n_units,
                      float* out, hipStream_t s);
+int diag_stream_ingest(const void* buf, int64_t bytes, int workgroups, int in_flight, unsigned* sink, hipStream_t s);
 int64_t enc_train_workspace_bytes(const PfEmbedTrainDesc* desc, int64_t n_events);
 int enc_train_forward(const PfEmbedTrainDesc* desc, const void* packed, const float* raw, const float* strain,
                       const float* extra_tokens, const float* token_bias, const float* pool_q, int64_t n_events, float* pooled,
@@ -674,6 +675,14 @@ int32_t pf_flow_rows_per_workgroup(const PfFlowDesc* desc, int64_t batch) {
     pf::FlowPlan L;
     if (compute_layout_of(desc, L) != PF_OK) return -1;
     return pf::rows_per_workgroup(L, batch);
+}
+
+int pf_diag_stream_ingest(const void* buf, int64_t bytes, int32_t workgroups, int32_t in_flight, uint32_t* sink, void* stream) {
+    if (!buf || !sink || misaligned(buf, 16) || bytes < 128 * 1024 || workgroups < 1 || workgroups > 65535)
+        return fail(PF_ERR_BAD_ARG, "pf_diag_stream_ingest: 16-byte aligned buffer of >= 128 KiB, 1..65535 workgroups");
+    if (in_flight != 2 && in_flight != 4 && in_flight != 8 && in_flight != 16)
+        return fail(PF_ERR_BAD_ARG, "pf_diag_stream_ingest: in_flight must be 2, 4, 8 or 16");
+    return finish(pf::diag_stream_ingest(buf, bytes, workgroups, in_flight, sink, static_cast<hipStream_t>(stream)), "");
 }
 
 int pf_geom_twiddles(float* host_table) {

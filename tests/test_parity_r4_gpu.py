@@ -1,0 +1,79 @@
+"""Round-4 parity cases:
+
+  * the 8-layer D15 / C288 / H256 / K16 flow at its DEFAULT initialisation (final layer x1), 4096 rows: north_star's
+    tolerance -- 1e-5 relative fp32 on the NLL -- asserted on EVERY row against the float64 oracle, z and log|det| with it;
+  * the same flow with the final layers x30 (BASELINE.md section 3's literal factor) at the full depth L = 8: the
+    distances of the HIP fp32 path AND of the CPU fp32 oracle from float64 are recorded (printed, and returned in the
+    test's user properties), not asserted at 1e-5 -- at this scale an 8-layer random flow amplifies fp32 rounding by
+    orders of magnitude in float64 arithmetic itself; what IS asserted is that the HIP path is no further from float64
+    than the CPU fp32 evaluation of the reference's algorithm is (factor 4 at p50 / p99).
+"""
+import pytest
+import torch
+
+from helpers import make_pair
+
+pytestmark = pytest.mark.gpu
+D, C, H, L, K, TB = 15, 288, 256, 8, 16, 5.0
+
+
+def _inputs(batch, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(batch, D, generator=g) * 2 - 1
+    m = torch.rand(batch, D, generator=g) < 0.02
+    x = torch.where(m, (torch.rand(batch, D, generator=g) * 2 - 1) * 6.0, x)       # 2 % of entries in the tails
+    return x, torch.randn(batch, C, generator=g)
+
+
+def test_default_init_eight_layers_every_row_within_1e5():
+    ref, ref64, flow = make_pair(D, C, H, L, K, TB, scale=1.0)
+    x, ctx = _inputs(4096)
+    flow.precision = "fp32"
+    with torch.no_grad():
+        n64 = ref64.compute_psd_aware_nll(x.double(), ctx.double(), torch.zeros_like(x).double())
+        z64, ld64 = ref64(x.double(), ctx.double())
+        n32 = ref.compute_psd_aware_nll(x, ctx, torch.zeros_like(x)).double()
+        got = flow.compute_psd_aware_nll(x.cuda(), ctx.cuda(), None).cpu().double()
+        z, ld = flow(x.cuda(), ctx.cuda())
+    den = n64.abs().clamp_min(1.0)
+    rel, rel_cpu = (got - n64).abs() / den, (n32 - n64).abs() / den
+    ez = (z.cpu().double() - z64).abs().max().item()
+    eld = ((ld.cpu().double() - ld64).abs() / ld64.abs().clamp_min(1.0)).max().item()
+    print(f"\n[x1, L = 8, 4096 rows] rel nll vs fp64: HIP p50 {rel.median():.2e} p99 {rel.quantile(0.99):.2e} max {rel.max():.2e}; "
+          f"CPU fp32 p50 {rel_cpu.median():.2e} max {rel_cpu.max():.2e}; |z - z64| max {ez:.2e}; rel log|det| max {eld:.2e}")
+    assert rel.max().item() < 1e-5, rel.max().item()             # EVERY row (measured 2e-6 on the worst row)
+    assert ez < 2e-5 and eld < 1e-5, (ez, eld)
+    # and the log-density through the bf16 kernel follows the same-rounding oracle (recorded with its own bound)
+    from oracle import nflows_restated as nfr
+    flow.precision = "bf16"
+    with torch.no_grad():
+        with nfr.gemm_emulation("bf16"):
+            nemu = ref.compute_psd_aware_nll(x, ctx, torch.zeros_like(x)).double()
+        got16 = flow.compute_psd_aware_nll(x.cuda(), ctx.cuda(), None).cpu().double()
+    e = (got16 - nemu).abs()
+    print(f"   bf16 vs same-rounding oracle: p50 {e.median():.2e} p99 {e.quantile(0.99):.2e} max {e.max():.2e}")
+    assert e.median() < 2e-3 and e.quantile(0.99) < 5e-2, (e.median().item(), e.quantile(0.99).item())
+
+
+def test_x30_eight_layers_distances_are_recorded(record_property):
+    ref, ref64, flow = make_pair(D, C, H, L, K, TB, scale=30.0)
+    x, ctx = _inputs(4096)
+    flow.precision = "fp32"
+    with torch.no_grad():
+        n64 = ref64.compute_psd_aware_nll(x.double(), ctx.double(), torch.zeros_like(x).double())
+        n32 = ref.compute_psd_aware_nll(x, ctx, torch.zeros_like(x)).double()
+        got = flow.compute_psd_aware_nll(x.cuda(), ctx.cuda(), None).cpu().double()
+    finite = torch.isfinite(n64) & torch.isfinite(n32) & torch.isfinite(got)
+    den = n64.abs().clamp_min(1.0)
+    rel, rel_cpu = ((got - n64).abs() / den)[finite], ((n32 - n64).abs() / den)[finite]
+    rec = {"rows": 4096, "finite_rows": int(finite.sum()),
+           "hip_p50": rel.median().item(), "hip_p99": rel.quantile(0.99).item(), "hip_max": rel.max().item(),
+           "hip_frac_over_1e-5": (rel > 1e-5).double().mean().item(),
+           "cpu_p50": rel_cpu.median().item(), "cpu_p99": rel_cpu.quantile(0.99).item(), "cpu_max": rel_cpu.max().item(),
+           "cpu_frac_over_1e-5": (rel_cpu > 1e-5).double().mean().item()}
+    for k, v in rec.items():
+        record_property(k, v)
+    print("\n[x30, L = 8, 4096 rows] rel nll vs fp64 (recorded, not asserted at 1e-5): " + ", ".join(f"{k} {v:.3g}" for k, v in rec.items()))
+    assert rec["finite_rows"] >= 0.99 * 4096
+    # the HIP path is an fp32 evaluation like the CPU oracle's: no further from float64 than 4x that one
+    assert rec["hip_p50"] < 4 * rec["cpu_p50"] + 1e-7 and rec["hip_p99"] < 4 * rec["cpu_p99"] + 1e-6, rec
