@@ -470,8 +470,12 @@ static int launch_strip_rd(const DenseArgs& a, hipStream_t s) {
 
 // Tiles per wave and pass (TP) of a strip launch -- ONE rule for the launcher and for dense_nt's LDS budget (they once
 // differed for a chunked reduction over 13..15 tiles).  A chunked reduction keeps its accumulators across chunks: one pass
-// over all tiles (<= 16); otherwise 3 tiles per wave and pass, 4 where that divides the tile count evenly.
-static int strip_tiles_per_pass(int ntiles, int nchunks) {
+// over all tiles (<= 16); otherwise 3 tiles per wave and pass, 4 where that divides the tile count evenly.  Column groups
+// (n_group: few-row problems whose time is one workgroup's latency) of <= 4 / <= 8 tiles take 1 / 2 tiles per wave, so that
+// all four waves multiply: out_proj's 1024 x 1728 -> 512 in fp32, 64 workgroups of 4 tiles, 195 us with two waves working.
+static int strip_tiles_per_pass(int ntiles, int nchunks, bool grouped) {
+    if (grouped && ntiles <= 4) return 1;
+    if (grouped && ntiles <= 8) return 2;
     return ((nchunks > 1 && ntiles > 12) || (nchunks == 1 && ntiles % 16 == 0 && ntiles % 12 != 0)) ? 4 : 3;
 }
 
@@ -479,7 +483,12 @@ template <bool BF16, int EPI>
 static int launch_strip_tp(const DenseArgs& a, hipStream_t s) {
     const int ntiles = (a.n_group > 0 ? a.n_group : a.N) / 16, nchunks = a.K / a.KC;      // tiles ONE workgroup owns
     if (nchunks > 1 && ntiles > 16) return PF_ERR_UNSUPPORTED;
-    return strip_tiles_per_pass(ntiles, nchunks) == 4 ? launch_strip_rd<BF16, EPI, 4>(a, s) : launch_strip_rd<BF16, EPI, 3>(a, s);
+    const int tp = strip_tiles_per_pass(ntiles, nchunks, a.n_group > 0);
+    if constexpr (EPI == kEpiPlain) {                                                     // (grouping exists for the plain epilogue only)
+        if (tp == 1) return launch_strip_rd<BF16, EPI, 1>(a, s);
+        if (tp == 2) return launch_strip_rd<BF16, EPI, 2>(a, s);
+    }
+    return tp == 4 ? launch_strip_rd<BF16, EPI, 4>(a, s) : launch_strip_rd<BF16, EPI, 3>(a, s);
 }
 
 int dense_nt(bool bf16, int epilogue, const DenseArgs& a0, hipStream_t s) {
@@ -507,7 +516,7 @@ int dense_nt(bool bf16, int epilogue, const DenseArgs& a0, hipStream_t s) {
     // the strip image (128 rows x KC) + the epilogue's staging must fit 160 KiB of LDS: halve the chunk while it does not
     // (fp32 with KC = 256: 128 KiB of image alone)
     auto lds_of = [&](int kc) {
-        const int tp = strip_tiles_per_pass(n_eff() / 16, a.K / kc);
+        const int tp = strip_tiles_per_pass(n_eff() / 16, a.K / kc, a.n_group > 0);
         const int oesz = (epilogue == kEpiResid || epilogue == kEpiMul || !bf16 || a.out_f32) ? 4 : 2;
         return (size_t)3 * 128 * 8 + 128 * 4 + (size_t)128 * kc * (bf16 ? 2 : 4) + (size_t)2 * (epilogue == kEpiGelu ? 2 : 1) * 16 * (4 * tp * 16 * oesz + 16);
     };

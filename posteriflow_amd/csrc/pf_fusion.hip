@@ -21,11 +21,14 @@
 //   attention, per (head, 16-query tile): S^T = K . Q^T is 12 MFMAs (the head dimension is one k-step),
 //   softmax over keys in registers (columns = queries: 4 rows per lane x 12 tiles, then two xor-shuffles),
 //   O^T = V^T . P^T with P taken from the S accumulators WITHOUT leaving registers: the k-step's key
-//   order is permuted to the accumulator layout (slot 8g+j <- key 32s+4g+j | 32s+16+4g+j-4) and V^T is
-//   read from LDS in the same order.  Each head's output goes through LDS once into the out-projection,
+//   order is permuted to the accumulator layout (slot 8g+j <- key 32s+4g+j | 32s+16+4g+j-4) and V is kept
+//   token-major like K ([token][32 dims], 8-byte stores from the accumulator layout) and read TRANSPOSED in
+//   that order by ds_read_b64_tr_b16 (a 16-lane group fetches keys 4g .. 4g+3 x 16 dims and each lane gets its
+//   dim's four keys; round 4: the V^T image written by 2-byte scatter stores was 25 % of the LDS-active cycles
+//   in bank conflicts).  Each head's output goes through LDS once into the out-projection,
 //   which accumulates over heads in registers; the FFN hidden layer goes through LDS in 4 chunks of 192
 //   and never exists in full.  Two heads are in flight per iteration (24 (head, query tile) units = 3 per wave; O goes over
-//   the Q tile its wave consumed).  LDS: 73 728 (normalised tokens) + 74 752 (2 x (Q/O|K|V^T) or hidden chunk) + 6 144.
+//   the Q tile its wave consumed).  LDS: 73 728 (normalised tokens) + 73 728 (2 x (Q/O|K|V) or hidden chunk) + 6 144.
 // bf16 operands, fp32 accumulation, fp32 LayerNorm / softmax / GELU (erf) / residual.
 #include <hip/hip_runtime.h>
 
@@ -51,13 +54,14 @@ static_assert(kWaves == 8 || kWaves == 4, "4 feature blocks x 1 or 2 token halve
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 constexpr int kE = 192, kHeads = 6, kHd = 32, kFF = 768, kLayers = 3, kPoolQ = 8;
 constexpr int kTok = 192, kTT = 12;                   // padded tokens, token tiles
-constexpr int kXS = 384, kQS = 64, kVS = 400;           // LDS byte strides: [tok][192], [tok][32] (XOR-swizzled), V^T [32][192]
+constexpr int kXS = 384, kQS = 64;                      // LDS byte strides: [tok][192], [tok][32] (XOR-swizzled)
 constexpr int kBuf = kTok * kXS;                       // 73 728
-constexpr int kHeadSet = 2 * kTok * kQS + kHd * kVS;   // one head's Q (later O) | K | V^T: 37 376
-constexpr int kBufB = 2 * kHeadSet > kBuf ? 2 * kHeadSet : kBuf;       // two heads in flight / an FFN hidden chunk: 74 752
+constexpr int kHeadSet = 3 * kTok * kQS;               // one head's Q (later O) | K | V, each [tok][32]: 36 864
+constexpr int kBufB = 2 * kHeadSet > kBuf ? 2 * kHeadSet : kBuf;       // two heads in flight / an FFN hidden chunk: 73 728
 constexpr int kLds = kBuf + kBufB + 4 * kTok * 8;     // + per-wave token statistics
 constexpr int kFrag = 1024;
 
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(kThreads) void fusion_kernel(FusionParams p) {
     char* const hb = smem + kBuf;                // FFN hidden chunk, bf16 [192][384 B]   (aliases the head sets below)
     // two heads are in flight at a time (24 (head, query tile) units = 3 per wave; with one head the 12 tiles left
     // half the waves idle for a third of the attention phase): head slot hs at hb + hs * kHeadSet holds
-    // Q [192][64 B] -- overwritten tile by tile with O by the wave that consumed the tile -- | K [192][64 B] | V^T [32][400 B]
+    // Q [192][64 B] -- overwritten tile by tile with O by the wave that consumed the tile -- | K [192][64 B] | V [192][64 B]
     char* const qb = smem + kBuf;
     char* const kb = qb + kTok * kQS;
     char* const vt = kb + kTok * kQS;
@@ -130,6 +134,14 @@ __global__ __launch_bounds__(kThreads) void fusion_kernel(FusionParams p) {
     const int gsw = g ^ ((c >> 1) & 7);
     const int xlane_even = c * kXS + (gsw << 4), xlane_odd = c * kXS + ((gsw ^ 4) << 4);
     const int qlane = c * kQS + ((g ^ ((4 - (c >> 2)) & 3)) << 4);
+    // transposed reads of V (ds_read_b64_tr_b16): the 16 lanes of group g fetch the block keys 4 g .. 4 g + 3 (+ 32 s, + 16
+    // for the second half of the k-step) x dims 16 dt .. 16 dt + 15 -- lane 4 q + p supplies the address of key row q, dims
+    // 4 p .. 4 p + 3 -- and lane c receives dim 16 dt + c of the four keys: the A fragment O^T = V^T . P^T wants.  The rows'
+    // swizzle term (4 - ((row >> 2) & 3)) & 3 is (4 - g) & 3 for every row of the lane's blocks (32 s, 16 are multiples of 16)
+    int vtr[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+        vtr[dt] = (4 * g + (c >> 2)) * kQS + (((2 * dt + ((c & 3) >> 1)) ^ ((4 - g) & 3)) << 4) + 8 * (c & 1);
     // per-lane parts of the swizzled STORE offsets (accumulator layout: 4 features 16 t + 4 g .. of token c)
     int wx[3], qw[2];
 #pragma unroll
@@ -306,13 +318,13 @@ __global__ __launch_bounds__(kThreads) void fusion_kernel(FusionParams p) {
             for (int e = 0; e < 4; ++e) { pf[e] = (__bf16)s[2 * ss][e]; pf[4 + e] = (__bf16)s[2 * ss + 1][e]; }
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
-                const char* row = vt + (16 * dt + c) * kVS;
-                const bf16x4 lo = *reinterpret_cast<const bf16x4*>(row + (32 * ss + 4 * g) * 2);
-                const bf16x4 hi = *reinterpret_cast<const bf16x4*>(row + (32 * ss + 16 + 4 * g) * 2);
-                bf16x8 vf;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { vf[e] = lo[e]; vf[4 + e] = hi[e]; }
-                o[dt] = mfma(vf, pf, o[dt]);
+                typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+                const char* blk = vt + 32 * ss * kQS + vtr[dt];
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(blk));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(blk + 16 * kQS));
+                typedef __attribute__((ext_vector_type(8))) short s16x8;
+                const s16x8 v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                o[dt] = mfma(__builtin_bit_cast(bf16x8, v8), pf, o[dt]);
             }
         }
         const float inv = __builtin_amdgcn_rcpf(sum);
@@ -322,11 +334,6 @@ __global__ __launch_bounds__(kThreads) void fusion_kernel(FusionParams p) {
     // projection epilogues: a 16 x 16 tile of Q / K (token-major rows) or V (transposed)
     auto put_qk = [&](char* buf, int dt, int tt, f32x4 v) {
         *reinterpret_cast<bf16x4*>(buf + tt * (16 * kQS) + qw[dt]) = to_bf16(v);
-    };
-    auto put_vt = [&](char* vt, int dt, int tt, f32x4 v) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            *reinterpret_cast<__bf16*>(vt + (16 * dt + 4 * g + e) * kVS + (16 * tt + c) * 2) = (__bf16)v[e];
     };
 
     for (int l = 0; l < kLayers; ++l) {
@@ -392,7 +399,7 @@ __global__ __launch_bounds__(kThreads) void fusion_kernel(FusionParams p) {
                                     else put_qk(k_, 0, tt, v);
                                 } else {
                                     if (i == 0) put_qk(k_, 1, tt, v);
-                                    else put_vt(v_, i - 1, tt, v);
+                                    else put_qk(v_, i - 1, tt, v);
                                 }
                             }
                         }
@@ -491,7 +498,7 @@ __global__ __launch_bounds__(kThreads) void fusion_kernel(FusionParams p) {
 #pragma unroll
                 for (int j = 0; j < kQT; ++j) {
                     if (fb2 == 0) put_qk(kb, i, kQT * tb4 + j, t[i][j] + b4);
-                    else put_vt(vt, i, kQT * tb4 + j, t[i][j] + b4);
+                    else put_qk(vt, i, kQT * tb4 + j, t[i][j] + b4);
                 }
             }
             // the head's 8 queries (rows 8..15 of the tile are zero)

@@ -105,7 +105,7 @@ def test_every_encoder_gradient_matches_float64_autograd_through_the_oracle(ndet
         rel = ((g - w).abs().max() / w.abs().max().clamp_min(1e-30)).item()
         worst = max(worst, (rel, name))
         n += 1
-        assert rel < 1e-3, (name, rel)
+        assert rel < 1e-5, (name, rel)          # measured: 2.65e-6 on the worst tensor
     print(f"  {n} parameter tensors, worst relative error {worst[0]:.2e} ({worst[1]})")
     # the pool's query rows: gradient through the host-side projection only
     assert enc.pool_attn.in_proj_weight.grad[:192].abs().max() > 0

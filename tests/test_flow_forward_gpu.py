@@ -213,7 +213,7 @@ def test_masked_context_conditioner_a14():
                 assert ez < max(4 * (z32.double() - z64).abs().max().item(), 2e-5)
                 assert eld < max(4 * (ld32.double() - ld64).abs().max().item(), 5e-5)
             else:
-                assert ez < 0.5 and eld < 4.0
+                assert ez < 0.1 and eld < 0.65          # bf16 operands on a 3-layer map (measured 4.4e-2 / 0.30; 2x)
         flow.precision = "fp32"
         zz = torch.randn(64, D)
         xi, _, flags = flow._inverse_call(zz.cuda(), flow._permute_context_blocks(ctx[:64].cuda()).contiguous(), 64)
@@ -224,7 +224,7 @@ def test_masked_context_conditioner_a14():
     flow.compute_psd_aware_nll(xg, ctx[:32].cuda(), None).sum().backward()
     xr_ = x[:32].clone().requires_grad_(True)
     ref.compute_psd_aware_nll(xr_, ctx[:32], torch.zeros(32, D)).sum().backward()
-    assert ((xg.grad.cpu() - xr_.grad).abs().max() / xr_.grad.abs().max()) < 1e-3
+    assert ((xg.grad.cpu() - xr_.grad).abs().max() / xr_.grad.abs().max()) < 1e-4      # measured 4.3e-5
 
 
 @pytest.mark.gpu
@@ -262,7 +262,8 @@ def test_masked_context_per_position_mask_full_context_false():
         assert (moved[:-1] == 0).all() and moved[-1] > 1e-3, moved
         flow.precision = "bf16"
         zb, ldb = flow(x.cuda(), ctx.cuda())
-        assert (zb.cpu().double() - z64).abs().max() < 0.5 and (ldb.cpu().double() - ld64).abs().max() < 4.0
+        # bf16 operands (measured 2.0e-2 / 0.18; 2x)
+        assert (zb.cpu().double() - z64).abs().max() < 0.04 and (ldb.cpu().double() - ld64).abs().max() < 0.4
         flow.precision = "fp32"
         zz = torch.randn(64, D)
         xi, _, flags = flow._inverse_call(zz.cuda(), flow._permute_context_blocks(ctx[:64].cuda()).contiguous(), 64)
@@ -273,10 +274,10 @@ def test_masked_context_per_position_mask_full_context_false():
     xr_, cr_ = x[:32].clone().requires_grad_(True), ctx[:32].clone().requires_grad_(True)
     ref.compute_psd_aware_nll(xr_, cr_, torch.zeros(32, D)).sum().backward()
     relg = lambda a, b: ((a - b).abs().max() / b.abs().max()).item()
-    assert relg(xg.grad.cpu(), xr_.grad) < 1e-3 and relg(cg.grad.cpu(), cr_.grad) < 1e-3
+    assert relg(xg.grad.cpu(), xr_.grad) < 4e-5 and relg(cg.grad.cpu(), cr_.grad) < 4e-5      # measured 1.9e-5 / 1.7e-5
     g_ref = dict(ref.named_parameters())["transform._transforms.0.autoregressive_net.context_layer.weight"].grad
     g_got = flow._ar_transforms[0].autoregressive_net.context_layer.weight.grad.cpu()
-    assert relg(g_got, g_ref) < 1e-3 and (g_got[net.context_layer.mask.cpu() == 0] == 0).all()
+    assert relg(g_got, g_ref) < 4e-5 and (g_got[net.context_layer.mask.cpu() == 0] == 0).all()
 
 
 @pytest.mark.gpu
@@ -327,7 +328,7 @@ def test_rows_per_workgroup_choice_and_parity(B, rows):
         idx = torch.linspace(0, B - 1, 64).long()
         want = ref.compute_psd_aware_nll(x[idx], ctx[idx], torch.zeros(64, 15))
     err = (got.cpu()[idx] - want).abs() / want.abs().clamp_min(1.0)
-    assert err.median() < 2e-2 and err.max() < 0.3
+    assert err.median() < 1.5e-3 and err.max() < 8e-3          # bf16 on the 2-layer flow: measured <= 7e-4 / 3.5e-3 (2x)
 
 
 @pytest.mark.gpu

@@ -79,9 +79,9 @@ def test_random_shape_bf16_and_gradients(D, C, H, K, L, tb, B, permute, seed):
     nll.sum().backward()
     rel = lambda a, b: ((a - b).abs().max() / b.abs().max().clamp_min(1e-9)).item()
     assert rel(nll.detach().cpu(), nll_ref.detach()) < 1e-4
-    assert rel(xg.grad.cpu(), xr.grad) < 1e-3
+    assert rel(xg.grad.cpu(), xr.grad) < 5e-5                 # measured <= 2.4e-5 over the eight shapes
     if ctx is not None:
-        assert rel(cg.grad.cpu(), cr.grad) < 1e-3
+        assert rel(cg.grad.cpu(), cr.grad) < 5e-5             # measured <= 2.0e-5
     ref_params = dict(ref.named_parameters())
     for name, p in flow.named_parameters():
         if name.startswith("transform.") and p.grad is not None and ref_params[name].grad.abs().max() > 1e-6:
@@ -91,7 +91,7 @@ def test_random_shape_bf16_and_gradients(D, C, H, K, L, tb, B, permute, seed):
         got = flow.compute_psd_aware_nll(x.cuda(), None if ctx is None else ctx.cuda(), None).cpu()
     assert torch.isfinite(got).all()
     err = (got - nll_ref.detach()).abs() / nll_ref.detach().abs().clamp_min(1.0)
-    assert err.median() < 2e-2 and err.max() < 0.5, (err.median(), err.max())
+    assert err.median() < 4e-3 and err.max() < 1.5e-2, (err.median(), err.max())      # measured <= 1.7e-3 / 6.3e-3
 
 
 @pytest.mark.parametrize("D,block,H,K,L", [(4, 5, 64, 8, 2), (7, 16, 128, 16, 3), (12, 3, 192, 13, 2), (15, 20, 256, 16, 2)])

@@ -132,4 +132,4 @@ def test_wide_full_size_statistics():
     assert torch.isfinite(w).all()
     assert abs(w.double().mean().item() - a.double().mean().item()) < 1e-4 * abs(a.double().mean().item())
     err = (w.cpu()[idx] - want).abs() / want.abs().clamp_min(1.0)
-    assert err.median() < 2e-2 and err.max() < 0.3
+    assert err.median() < 1e-2 and err.max() < 0.16           # bf16 on the 8-layer x2 flow, 64 rows: measured 4.7e-3 / 7.9e-2 (2x)
