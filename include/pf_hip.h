@@ -469,6 +469,11 @@ typedef struct PfDenseTnArgs {  /* dW[n1][n2] += sum_m G[m][n1] A[m][n2],  db[n1
 /* mode 0: W[n][k] = src[n * ld + k]; 1: W[n][k] = src[k * ld + n]; out: pf_dense_frag_bytes(precision, N, K) bytes */
 int64_t pf_dense_frag_bytes(int32_t precision, int32_t N, int32_t K);
 int pf_dense_pack_matrix(int32_t precision, const float* src, int32_t mode, int32_t ld, int32_t N, int32_t K, void* out, void* stream);
+/* an nn.Linear weight [n][k] (row stride ld) zero-extended to [n_padded][k_padded] as fragments, in ONE launch and without
+ * a padded copy: the forward form (mode 0) at out and, when with_transposed, W^T [k_padded][n_padded] (the data gradient's
+ * operand) behind it at out + pf_dense_frag_bytes(precision, n_padded, k_padded) */
+int pf_dense_pack_linear(int32_t precision, const float* weight, int32_t ld, int32_t n, int32_t k, int32_t n_padded,
+                         int32_t k_padded, int32_t with_transposed, void* out, void* stream);
 int pf_dense_nt(int32_t precision, int32_t epilogue, const PfDenseArgs* args, void* stream);
 int pf_dense_tn(int32_t precision, const PfDenseTnArgs* args, void* stream);
 /* dropout factor of the training path, for tests that rebuild the masks: 0 or 1 / (1 - p) */

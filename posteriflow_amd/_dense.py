@@ -65,9 +65,7 @@ def _pad_cols(t: torch.Tensor, width: int, dtype) -> torch.Tensor:
         return t
     if t.shape[1] == width:
         return t.to(dtype).contiguous()
-    out = torch.zeros(t.shape[0], width, dtype=dtype, device=t.device)
-    out[:, : t.shape[1]] = t
-    return out
+    return torch.nn.functional.pad(t.to(dtype), (0, width - t.shape[1]))       # one kernel
 
 
 class _Packed:
@@ -79,27 +77,25 @@ class _Packed:
         n, k = weight.shape
         self.n, self.k, self.np_, self.kp = n, k, _padded(n, prec), _padded(k, prec)
         self.prec = prec
-        wp = torch.zeros(self.np_, self.kp, dtype=torch.float32, device=dev)
-        wp[:n, :k] = weight.detach().float()
         self.kc_f = _kc(self.kp, prec)
         self.kc_t = _kc(self.np_, prec)
-        s = _stream(dev)
-
-        def pack(src, mode, ld, N, K):
-            nbytes = L.pf_dense_frag_bytes(prec, N, K)
-            if nbytes < 0:
-                raise NotImplementedError(f"pf_dense_frag_bytes({N}, {K})")
-            out = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            _lib.check(L.pf_dense_pack_matrix(prec, src.data_ptr(), mode, ld, N, K, out.data_ptr(), s), "pf_dense_pack_matrix")
-            return out
-
-        self.fwd = pack(wp, 0, self.kp, self.np_, self.kp)                       # W_p   [Np][Kp]: forward
-        self.bwd = pack(wp, 1, self.kp, self.kp, self.np_) if want_transposed else None   # W_p^T [Kp][Np]: dX = G W
-        self._keep = wp     # (pack kernels are asynchronous: the padded copy must outlive them; it is small)
+        w = weight.detach()
+        if w.dtype != torch.float32 or w.stride(1) != 1:
+            w = w.float().contiguous()
+        one = L.pf_dense_frag_bytes(prec, self.np_, self.kp)
+        if one < 0:
+            raise NotImplementedError(f"pf_dense_frag_bytes({self.np_}, {self.kp})")
+        # ONE launch: the forward form and (behind it) the transposed form, zero-extended inside the pack kernel
+        buf = torch.empty(one * (2 if want_transposed else 1), dtype=torch.uint8, device=dev)
+        _lib.check(L.pf_dense_pack_linear(prec, w.data_ptr(), w.stride(0), n, k, self.np_, self.kp, 1 if want_transposed else 0,
+                                          buf.data_ptr(), _stream(dev)), "pf_dense_pack_linear")
+        self.fwd = buf[:one]                                                     # W_p   [Np][Kp]: forward
+        self.bwd = buf[one:] if want_transposed else None                        # W_p^T [Kp][Np]: dX = G W
+        self._keep = w      # (the pack kernel is asynchronous)
         self.bias = None
         if bias is not None:
-            self.bias = torch.zeros(self.np_, dtype=torch.float32, device=dev)
-            self.bias[:n] = bias.detach().float()
+            b = bias.detach().float()
+            self.bias = b if self.np_ == n else torch.nn.functional.pad(b, (0, self.np_ - n))
 
 
 def _packed(state: Dict, name: str, weight: torch.Tensor, bias: Optional[torch.Tensor], prec: int,

@@ -129,6 +129,8 @@ SYMBOLS = {
                                   C.c_void_p, C.c_int64, C.c_void_p]),
     "pf_pack_bf16_frags": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "pf_flow_inc_layer_bytes": (C.c_int64, [_P]),
+    "pf_dense_pack_linear": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                       C.c_void_p, C.c_void_p]),
     "pf_diag_stream_ingest": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "pf_flow_ctx_project_rows": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                            C.c_void_p, C.c_void_p]),

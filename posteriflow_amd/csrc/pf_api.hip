@@ -564,6 +564,23 @@ int pf_dense_pack_matrix(int32_t precision, const float* src, int32_t mode, int3
     tab.e[0].src_off = 0; tab.e[0].dst_off = 0; tab.e[0].mode = mode; tab.e[0].ld = ld; tab.e[0].N = N; tab.e[0].K = K;
     return finish(pf::dense_pack(precision == PF_PREC_BF16, src, tab, out, static_cast<hipStream_t>(stream)), "");
 }
+int pf_dense_pack_linear(int32_t precision, const float* weight, int32_t ld, int32_t n, int32_t k, int32_t n_padded, int32_t k_padded,
+                         int32_t with_transposed, void* out, void* stream) {
+    if (pf_dense_frag_bytes(precision, n_padded, k_padded) < 0 || (with_transposed && pf_dense_frag_bytes(precision, k_padded, n_padded) < 0))
+        return fail(PF_ERR_BAD_ARG, "pf_dense_pack_linear: padded sizes must be multiples of 32 (bf16) / 16 (fp32)");
+    if (!weight || !out || misaligned(out, 16) || n <= 0 || k <= 0 || n > n_padded || k > k_padded || ld < k)
+        return fail(PF_ERR_BAD_ARG, "pf_dense_pack_linear: null / misaligned pointer, or n > n_padded, k > k_padded, ld < k");
+    pf::DensePackTable tab{};
+    tab.n = with_transposed ? 2 : 1;
+    tab.e[0].src_off = 0; tab.e[0].dst_off = 0; tab.e[0].mode = 0; tab.e[0].ld = ld; tab.e[0].N = n_padded; tab.e[0].K = k_padded;
+    tab.e[0].n_valid = n; tab.e[0].k_valid = k;
+    if (with_transposed) {          // W^T [k_padded][n_padded] behind the forward form: the data gradient's operand
+        tab.e[1] = tab.e[0];
+        tab.e[1].dst_off = pf::dense_frag_count(precision == PF_PREC_BF16, n_padded, k_padded);
+        tab.e[1].mode = 1; tab.e[1].N = k_padded; tab.e[1].K = n_padded; tab.e[1].n_valid = k; tab.e[1].k_valid = n;
+    }
+    return finish(pf::dense_pack(precision == PF_PREC_BF16, weight, tab, out, static_cast<hipStream_t>(stream)), "");
+}
 int pf_dense_nt(int32_t precision, int32_t epilogue, const PfDenseArgs* a, void* stream) {
     if (!prec2(precision) || !a) return fail(PF_ERR_BAD_ARG, "pf_dense_nt: null args or bad precision");
     if (a->M > 0 && (!a->A || !a->wfrags || !a->out || a->rows_per_seq <= 0)) return fail(PF_ERR_BAD_ARG, "pf_dense_nt: null pointer");

@@ -44,6 +44,8 @@ struct DensePackEntry {
     int32_t ld, N, K;
     int32_t cin, cout, kw, s;
     int32_t nks_total, ks_off;    // > 0: this matrix is k-steps ks_off .. of a wider packed matrix with nks_total k-steps per tile
+    int32_t n_valid, k_valid;     // > 0 (modes 0 / 1): P[n][k] with n >= n_valid or k >= k_valid is zero and the source is not read
+                                  // there -- a matrix zero-extended to the kernels' multiples without a padded copy
 };
 constexpr int kMaxPackEntries = 48;
 struct DensePackTable { int32_t n; DensePackEntry e[kMaxPackEntries]; };

@@ -53,7 +53,8 @@ __global__ __launch_bounds__(256) void dense_pack_kernel(const float* __restrict
                 const int u = k / e.cout, co = k - u * e.cout;
                 src = e.src_off + ((int64_t)co * e.cin + ci) * e.kw + e.s * (e.kw / e.s - 1 - u) + t;
             }
-            v[j] = raw[src];
+            const bool outside = (e.n_valid > 0 && n >= e.n_valid) || (e.k_valid > 0 && k >= e.k_valid);
+            v[j] = outside ? 0.f : raw[src];
         }
         u32x4 o;
         if constexpr (BF16) {

@@ -459,8 +459,14 @@ int enc_train_backward(const PfEmbedTrainDesc* desc, const void* packed, const f
         t.ldg = c.cout; t.lda = c.s * c.cin; t.M = d.N * c.lout; t.rows_per_seq = c.lout; t.N1 = c.cout; t.N2 = c.kw * c.cin;
         t.dW = conv_tmp[l]; t.ldw = c.cin * c.kw; t.conv_cin = 0; t.conv_kw = 0; t.db = grad_raw + r.conv_b[l];
         t.splits = 0;
+        if (l == 0) {
+            // the last weight gradient (conv1: 6.3 M positions x 32 x 64) stays on the caller's stream: on the side stream it
+            // queued behind conv2's weight gradient (0.7 ms, started one kernel earlier) and the step ended with 0.25 ms of
+            // one kernel on an otherwise idle GPU; here it runs beside that kernel's tail
+            PF_TRY(dense_tn(d.bf16, t, s));
+            break;
+        }
         PF_TRY(on_side([&](hipStream_t q) { return dense_tn(d.bf16, t, q); }));
-        if (l == 0) break;
         // data gradient: transposed convolution as a GEMM over windows of the padded gradient image, times gelu' of the
         // previous layer, written into that layer's padded image (or the plain G1 of the first layer)
         const Conv& cp = kConv[l - 1];

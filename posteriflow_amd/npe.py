@@ -550,6 +550,13 @@ class CoherentEncoder(LeanStrainEncoder):
             edges = self._geometry_plan()
             if edges is not None:
                 return self._geometry_rel_hip(clean, edges)
+        if clean.is_cuda and not self.__dict__.get("_fft_route_logged"):
+            # not the default path: say so once -- taken when the strain requires a gradient or the band
+            # membership is not a partition into intervals (not constructible through the reference's constructor)
+            self.__dict__["_fft_route_logged"] = True
+            import logging
+            logging.getLogger(__name__).warning("posteriflow_amd: CoherentEncoder geometry features by torch.fft tensor ops "
+                                                "(strain requires grad, or non-interval bands); pf_geom_features not used")
         spec = torch.fft.rfft(clean.float().contiguous(), norm="ortho", dim=-1)
         spec = spec[..., self.band_lo: self.band_lo + self.Nf]
         re, im = spec.real, spec.imag
