@@ -200,3 +200,47 @@ def test_flat_parameter_mode_of_the_encoder():
     c = npe.LeanStrainEncoder().cuda()
     c.load_state_dict(b.state_dict())                          # flat -> plain
     assert torch.equal(c.stem[0].weight, a.stem[0].weight)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_no_grad_call_takes_the_forward_only_workspace_and_gives_the_same_context(precision, monkeypatch):
+    """a call without gradients of the training-path embedding (fp32 parity mode, or train() mode) uses the
+    forward-only workspace -- the layers share one set of activation buffers, none of the backward's temporaries exist -- in
+    chunks of events.  Same context as the differentiable call, bit for bit (same kernels, same order); a strain that requires
+    a gradient is refused instead of silently getting none."""
+    from posteriflow_amd import npe, _enc_train, _lib
+    import ctypes as C
+    torch.manual_seed(5)
+    enc = npe.LeanStrainEncoder().cuda().eval()          # eval: no dropout, the two calls are comparable
+    enc.precision = precision
+    strain = torch.randn(11, 3, 16384, device="cuda")
+    if precision == "bf16":
+        enc.train()                                       # bf16 + eval would take the fused inference kernels
+        for m in enc.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        for l in enc.fusion.layers:
+            l.self_attn.dropout = 0.0
+    seen = []
+    real = _lib.lib().pf_embed_train_workspace_bytes
+
+    class Spy:                                            # records (forward_only, events) of every workspace query
+        def __call__(self, desc, n):
+            seen.append((int(desc._obj.forward_only), int(n)))
+            return real(desc, n)
+    monkeypatch.setattr(_lib.lib(), "pf_embed_train_workspace_bytes", Spy(), raising=False)
+    want = enc(strain)                                    # parameters require grad: the differentiable route
+    assert want.requires_grad and seen and all(f == 0 for f, _ in seen)
+    seen.clear()
+    monkeypatch.setattr(_enc_train, "FWD_ONLY_CHUNK", 4)
+    with torch.no_grad():
+        got = enc(strain)
+    assert [n for _, n in seen] == [4, 4, 3] and all(f == 1 for f, _ in seen), seen
+    assert not got.requires_grad and torch.equal(got, want.detach())
+    for p in enc.parameters():                            # frozen parameters under grad mode: forward-only as well
+        p.requires_grad_(False)
+    seen.clear()
+    got2 = enc(strain)
+    assert all(f == 1 for f, _ in seen) and torch.equal(got2, want.detach())
+    with pytest.raises(NotImplementedError):
+        enc(strain.clone().requires_grad_(True))
