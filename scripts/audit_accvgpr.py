@@ -8,7 +8,13 @@ instruction, N + 1 for `s_nop N` -- until the number the matrix pipe needs has p
 window that reads or overwrites a register of the MFMA's destination is reported, except
   * a following MFMA that takes the destination whole as its C operand (the accumulate chain needs 0 states);
   * a following MFMA that writes the same destination (back-to-back issue is interlocked by the pipe itself when
-    srcC == vdst, and a plain overwrite is ordered in the pipe).
+    srcC == vdst, and a plain overwrite is ordered in the pipe);
+  * a memory LOAD (ds_read* / global_load* / buffer_load* / flat_load* / scratch_load*) whose destination is the MFMA's:
+    a dead MFMA result whose registers the allocator reuses for a fragment load.  LLVM's recogniser has no
+    "XDL write VGPR -> VMEM / LDS write-back" rule (its WAW rule covers VALU writes; for memory instructions only VGPRs they
+    READ -- address, store data -- are checked), and the load's data cannot land before the MFMA retires: the window is at
+    most 10 wait states, an LDS return takes >= 64 cycles, an L2 hit >= 180.  First seen in round 4's one-tile-per-wave strip
+    GEMM (`dense_strip_kernel<false, 0, 1, 4>`), where a clamped tail tile's product is computed and never stored.
 Required wait states (LLVM GCNHazardRecognizer, gfx950 column of "XDL/SMFMA write VGPR -> VALU / VMEM / LDS read,
 VALU write"): passes + 3 (+ 1 on gfx950 above 2 passes) for the XDL (bf16/f16/i8/fp8) forms, passes + 2 for the
 f32-input forms; passes = issue cycles / 4 (MI355X_MICROARCH.md cycle constants: 16x16x32 bf16 16 cycles, 32x32x16 bf16
@@ -173,6 +179,15 @@ def audit_function(name, insns, base, findings):
                     if hazard is None and ndst and overlaps(ndst[0], dst):
                         break       # same accumulator taken over by the next MFMA: the pipe orders it, window ends
                 elif nxt.mn not in ("s_nop", "s_waitcnt", "s_barrier", "s_endpgm") and not nxt.mn.startswith("s_"):
+                    is_load = nxt.mn.startswith(("ds_read", "global_load", "buffer_load", "flat_load", "scratch_load"))
+                    if is_load and nops and any(overlaps(r, dst) for r in regs(nops[0])) and \
+                            not any(overlaps(r, dst) for o in nops[1:] for r in regs(o)):
+                        ld = regs(nops[0])[0]
+                        if ld[0] == dst[0] and ld[1] <= dst[1] and ld[2] >= dst[2]:
+                            break   # the WHOLE destination is handed to a load's return data: the window ends (docstring)
+                        ws += wait_states(nxt)      # part of it: not a hazard by itself, the rest stays watched
+                        j += 1
+                        continue
                     for idx, o in enumerate(nops):
                         if any(overlaps(r, dst) for r in regs(o)):
                             hazard = ("reads" if idx > 0 or nxt.mn.startswith(("global_store", "buffer_store",
