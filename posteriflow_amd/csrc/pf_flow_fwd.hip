@@ -21,6 +21,21 @@ PF_DECL(1, 4) PF_DECL(1, 8) PF_DECL(1, 12) PF_DECL(1, 16)
 
 int launch_flow_wide_d15(const FwdParams&, hipStream_t);
 int launch_flow_wide_d11(const FwdParams&, hipStream_t);
+int launch_flow_mid_d15(const FwdParams&, hipStream_t);
+int launch_flow_mid_d11(const FwdParams&, hipStream_t);
+
+// A PF_FLAG_WIDE plan is served by two kernels over the same packed stream: the mid-batch kernel (64 rows per workgroup, 8
+// waves = two per SIMD: pf_flow_mid_kernel.h) and the large-batch kernel (128 rows per workgroup, one wave per SIMD).  A launch
+// costs rounds x round time (measured: a round of 256 64-row workgroups 217 us, of 256 128-row workgroups ~310 us when every
+// round is full): up to 16 384 rows the mid kernel's single round wins, above it the large-batch kernel's fewer rounds.
+// $PF_FLOW_MID (test knob, read per call): 0 never the mid kernel, 1 always.
+constexpr double kMidRoundUs = 217.0, kWideRoundUs = 310.0;
+static bool use_mid(const FlowPlan& L, int64_t batch) {
+    if (!L.wide) return false;
+    if (const char* e = getenv("PF_FLOW_MID")) return atoi(e) != 0;
+    const int64_t mid_rounds = ((batch + 63) / 64 + 255) / 256, wide_rounds = ((batch + 127) / 128 + 255) / 256;
+    return mid_rounds * kMidRoundUs < wide_rounds * kWideRoundUs;
+}
 
 size_t fwd_lds_bytes_host(const FlowPlan& L, int R) {
     const size_t par = (size_t)L.D * 16 * 52 * sizeof(float);
@@ -30,7 +45,7 @@ size_t fwd_lds_bytes_host(const FlowPlan& L, int R) {
 }
 
 static int rows_per_workgroup_dir(const FlowPlan& L, int64_t batch, bool inverse) {
-    if (L.wide) return wide::kRowsPerWG;
+    if (L.wide) return use_mid(L, batch) ? 64 : wide::kRowsPerWG;
     if (L.generic) return 16;
     // A workgroup streams the whole weight set whatever its row count, so more rows per workgroup (R groups
     // of 16) amortise the stream -- but a launch costs ceil(workgroups / 256 CUs) rounds, and a round of
@@ -62,7 +77,7 @@ int rows_per_workgroup(const FlowPlan& L, int64_t batch) { return rows_per_workg
 
 // the kernel launch_flow_forward picks for (plan, batch), as rocprofv3 prints it
 void forward_kernel_name(const FlowPlan& L, int64_t batch, char* out, size_t n) {
-    if (L.wide) { snprintf(out, n, "pf::flow_wide_kernel<%d, %d>", L.D, L.CKM); return; }
+    if (L.wide) { snprintf(out, n, use_mid(L, batch) ? "pf::flow_mid_kernel<%d, %d>" : "pf::flow_wide_kernel<%d, %d>", L.D, L.CKM); return; }
     if (L.generic) { snprintf(out, n, "pf::flow_generic_kernel<%s, false>", L.bf16 ? "true" : "false"); return; }
     const int R = L.dense == 1 ? 1 : rows_per_workgroup(L, batch) / 16;
     snprintf(out, n, "pf::flow_kernel<%s, %d, %d, %d, %d, false>", L.bf16 ? "true" : "false", L.NT, R, L.CKM, L.dense);
@@ -74,7 +89,12 @@ int launch_flow_forward(const FwdParams& p_in, hipStream_t s) {
     if (p_in.batch == 0) return PF_OK;
     if (p_in.plan.generic) return p_in.drop_thresh ? (int)PF_ERR_UNSUPPORTED : launch_flow_generic(p_in, false, s);
     if (p_in.plan.wide) {
-        if (p_in.drop_thresh) return PF_ERR_UNSUPPORTED;   // the large-batch kernel is an evaluation kernel
+        if (p_in.drop_thresh) return PF_ERR_UNSUPPORTED;   // the large-batch kernels are evaluation kernels
+        if (use_mid(p_in.plan, p_in.batch)) {
+            if (p_in.plan.D == 15) return launch_flow_mid_d15(p_in, s);
+            if (p_in.plan.D == 11) return launch_flow_mid_d11(p_in, s);
+            return PF_ERR_UNSUPPORTED;
+        }
         if (p_in.plan.D == 15) return launch_flow_wide_d15(p_in, s);
         if (p_in.plan.D == 11) return launch_flow_wide_d11(p_in, s);
         return PF_ERR_UNSUPPORTED;

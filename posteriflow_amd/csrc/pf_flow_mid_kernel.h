@@ -1,0 +1,559 @@
+// pf_flow_mid_kernel.h -- mid-batch forward pass of the masked-autoregressive RQS flow for gfx950 (MI355X): the design
+// between the 16-row kernel (pf_flow_fwd_kernel.h: every workgroup streams the whole weight set for 16-48 rows) and the
+// large-batch kernel (pf_flow_wide_kernel.h: 128 rows per workgroup, one wave per SIMD, 512 registers per wave).
+// Same function (NSFPosteriorFlow.forward / compute_psd_aware_nll, src/ahsd/models/flows.py:610-618, 727-779, executing
+// nflows' MADE + RQS), same packed stream as the large-batch kernel (PF_FLAG_WIDE layout, pf_wide_layout.h: 32-unit x 16-k
+// fragments in the accumulator-permuted k order, masked k-steps absent), different work split:
+//
+//   workgroup = 64 batch rows, 8 waves = 4 unit blocks x 2 row blocks, TWO waves per SIMD (<= 256 registers each), so that
+//   one wave's MFMA chain runs under the other's epilogue / LDS / load issue -- with one wave per SIMD those costs add
+//   (LABLOG 4.9).  Wave (ub, rb) owns the hidden tiles TA = ub and TB = 7 - ub (32 units each: the masked k lengths of such
+//   a pair sum to the same count for every ub) for the 32 rows of row block rb, on v_mfma_f32_32x32x16_bf16.
+//   Its residual state h (2 tiles x 16 accumulator registers) stays in registers; the bf16 activations a dependent GEMM
+//   needs from the other unit blocks are exchanged through LDS in B-fragment order (a 32 x 32 accumulator tile converted
+//   pairwise to bf16 IS two k-steps of the next GEMM's B operand in this layout's k order): 4 KiB written and 16 KiB read
+//   per wave and GEMM, one barrier per dependent GEMM, two buffers.  The bf16 context of a row block lives in LDS as B
+//   fragments (36 KiB for C = 288) and is read per k-step.
+//   Weight fragments come straight from L2 into registers (buffer loads, two rings of kP fragments alternating between
+//   consecutive MFMA chains so that a chain's first fragments are requested while the previous chain runs); the two row
+//   blocks of a unit block request the same fragments at about the same time.
+//   Final layer + spline: the (D + 1) / 2 feature batches (widths | heights of two features + their derivatives = three
+//   32-unit tiles, as in the large-batch kernel) are dealt to the unit blocks in balanced pairs (m, NB - 1 - m); a wave
+//   transposes its 64 (row, feature) pairs through a private LDS area (overlaying the activation buffers, which are dead
+//   by then) and evaluates one pair per lane with rqs_pair_fast16.
+//
+// Numerics = the large-batch kernel's: bf16 operands (x as a hi + lo pair), fp32 accumulation, fp32 residual / bias /
+// spline; bias added after the chain.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "pf_flow_fwd_kernel.h"
+#include "pf_wide_layout.h"
+
+#ifndef PF_MID_ABLATE
+#define PF_MID_ABLATE 0   // timing experiments only: 1 no spline, 2 every weight load on one address, 4 no MFMA, 8 no barriers, 16 no sigmoid
+#endif
+
+#ifndef PF_MID_TRACE
+#define PF_MID_TRACE 0    // diagnostic build: wave PF_MID_TRACE_WAVE of workgroup 0 accumulates s_memtime spans into p.fail_flags
+#endif
+#ifndef PF_MID_TRACE_WAVE
+#define PF_MID_TRACE_WAVE 0
+#endif
+
+namespace pf {
+namespace mid {
+constexpr int kRowsPerWG = 64, kWaves = 8, kThreads = 64 * kWaves;
+constexpr int kXS = 16;                                            // floats per row of the x / z exchange
+constexpr int kPS = wide::kParStride;                              // floats per (row, feature) pair of the spline transpose
+constexpr int kP = 8;                                              // weight fragments in flight per ring (two rings)
+constexpr int kActBytes = 2 * 2 * wide::kKSteps * wide::kFrag;     // [buffer][row block][k-step][1 KiB]
+constexpr int kParBytes = kWaves * 64 * kPS * 4;                   // wave-private spline transposes (overlay the above)
+constexpr int kRegionA = kParBytes > kActBytes ? kParBytes : kActBytes;
+constexpr int ctx_bytes(int CKS) { return 2 * CKS * wide::kFrag; }
+constexpr int kXBytes = 2 * 2 * 32 * kXS * 4;                      // [row block][current | next][32 rows][kXS]
+constexpr int lds_bytes(int CKS) { return kRegionA + ctx_bytes(CKS) + kXBytes + wide::kBiasFloats * 4; }
+}  // namespace mid
+
+template <int D, int CKS>
+__global__ __launch_bounds__(mid::kThreads) void flow_mid_kernel(const FwdParams p) {
+    namespace W = wide;
+    namespace M = mid;
+    typedef __attribute__((ext_vector_type(16))) float f32x16;
+    typedef __attribute__((ext_vector_type(4))) unsigned int mu32x4;
+    typedef __attribute__((address_space(3))) mu32x4 lds_mu32x4_t;
+    typedef __attribute__((address_space(3))) f32x4 lds_mf32x4_t;
+    typedef __attribute__((address_space(3))) float lds_mf32_t;
+    constexpr int NFP = W::n_frags_padded(D, CKS);
+    constexpr int NB = W::n_batches(D);
+    constexpr int P = M::kP, PS = M::kPS, XS = M::kXS;
+    static_assert(D >= 2 && D <= 16 && CKS > 0, "2 <= D <= 16, conditional flow");
+    static_assert(M::lds_bytes(CKS) <= 160 * 1024, "LDS budget");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 31, hf = lane >> 5;
+    const int ub = wave & 3, rb = wave >> 2;
+    char* const s_act = smem;
+    float* const s_par = reinterpret_cast<float*>(smem) + wave * (64 * PS);
+    char* const s_ctx = smem + M::kRegionA;
+    float* const s_x = reinterpret_cast<float*>(s_ctx + M::ctx_bytes(CKS));
+    float* const s_bias = s_x + 2 * 2 * 32 * XS;
+    const int C = p.plan.C, NL = p.plan.L;
+    const int64_t row0 = (int64_t)blockIdx.x * M::kRowsPerWG;
+    int64_t row = row0 + 32 * rb + n;
+    const bool live = row < p.batch;
+    if (!live) row = p.batch - 1;
+
+    auto lds_a = [](const void* q) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)q; };
+    auto ld_u4 = [](uint32_t a) { return *reinterpret_cast<const lds_mu32x4_t*>(a); };
+    auto st_u4 = [](uint32_t a, mu32x4 v) { *reinterpret_cast<lds_mu32x4_t*>(a) = v; };
+    auto ld_f4 = [](uint32_t a) { return *reinterpret_cast<const lds_mf32x4_t*>(a); };
+    auto st_f4 = [](uint32_t a, f32x4 v) { *reinterpret_cast<lds_mf32x4_t*>(a) = v; };
+    auto ld_f = [](uint32_t a) { return *reinterpret_cast<const lds_mf32_t*>(a); };
+    auto st_f = [](uint32_t a, float v) { *reinterpret_cast<lds_mf32_t*>(a) = v; };
+
+    // ---- staging: context as B fragments (lane (n, hf) element j of k-step ks = ctx[row][16 ks + 8 hf + j]), x, biases ----
+    for (int f = wave; f < 2 * CKS; f += M::kWaves) {
+        const int rbf = f / CKS, ks = f - rbf * CKS;
+        int64_t r = row0 + 32 * rbf + n;
+        if (r >= p.batch) r = p.batch - 1;
+        const float* crow = p.ctx + r * C;
+        bf16x8 o;
+        if ((C & 3) == 0) {
+            const int c0 = 16 * ks + 8 * hf;
+            f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+            if (c0 < C) v0 = *reinterpret_cast<const f32x4*>(crow + c0);
+            if (c0 + 4 < C) v1 = *reinterpret_cast<const f32x4*>(crow + c0 + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { o[j] = (__bf16)v0[j]; o[4 + j] = (__bf16)v1[j]; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c0 = 16 * ks + 8 * hf + j;
+                o[j] = (__bf16)(c0 < C ? crow[c0] : 0.f);
+            }
+        }
+        *reinterpret_cast<bf16x8*>(s_ctx + (size_t)(rbf * CKS + ks) * W::kFrag + lane * 16) = o;
+    }
+    // x^T of the 64 rows: position d of layer 0 <- x[row][ar_perm[D-1-d]] (ReversePermutation first)
+    for (int i = tid; i < 64 * 16; i += M::kThreads) {
+        const int r64 = i >> 4, d = i & 15;
+        int64_t r = row0 + r64;
+        if (r >= p.batch) r = p.batch - 1;
+        float v = 0.f;
+        if (d < D) {
+            const int sd = D - 1 - d;
+            v = p.x[r * D + (p.ar_perm ? p.ar_perm[sd] : sd)];
+        }
+        float* dst = s_x + ((r64 >> 5) * 2) * 32 * XS + (r64 & 31) * XS + d;
+        dst[0] = v;
+        dst[32 * XS] = 0.f;
+    }
+    const float* gbias = reinterpret_cast<const float*>(p.packed + W::stream_frags(D, CKS, NL) * W::kFrag);
+    for (int s = tid; s < W::kBiasFloats / 4; s += M::kThreads)
+        reinterpret_cast<f32x4*>(s_bias)[s] = reinterpret_cast<const f32x4*>(gbias)[s];
+    if (p.zero_pair && blockIdx.x == 0 && tid < 2 * PF_REDUCE_SLOTS) p.zero_pair[tid] = 0.f;
+    __syncthreads();
+
+    // ---- per-lane LDS addresses ---------------------------------------------------------------------------------------
+    const uint32_t act_l = lds_a(s_act) + rb * (W::kKSteps * W::kFrag) + lane * 16;      // + buffer * 32 KiB + ks * 1 KiB
+    const uint32_t sb = lds_a(s_bias + 4 * hf);
+    const uint32_t spw = lds_a(s_par + n * PS + 4 * hf);
+    uint32_t sxc = lds_a(s_x + (rb * 2) * 32 * XS + n * XS);
+    uint32_t sxn = sxc + 32 * XS * 4;
+
+    // ---- weight fragments: buffer loads, entry E of the layer at byte offset `base` -----------------------------------------
+    __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.packed), 0, 0x7fffffff, 0x00020000);
+    const int lane16 = lane * 16;
+    auto ldA = [&](int base, int E) -> mu32x4 {
+        if (PF_MID_ABLATE & 2) return __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16, 0, 0);
+        return __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16, base + E * W::kFrag, 0);
+    };
+    mu32x4 ring0[P], ring1[P];
+    // request the first fragments of a chain of N entries starting at E0
+    auto begin = [&](auto e0, auto nn, mu32x4 (&ring)[P], int base) {
+        constexpr int E0 = decltype(e0)::value, N = decltype(nn)::value;
+        static_for<0, (N < P ? N : P)>([&](auto i) { ring[decltype(i)::value] = ldA(base, E0 + decltype(i)::value); });
+    };
+    // walk the chain: body(k, fragment) issues the MFMA of k-step k; fragment k + P is requested behind it
+    auto run = [&](auto e0, auto nn, mu32x4 (&ring)[P], int base, auto&& body) {
+        constexpr int E0 = decltype(e0)::value, N = decltype(nn)::value;
+        static_for<0, N>([&](auto kk) {
+            constexpr int k = decltype(kk)::value;
+            const mu32x4 a = ring[k % P];
+            if constexpr (k + P < N) ring[k % P] = ldA(base, E0 + k + P);
+            body(kk, a);
+        });
+    };
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto mma = [&](auto first, const mu32x4& a, const bf16x8& b, f32x16& acc) {
+        if (PF_MID_ABLATE & 4) { asm volatile("" :: "v"(a), "v"(b)); if constexpr (decltype(first)::value) acc = zero16; return; }
+        if constexpr (decltype(first)::value)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), b, zero16, 0, 0, 0);
+        else
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), b, acc, 0, 0, 0);
+    };
+    // registers 8 s .. 8 s + 7 of an accumulator tile -> the B fragment of k-step 2 T + s of the next GEMM
+    auto to_b = [&](const f32x16& v, int s, bool relu) {
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float t = v[8 * s + j];
+            o[j] = (__bf16)(relu ? fmaxf(t, 0.f) : t);
+        }
+        return __builtin_bit_cast(mu32x4, o);
+    };
+    unsigned long long tbar = 0;
+    auto barrier = [&]() {
+        if (PF_MID_ABLATE & 8) return;
+        const unsigned long long t0 = PF_MID_TRACE ? __builtin_amdgcn_s_memtime() : 0ull;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (PF_MID_TRACE) tbar += __builtin_amdgcn_s_memtime() - t0;
+    };
+
+    float ld_acc = 0.f;
+    int lbase = 0;                                         // byte offset of the current layer's fragments
+    // diagnostic spans (PF_MID_TRACE): 0 stage 1, 1 W0 (incl. its exchange), 2 W1 + gate, 3 final exchange + GEMMs, 4 transposes +
+    // splines, 5 layer end (barrier + bias reload), 6 barriers (inside the other spans), 7 whole kernel
+    unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto tick = [&]() -> unsigned long long { return PF_MID_TRACE ? __builtin_amdgcn_s_memtime() : 0ull; };
+    const unsigned long long t_begin = tick();
+    unsigned long long ts = t_begin;
+    auto span = [&](int i) { if (PF_MID_TRACE) { const unsigned long long t = tick(); tr[i] += t - ts; ts = t; } };
+
+    const uint32_t sx_base = lds_a(s_x);
+    int sxc_off = 0;                                        // 0 / 1: which half of the x exchange is the current layer's input
+    // per-lane LDS addresses of BOTH row blocks (the front part of a layer -- stage 1 and the residual blocks -- is split by
+    // hidden tile, not by row block: see `front`)
+    const uint32_t act_0 = lds_a(s_act) + lane * 16;                                      // + rb * 16 KiB + buffer * 32 KiB + ks * 1 KiB
+    const uint32_t ctx_0 = lds_a(s_ctx) + lane * 16;                                      // + rb * CKS KiB + ks * 1 KiB
+    constexpr int kActRb = W::kKSteps * W::kFrag, kCtxRb = CKS * W::kFrag;
+    f32x16 h[2];                                             // residual state of this wave's tile: row block 0 | 1
+
+    // ---- front part of a layer, for the wave that owns hidden tile T (compile time) for BOTH row blocks ------------------
+    // Stage 1 and the residual blocks are split over the 8 waves by TILE (wave w < 4: tile w, wave w >= 4: tile 11 - w, so
+    // that the two waves of a SIMD own a light and a heavy tile of the masked layers): a weight fragment is fetched ONCE per
+    // workgroup and multiplied with both row blocks' B operands (first version: a wave owned two tiles of ONE row block, both
+    // row-block waves fetched every fragment, and the CU's vector-memory path -- ~95 GB/s -- was the bound: 15 MB per
+    // workgroup = 158 of 243 us).  Chains alternate between the two rings; stage 1 runs on ring1.
+    auto front = [&](auto tc, auto ubc, int l) {
+        constexpr int T = decltype(tc)::value, UB = decltype(ubc)::value;
+        constexpr bool HAS0 = 2 * UB <= NB - 1;
+        constexpr int M0 = UB;
+        (void)l;
+        // ---- stage 1: h = W_in x + b_in + relu(W_c ctx + b_c) --------------------------------------------------------
+        {
+            bf16x8 xhi[2], xlo[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const uint32_t sx = sx_base + ((r * 2 + sxc_off) * 32 * XS + n * XS) * 4;
+                const f32x4 v0 = ld_f4(sx + 32 * hf), v1 = ld_f4(sx + 32 * hf + 16);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float v = j < 4 ? v0[j & 3] : v1[j & 3];
+                    const __bf16 hi = (__bf16)v;
+                    xhi[r][j] = hi;
+                    xlo[r][j] = (__bf16)(v - (float)hi);
+                }
+            }
+            f32x16 a1[2], a2[2];
+            begin(ic<W::e_blk(D, CKS, 0) + W::w0_off(D, T)>{}, ic<W::kH16(D, T)>{}, ring0, lbase);
+            run(ic<W::e_in(CKS, T)>{}, ic<2 + CKS>{}, ring1, lbase, [&](auto kk, const mu32x4& a) {
+                constexpr int k = decltype(kk)::value;
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    if constexpr (k == 0) mma(ic<1>{}, a, xhi[r], a1[r]);
+                    else if constexpr (k == 1) mma(ic<0>{}, a, xlo[r], a1[r]);
+                    else mma(ic<(k == 2)>{}, a, __builtin_bit_cast(bf16x8, ld_u4(ctx_0 + r * kCtxRb + (k - 2) * W::kFrag)), a2[r]);
+                }
+            });
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 bi = ld_f4(sb + 4 * (W::kBiasIn + 8 * (4 * T + q)));
+                const f32x4 bc = ld_f4(sb + 4 * (W::kBiasCtx + 8 * (4 * T + q)));
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        h[r][4 * q + e] = a1[r][4 * q + e] + bi[e] + fmaxf(a2[r][4 * q + e] + bc[e], 0.f);
+            }
+        }
+        span(0);
+        // ---- residual blocks: h += (W1 relu(W0 relu(h) + b0) + b1) * sigmoid(W_g ctx + b_g) ---------------------------
+        static_for<0, 2>([&](auto bb) {
+            constexpr int b = decltype(bb)::value;
+            constexpr int EB = W::e_blk(D, CKS, b), EW1 = EB + W::w0_len(D);
+            constexpr int OB0 = W::kBiasBlk + 768 * b, OB1 = OB0 + 256, OBG = OB0 + 512;
+            constexpr int NW = W::kH16(D, T);
+            // relu(h) of every tile -> buffer 0 -> everyone's B operand
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                st_u4(act_0 + r * kActRb + (2 * T) * W::kFrag, to_b(h[r], 0, true));
+                st_u4(act_0 + r * kActRb + (2 * T + 1) * W::kFrag, to_b(h[r], 1, true));
+            }
+            barrier();
+            // W0: t = relu(W0 . + b0) -> buffer 1.  (B fragments are read from LDS per k-step: 2 KiB per weight fragment and wave)
+            {
+                f32x16 acc[2];
+                begin(ic<EW1 + W::w1_off(D, CKS, T)>{}, ic<NW + CKS>{}, ring1, lbase);
+                run(ic<EB + W::w0_off(D, T)>{}, ic<NW>{}, ring0, lbase, [&](auto kk, const mu32x4& a) {
+                    constexpr int k = decltype(kk)::value;
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+                        mma(ic<(k == 0)>{}, a, __builtin_bit_cast(bf16x8, ld_u4(act_0 + r * kActRb + k * W::kFrag)), acc[r]);
+                });
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 b0 = ld_f4(sb + 4 * (OB0 + 8 * (4 * T + q)));
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[r][4 * q + e] = acc[r][4 * q + e] + b0[e];
+                }
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    st_u4(act_0 + M::kActBytes / 2 + r * kActRb + (2 * T) * W::kFrag, to_b(acc[r], 0, true));
+                    st_u4(act_0 + M::kActBytes / 2 + r * kActRb + (2 * T + 1) * W::kFrag, to_b(acc[r], 1, true));
+                }
+            }
+            span(1);
+            barrier();
+            // W1 + gate
+            {
+                f32x16 accw[2], accg[2];
+                // what ring0 serves next: the next block's W0, or the first final-layer chain of this wave's unit block
+                if constexpr (b == 0) begin(ic<W::e_blk(D, CKS, 1) + W::w0_off(D, T)>{}, ic<NW>{}, ring0, lbase);
+                else if constexpr (HAS0) begin(ic<W::e_out(D, CKS) + W::out_off(D, M0)>{}, ic<W::kO16(D, 2 * M0)>{}, ring0, lbase);
+                run(ic<EW1 + W::w1_off(D, CKS, T)>{}, ic<NW + CKS>{}, ring1, lbase, [&](auto kk, const mu32x4& a) {
+                    constexpr int k = decltype(kk)::value;
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        if constexpr (k < NW)
+                            mma(ic<(k == 0)>{}, a, __builtin_bit_cast(bf16x8, ld_u4(act_0 + M::kActBytes / 2 + r * kActRb + k * W::kFrag)), accw[r]);
+                        else
+                            mma(ic<(k == NW)>{}, a, __builtin_bit_cast(bf16x8, ld_u4(ctx_0 + r * kCtxRb + (k - NW) * W::kFrag)), accg[r]);
+                    }
+                });
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 b1 = ld_f4(sb + 4 * (OB1 + 8 * (4 * T + q)));
+                    const f32x4 bg = ld_f4(sb + 4 * (OBG + 8 * (4 * T + q)));
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            h[r][4 * q + e] += (accw[r][4 * q + e] + b1[e]) *
+                                               ((PF_MID_ABLATE & 16) ? accg[r][4 * q + e] + bg[e] : pf_sigmoid<true>(accg[r][4 * q + e] + bg[e]));
+                }
+            }
+            span(2);
+        });
+        // h -> buffer 0: the final layer's B operand (no activation in front of it)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            st_u4(act_0 + r * kActRb + (2 * T) * W::kFrag, to_b(h[r], 0, false));
+            st_u4(act_0 + r * kActRb + (2 * T + 1) * W::kFrag, to_b(h[r], 1, false));
+        }
+    };
+
+    // ---- back part of a layer (final masked layer + spline), for the unit block UB of row block rb (run time) ---------------
+    auto back = [&](auto ubc, int l) {
+        constexpr int UB = decltype(ubc)::value;
+        constexpr bool HAS0 = 2 * UB <= NB - 1;            // feature batches of this unit block: m0 = UB, m1 = NB - 1 - UB
+        constexpr bool HAS1 = NB - 1 - UB > UB;
+        constexpr int M0 = UB, M1 = NB - 1 - UB;
+        // ---- final masked layer + spline ----------------------------------------------------------------------------------
+        barrier();
+        mu32x4 bin[W::kKSteps];                               // (h is dead from here: its registers hold the final layer's B operand)
+#pragma unroll
+        for (int k = 0; k < W::kKSteps; ++k) bin[k] = ld_u4(act_l + k * W::kFrag);
+        barrier();                                            // everyone holds h: the buffers become the spline transposes
+        // one feature batch: three chains (widths | heights of feature 2 m, of 2 m + 1, the derivatives of both), the
+        // parameters + bias into this wave's transpose, one (row, feature) pair per lane
+        // The three parts of a batch are separate so that BOTH batches' chains run before the first spline: the spline needs
+        // ~100 registers, and with the 64 registers of `bin` and a ring of prefetched fragments alive beside it the kernel
+        // spilled -- and a scratch reload is a vector-memory load that waits, in order, behind every weight fragment in flight.
+        auto gemm = [&](auto mm, mu32x4 (&ra)[P], mu32x4 (&rb_)[P], auto&& begin_next, f32x16& accA, f32x16& accB, f32x16& accD) {
+            constexpr int MB = decltype(mm)::value;
+            constexpr int E0 = W::e_out(D, CKS) + W::out_off(D, MB);
+            constexpr int NA = W::kO16(D, 2 * MB), NBf = W::kWHb(D, MB), ND = W::kDD(D, MB);
+            constexpr bool HASB = 2 * MB + 1 < D;
+            accA = zero16; accB = zero16; accD = zero16;
+            // ra holds the first fragments of chain A on entry
+            if constexpr (HASB) begin(ic<E0 + NA>{}, ic<NBf>{}, rb_, lbase);
+            else begin(ic<E0 + NA>{}, ic<ND>{}, rb_, lbase);
+            run(ic<E0>{}, ic<NA>{}, ra, lbase, [&](auto kk, const mu32x4& a) {
+                constexpr int k = decltype(kk)::value;
+                mma(ic<(k == 0)>{}, a, __builtin_bit_cast(bf16x8, bin[k]), accA);
+            });
+            if constexpr (HASB) {
+                begin(ic<E0 + NA + NBf>{}, ic<ND>{}, ra, lbase);
+                run(ic<E0 + NA>{}, ic<NBf>{}, rb_, lbase, [&](auto kk, const mu32x4& a) {
+                    constexpr int k = decltype(kk)::value;
+                    mma(ic<(k == 0)>{}, a, __builtin_bit_cast(bf16x8, bin[k]), accB);
+                });
+                begin_next(rb_);
+                run(ic<E0 + NA + NBf>{}, ic<ND>{}, ra, lbase, [&](auto kk, const mu32x4& a) {
+                    constexpr int k = decltype(kk)::value;
+                    mma(ic<(k == 0)>{}, a, __builtin_bit_cast(bf16x8, bin[k]), accD);
+                });
+            } else {
+                begin_next(ra);
+                run(ic<E0 + NA>{}, ic<ND>{}, rb_, lbase, [&](auto kk, const mu32x4& a) {
+                    constexpr int k = decltype(kk)::value;
+                    mma(ic<(k == 0)>{}, a, __builtin_bit_cast(bf16x8, bin[k]), accD);
+                });
+            }
+        };
+        // accumulator quad q (units 8 q + 4 hf .. + 3 of the tile) + bias -> the transpose of lane pair (n, feature)
+        auto put = [&](auto mm, const f32x16& accA, const f32x16& accB, const f32x16& accD) {
+            constexpr int MB = decltype(mm)::value;
+            constexpr bool HASB = 2 * MB + 1 < D;
+            constexpr int OB = W::kBiasOut + 96 * MB;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 ba = ld_f4(sb + 4 * (OB + 8 * q));
+                st_f4(spw + 4 * (8 * q), f32x4{accA[4 * q] + ba[0], accA[4 * q + 1] + ba[1], accA[4 * q + 2] + ba[2], accA[4 * q + 3] + ba[3]});
+                if constexpr (HASB) {
+                    const f32x4 bbv = ld_f4(sb + 4 * (OB + 8 * (4 + q)));
+                    st_f4(spw + 4 * (32 * PS + 8 * q),
+                          f32x4{accB[4 * q] + bbv[0], accB[4 * q + 1] + bbv[1], accB[4 * q + 2] + bbv[2], accB[4 * q + 3] + bbv[3]});
+                }
+                const f32x4 bd = ld_f4(sb + 4 * (OB + 8 * (8 + q)));
+                st_f4(spw + 4 * ((q >> 1) * 32 * PS + 32 + 8 * (q & 1)),
+                      f32x4{accD[4 * q] + bd[0], accD[4 * q + 1] + bd[1], accD[4 * q + 2] + bd[2], accD[4 * q + 3] + bd[3]});
+            }
+        };
+        auto spline = [&](auto mm) {
+            constexpr int MB = decltype(mm)::value;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // wave-private transpose: the wave's own writes, no barrier
+            const int f = 2 * MB + hf;
+            if (f < D) {
+                const float xv = ld_f(sxc + 4 * f);
+                if (p.u_save && live) p.u_save[((int64_t)l * p.batch + row) * D + f] = xv;
+                float y, ld;
+                if (PF_MID_ABLATE & 1) { y = xv + s_par[lane * PS]; ld = 0.f; }
+                else rqs_pair_fast16(s_par + lane * PS, xv, p, y, ld);
+                ld_acc += ld;
+                st_f(sxn + 4 * (D - 1 - f), y);                 // the next layer starts with ReversePermutation
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the transpose is read: it may be rewritten)
+        };
+        if constexpr (HAS0 && HAS1) {
+            // batch M0 starts on ring0 (requested above); its last chain runs on ring0 when HASB (A, B, D = ring0, ring1, ring0)
+            constexpr bool HASB0 = 2 * M0 + 1 < D;
+            f32x16 a0, b0, d0, a1, b1, d1;
+            gemm(ic<M0>{}, ring0, ring1, [&](mu32x4 (&r)[P]) { begin(ic<W::e_out(D, CKS) + W::out_off(D, M1)>{}, ic<W::kO16(D, 2 * M1)>{}, r, lbase); },
+                 a0, b0, d0);
+            put(ic<M0>{}, a0, b0, d0);
+            // the free ring (where M1's first chain was requested): ring1 when M0 has three chains, ring0 otherwise
+            if constexpr (HASB0) gemm(ic<M1>{}, ring1, ring0, [&](mu32x4 (&r)[P]) { (void)r; }, a1, b1, d1);
+            else gemm(ic<M1>{}, ring0, ring1, [&](mu32x4 (&r)[P]) { (void)r; }, a1, b1, d1);
+            span(3);
+            spline(ic<M0>{});
+            put(ic<M1>{}, a1, b1, d1);
+            spline(ic<M1>{});
+            span(4);
+        } else if constexpr (HAS0) {
+            f32x16 a0, b0, d0;
+            gemm(ic<M0>{}, ring0, ring1, [&](mu32x4 (&r)[P]) { (void)r; }, a0, b0, d0);
+            put(ic<M0>{}, a0, b0, d0);
+            span(3);
+            spline(ic<M0>{});
+            span(4);
+        }
+    };
+
+    // wave w owns hidden tile w (w < 4) or 11 - w (w >= 4) in the front part and the batches of unit block w & 3 for row
+    // block w >> 2 in the back part; the front part's code is per wave (tile and unit block are compile-time constants there)
+    auto stage1_begin = [&](int base) {                     // the first fragments of this wave's stage-1 chain -> ring1
+#ifndef PF_MID_TILEMAP
+#define PF_MID_TILEMAP 0   // wave -> hidden tile: 0: (0 1 2 3 | 7 6 5 4) light + heavy per SIMD; 1: (7 5 3 1 | 6 4 2 0) like with like
+#endif
+#if PF_MID_TILEMAP == 0
+#define PF_MID_T0 0
+#define PF_MID_T1 1
+#define PF_MID_T2 2
+#define PF_MID_T3 3
+#define PF_MID_T4 7
+#define PF_MID_T5 6
+#define PF_MID_T6 5
+#define PF_MID_T7 4
+#else
+#define PF_MID_T0 7
+#define PF_MID_T1 5
+#define PF_MID_T2 3
+#define PF_MID_T3 1
+#define PF_MID_T4 6
+#define PF_MID_T5 4
+#define PF_MID_T6 2
+#define PF_MID_T7 0
+#endif
+        if (wave == 0) begin(ic<W::e_in(CKS, PF_MID_T0)>{}, ic<2 + CKS>{}, ring1, base);
+        else if (wave == 1) begin(ic<W::e_in(CKS, PF_MID_T1)>{}, ic<2 + CKS>{}, ring1, base);
+        else if (wave == 2) begin(ic<W::e_in(CKS, PF_MID_T2)>{}, ic<2 + CKS>{}, ring1, base);
+        else if (wave == 3) begin(ic<W::e_in(CKS, PF_MID_T3)>{}, ic<2 + CKS>{}, ring1, base);
+        else if (wave == 4) begin(ic<W::e_in(CKS, PF_MID_T4)>{}, ic<2 + CKS>{}, ring1, base);
+        else if (wave == 5) begin(ic<W::e_in(CKS, PF_MID_T5)>{}, ic<2 + CKS>{}, ring1, base);
+        else if (wave == 6) begin(ic<W::e_in(CKS, PF_MID_T6)>{}, ic<2 + CKS>{}, ring1, base);
+        else begin(ic<W::e_in(CKS, PF_MID_T7)>{}, ic<2 + CKS>{}, ring1, base);
+    };
+    stage1_begin(0);
+    for (int l = 0; l < NL; ++l) {
+        if (wave == 0) front(ic<PF_MID_T0>{}, ic<0>{}, l);
+        else if (wave == 1) front(ic<PF_MID_T1>{}, ic<1>{}, l);
+        else if (wave == 2) front(ic<PF_MID_T2>{}, ic<2>{}, l);
+        else if (wave == 3) front(ic<PF_MID_T3>{}, ic<3>{}, l);
+        else if (wave == 4) front(ic<PF_MID_T4>{}, ic<0>{}, l);
+        else if (wave == 5) front(ic<PF_MID_T5>{}, ic<1>{}, l);
+        else if (wave == 6) front(ic<PF_MID_T6>{}, ic<2>{}, l);
+        else front(ic<PF_MID_T7>{}, ic<3>{}, l);
+        // the next layer's biases: requested now, parked in LDS behind the layer's end (their L2 round trip runs under the back part)
+        constexpr int NBQ4 = W::kBiasFloats / 4;
+        static_assert(NBQ4 <= 2 * M::kThreads, "two bias quads per thread");
+        f32x4 nb0, nb1;
+        {
+            const f32x4* gb = reinterpret_cast<const f32x4*>(gbias + (int64_t)(l + 1 < NL ? l + 1 : l) * W::kBiasFloats);
+            nb0 = gb[tid];
+            nb1 = gb[tid + M::kThreads < NBQ4 ? tid + M::kThreads : 0];
+        }
+        if (ub == 0) back(ic<0>{}, l);
+        else if (ub == 1) back(ic<1>{}, l);
+        else if (ub == 2) back(ic<2>{}, l);
+        else back(ic<3>{}, l);
+        stage1_begin(lbase + NFP * W::kFrag);               // (beyond the last layer: the stream's zero tail; never multiplied)
+        sxc_off ^= 1;
+        lbase += NFP * W::kFrag;
+        { const uint32_t t = sxc; sxc = sxn; sxn = t; }
+        // the layer's end: every spline has written its z; the next layer's biases replace this layer's
+        barrier();
+        if (l + 1 < NL) {
+            reinterpret_cast<f32x4*>(s_bias)[tid] = nb0;
+            if (tid + M::kThreads < NBQ4) reinterpret_cast<f32x4*>(s_bias)[tid + M::kThreads] = nb1;
+            barrier();
+        }
+        span(5);
+    }
+    if (PF_MID_TRACE && p.fail_flags && blockIdx.x == 0 && wave == PF_MID_TRACE_WAVE && lane == 0) {
+        tr[6] = tbar;
+        tr[7] = tick() - t_begin;
+        for (int i = 0; i < 8; ++i) reinterpret_cast<unsigned long long*>(p.fail_flags)[i] = tr[i];
+    }
+
+    // ---- epilogue: log-det of a row = sum over its features (two lanes x four unit blocks), base density, stores ------------
+    float* const s_red = reinterpret_cast<float*>(smem);       // [row block][unit block][32 rows] (the transposes are dead)
+    const float ld_half = ld_acc + __shfl_xor(ld_acc, 32, 64);
+    if (hf == 0) s_red[(rb * 4 + ub) * 32 + n] = ld_half;
+    __syncthreads();
+    float my_nll = 0.f, my_cnt = 0.f;
+    if (ub == 0) {
+        const float ld_row = (s_red[(rb * 4 + 0) * 32 + n] + s_red[(rb * 4 + 1) * 32 + n]) + (s_red[(rb * 4 + 2) * 32 + n] + s_red[(rb * 4 + 3) * 32 + n]);
+        if (hf == 0 && live) {
+            float q = 0.f, sls = 0.f;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const float zv = ld_f(sxc + 4 * (D - 1 - d));     // stored reversed
+                if (p.log_sigma) {                                  // PSDScaledNormal.log_prob, flows.py:73-83
+                    const float ls = p.log_sigma[row * D + d];
+                    const float zs = zv / expf(ls);
+                    q += zs * zs; sls += ls;
+                } else {
+                    q += zv * zv;
+                }
+                if (p.z) p.z[row * D + d] = zv;
+            }
+            if (p.logdet) p.logdet[row] = ld_row;
+            my_nll = 0.5f * (q + 2.f * sls + (float)D * 1.8378770664093453f) - ld_row;
+            my_cnt = 1.f;
+            if (p.nll) p.nll[row] = my_nll;
+        }
+        if (p.nll_sum) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { my_nll += __shfl_xor(my_nll, o, 64); my_cnt += __shfl_xor(my_cnt, o, 64); }
+            if (lane == 0) { float* acc = p.nll_sum + 2 * ((2 * blockIdx.x + rb) % PF_REDUCE_SLOTS); atomicAdd(acc, my_nll); atomicAdd(acc + 1, my_cnt); }
+        }
+    }
+}
+
+}  // namespace pf

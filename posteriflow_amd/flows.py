@@ -556,9 +556,12 @@ class NSFPosteriorFlow(nn.Module):
         return launch
 
     # ---- plumbing -------------------------------------------------------------
-    # ---- the large-batch ("wide") forward kernel: 128 rows per workgroup, weights fetched once per workgroup ----
-    wide_min_batch: int = 20480     # rows from which pf_flow_forward is given the PF_FLAG_WIDE layout (measured crossover:
-                                    # one round of 128-row workgroups = 415 us up to 32768 rows; the 16-row kernel 320 us at 16384)
+    # ---- the PF_FLAG_WIDE layout: 32-unit x 16-k fragments shared by the mid-batch kernel (64 rows per workgroup, two waves
+    # per SIMD: up to 16 384 rows) and the large-batch kernel (128 rows per workgroup, weights through an LDS ring: above);
+    # pf_flow_forward picks between the two by rounds x round time ----
+    wide_min_batch: int = 8193      # rows from which pf_flow_forward is given the PF_FLAG_WIDE layout (measured: the 16-row
+                                    # kernel takes 142 us up to 8192 rows and 232 / 284 us at 12 288 / 16 384; a round of the
+                                    # mid-batch kernel 204 / 217 us there; the large-batch kernel ~340 us up to 32 768 rows)
 
     def _use_wide(self, batch: int) -> bool:
         env = os.environ.get("PF_FLOW_WIDE", "")

@@ -1,5 +1,8 @@
-"""GPU parity of the large-batch ("wide") forward kernel (csrc/pf_flow_wide_kernel.h, PF_FLAG_WIDE): 128 rows per
-workgroup, every wave owns 32 rows through all layers, weights fetched once per workgroup through an LDS ring.
+"""GPU parity of the two kernels over the PF_FLAG_WIDE layout: the large-batch ("wide") forward kernel
+(csrc/pf_flow_wide_kernel.h: 128 rows per workgroup, every wave owns 32 rows through all layers, weights fetched once per
+workgroup through an LDS ring) and the mid-batch kernel (csrc/pf_flow_mid_kernel.h, round 4: 64 rows per workgroup, 8 waves =
+two per SIMD, a wave owns one hidden tile for both row blocks; what pf_flow_forward dispatches up to 16 384 rows).  Every
+test runs for both ($PF_FLOW_MID forces one or the other at any batch size).
 
 It computes the same function in the same arithmetic as the bf16 mode of the 16-row kernel (bf16 operands, x as a hi + lo
 pair, fp32 accumulate / residual / spline) but sums in a different order, so it is checked
@@ -10,12 +13,29 @@ pair, fp32 accumulate / residual / spline) but sums in a different order, so it 
   * for ragged batches, a permuted autoregressive order, a PSD log-scale, the in-kernel loss reduction and the
     training forward's layer inputs.
 """
+import os
+
 import pytest
 import torch
 
 from helpers import flow_inputs, make_pair
 
 pytestmark = pytest.mark.gpu
+
+KERNELS = {"wide": ("0", "pf::flow_wide_kernel<%d, 18>", 128), "mid": ("1", "pf::flow_mid_kernel<%d, 18>", 64)}
+
+
+@pytest.fixture(params=["wide", "mid"])
+def kernel(request):
+    """forces one of the two PF_FLAG_WIDE kernels for the duration of a test; yields (name template, rows per workgroup)"""
+    env, name, rows = KERNELS[request.param]
+    old = os.environ.get("PF_FLOW_MID")
+    os.environ["PF_FLOW_MID"] = env
+    yield name, rows
+    if old is None:
+        os.environ.pop("PF_FLOW_MID", None)
+    else:
+        os.environ["PF_FLOW_MID"] = old
 
 
 def _pair(D, L, scale=1.0):
@@ -34,7 +54,7 @@ def _both(flow, fn):
 
 
 @pytest.mark.parametrize("D,L,B,scale", [(15, 8, 1024, 1.0), (11, 10, 300, 1.0), (15, 2, 4096 + 17, 2.0), (15, 8, 128, 1.0)])
-def test_wide_forward_matches_the_oracle_and_the_16_row_kernel(D, L, B, scale):
+def test_wide_forward_matches_the_oracle_and_the_16_row_kernel(D, L, B, scale, kernel):
     from oracle import nflows_restated as nfr
     from posteriflow_amd import _lib
     ref, ref64, flow = _pair(D, L, scale)
@@ -44,8 +64,8 @@ def test_wide_forward_matches_the_oracle_and_the_16_row_kernel(D, L, B, scale):
             zemu, ldemu = ref(x, ctx)
         z64, ld64 = ref64(x.double(), ctx.double())
         (za, lda), (zw, ldw) = _both(flow, lambda: flow(x.cuda(), ctx.cuda()))
-        assert flow.forward_kernel_name(B) == f"pf::flow_wide_kernel<{D}, 18>"
-        assert _lib.lib().pf_flow_rows_per_workgroup(flow._desc(wide=True), B) == 128
+        assert flow.forward_kernel_name(B) == kernel[0] % D
+        assert _lib.lib().pf_flow_rows_per_workgroup(flow._desc(wide=True), B) == kernel[1]
     q = lambda t: "med %.1e p99 %.1e max %.1e" % tuple(t.quantile(torch.tensor([0.5, 0.99, 1.0], dtype=t.dtype)).tolist())
     ez_w, el_w = (zw.cpu() - zemu).abs().max(dim=1).values, (ldw.cpu() - ldemu).abs()
     ez_a, el_a = (za.cpu() - zemu).abs().max(dim=1).values, (lda.cpu() - ldemu).abs()
@@ -69,13 +89,13 @@ def test_wide_forward_matches_the_oracle_and_the_16_row_kernel(D, L, B, scale):
     assert e64(zw, ldw)[0] < max(1e-3, 1.5 * e64(za, lda)[0]) and e64(zw, ldw)[1] < max(1e-2, 1.5 * e64(za, lda)[1])
 
 
-def test_wide_ragged_order_log_sigma_reduction_and_layer_inputs():
+def test_wide_ragged_order_log_sigma_reduction_and_layer_inputs(kernel):
     D, L = 15, 3
     ref, _, flow = _pair(D, L)
     order = [2, 0, 1, 10, 9, 3, 4, 8, 5, 7, 6, 14, 12, 13, 11]
     ref.set_autoregressive_order(order)
     flow.set_autoregressive_order(order)
-    for B in (1, 31, 129, 1000):
+    for B in (1, 31, 64, 65, 129, 1000):
         x, ctx = flow_inputs(B, D, 288, 5.0, tails=B > 3)
         ls = torch.randn(B, D, generator=torch.Generator().manual_seed(B)) * 0.3
         xg, cg, lg = x.cuda().contiguous(), ctx.cuda().contiguous(), ls.cuda()
@@ -118,15 +138,27 @@ def test_wide_is_refused_where_it_is_not_built():
     assert _lib.lib().pf_flow_inverse(d, 16, 16, 16, 1, None, 1, 16, None, None, None, 0, None) == _lib.PF_ERR_UNSUPPORTED
 
 
-def test_wide_full_size_statistics():
-    """B = 65536 (the size the kernel exists for): finite everywhere, the same mean NLL as the 16-row kernel to
-    1e-4 relative, and 64 sampled rows against the fp32 oracle like test_rows_per_workgroup_choice_and_parity."""
-    D, L, B = 15, 8, 65536
+@pytest.mark.parametrize("B,name,rows", [(65536, "pf::flow_wide_kernel<15, 18>", 128), (16384, "pf::flow_mid_kernel<15, 18>", 64),
+                                         (9000, "pf::flow_mid_kernel<15, 18>", 64), (20000, "pf::flow_wide_kernel<15, 18>", 128),
+                                         (8192, "pf::flow_kernel<true, 16, 2, 9, 0, false>", 32)])
+def test_wide_full_size_statistics(B, name, rows):
+    """The sizes the two kernels exist for, through pf_flow_forward's OWN choice (no forcing): 65 536 rows -> the large-batch
+    kernel, 16 384 / 9 000 -> the mid-batch kernel, 8 192 -> still the 16-row kernel.  Finite everywhere, the same mean NLL as
+    the 16-row kernel to 1e-4 relative, and 64 sampled rows against the fp32 oracle like
+    test_rows_per_workgroup_choice_and_parity."""
+    from posteriflow_amd import _lib
+    D, L = 15, 8
     ref, _, flow = _pair(D, L, 2.0)
+    assert "PF_FLOW_MID" not in os.environ and "PF_FLOW_WIDE" not in os.environ
+    assert flow.forward_kernel_name(B) == name
+    assert _lib.lib().pf_flow_rows_per_workgroup(flow._desc(wide=flow._use_wide(B)), B) == rows
     x, ctx = flow_inputs(B, D, 288, 5.0)
     xg, cg = x.cuda(), ctx.cuda()
     with torch.no_grad():
-        a, w = _both(flow, lambda: flow.compute_psd_aware_nll(xg, cg, None))
+        flow.wide_min_batch = 1 << 40
+        a = flow.compute_psd_aware_nll(xg, cg, None)
+        flow.wide_min_batch = type(flow).wide_min_batch          # the product's own threshold
+        w = flow.compute_psd_aware_nll(xg, cg, None)
         idx = torch.linspace(0, B - 1, 64).long()
         want = ref.compute_psd_aware_nll(x[idx], ctx[idx], torch.zeros(64, D))
     assert torch.isfinite(w).all()
