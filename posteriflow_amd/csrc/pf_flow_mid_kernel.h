@@ -34,6 +34,12 @@
 #define PF_MID_ABLATE 0   // timing experiments only: 1 no spline, 2 every weight load on one address, 4 no MFMA, 8 no barriers, 16 no sigmoid
 #endif
 
+#ifndef PF_MID_BD
+#define PF_MID_BD 2                      // k-steps of B operands (LDS) in flight ahead of the MFMAs of the front part
+#endif
+#ifndef PF_MID_S1_EARLY
+#define PF_MID_S1_EARLY 1
+#endif
 #ifndef PF_MID_TRACE
 #define PF_MID_TRACE 0    // diagnostic build: wave PF_MID_TRACE_WAVE of workgroup 0 accumulates s_memtime spans into p.fail_flags
 #endif
@@ -137,9 +143,9 @@ __global__ __launch_bounds__(mid::kThreads) void flow_mid_kernel(const FwdParams
     __syncthreads();
 
     // ---- per-lane LDS addresses ---------------------------------------------------------------------------------------
-    const uint32_t act_l = lds_a(s_act) + rb * (W::kKSteps * W::kFrag) + lane * 16;      // + buffer * 32 KiB + ks * 1 KiB
-    const uint32_t sb = lds_a(s_bias + 4 * hf);
-    const uint32_t spw = lds_a(s_par + n * PS + 4 * hf);
+    uint32_t act_l = lds_a(s_act) + rb * (W::kKSteps * W::kFrag) + lane * 16;      // + buffer * 32 KiB + ks * 1 KiB
+    uint32_t sb = lds_a(s_bias + 4 * hf);
+    uint32_t spw = lds_a(s_par + n * PS + 4 * hf);
     uint32_t sxc = lds_a(s_x + (rb * 2) * 32 * XS + n * XS);
     uint32_t sxn = sxc + 32 * XS * 4;
 
@@ -152,20 +158,53 @@ __global__ __launch_bounds__(mid::kThreads) void flow_mid_kernel(const FwdParams
     };
     mu32x4 ring0[P], ring1[P];
     // request the first fragments of a chain of N entries starting at E0
-    auto begin = [&](auto e0, auto nn, mu32x4 (&ring)[P], int base) {
+    auto begin = [&](auto e0, auto nn, auto& ring, int base) {
         constexpr int E0 = decltype(e0)::value, N = decltype(nn)::value;
-        static_for<0, (N < P ? N : P)>([&](auto i) { ring[decltype(i)::value] = ldA(base, E0 + decltype(i)::value); });
+        constexpr int RP = (int)(sizeof(ring) / sizeof(ring[0]));
+        static_for<0, (N < RP ? N : RP)>([&](auto i) { ring[decltype(i)::value] = ldA(base, E0 + decltype(i)::value); });
     };
     // walk the chain: body(k, fragment) issues the MFMA of k-step k; fragment k + P is requested behind it
-    auto run = [&](auto e0, auto nn, mu32x4 (&ring)[P], int base, auto&& body) {
+    auto run = [&](auto e0, auto nn, auto& ring, int base, auto&& body) {
         constexpr int E0 = decltype(e0)::value, N = decltype(nn)::value;
+        constexpr int RP = (int)(sizeof(ring) / sizeof(ring[0]));
         static_for<0, N>([&](auto kk) {
             constexpr int k = decltype(kk)::value;
-            const mu32x4 a = ring[k % P];
-            if constexpr (k + P < N) ring[k % P] = ldA(base, E0 + k + P);
+            const mu32x4 a = ring[k % RP];
+            if constexpr (k + RP < N) ring[k % RP] = ldA(base, E0 + k + RP);
             body(kk, a);
         });
     };
+    // the front part's chains: the B operands (activations / context in LDS) of k-step k + PF_MID_BD are requested right behind the
+    // MFMAs of k-step k, in that order (sched_barrier): left to the compiler every ds_read sat one instruction ahead of the MFMA
+    // that needs it, and a heavy wave paid an LDS round trip per k-step (320 cycles per step against 64 of MFMA)
+    auto run_b = [&](auto e0, auto nn, auto& ring, int base, auto&& ldb, auto&& mm) {
+        constexpr int E0 = decltype(e0)::value, N = decltype(nn)::value;
+        constexpr int RP = (int)(sizeof(ring) / sizeof(ring[0]));
+        constexpr int BD = PF_MID_BD;
+        mu32x4 bq[BD][2];
+        static_for<0, (N < BD ? N : BD)>([&](auto i) {
+            bq[decltype(i)::value][0] = ldb(i, ic<0>{});
+            bq[decltype(i)::value][1] = ldb(i, ic<1>{});
+        });
+        static_for<0, N>([&](auto kk) {
+            constexpr int k = decltype(kk)::value;
+            const mu32x4 a = ring[k % RP];
+            if constexpr (k + RP < N) ring[k % RP] = ldA(base, E0 + k + RP);
+            mm(kk, ic<0>{}, a, bq[k % BD][0]);
+            mm(kk, ic<1>{}, a, bq[k % BD][1]);
+            if constexpr (k + BD < N) {
+                bq[k % BD][0] = ldb(ic<k + BD>{}, ic<0>{});
+                bq[k % BD][1] = ldb(ic<k + BD>{}, ic<1>{});
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    // the back part (short chains) runs on the two halves of ring0, so that ring1 can hold the next layer's first stage-1
+    // fragments from the start of the back part (requested right before stage 1 their L2 round trip was 10 % of the kernel)
+    static_assert(P % 2 == 0, "ring halves");
+    typedef mu32x4 half_ring_t[P / 2];
+    half_ring_t& half0 = *reinterpret_cast<half_ring_t*>(&ring0[0]);
+    half_ring_t& half1 = *reinterpret_cast<half_ring_t*>(&ring0[P / 2]);
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     auto mma = [&](auto first, const mu32x4& a, const bf16x8& b, f32x16& acc) {
         if (PF_MID_ABLATE & 4) { asm volatile("" :: "v"(a), "v"(b)); if constexpr (decltype(first)::value) acc = zero16; return; }
@@ -202,12 +241,12 @@ __global__ __launch_bounds__(mid::kThreads) void flow_mid_kernel(const FwdParams
     unsigned long long ts = t_begin;
     auto span = [&](int i) { if (PF_MID_TRACE) { const unsigned long long t = tick(); tr[i] += t - ts; ts = t; } };
 
-    const uint32_t sx_base = lds_a(s_x);
+    uint32_t sx_base = lds_a(s_x);
     int sxc_off = 0;                                        // 0 / 1: which half of the x exchange is the current layer's input
     // per-lane LDS addresses of BOTH row blocks (the front part of a layer -- stage 1 and the residual blocks -- is split by
     // hidden tile, not by row block: see `front`)
-    const uint32_t act_0 = lds_a(s_act) + lane * 16;                                      // + rb * 16 KiB + buffer * 32 KiB + ks * 1 KiB
-    const uint32_t ctx_0 = lds_a(s_ctx) + lane * 16;                                      // + rb * CKS KiB + ks * 1 KiB
+    uint32_t act_0 = lds_a(s_act) + lane * 16;                                      // + rb * 16 KiB + buffer * 32 KiB + ks * 1 KiB
+    uint32_t ctx_0 = lds_a(s_ctx) + lane * 16;                                      // + rb * CKS KiB + ks * 1 KiB
     constexpr int kActRb = W::kKSteps * W::kFrag, kCtxRb = CKS * W::kFrag;
     f32x16 h[2];                                             // residual state of this wave's tile: row block 0 | 1
 
@@ -239,15 +278,18 @@ __global__ __launch_bounds__(mid::kThreads) void flow_mid_kernel(const FwdParams
             }
             f32x16 a1[2], a2[2];
             begin(ic<W::e_blk(D, CKS, 0) + W::w0_off(D, T)>{}, ic<W::kH16(D, T)>{}, ring0, lbase);
-            run(ic<W::e_in(CKS, T)>{}, ic<2 + CKS>{}, ring1, lbase, [&](auto kk, const mu32x4& a) {
-                constexpr int k = decltype(kk)::value;
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    if constexpr (k == 0) mma(ic<1>{}, a, xhi[r], a1[r]);
-                    else if constexpr (k == 1) mma(ic<0>{}, a, xlo[r], a1[r]);
-                    else mma(ic<(k == 2)>{}, a, __builtin_bit_cast(bf16x8, ld_u4(ctx_0 + r * kCtxRb + (k - 2) * W::kFrag)), a2[r]);
-                }
-            });
+            run_b(ic<W::e_in(CKS, T)>{}, ic<2 + CKS>{}, ring1, lbase,
+                  [&](auto kk, auto rc) -> mu32x4 {
+                      constexpr int k = decltype(kk)::value, r = decltype(rc)::value;
+                      if constexpr (k == 0) return __builtin_bit_cast(mu32x4, xhi[r]);
+                      else if constexpr (k == 1) return __builtin_bit_cast(mu32x4, xlo[r]);
+                      else return ld_u4(ctx_0 + r * kCtxRb + (k - 2) * W::kFrag);
+                  },
+                  [&](auto kk, auto rc, const mu32x4& a, const mu32x4& b) {
+                      constexpr int k = decltype(kk)::value, r = decltype(rc)::value;
+                      if constexpr (k < 2) mma(ic<(k == 0)>{}, a, __builtin_bit_cast(bf16x8, b), a1[r]);
+                      else mma(ic<(k == 2)>{}, a, __builtin_bit_cast(bf16x8, b), a2[r]);
+                  });
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const f32x4 bi = ld_f4(sb + 4 * (W::kBiasIn + 8 * (4 * T + q)));
@@ -277,12 +319,11 @@ __global__ __launch_bounds__(mid::kThreads) void flow_mid_kernel(const FwdParams
             {
                 f32x16 acc[2];
                 begin(ic<EW1 + W::w1_off(D, CKS, T)>{}, ic<NW + CKS>{}, ring1, lbase);
-                run(ic<EB + W::w0_off(D, T)>{}, ic<NW>{}, ring0, lbase, [&](auto kk, const mu32x4& a) {
-                    constexpr int k = decltype(kk)::value;
-#pragma unroll
-                    for (int r = 0; r < 2; ++r)
-                        mma(ic<(k == 0)>{}, a, __builtin_bit_cast(bf16x8, ld_u4(act_0 + r * kActRb + k * W::kFrag)), acc[r]);
-                });
+                run_b(ic<EB + W::w0_off(D, T)>{}, ic<NW>{}, ring0, lbase,
+                      [&](auto kk, auto rc) -> mu32x4 { return ld_u4(act_0 + decltype(rc)::value * kActRb + decltype(kk)::value * W::kFrag); },
+                      [&](auto kk, auto rc, const mu32x4& a, const mu32x4& b) {
+                          mma(ic<(decltype(kk)::value == 0)>{}, a, __builtin_bit_cast(bf16x8, b), acc[decltype(rc)::value]);
+                      });
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const f32x4 b0 = ld_f4(sb + 4 * (OB0 + 8 * (4 * T + q)));
@@ -304,17 +345,18 @@ __global__ __launch_bounds__(mid::kThreads) void flow_mid_kernel(const FwdParams
                 f32x16 accw[2], accg[2];
                 // what ring0 serves next: the next block's W0, or the first final-layer chain of this wave's unit block
                 if constexpr (b == 0) begin(ic<W::e_blk(D, CKS, 1) + W::w0_off(D, T)>{}, ic<NW>{}, ring0, lbase);
-                else if constexpr (HAS0) begin(ic<W::e_out(D, CKS) + W::out_off(D, M0)>{}, ic<W::kO16(D, 2 * M0)>{}, ring0, lbase);
-                run(ic<EW1 + W::w1_off(D, CKS, T)>{}, ic<NW + CKS>{}, ring1, lbase, [&](auto kk, const mu32x4& a) {
-                    constexpr int k = decltype(kk)::value;
-#pragma unroll
-                    for (int r = 0; r < 2; ++r) {
-                        if constexpr (k < NW)
-                            mma(ic<(k == 0)>{}, a, __builtin_bit_cast(bf16x8, ld_u4(act_0 + M::kActBytes / 2 + r * kActRb + k * W::kFrag)), accw[r]);
-                        else
-                            mma(ic<(k == NW)>{}, a, __builtin_bit_cast(bf16x8, ld_u4(ctx_0 + r * kCtxRb + (k - NW) * W::kFrag)), accg[r]);
-                    }
-                });
+                else if constexpr (HAS0) begin(ic<W::e_out(D, CKS) + W::out_off(D, M0)>{}, ic<W::kO16(D, 2 * M0)>{}, half0, lbase);
+                run_b(ic<EW1 + W::w1_off(D, CKS, T)>{}, ic<NW + CKS>{}, ring1, lbase,
+                      [&](auto kk, auto rc) -> mu32x4 {
+                          constexpr int k = decltype(kk)::value, r = decltype(rc)::value;
+                          if constexpr (k < NW) return ld_u4(act_0 + M::kActBytes / 2 + r * kActRb + k * W::kFrag);
+                          else return ld_u4(ctx_0 + r * kCtxRb + (k - NW) * W::kFrag);
+                      },
+                      [&](auto kk, auto rc, const mu32x4& a, const mu32x4& b) {
+                          constexpr int k = decltype(kk)::value, r = decltype(rc)::value;
+                          if constexpr (k < NW) mma(ic<(k == 0)>{}, a, __builtin_bit_cast(bf16x8, b), accw[r]);
+                          else mma(ic<(k == NW)>{}, a, __builtin_bit_cast(bf16x8, b), accg[r]);
+                      });
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const f32x4 b1 = ld_f4(sb + 4 * (OB1 + 8 * (4 * T + q)));
@@ -354,7 +396,7 @@ __global__ __launch_bounds__(mid::kThreads) void flow_mid_kernel(const FwdParams
         // The three parts of a batch are separate so that BOTH batches' chains run before the first spline: the spline needs
         // ~100 registers, and with the 64 registers of `bin` and a ring of prefetched fragments alive beside it the kernel
         // spilled -- and a scratch reload is a vector-memory load that waits, in order, behind every weight fragment in flight.
-        auto gemm = [&](auto mm, mu32x4 (&ra)[P], mu32x4 (&rb_)[P], auto&& begin_next, f32x16& accA, f32x16& accB, f32x16& accD) {
+        auto gemm = [&](auto mm, half_ring_t& ra, half_ring_t& rb_, auto&& begin_next, f32x16& accA, f32x16& accB, f32x16& accD) {
             constexpr int MB = decltype(mm)::value;
             constexpr int E0 = W::e_out(D, CKS) + W::out_off(D, MB);
             constexpr int NA = W::kO16(D, 2 * MB), NBf = W::kWHb(D, MB), ND = W::kDD(D, MB);
@@ -424,12 +466,12 @@ __global__ __launch_bounds__(mid::kThreads) void flow_mid_kernel(const FwdParams
             // batch M0 starts on ring0 (requested above); its last chain runs on ring0 when HASB (A, B, D = ring0, ring1, ring0)
             constexpr bool HASB0 = 2 * M0 + 1 < D;
             f32x16 a0, b0, d0, a1, b1, d1;
-            gemm(ic<M0>{}, ring0, ring1, [&](mu32x4 (&r)[P]) { begin(ic<W::e_out(D, CKS) + W::out_off(D, M1)>{}, ic<W::kO16(D, 2 * M1)>{}, r, lbase); },
+            gemm(ic<M0>{}, half0, half1, [&](half_ring_t& r) { begin(ic<W::e_out(D, CKS) + W::out_off(D, M1)>{}, ic<W::kO16(D, 2 * M1)>{}, r, lbase); },
                  a0, b0, d0);
             put(ic<M0>{}, a0, b0, d0);
             // the free ring (where M1's first chain was requested): ring1 when M0 has three chains, ring0 otherwise
-            if constexpr (HASB0) gemm(ic<M1>{}, ring1, ring0, [&](mu32x4 (&r)[P]) { (void)r; }, a1, b1, d1);
-            else gemm(ic<M1>{}, ring0, ring1, [&](mu32x4 (&r)[P]) { (void)r; }, a1, b1, d1);
+            if constexpr (HASB0) gemm(ic<M1>{}, half1, half0, [&](half_ring_t& r) { (void)r; }, a1, b1, d1);
+            else gemm(ic<M1>{}, half0, half1, [&](half_ring_t& r) { (void)r; }, a1, b1, d1);
             span(3);
             spline(ic<M0>{});
             put(ic<M1>{}, a1, b1, d1);
@@ -437,7 +479,7 @@ __global__ __launch_bounds__(mid::kThreads) void flow_mid_kernel(const FwdParams
             span(4);
         } else if constexpr (HAS0) {
             f32x16 a0, b0, d0;
-            gemm(ic<M0>{}, ring0, ring1, [&](mu32x4 (&r)[P]) { (void)r; }, a0, b0, d0);
+            gemm(ic<M0>{}, half0, half1, [&](half_ring_t& r) { (void)r; }, a0, b0, d0);
             put(ic<M0>{}, a0, b0, d0);
             span(3);
             spline(ic<M0>{});
@@ -481,6 +523,10 @@ __global__ __launch_bounds__(mid::kThreads) void flow_mid_kernel(const FwdParams
     };
     stage1_begin(0);
     for (int l = 0; l < NL; ++l) {
+        // per-lane LDS bases re-"defined" at the top of every layer: left alone, the compiler hoists every base + constant out
+        // of the layer loop into its own register and spills them (37 spilled VGPRs, reloaded behind the weight loads in
+        // flight); this way base + constant stays an instruction offset (all of them fit the 16-bit field)
+        asm volatile("" : "+v"(act_0), "+v"(ctx_0), "+v"(act_l), "+v"(sb), "+v"(spw), "+v"(sx_base), "+v"(sxc), "+v"(sxn));
         if (wave == 0) front(ic<PF_MID_T0>{}, ic<0>{}, l);
         else if (wave == 1) front(ic<PF_MID_T1>{}, ic<1>{}, l);
         else if (wave == 2) front(ic<PF_MID_T2>{}, ic<2>{}, l);
@@ -498,11 +544,13 @@ __global__ __launch_bounds__(mid::kThreads) void flow_mid_kernel(const FwdParams
             nb0 = gb[tid];
             nb1 = gb[tid + M::kThreads < NBQ4 ? tid + M::kThreads : 0];
         }
+        if (PF_MID_S1_EARLY) stage1_begin(lbase + NFP * W::kFrag);  // next layer's stage 1 -> ring1, free from here (beyond the last
+                                                            // layer: the stream's zero tail; never multiplied)
         if (ub == 0) back(ic<0>{}, l);
         else if (ub == 1) back(ic<1>{}, l);
         else if (ub == 2) back(ic<2>{}, l);
         else back(ic<3>{}, l);
-        stage1_begin(lbase + NFP * W::kFrag);               // (beyond the last layer: the stream's zero tail; never multiplied)
+        if (!PF_MID_S1_EARLY) stage1_begin(lbase + NFP * W::kFrag);
         sxc_off ^= 1;
         lbase += NFP * W::kFrag;
         { const uint32_t t = sxc; sxc = sxn; sxn = t; }
