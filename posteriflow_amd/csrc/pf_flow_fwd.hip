@@ -26,10 +26,10 @@ int launch_flow_mid_d11(const FwdParams&, hipStream_t);
 
 // A PF_FLAG_WIDE plan is served by two kernels over the same packed stream: the mid-batch kernel (64 rows per workgroup, 8
 // waves = two per SIMD: pf_flow_mid_kernel.h) and the large-batch kernel (128 rows per workgroup, one wave per SIMD).  A launch
-// costs rounds x round time (measured: a round of 256 64-row workgroups 217 us, of 256 128-row workgroups ~310 us when every
+// costs rounds x round time (measured: a round of 256 64-row workgroups 192 us, of 256 128-row workgroups ~310 us when every
 // round is full): up to 16 384 rows the mid kernel's single round wins, above it the large-batch kernel's fewer rounds.
 // $PF_FLOW_MID (test knob, read per call): 0 never the mid kernel, 1 always.
-constexpr double kMidRoundUs = 217.0, kWideRoundUs = 310.0;
+constexpr double kMidRoundUs = 192.0, kWideRoundUs = 310.0;
 static bool use_mid(const FlowPlan& L, int64_t batch) {
     if (!L.wide) return false;
     if (const char* e = getenv("PF_FLOW_MID")) return atoi(e) != 0;

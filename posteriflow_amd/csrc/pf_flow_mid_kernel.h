@@ -5,22 +5,26 @@
 // nflows' MADE + RQS), same packed stream as the large-batch kernel (PF_FLAG_WIDE layout, pf_wide_layout.h: 32-unit x 16-k
 // fragments in the accumulator-permuted k order, masked k-steps absent), different work split:
 //
-//   workgroup = 64 batch rows, 8 waves = 4 unit blocks x 2 row blocks, TWO waves per SIMD (<= 256 registers each), so that
-//   one wave's MFMA chain runs under the other's epilogue / LDS / load issue -- with one wave per SIMD those costs add
-//   (LABLOG 4.9).  Wave (ub, rb) owns the hidden tiles TA = ub and TB = 7 - ub (32 units each: the masked k lengths of such
-//   a pair sum to the same count for every ub) for the 32 rows of row block rb, on v_mfma_f32_32x32x16_bf16.
-//   Its residual state h (2 tiles x 16 accumulator registers) stays in registers; the bf16 activations a dependent GEMM
-//   needs from the other unit blocks are exchanged through LDS in B-fragment order (a 32 x 32 accumulator tile converted
-//   pairwise to bf16 IS two k-steps of the next GEMM's B operand in this layout's k order): 4 KiB written and 16 KiB read
-//   per wave and GEMM, one barrier per dependent GEMM, two buffers.  The bf16 context of a row block lives in LDS as B
-//   fragments (36 KiB for C = 288) and is read per k-step.
-//   Weight fragments come straight from L2 into registers (buffer loads, two rings of kP fragments alternating between
-//   consecutive MFMA chains so that a chain's first fragments are requested while the previous chain runs); the two row
-//   blocks of a unit block request the same fragments at about the same time.
-//   Final layer + spline: the (D + 1) / 2 feature batches (widths | heights of two features + their derivatives = three
-//   32-unit tiles, as in the large-batch kernel) are dealt to the unit blocks in balanced pairs (m, NB - 1 - m); a wave
-//   transposes its 64 (row, feature) pairs through a private LDS area (overlaying the activation buffers, which are dead
-//   by then) and evaluates one pair per lane with rqs_pair_fast16.
+//   workgroup = 64 batch rows = two row blocks of 32, 8 waves, TWO waves per SIMD (<= 256 registers each), so that one
+//   wave's MFMA chain runs under the other's epilogue / LDS / load issue -- with one wave per SIMD those costs add
+//   (LABLOG 4.9) -- on v_mfma_f32_32x32x16_bf16.
+//   Front part of a layer (stage 1, two residual blocks): wave w owns ONE hidden tile (32 units; waves 0-3: tiles 0-3, waves
+//   4-7: tiles 7-4, a light and a heavy tile of the masked layers per SIMD) for BOTH row blocks: a weight fragment is
+//   fetched once per workgroup, straight from L2 into a register ring (buffer loads, two rings of PF_MID_P fragments
+//   alternating between consecutive chains so that a chain's first fragments are requested while the previous chain runs),
+//   and multiplied with both row blocks' B operands.  The residual state h (2 x 16 accumulator registers) stays in
+//   registers; the bf16 activations a dependent GEMM needs from the other tiles go through LDS in B-fragment order (a
+//   32 x 32 accumulator tile converted pairwise to bf16 IS two k-steps of the next GEMM's B operand in this layout's k
+//   order): one barrier per dependent GEMM, two buffers.  The bf16 context lives in LDS as B fragments (36 KiB for
+//   C = 288).  B operands are read per k-step, PF_MID_BD k-steps AHEAD of their MFMAs in an order pinned by sched_barrier:
+//   left to the compiler every ds_read sat right in front of its MFMA and a k-step cost an LDS round trip (216 -> 192 us).
+//   Back part (final masked layer + spline): wave w owns ONE feature batch (widths | heights of two features + their
+//   derivatives = three 32-unit tiles, consecutive in the stream: one chain) for both row blocks, B = h from buffer 0;
+//   after a barrier the transposes (wave-private, overlaying the activation buffers) take the parameters and one
+//   (row, feature) pair per lane goes through rqs_pair_fast16, row block after row block.
+//   What bounds it (ablations, LABLOG R4.9): LDS reads of the B operands (2 KiB per fragment and wave = 1.9 MB per layer:
+//   ~50 us at the LDS peak), the MFMAs (50 us) and the weight stream (7.7 MB per workgroup = 85 us at the CU's ingest rate)
+//   overlap only partly; balancing the waves' k-step counts does not change the time (built and measured).
 //
 // Numerics = the large-batch kernel's: bf16 operands (x as a hi + lo pair), fp32 accumulation, fp32 residual / bias /
 // spline; bias added after the chain.
@@ -34,6 +38,9 @@
 #define PF_MID_ABLATE 0   // timing experiments only: 1 no spline, 2 every weight load on one address, 4 no MFMA, 8 no barriers, 16 no sigmoid
 #endif
 
+#ifndef PF_MID_P
+#define PF_MID_P 6                       // weight fragments in flight per ring
+#endif
 #ifndef PF_MID_BD
 #define PF_MID_BD 2                      // k-steps of B operands (LDS) in flight ahead of the MFMAs of the front part
 #endif
@@ -52,7 +59,7 @@ namespace mid {
 constexpr int kRowsPerWG = 64, kWaves = 8, kThreads = 64 * kWaves;
 constexpr int kXS = 16;                                            // floats per row of the x / z exchange
 constexpr int kPS = wide::kParStride;                              // floats per (row, feature) pair of the spline transpose
-constexpr int kP = 8;                                              // weight fragments in flight per ring (two rings)
+constexpr int kP = PF_MID_P;                                             // weight fragments in flight per ring (two rings)
 constexpr int kActBytes = 2 * 2 * wide::kKSteps * wide::kFrag;     // [buffer][row block][k-step][1 KiB]
 constexpr int kParBytes = kWaves * 64 * kPS * 4;                   // wave-private spline transposes (overlay the above)
 constexpr int kRegionA = kParBytes > kActBytes ? kParBytes : kActBytes;
@@ -143,11 +150,8 @@ __global__ __launch_bounds__(mid::kThreads) void flow_mid_kernel(const FwdParams
     __syncthreads();
 
     // ---- per-lane LDS addresses ---------------------------------------------------------------------------------------
-    uint32_t act_l = lds_a(s_act) + rb * (W::kKSteps * W::kFrag) + lane * 16;      // + buffer * 32 KiB + ks * 1 KiB
     uint32_t sb = lds_a(s_bias + 4 * hf);
     uint32_t spw = lds_a(s_par + n * PS + 4 * hf);
-    uint32_t sxc = lds_a(s_x + (rb * 2) * 32 * XS + n * XS);
-    uint32_t sxn = sxc + 32 * XS * 4;
 
     // ---- weight fragments: buffer loads, entry E of the layer at byte offset `base` -----------------------------------------
     __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.packed), 0, 0x7fffffff, 0x00020000);
@@ -163,19 +167,8 @@ __global__ __launch_bounds__(mid::kThreads) void flow_mid_kernel(const FwdParams
         constexpr int RP = (int)(sizeof(ring) / sizeof(ring[0]));
         static_for<0, (N < RP ? N : RP)>([&](auto i) { ring[decltype(i)::value] = ldA(base, E0 + decltype(i)::value); });
     };
-    // walk the chain: body(k, fragment) issues the MFMA of k-step k; fragment k + P is requested behind it
-    auto run = [&](auto e0, auto nn, auto& ring, int base, auto&& body) {
-        constexpr int E0 = decltype(e0)::value, N = decltype(nn)::value;
-        constexpr int RP = (int)(sizeof(ring) / sizeof(ring[0]));
-        static_for<0, N>([&](auto kk) {
-            constexpr int k = decltype(kk)::value;
-            const mu32x4 a = ring[k % RP];
-            if constexpr (k + RP < N) ring[k % RP] = ldA(base, E0 + k + RP);
-            body(kk, a);
-        });
-    };
-    // the front part's chains: the B operands (activations / context in LDS) of k-step k + PF_MID_BD are requested right behind the
-    // MFMAs of k-step k, in that order (sched_barrier): left to the compiler every ds_read sat one instruction ahead of the MFMA
+    // walk a chain: fragment k + ring depth is requested behind the MFMAs of k-step k, and the B operands (activations / context in
+    // LDS) of k-step k + PF_MID_BD right behind them, in that order (sched_barrier): left to the compiler every ds_read sat one instruction ahead of the MFMA
     // that needs it, and a heavy wave paid an LDS round trip per k-step (320 cycles per step against 64 of MFMA)
     auto run_b = [&](auto e0, auto nn, auto& ring, int base, auto&& ldb, auto&& mm) {
         constexpr int E0 = decltype(e0)::value, N = decltype(nn)::value;
@@ -199,12 +192,6 @@ __global__ __launch_bounds__(mid::kThreads) void flow_mid_kernel(const FwdParams
             __builtin_amdgcn_sched_barrier(0);
         });
     };
-    // the back part (short chains) runs on the two halves of ring0, so that ring1 can hold the next layer's first stage-1
-    // fragments from the start of the back part (requested right before stage 1 their L2 round trip was 10 % of the kernel)
-    static_assert(P % 2 == 0, "ring halves");
-    typedef mu32x4 half_ring_t[P / 2];
-    half_ring_t& half0 = *reinterpret_cast<half_ring_t*>(&ring0[0]);
-    half_ring_t& half1 = *reinterpret_cast<half_ring_t*>(&ring0[P / 2]);
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     auto mma = [&](auto first, const mu32x4& a, const bf16x8& b, f32x16& acc) {
         if (PF_MID_ABLATE & 4) { asm volatile("" :: "v"(a), "v"(b)); if constexpr (decltype(first)::value) acc = zero16; return; }
@@ -231,7 +218,7 @@ __global__ __launch_bounds__(mid::kThreads) void flow_mid_kernel(const FwdParams
         if (PF_MID_TRACE) tbar += __builtin_amdgcn_s_memtime() - t0;
     };
 
-    float ld_acc = 0.f;
+    float ld_acc[2] = {0.f, 0.f};                           // log-det terms of this lane's (row n of row block r, feature) pairs
     int lbase = 0;                                         // byte offset of the current layer's fragments
     // diagnostic spans (PF_MID_TRACE): 0 stage 1, 1 W0 (incl. its exchange), 2 W1 + gate, 3 final exchange + GEMMs, 4 transposes +
     // splines, 5 layer end (barrier + bias reload), 6 barriers (inside the other spans), 7 whole kernel
@@ -250,16 +237,17 @@ __global__ __launch_bounds__(mid::kThreads) void flow_mid_kernel(const FwdParams
     constexpr int kActRb = W::kKSteps * W::kFrag, kCtxRb = CKS * W::kFrag;
     f32x16 h[2];                                             // residual state of this wave's tile: row block 0 | 1
 
+    // entries of feature batch m's final-layer chain (its three tiles are consecutive in the stream)
+    auto out_len_f = [](int m) constexpr { return m < 0 ? 0 : W::kO16(D, 2 * m) + (2 * m + 1 < D ? W::kWHb(D, m) : 0) + W::kDD(D, m); };
+#define out_len(m) (out_len_f(m))
     // ---- front part of a layer, for the wave that owns hidden tile T (compile time) for BOTH row blocks ------------------
     // Stage 1 and the residual blocks are split over the 8 waves by TILE (wave w < 4: tile w, wave w >= 4: tile 11 - w, so
     // that the two waves of a SIMD own a light and a heavy tile of the masked layers): a weight fragment is fetched ONCE per
     // workgroup and multiplied with both row blocks' B operands (first version: a wave owned two tiles of ONE row block, both
     // row-block waves fetched every fragment, and the CU's vector-memory path -- ~95 GB/s -- was the bound: 15 MB per
     // workgroup = 158 of 243 us).  Chains alternate between the two rings; stage 1 runs on ring1.
-    auto front = [&](auto tc, auto ubc, int l) {
-        constexpr int T = decltype(tc)::value, UB = decltype(ubc)::value;
-        constexpr bool HAS0 = 2 * UB <= NB - 1;
-        constexpr int M0 = UB;
+    auto front = [&](auto tc, auto mbc, int l) {
+        constexpr int T = decltype(tc)::value, MB = decltype(mbc)::value;   // MB: this wave's feature batch in the back part (< 0: none)
         (void)l;
         // ---- stage 1: h = W_in x + b_in + relu(W_c ctx + b_c) --------------------------------------------------------
         {
@@ -345,7 +333,7 @@ __global__ __launch_bounds__(mid::kThreads) void flow_mid_kernel(const FwdParams
                 f32x16 accw[2], accg[2];
                 // what ring0 serves next: the next block's W0, or the first final-layer chain of this wave's unit block
                 if constexpr (b == 0) begin(ic<W::e_blk(D, CKS, 1) + W::w0_off(D, T)>{}, ic<NW>{}, ring0, lbase);
-                else if constexpr (HAS0) begin(ic<W::e_out(D, CKS) + W::out_off(D, M0)>{}, ic<W::kO16(D, 2 * M0)>{}, half0, lbase);
+                else if constexpr (MB >= 0) begin(ic<W::e_out(D, CKS) + W::out_off(D, MB)>{}, ic<out_len(MB)>{}, ring0, lbase);
                 run_b(ic<EW1 + W::w1_off(D, CKS, T)>{}, ic<NW + CKS>{}, ring1, lbase,
                       [&](auto kk, auto rc) -> mu32x4 {
                           constexpr int k = decltype(kk)::value, r = decltype(rc)::value;
@@ -379,58 +367,41 @@ __global__ __launch_bounds__(mid::kThreads) void flow_mid_kernel(const FwdParams
         }
     };
 
-    // ---- back part of a layer (final masked layer + spline), for the unit block UB of row block rb (run time) ---------------
-    auto back = [&](auto ubc, int l) {
-        constexpr int UB = decltype(ubc)::value;
-        constexpr bool HAS0 = 2 * UB <= NB - 1;            // feature batches of this unit block: m0 = UB, m1 = NB - 1 - UB
-        constexpr bool HAS1 = NB - 1 - UB > UB;
-        constexpr int M0 = UB, M1 = NB - 1 - UB;
-        // ---- final masked layer + spline ----------------------------------------------------------------------------------
-        barrier();
-        mu32x4 bin[W::kKSteps];                               // (h is dead from here: its registers hold the final layer's B operand)
-#pragma unroll
-        for (int k = 0; k < W::kKSteps; ++k) bin[k] = ld_u4(act_l + k * W::kFrag);
-        barrier();                                            // everyone holds h: the buffers become the spline transposes
-        // one feature batch: three chains (widths | heights of feature 2 m, of 2 m + 1, the derivatives of both), the
-        // parameters + bias into this wave's transpose, one (row, feature) pair per lane
-        // The three parts of a batch are separate so that BOTH batches' chains run before the first spline: the spline needs
-        // ~100 registers, and with the 64 registers of `bin` and a ring of prefetched fragments alive beside it the kernel
-        // spilled -- and a scratch reload is a vector-memory load that waits, in order, behind every weight fragment in flight.
-        auto gemm = [&](auto mm, half_ring_t& ra, half_ring_t& rb_, auto&& begin_next, f32x16& accA, f32x16& accB, f32x16& accD) {
-            constexpr int MB = decltype(mm)::value;
+    // ---- back part of a layer (final masked layer + spline), for the wave that owns feature batch MB for BOTH row blocks --------
+    // A batch = widths | heights of feature 2 MB, of 2 MB + 1, the derivatives of both: three 32-unit tiles whose fragments are
+    // consecutive in the stream -- ONE chain of NA + NB + ND entries on ring0, every fragment multiplied with both row blocks'
+    // h (B operand read from buffer 0 like the front part's; first version: a wave owned two batches of ONE row block with h
+    // preloaded into 64 registers, every final-layer fragment was fetched by two waves and fed one MFMA, and with four
+    // fragments in flight per wave the back part was 40 % of the kernel).  The transposes overlay the activation buffers,
+    // so nobody writes one before everybody is done with h (second barrier).
+    auto back = [&](auto mbc, int l) {
+        constexpr int MB = decltype(mbc)::value;
+        constexpr bool HASM = MB >= 0;
+        barrier();                                            // h of every tile is in buffer 0
+        f32x16 acc[3][2];                                     // [widths | heights of 2 MB, of 2 MB + 1, derivatives][row block]
+        if constexpr (HASM) {
             constexpr int E0 = W::e_out(D, CKS) + W::out_off(D, MB);
-            constexpr int NA = W::kO16(D, 2 * MB), NBf = W::kWHb(D, MB), ND = W::kDD(D, MB);
             constexpr bool HASB = 2 * MB + 1 < D;
-            accA = zero16; accB = zero16; accD = zero16;
-            // ra holds the first fragments of chain A on entry
-            if constexpr (HASB) begin(ic<E0 + NA>{}, ic<NBf>{}, rb_, lbase);
-            else begin(ic<E0 + NA>{}, ic<ND>{}, rb_, lbase);
-            run(ic<E0>{}, ic<NA>{}, ra, lbase, [&](auto kk, const mu32x4& a) {
-                constexpr int k = decltype(kk)::value;
-                mma(ic<(k == 0)>{}, a, __builtin_bit_cast(bf16x8, bin[k]), accA);
-            });
-            if constexpr (HASB) {
-                begin(ic<E0 + NA + NBf>{}, ic<ND>{}, ra, lbase);
-                run(ic<E0 + NA>{}, ic<NBf>{}, rb_, lbase, [&](auto kk, const mu32x4& a) {
-                    constexpr int k = decltype(kk)::value;
-                    mma(ic<(k == 0)>{}, a, __builtin_bit_cast(bf16x8, bin[k]), accB);
-                });
-                begin_next(rb_);
-                run(ic<E0 + NA + NBf>{}, ic<ND>{}, ra, lbase, [&](auto kk, const mu32x4& a) {
-                    constexpr int k = decltype(kk)::value;
-                    mma(ic<(k == 0)>{}, a, __builtin_bit_cast(bf16x8, bin[k]), accD);
-                });
-            } else {
-                begin_next(ra);
-                run(ic<E0 + NA>{}, ic<ND>{}, rb_, lbase, [&](auto kk, const mu32x4& a) {
-                    constexpr int k = decltype(kk)::value;
-                    mma(ic<(k == 0)>{}, a, __builtin_bit_cast(bf16x8, bin[k]), accD);
-                });
-            }
-        };
+            constexpr int NA = W::kO16(D, 2 * MB), NBB = HASB ? W::kWHb(D, MB) : 0, ND = W::kDD(D, MB);
+            static_assert(NA + NBB + ND == out_len(MB), "chain length");
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { acc[c][0] = zero16; acc[c][1] = zero16; }
+            run_b(ic<E0>{}, ic<NA + NBB + ND>{}, ring0, lbase,
+                  [&](auto kk, auto rc) -> mu32x4 {
+                      constexpr int k = decltype(kk)::value, r = decltype(rc)::value;
+                      constexpr int kl = k < NA ? k : k < NA + NBB ? k - NA : k - NA - NBB;
+                      return ld_u4(act_0 + r * kActRb + kl * W::kFrag);
+                  },
+                  [&](auto kk, auto rc, const mu32x4& a, const mu32x4& b) {
+                      constexpr int k = decltype(kk)::value, r = decltype(rc)::value;
+                      constexpr int c = k < NA ? 0 : k < NA + NBB ? 1 : 2;
+                      mma(ic<0>{}, a, __builtin_bit_cast(bf16x8, b), acc[c][r]);
+                  });
+        }
+        span(3);
+        barrier();                                            // everyone is done with h: the buffers become the spline transposes
         // accumulator quad q (units 8 q + 4 hf .. + 3 of the tile) + bias -> the transpose of lane pair (n, feature)
-        auto put = [&](auto mm, const f32x16& accA, const f32x16& accB, const f32x16& accD) {
-            constexpr int MB = decltype(mm)::value;
+        auto put = [&](const f32x16& accA, const f32x16& accB, const f32x16& accD) {
             constexpr bool HASB = 2 * MB + 1 < D;
             constexpr int OB = W::kBiasOut + 96 * MB;
 #pragma unroll
@@ -447,48 +418,37 @@ __global__ __launch_bounds__(mid::kThreads) void flow_mid_kernel(const FwdParams
                       f32x4{accD[4 * q] + bd[0], accD[4 * q + 1] + bd[1], accD[4 * q + 2] + bd[2], accD[4 * q + 3] + bd[3]});
             }
         };
-        auto spline = [&](auto mm) {
-            constexpr int MB = decltype(mm)::value;
+        // one (row, feature) pair per lane: row n of row block r, feature 2 MB + hf
+        auto spline = [&](auto rc) {
+            constexpr int r = decltype(rc)::value;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // wave-private transpose: the wave's own writes, no barrier
             const int f = 2 * MB + hf;
             if (f < D) {
-                const float xv = ld_f(sxc + 4 * f);
-                if (p.u_save && live) p.u_save[((int64_t)l * p.batch + row) * D + f] = xv;
+                const uint32_t sxr = sx_base + ((r * 2) * 32 * XS + n * XS) * 4;
+                const float xv = ld_f(sxr + sxc_off * (32 * XS * 4) + 4 * f);
+                const int64_t rr = row0 + 32 * r + n;
+                if (p.u_save && rr < p.batch) p.u_save[((int64_t)l * p.batch + rr) * D + f] = xv;
                 float y, ld;
                 if (PF_MID_ABLATE & 1) { y = xv + s_par[lane * PS]; ld = 0.f; }
                 else rqs_pair_fast16(s_par + lane * PS, xv, p, y, ld);
-                ld_acc += ld;
-                st_f(sxn + 4 * (D - 1 - f), y);                 // the next layer starts with ReversePermutation
+                ld_acc[r] += ld;
+                st_f(sxr + (sxc_off ^ 1) * (32 * XS * 4) + 4 * (D - 1 - f), y);   // the next layer starts with ReversePermutation
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the transpose is read: it may be rewritten)
         };
-        if constexpr (HAS0 && HAS1) {
-            // batch M0 starts on ring0 (requested above); its last chain runs on ring0 when HASB (A, B, D = ring0, ring1, ring0)
-            constexpr bool HASB0 = 2 * M0 + 1 < D;
-            f32x16 a0, b0, d0, a1, b1, d1;
-            gemm(ic<M0>{}, half0, half1, [&](half_ring_t& r) { begin(ic<W::e_out(D, CKS) + W::out_off(D, M1)>{}, ic<W::kO16(D, 2 * M1)>{}, r, lbase); },
-                 a0, b0, d0);
-            put(ic<M0>{}, a0, b0, d0);
-            // the free ring (where M1's first chain was requested): ring1 when M0 has three chains, ring0 otherwise
-            if constexpr (HASB0) gemm(ic<M1>{}, half1, half0, [&](half_ring_t& r) { (void)r; }, a1, b1, d1);
-            else gemm(ic<M1>{}, half0, half1, [&](half_ring_t& r) { (void)r; }, a1, b1, d1);
-            span(3);
-            spline(ic<M0>{});
-            put(ic<M1>{}, a1, b1, d1);
-            spline(ic<M1>{});
-            span(4);
-        } else if constexpr (HAS0) {
-            f32x16 a0, b0, d0;
-            gemm(ic<M0>{}, half0, half1, [&](half_ring_t& r) { (void)r; }, a0, b0, d0);
-            put(ic<M0>{}, a0, b0, d0);
-            span(3);
-            spline(ic<M0>{});
-            span(4);
+        if constexpr (HASM) {
+            put(acc[0][0], acc[1][0], acc[2][0]);
+            spline(ic<0>{});
+            put(acc[0][1], acc[1][1], acc[2][1]);
+            spline(ic<1>{});
         }
+        span(4);
     };
 
-    // wave w owns hidden tile w (w < 4) or 11 - w (w >= 4) in the front part and the batches of unit block w & 3 for row
-    // block w >> 2 in the back part; the front part's code is per wave (tile and unit block are compile-time constants there)
+    // wave w owns hidden tile w (w < 4) or 11 - w (w >= 4) in the front part and, in the back part, feature batch NB - 1 - w
+    // (w < 4: the long chains go to the waves with the short hidden tiles) or w - 4 (w >= 4); both parts' code is per wave
+    // (tile and batch are compile-time constants there)
+#define mb_of(w) ((w) < 4 ? NB - 1 - (w) : ((w) - 4 < NB - 4 ? (w) - 4 : -1))
     auto stage1_begin = [&](int base) {                     // the first fragments of this wave's stage-1 chain -> ring1
 #ifndef PF_MID_TILEMAP
 #define PF_MID_TILEMAP 0   // wave -> hidden tile: 0: (0 1 2 3 | 7 6 5 4) light + heavy per SIMD; 1: (7 5 3 1 | 6 4 2 0) like with like
@@ -526,15 +486,15 @@ __global__ __launch_bounds__(mid::kThreads) void flow_mid_kernel(const FwdParams
         // per-lane LDS bases re-"defined" at the top of every layer: left alone, the compiler hoists every base + constant out
         // of the layer loop into its own register and spills them (37 spilled VGPRs, reloaded behind the weight loads in
         // flight); this way base + constant stays an instruction offset (all of them fit the 16-bit field)
-        asm volatile("" : "+v"(act_0), "+v"(ctx_0), "+v"(act_l), "+v"(sb), "+v"(spw), "+v"(sx_base), "+v"(sxc), "+v"(sxn));
-        if (wave == 0) front(ic<PF_MID_T0>{}, ic<0>{}, l);
-        else if (wave == 1) front(ic<PF_MID_T1>{}, ic<1>{}, l);
-        else if (wave == 2) front(ic<PF_MID_T2>{}, ic<2>{}, l);
-        else if (wave == 3) front(ic<PF_MID_T3>{}, ic<3>{}, l);
-        else if (wave == 4) front(ic<PF_MID_T4>{}, ic<0>{}, l);
-        else if (wave == 5) front(ic<PF_MID_T5>{}, ic<1>{}, l);
-        else if (wave == 6) front(ic<PF_MID_T6>{}, ic<2>{}, l);
-        else front(ic<PF_MID_T7>{}, ic<3>{}, l);
+        asm volatile("" : "+v"(act_0), "+v"(ctx_0), "+v"(sb), "+v"(spw), "+v"(sx_base));
+        if (wave == 0) front(ic<PF_MID_T0>{}, ic<mb_of(0)>{}, l);
+        else if (wave == 1) front(ic<PF_MID_T1>{}, ic<mb_of(1)>{}, l);
+        else if (wave == 2) front(ic<PF_MID_T2>{}, ic<mb_of(2)>{}, l);
+        else if (wave == 3) front(ic<PF_MID_T3>{}, ic<mb_of(3)>{}, l);
+        else if (wave == 4) front(ic<PF_MID_T4>{}, ic<mb_of(4)>{}, l);
+        else if (wave == 5) front(ic<PF_MID_T5>{}, ic<mb_of(5)>{}, l);
+        else if (wave == 6) front(ic<PF_MID_T6>{}, ic<mb_of(6)>{}, l);
+        else front(ic<PF_MID_T7>{}, ic<mb_of(7)>{}, l);
         // the next layer's biases: requested now, parked in LDS behind the layer's end (their L2 round trip runs under the back part)
         constexpr int NBQ4 = W::kBiasFloats / 4;
         static_assert(NBQ4 <= 2 * M::kThreads, "two bias quads per thread");
@@ -546,14 +506,17 @@ __global__ __launch_bounds__(mid::kThreads) void flow_mid_kernel(const FwdParams
         }
         if (PF_MID_S1_EARLY) stage1_begin(lbase + NFP * W::kFrag);  // next layer's stage 1 -> ring1, free from here (beyond the last
                                                             // layer: the stream's zero tail; never multiplied)
-        if (ub == 0) back(ic<0>{}, l);
-        else if (ub == 1) back(ic<1>{}, l);
-        else if (ub == 2) back(ic<2>{}, l);
-        else back(ic<3>{}, l);
+        if (wave == 0) back(ic<mb_of(0)>{}, l);
+        else if (wave == 1) back(ic<mb_of(1)>{}, l);
+        else if (wave == 2) back(ic<mb_of(2)>{}, l);
+        else if (wave == 3) back(ic<mb_of(3)>{}, l);
+        else if (wave == 4) back(ic<mb_of(4)>{}, l);
+        else if (wave == 5) back(ic<mb_of(5)>{}, l);
+        else if (wave == 6) back(ic<mb_of(6)>{}, l);
+        else back(ic<mb_of(7)>{}, l);
         if (!PF_MID_S1_EARLY) stage1_begin(lbase + NFP * W::kFrag);
         sxc_off ^= 1;
         lbase += NFP * W::kFrag;
-        { const uint32_t t = sxc; sxc = sxn; sxn = t; }
         // the layer's end: every spline has written its z; the next layer's biases replace this layer's
         barrier();
         if (l + 1 < NL) {
@@ -570,13 +533,18 @@ __global__ __launch_bounds__(mid::kThreads) void flow_mid_kernel(const FwdParams
     }
 
     // ---- epilogue: log-det of a row = sum over its features (two lanes x four unit blocks), base density, stores ------------
-    float* const s_red = reinterpret_cast<float*>(smem);       // [row block][unit block][32 rows] (the transposes are dead)
-    const float ld_half = ld_acc + __shfl_xor(ld_acc, 32, 64);
-    if (hf == 0) s_red[(rb * 4 + ub) * 32 + n] = ld_half;
+    float* const s_red = reinterpret_cast<float*>(smem);       // [row block][wave][32 rows] (the transposes are dead)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const float ld_half = ld_acc[r] + __shfl_xor(ld_acc[r], 32, 64);
+        if (hf == 0) s_red[(r * 8 + wave) * 32 + n] = ld_half;
+    }
     __syncthreads();
     float my_nll = 0.f, my_cnt = 0.f;
     if (ub == 0) {
-        const float ld_row = (s_red[(rb * 4 + 0) * 32 + n] + s_red[(rb * 4 + 1) * 32 + n]) + (s_red[(rb * 4 + 2) * 32 + n] + s_red[(rb * 4 + 3) * 32 + n]);
+        const float* sr = s_red + rb * 8 * 32 + n;
+        const float ld_row = ((sr[0] + sr[32]) + (sr[64] + sr[96])) + ((sr[128] + sr[160]) + (sr[192] + sr[224]));
+        const uint32_t sxc = sx_base + ((rb * 2 + sxc_off) * 32 * XS + n * XS) * 4;     // the last layer's output
         if (hf == 0 && live) {
             float q = 0.f, sls = 0.f;
 #pragma unroll
