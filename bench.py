@@ -357,16 +357,19 @@ def extras(flow, dev, batch):
         launch = flow.bind_nll(xb, cb, ob)
         dt = timed(launch, 20)
         out["forward_samples_per_s_65536"] = nb / dt
+        out["forward_kernel_65536"] = flow.forward_kernel_name(nb)
         out["forward_tflops_65536"] = nb * flops_per_sample() / dt / 1e12
         out["forward_roofline_frac_65536"] = out["forward_tflops_65536"] / PEAK_TFLOPS[flow.precision]
         out["forward_roofline_frac_mask_aware_65536"] = (nb * masked_flops_per_sample() / dt / 1e12
                                                          / PEAK_TFLOPS[flow.precision])
         del xb, cb, ob
-        nm = 16384                               # between the 16-row kernel's sweet spot and the large-batch kernel's
+        nm = 16384                               # one round of the mid-batch kernel (64 rows per workgroup, two waves per SIMD)
         xb, cb = make_inputs(nm, 4, dev)
         ob = torch.empty(nm, device=dev)
         dt = timed(flow.bind_nll(xb, cb, ob), 20)
         out["forward_samples_per_s_16384"] = nm / dt
+        out["forward_kernel_16384"] = flow.forward_kernel_name(nm)
+        out["forward_kernel_us_16384"] = dt * 1e6
         out["forward_roofline_frac_16384"] = nm * flops_per_sample() / dt / 1e12 / PEAK_TFLOPS[flow.precision]
         del xb, cb, ob
         ctx1 = torch.randn(1, C, device=dev)

@@ -333,7 +333,10 @@ def test_flat_parameter_mode_gives_the_same_gradients_and_state_dict(precision):
     assert got.shape == want.shape
     rel = ((got - want).abs().max() / want.abs().max()).item()        # float atomics: summation order varies run to run
     print(f"\n[flat mode {precision}] |grad - per-parameter grad| / max = {rel:.2e}")
-    assert rel < 1e-5 and torch.allclose(xg2.grad, gx, rtol=1e-5, atol=1e-6) and torch.allclose(cg2.grad, gc, rtol=1e-4, atol=1e-6)
+    # the context gradient is a split reduction ending in float atomics as well: compared norm-wise like the leaf's gradient (an
+    # element-wise rtol on entries that are small against the partial sums they come from failed once in ~10 runs)
+    rel_c = ((cg2.grad - gc).abs().max() / gc.abs().max()).item()
+    assert rel < 1e-5 and torch.allclose(xg2.grad, gx, rtol=1e-5, atol=1e-6) and rel_c < 1e-5, (rel, rel_c)
     names = dict(flat.named_gradient_views())
     assert names["transform._transforms.1.autoregressive_net.final_layer.weight"].shape == (D * 47, H)
     before = flat._ar_transforms[0].autoregressive_net.initial_layer.weight.detach().clone()
