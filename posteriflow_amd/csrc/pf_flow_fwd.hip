@@ -26,15 +26,17 @@ int launch_flow_mid_d11(const FwdParams&, hipStream_t);
 
 // A PF_FLAG_WIDE plan is served by two kernels over the same packed stream: the mid-batch kernel (64 rows per workgroup, 8
 // waves = two per SIMD: pf_flow_mid_kernel.h) and the large-batch kernel (128 rows per workgroup, one wave per SIMD).  A launch
-// costs rounds x round time (measured: a round of 256 64-row workgroups 192 us, of 256 128-row workgroups ~310 us when every
-// round is full): up to 16 384 rows the mid kernel's single round wins, above it the large-batch kernel's fewer rounds.
+// costs first round + (rounds - 1) x following round (measured, us: 256 64-row workgroups 182 / 162 -- consecutive rounds
+// overlap at their ends --, 256 128-row workgroups 325 / 295): the mid kernel wins where the large-batch kernel's last round
+// would be mostly empty (8 193 - 16 384 rows, 32 769 - 49 152, 65 537 - 81 920, ...), the large-batch kernel elsewhere
+// (measured at 32 768 / 40 000 / 49 152 / 65 536 rows: 325 / 575 / 586 / 620 us against 348 / 475 / 504 / 662).
 // $PF_FLOW_MID (test knob, read per call): 0 never the mid kernel, 1 always.
-constexpr double kMidRoundUs = 192.0, kWideRoundUs = 310.0;
+constexpr double kMidFirstUs = 182.0, kMidNextUs = 162.0, kWideFirstUs = 325.0, kWideNextUs = 295.0;
 static bool use_mid(const FlowPlan& L, int64_t batch) {
     if (!L.wide) return false;
     if (const char* e = getenv("PF_FLOW_MID")) return atoi(e) != 0;
     const int64_t mid_rounds = ((batch + 63) / 64 + 255) / 256, wide_rounds = ((batch + 127) / 128 + 255) / 256;
-    return mid_rounds * kMidRoundUs < wide_rounds * kWideRoundUs;
+    return kMidFirstUs + (mid_rounds - 1) * kMidNextUs < kWideFirstUs + (wide_rounds - 1) * kWideNextUs;
 }
 
 size_t fwd_lds_bytes_host(const FlowPlan& L, int R) {
