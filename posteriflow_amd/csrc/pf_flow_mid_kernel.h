@@ -154,7 +154,8 @@ __global__ __launch_bounds__(mid::kThreads) void flow_mid_kernel(const FwdParams
     uint32_t spw = lds_a(s_par + n * PS + 4 * hf);
 
     // ---- weight fragments: buffer loads, entry E of the layer at byte offset `base` -----------------------------------------
-    __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.packed), 0, 0x7fffffff, 0x00020000);
+    // (num_records = the packed buffer's size: a fragment request past its end would return zeros instead of touching memory)
+    __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.packed), 0, (int)W::packed_bytes(D, CKS, NL), 0x00020000);
     const int lane16 = lane * 16;
     auto ldA = [&](int base, int E) -> mu32x4 {
         if (PF_MID_ABLATE & 2) return __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16, 0, 0);
@@ -504,8 +505,11 @@ __global__ __launch_bounds__(mid::kThreads) void flow_mid_kernel(const FwdParams
             nb0 = gb[tid];
             nb1 = gb[tid + M::kThreads < NBQ4 ? tid + M::kThreads : 0];
         }
-        if (PF_MID_S1_EARLY) stage1_begin(lbase + NFP * W::kFrag);  // next layer's stage 1 -> ring1, free from here (beyond the last
-                                                            // layer: the stream's zero tail; never multiplied)
+        // next layer's stage 1 -> ring1, free from here.  Behind the last layer there is no next layer: the request is aimed at
+        // layer 0 (never multiplied) -- entry 146 of a "layer L" would lie up to 146 KiB behind the stream, past the end of the
+        // packed buffer when L < 7 (72 KiB of zero tail + 11 KiB of biases per layer)
+        const int next_base = l + 1 < NL ? lbase + NFP * W::kFrag : 0;
+        if (PF_MID_S1_EARLY) stage1_begin(next_base);
         if (wave == 0) back(ic<mb_of(0)>{}, l);
         else if (wave == 1) back(ic<mb_of(1)>{}, l);
         else if (wave == 2) back(ic<mb_of(2)>{}, l);
@@ -514,7 +518,7 @@ __global__ __launch_bounds__(mid::kThreads) void flow_mid_kernel(const FwdParams
         else if (wave == 5) back(ic<mb_of(5)>{}, l);
         else if (wave == 6) back(ic<mb_of(6)>{}, l);
         else back(ic<mb_of(7)>{}, l);
-        if (!PF_MID_S1_EARLY) stage1_begin(lbase + NFP * W::kFrag);
+        if (!PF_MID_S1_EARLY) stage1_begin(next_base);
         sxc_off ^= 1;
         lbase += NFP * W::kFrag;
         // the layer's end: every spline has written its z; the next layer's biases replace this layer's
