@@ -560,8 +560,9 @@ class NSFPosteriorFlow(nn.Module):
     # per SIMD: up to 16 384 rows) and the large-batch kernel (128 rows per workgroup, weights through an LDS ring: above);
     # pf_flow_forward picks between the two by rounds x round time ----
     wide_min_batch: int = 8193      # rows from which pf_flow_forward is given the PF_FLAG_WIDE layout (measured: the 16-row
-                                    # kernel takes 142 us up to 8192 rows and 232 / 284 us at 12 288 / 16 384; a round of the
-                                    # mid-batch kernel 204 / 217 us there; the large-batch kernel ~340 us up to 32 768 rows)
+                                    # kernel takes 143 us up to 8192 rows and 232 / 284 us at 12 288 / 16 384; a round of the
+                                    # mid-batch kernel 165 / 182 us there (149 at 8 192); the large-batch kernel 325 us up to
+                                    # 32 768 rows; which of the two runs: pf_flow_fwd.hip `use_mid`)
 
     def _use_wide(self, batch: int) -> bool:
         env = os.environ.get("PF_FLOW_WIDE", "")

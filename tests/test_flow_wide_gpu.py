@@ -140,10 +140,12 @@ def test_wide_is_refused_where_it_is_not_built():
 
 @pytest.mark.parametrize("B,name,rows", [(65536, "pf::flow_wide_kernel<15, 18>", 128), (16384, "pf::flow_mid_kernel<15, 18>", 64),
                                          (9000, "pf::flow_mid_kernel<15, 18>", 64), (20000, "pf::flow_wide_kernel<15, 18>", 128),
+                                         (40000, "pf::flow_mid_kernel<15, 18>", 64),
                                          (8192, "pf::flow_kernel<true, 16, 2, 9, 0, false>", 32)])
 def test_wide_full_size_statistics(B, name, rows):
     """The sizes the two kernels exist for, through pf_flow_forward's OWN choice (no forcing): 65 536 rows -> the large-batch
-    kernel, 16 384 / 9 000 -> the mid-batch kernel, 8 192 -> still the 16-row kernel.  Finite everywhere, the same mean NLL as
+    kernel, 16 384 / 9 000 -> the mid-batch kernel (one round), 40 000 -> the mid-batch kernel again (three rounds against two
+    mostly-empty ones of the large-batch kernel), 20 000 -> the large-batch kernel, 8 192 -> still the 16-row kernel.  Finite everywhere, the same mean NLL as
     the 16-row kernel to 1e-4 relative, and 64 sampled rows against the fp32 oracle like
     test_rows_per_workgroup_choice_and_parity."""
     from posteriflow_amd import _lib
