@@ -85,9 +85,15 @@ int dense_pack(bool bf16, const float* raw, const DensePackTable& tab, void* pac
 // (tile i, k-step t) has been multiplied -- across chunk, pass and epilogue boundaries -- so a wave always has RD * TP
 // one-KiB loads in flight.  (First version: one k-step ahead = 24 MFMAs = 0.16 us of cover for a ~1 us L2 round trip; the
 // QKV projection of 187 K rows took 180 us against 17 us of MFMA time and 58 us of HBM time.)
-template <bool BF16, int EPI, int TP, int RD>
-__global__ __launch_bounds__(256, TP <= 3 ? 2 : 1) void dense_strip_kernel(const DenseArgs p_in) {
-    constexpr int BM = 128, CG = 8;
+#ifndef PF_DENSE_BM64_OCC
+#define PF_DENSE_BM64_OCC 4     // waves per SIMD the 64-row variant is compiled for (registers: 512 / that)
+#endif
+template <bool BF16, int EPI, int TP, int RD, int BM>
+__global__ __launch_bounds__(256, BM == 64 ? PF_DENSE_BM64_OCC : (TP <= 3 ? 2 : 1)) void dense_strip_kernel(const DenseArgs p_in) {
+    // BM rows per workgroup: 128, or 64 (half the accumulators and half the LDS image: four workgroups per CU instead of two --
+    // a strip is load, multiply, store one after the other, and what overlaps them is the other workgroups of the CU)
+    constexpr int CG = BM / 16;
+    static_assert(BM == 128 || BM == 64, "rows per workgroup");
     constexpr int KSTEP = BF16 ? 32 : 16, ESZ = BF16 ? 2 : 4, EPC = 16 / ESZ;
     DenseArgs p = p_in;
     if constexpr (EPI == kEpiPlain) {
@@ -438,15 +444,15 @@ __global__ __launch_bounds__(256, TP <= 3 ? 2 : 1) void dense_strip_kernel(const
     }
 }
 
-template <bool BF16, int EPI, int TP, int RD>
-static int launch_strip(const DenseArgs& a, hipStream_t s) {
+template <bool BF16, int EPI, int TP, int RD, int BM>
+static int launch_strip_bm(const DenseArgs& a, hipStream_t s) {
     const int oesz = (EPI == kEpiResid || EPI == kEpiMul || !BF16 || a.out_f32) ? 4 : 2;      // staged element: fp32 for the two-operand epilogues
     const size_t stage = (size_t)2 * (EPI == kEpiGelu ? 2 : 1) * 16 * (4 * TP * 16 * oesz + 16);
-    const size_t lds = 3 * 128 * sizeof(int64_t) + 128 * sizeof(int32_t) + (size_t)128 * a.KC * (BF16 ? 2 : 4) + stage;
-    auto k = dense_strip_kernel<BF16, EPI, TP, RD>;
+    const size_t lds = 3 * BM * sizeof(int64_t) + BM * sizeof(int32_t) + (size_t)BM * a.KC * (BF16 ? 2 : 4) + stage;
+    auto k = dense_strip_kernel<BF16, EPI, TP, RD, BM>;
     if (lds > 160 * 1024) return PF_ERR_UNSUPPORTED;
     if (lds > 64 * 1024 && !opt_in_lds(reinterpret_cast<const void*>(k), (int)lds)) return PF_ERR_HIP;
-    const unsigned grid = (unsigned)((a.M + 127) / 128);
+    const unsigned grid = (unsigned)((a.M + BM - 1) / BM);
     if (grid == 0) return PF_OK;
     // splits: ceil(nchunks / k_splits) chunks each -- only the splits that own a chunk are launched
     const int nchunks = a.K / a.KC, ksp = a.k_splits > 1 ? a.k_splits : 1, cps = (nchunks + ksp - 1) / ksp;
@@ -454,6 +460,23 @@ static int launch_strip(const DenseArgs& a, hipStream_t s) {
     const unsigned nz = a.n_group > 0 ? (unsigned)((a.N + a.n_group - 1) / a.n_group) : 1u;
     hipLaunchKernelGGL(k, dim3(grid, ny, nz), dim3(256), lds, s, a);
     return launch_status();
+}
+
+// 64-row strips: bf16, one chunk, three tiles per wave (the encoder's big-M GEMMs), enough strips to fill the chip twice over.
+// $PF_DENSE_BM (test knob, read once): 128 never, 64 wherever built.
+static int strip_rows(bool bf16, int tp, const DenseArgs& a) {
+    static const int forced = [] { const char* e = getenv("PF_DENSE_BM"); return e ? atoi(e) : 0; }();
+    const bool built = bf16 && tp == 3 && a.K == a.KC && a.k_splits <= 1 && a.n_group == 0;
+    if (!built || forced == 128) return 128;
+    if (forced == 64) return 64;
+    return a.M >= (int64_t)64 * 256 * 8 ? 64 : 128;
+}
+template <bool BF16, int EPI, int TP, int RD>
+static int launch_strip(const DenseArgs& a, hipStream_t s) {
+    if constexpr (BF16 && TP == 3) {
+        if (strip_rows(true, TP, a) == 64) return launch_strip_bm<BF16, EPI, TP, RD, 64>(a, s);
+    }
+    return launch_strip_bm<BF16, EPI, TP, RD, 128>(a, s);
 }
 
 template <bool BF16, int EPI, int TP>

@@ -35,6 +35,14 @@
 //   4-lanes-per-pair in-register evaluation (measured: the kernel is
 //   instruction-issue-bound, profiles/README.md).
 #pragma once
+#ifndef PF_FWD_BENDS
+#define PF_FWD_BENDS 1     // 1: activation fragments requested from both ends inwards (see load_b_ends)
+#endif
+#if PF_FWD_BENDS
+#define PF_LOAD_B load_b_ends
+#else
+#define PF_LOAD_B load_b
+#endif
 #include <hip/hip_runtime.h>
 
 #include "pf_status.h"
@@ -483,6 +491,19 @@ __device__ __forceinline__ void flow_body(const FwdParams& p) {
             for (int r = 0; r < R; ++r)
                 bk[ks][r] = *reinterpret_cast<const u32x4*>(src + ((size_t)(ks * R + r) * 64 + lane) * 16);
     };
+    // the same, requested from both ends inwards (0, N-1, 1, N-2, ...): gemm_pair's k-step I multiplies fragment I (first tile,
+    // ascending) or N-1-I (second tile, descending) depending on the wave, so in this order step I needs only the first 2 (I + 1)
+    // reads instead of all of them (the first MFMA after every barrier waited for the whole buffer)
+    auto load_b_ends = [&](const char* src, auto n, u32x4 (&bk)[decltype(n)::value][R]) {
+        constexpr int N = decltype(n)::value;
+        static_for<0, N>([&](auto i) {
+            constexpr int I = decltype(i)::value;
+            constexpr int ks = (I & 1) ? N - 1 - (I >> 1) : (I >> 1);
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                bk[ks][r] = *reinterpret_cast<const u32x4*>(src + ((size_t)(ks * R + r) * 64 + lane) * 16);
+        });
+    };
     u32x4 cb[CTX_REGS ? CKM : 1][R];
     if constexpr (CTX_REGS) load_b(s_ctx, ic<CKM>{}, cb);
 
@@ -679,7 +700,7 @@ __device__ __forceinline__ void flow_body(const FwdParams& p) {
             store_act(s_act0, tA, tAv);
             store_act(s_act0, tB, tBv);
             barrier();
-            load_b(s_act0, ic<HK>{}, bk);
+            PF_LOAD_B(s_act0, ic<HK>{}, bk);
             zero(tAv); zero(tBv);
             gemm_pair(ic<EB>{}, ic<KHS>{}, kA, bk, tAv, tBv);
             {
@@ -714,7 +735,7 @@ __device__ __forceinline__ void flow_body(const FwdParams& p) {
             store_act(s_act1, tA, tAv);
             store_act(s_act1, tB, tBv);
             barrier();
-            load_b(s_act1, ic<HK>{}, bk);
+            PF_LOAD_B(s_act1, ic<HK>{}, bk);
             zero(tAv); zero(tBv);
             gemm_pair(ic<EB + KHS>{}, ic<KHS>{}, kA, bk, tAv, tBv);
             const f32x4 b1A = load_bias(tA, kSlotBlk + 3 * b + 1), b1B = load_bias(tB, kSlotBlk + 3 * b + 1);
@@ -749,7 +770,7 @@ __device__ __forceinline__ void flow_body(const FwdParams& p) {
         f32x4 pA[3][R], pB[3][R];
         {
             u32x4 bk[HK][R];
-            load_b(s_act0, ic<HK>{}, bk);
+            PF_LOAD_B(s_act0, ic<HK>{}, bk);
             static_for<0, 3>([&](auto qq) {
                 constexpr int q = decltype(qq)::value;
                 zero(pA[q]); zero(pB[q]);
