@@ -85,8 +85,11 @@ int dense_pack(bool bf16, const float* raw, const DensePackTable& tab, void* pac
 // (tile i, k-step t) has been multiplied -- across chunk, pass and epilogue boundaries -- so a wave always has RD * TP
 // one-KiB loads in flight.  (First version: one k-step ahead = 24 MFMAs = 0.16 us of cover for a ~1 us L2 round trip; the
 // QKV projection of 187 K rows took 180 us against 17 us of MFMA time and 58 us of HBM time.)
+#ifndef PF_DENSE_BM64_MIN_ROUNDS
+#define PF_DENSE_BM64_MIN_ROUNDS 1   // 64-row strips from this many strips per CU (measured better from 23 K rows up: -16 .. -26 % at 47 K / 94 K rows, -4 .. -9 % at 187 K)
+#endif
 #ifndef PF_DENSE_BM64_OCC
-#define PF_DENSE_BM64_OCC 4     // waves per SIMD the 64-row variant is compiled for (registers: 512 / that)
+#define PF_DENSE_BM64_OCC 3     // waves per SIMD the 64-row variant is compiled for (registers: 512 / that; at 4 it spills 9-77 VGPRs and loses)
 #endif
 template <bool BF16, int EPI, int TP, int RD, int BM>
 __global__ __launch_bounds__(256, BM == 64 ? PF_DENSE_BM64_OCC : (TP <= 3 ? 2 : 1)) void dense_strip_kernel(const DenseArgs p_in) {
@@ -254,12 +257,12 @@ __global__ __launch_bounds__(256, BM == 64 ? PF_DENSE_BM64_OCC : (TP <= 3 ? 2 : 
                         u32x4 b[CG / 2];
 #pragma unroll
                         for (int cg = 0; cg < CG / 2; ++cg)
-                            b[cg] = *reinterpret_cast<const u32x4*>(brow + (size_t)(16 * (cg + 4 * hf)) * rowbytes + slot);
+                            b[cg] = *reinterpret_cast<const u32x4*>(brow + (size_t)(16 * (cg + (CG / 2) * hf)) * rowbytes + slot);
 #pragma unroll
                         for (int i = 0; i < TP; ++i)
 #pragma unroll
                             for (int cg = 0; cg < CG / 2; ++cg) {
-                                f32x4& ac = acc[i][cg + 4 * hf];
+                                f32x4& ac = acc[i][cg + (CG / 2) * hf];
                                 if constexpr (BF16) {
                                     ac = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                                         __builtin_bit_cast(bf16x8, ring[j][i]), __builtin_bit_cast(bf16x8, b[cg]), ac, 0, 0, 0);
@@ -466,14 +469,16 @@ static int launch_strip_bm(const DenseArgs& a, hipStream_t s) {
 // $PF_DENSE_BM (test knob, read once): 128 never, 64 wherever built.
 static int strip_rows(bool bf16, int tp, const DenseArgs& a) {
     static const int forced = [] { const char* e = getenv("PF_DENSE_BM"); return e ? atoi(e) : 0; }();
-    const bool built = bf16 && tp == 3 && a.K == a.KC && a.k_splits <= 1 && a.n_group == 0;
+    const bool built = bf16 && tp == 3 && a.k_splits <= 1 && a.n_group == 0;
     if (!built || forced == 128) return 128;
     if (forced == 64) return 64;
-    return a.M >= (int64_t)64 * 256 * 8 ? 64 : 128;
+    return a.M >= (int64_t)64 * 256 * PF_DENSE_BM64_MIN_ROUNDS ? 64 : 128;
 }
 template <bool BF16, int EPI, int TP, int RD>
 static int launch_strip(const DenseArgs& a, hipStream_t s) {
-    if constexpr (BF16 && TP == 3) {
+    // (the two-operand epilogues lose with 64 rows -- four 16-row groups leave their operand prefetch no room: 180 -> 257 us --
+    // and are not built)
+    if constexpr (BF16 && TP == 3 && (EPI == kEpiPlain || EPI == kEpiGelu)) {
         if (strip_rows(true, TP, a) == 64) return launch_strip_bm<BF16, EPI, TP, RD, 64>(a, s);
     }
     return launch_strip_bm<BF16, EPI, TP, RD, 128>(a, s);
