@@ -41,6 +41,9 @@
 #ifndef PF_MID_P
 #define PF_MID_P 6                       // weight fragments in flight per ring
 #endif
+#ifndef PF_MID_PRIO
+#define PF_MID_PRIO 1                    // s_setprio around the MFMA chains: the SIMD's other wave (epilogue, spline) yields issue slots to the chain (185 -> 180 us)
+#endif
 #ifndef PF_MID_BD
 #define PF_MID_BD 2                      // k-steps of B operands (LDS) in flight ahead of the MFMAs of the front part
 #endif
@@ -176,6 +179,7 @@ __global__ __launch_bounds__(mid::kThreads) void flow_mid_kernel(const FwdParams
         constexpr int RP = (int)(sizeof(ring) / sizeof(ring[0]));
         constexpr int BD = PF_MID_BD;
         mu32x4 bq[BD][2];
+        if (PF_MID_PRIO) __builtin_amdgcn_s_setprio(PF_MID_PRIO);
         static_for<0, (N < BD ? N : BD)>([&](auto i) {
             bq[decltype(i)::value][0] = ldb(i, ic<0>{});
             bq[decltype(i)::value][1] = ldb(i, ic<1>{});
@@ -192,6 +196,7 @@ __global__ __launch_bounds__(mid::kThreads) void flow_mid_kernel(const FwdParams
             }
             __builtin_amdgcn_sched_barrier(0);
         });
+        if (PF_MID_PRIO) __builtin_amdgcn_s_setprio(0);
     };
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     auto mma = [&](auto first, const mu32x4& a, const bf16x8& b, f32x16& acc) {
