@@ -12,13 +12,14 @@ def regs(tok):
     m = re.match(r"([va])(\d+)$", tok)
     return [(m.group(1), int(m.group(2)))] if m else []
 
-def main():
-    want = sys.argv[1] if len(sys.argv) > 1 else ""
+def scan(lib=LIB):
+    """-> {mangled kernel name: Counter{0..8: MFMAs whose LDS-fed operand was requested that many MFMAs earlier (8 = 8 or more),
+    "mfma": all MFMAs}}"""
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import tempfile
     from audit_accvgpr import code_objects
     with tempfile.TemporaryDirectory() as tmp:
-        out = "\n".join(subprocess.run([OBJDUMP, "-d", co], capture_output=True, text=True).stdout for co in code_objects(LIB, tmp))
+        out = "\n".join(subprocess.run([OBJDUMP, "-d", co], capture_output=True, text=True).stdout for co in code_objects(lib, tmp))
     kern, rows = None, {}
     writer, nm = {}, 0
     for line in out.splitlines():
@@ -42,11 +43,19 @@ def main():
             for r in regs(args[0]): writer.pop(r, None)
         elif op.startswith("v_") or op.startswith("buffer_load") or op.startswith("global_load"):
             for r in regs(args[0]): writer.pop(r, None)
+    return rows
+
+
+def main():
+    want = sys.argv[1] if len(sys.argv) > 1 else ""
+    rows = scan()
     for k, c in sorted(rows.items(), key=lambda kv: -kv[1]["mfma"]):
-        if c["mfma"] == 0 or want not in k: continue
-        fed = sum(v for kk, v in c.items() if kk != "mfma")
+        if c["mfma"] == 0: continue
         name = subprocess.run(["c++filt", k], capture_output=True, text=True).stdout.strip()[:90]
+        if want not in name and want not in k: continue
+        fed = sum(v for kk, v in c.items() if kk != "mfma")
         print(f"{name:90s} mfma {c['mfma']:5d} lds-fed {fed:5d}  distance 0:{c[0]:4d} 1:{c[1]:4d} 2:{c[2]:4d} 3:{c[3]:4d} 4-7:{sum(c[i] for i in range(4,8)):4d} 8+:{c[8]:4d}")
+
 
 if __name__ == "__main__":
     main()

@@ -52,3 +52,22 @@ def test_no_accumulator_is_read_inside_the_mfma_shadow():
     findings, n_co, n_mfma = a.audit(LIB)
     assert n_co >= 10 and n_mfma > 10000, (n_co, n_mfma)        # the audit really saw the kernels
     assert not findings, "\n".join(f"{f[0][:80]}: {f[1]} -> {f[2]} ({f[3]}/{f[4]})" for f in findings[:10])
+
+
+@pytest.mark.skipif(not os.path.exists(LIB), reason="libpfhip.so not built")
+def test_mid_batch_kernel_requests_its_lds_operands_ahead_of_their_mfmas():
+    """Round 4: the mid-batch flow kernel went 216 -> 192 us when the activation fragments (B operands, LDS) were requested
+    two k-steps ahead of the MFMAs that read them, in an order pinned by sched_barrier -- left to the compiler every ds_read
+    sat right in front of its MFMA.  Guard that schedule in the ISA: of the MFMAs fed from LDS, at most 6 % may have their
+    operand requested fewer than two MFMAs earlier (measured 4.3 %: chain heads behind a barrier)."""
+    spec = importlib.util.spec_from_file_location("audit_lds_distance", os.path.join(ROOT, "scripts", "audit_lds_distance.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    if not os.path.exists(mod.OBJDUMP):
+        pytest.skip("llvm-objdump not available")
+    rows = {k: c for k, c in mod.scan(LIB).items() if "flow_mid_kernel" in k}
+    assert len(rows) == 2, list(rows)                               # D = 15 and D = 11
+    for k, c in rows.items():
+        fed = sum(v for kk, v in c.items() if kk != "mfma")
+        assert c["mfma"] > 1500 and fed > 0.9 * c["mfma"], (k, dict(c))
+        assert c[0] + c[1] <= 0.06 * fed, (k, dict(c))
