@@ -53,8 +53,12 @@ extern "C" {
                               * layers; implies PF_FLAG_HOIST_CTX.  Raw layout unchanged (the block's
                               * context_layer weight/bias take the place of the gate's). */
 
-#define PF_FLAG_WIDE 4        /* forward only: the large-batch kernel (128 rows per workgroup, every wave owns 32 rows
-                              * through all layers, weights fetched once per workgroup through an LDS ring).  bf16,
+#define PF_FLAG_WIDE 4        /* forward only: the layout of the two kernels for many rows -- the large-batch kernel
+                              * (128 rows per workgroup, every wave owns 32 rows through all layers, weights fetched
+                              * once per workgroup through an LDS ring) and, since round 4, the mid-batch kernel (64 rows
+                              * per workgroup, two waves per SIMD, a wave owns one hidden tile for both 32-row blocks);
+                              * pf_flow_forward picks per call by rounds x measured round time (pf_flow_forward_kernel_name
+                              * / pf_flow_rows_per_workgroup tell which; $PF_FLOW_MID = 0 / 1 forces).  bf16,
                               * H = 256, K = 16, plain conditioner, (D, C) in {(15, 288), (11, 288)}; other shapes:
                               * PF_ERR_UNSUPPORTED from every entry point.  The packed buffer of a PF_FLAG_WIDE desc
                               * has its own layout (pf_flow_packed_bytes / pack_map / pack with the same desc). */
@@ -570,7 +574,8 @@ const char* pf_flow_forward_kernel_name(const PfFlowDesc* desc, int64_t batch);
  * partly masked fragments are multiplied whole.  Lies between the mask-aware useful count and the dense-GEMM count of
  * SURVEY 8d (bench.py reports all three). */
 int64_t pf_flow_issued_flop_per_row(const PfFlowDesc* desc);
-/* rows of the batch one workgroup processes for a given batch size (bench / tests) */
+/* rows of the batch one workgroup processes for a given batch size (bench / tests): 16 / 32 / 48 (16-row kernel), 64
+ * (mid-batch kernel) or 128 (large-batch kernel) */
 int32_t pf_flow_rows_per_workgroup(const PfFlowDesc* desc, int64_t batch);
 
 #ifdef __cplusplus
