@@ -202,8 +202,11 @@ def test_wide_pack_map_covers_exactly_the_unmasked_weights(lib, D, K, L):
     assert (packed - L * bias_floats * 4) % 1024 == 0 and (frags - 72) % (72 * L) == 0
     assert n == frags * 512 + L * bias_floats
     assert (m[(frags - 72) * 512: frags * 512] == -1).all()
-    assert h.pf_flow_rows_per_workgroup(C_byref(d), 100000) == 128
-    assert h.pf_flow_forward_kernel_name(C_byref(d), 100000) == f"pf::flow_wide_kernel<{D}, 18>".encode()
+    # the layout's two kernels, picked by rounds x measured round time: 128 rows per workgroup (large-batch) / 64 (mid-batch)
+    assert h.pf_flow_rows_per_workgroup(C_byref(d), 131072) == 128
+    assert h.pf_flow_forward_kernel_name(C_byref(d), 131072) == f"pf::flow_wide_kernel<{D}, 18>".encode()
+    assert h.pf_flow_rows_per_workgroup(C_byref(d), 16384) == 64
+    assert h.pf_flow_forward_kernel_name(C_byref(d), 16384) == f"pf::flow_mid_kernel<{D}, 18>".encode()
     # shapes the wide kernel is not built for are refused, not silently served by another layout
     for bad in (desc_of(lib, 7, 288, 256, 16, 2, "bf16", lib.PF_FLAG_WIDE), desc_of(lib, 15, 256, 256, 16, 2, "bf16", lib.PF_FLAG_WIDE),
                 desc_of(lib, 15, 288, 256, 9, 2, "bf16", lib.PF_FLAG_WIDE),
