@@ -88,6 +88,45 @@ def test_dense_nt_plain_matches_matmul(precision, m, k, n):
     assert got32.dtype == torch.float32 and (got32.double() - want).abs().max().item() < 2e-5 * want.abs().max().item() * (k ** 0.5)
 
 
+def test_dense_nt_64_row_strips_at_the_default_threshold():
+    """Round 4: from 16 384 rows the bf16 strip GEMM with the plain / GELU epilogue runs 64-row strips (three workgroups per CU).
+    A ragged M just above the threshold through the DEFAULT choice (no $PF_DENSE_BM): plain (single chunk and chunked K) and
+    GELU + derivative with dropout, against float64 matmul of the rounded operands; the same call below the threshold (128-row
+    strips) must give bit-identical rows -- a row's result does not depend on the strip it sits in."""
+    import os
+    from oracle.enc_dropout import factors
+    assert "PF_DENSE_BM" not in os.environ
+    precision = "bf16"
+    g = torch.Generator().manual_seed(64)
+    m = 16384 + 77
+    for k, n in ((192, 576), (768, 192)):
+        a = torch.randn(m, k, generator=g).cuda()
+        w = (torch.randn(n, k, generator=g) / math.sqrt(k)).cuda()
+        b = torch.randn(n, generator=g).cuda()
+        ad = a.to(act_dtype(precision)).contiguous()
+        got = dense_nt(precision, 0, ad, w, b).float()
+        want = rnd(a, precision).double() @ rnd(w, precision).double().t() + b.double()
+        err = (got.double() - want).abs().max().item()
+        print(f"\n[dense_nt 64-row strips {m}x{k}x{n}] max err {err:.2e}")
+        assert err < tol(precision, want.abs().max().item())
+        small = dense_nt(precision, 0, ad[:1000].contiguous(), w, b).float()            # 128-row strips
+        assert torch.equal(small, got[:1000])
+    k, n, p = 192, 768, 0.25
+    a = torch.randn(m, k, generator=g).cuda()
+    w = (torch.randn(n, k, generator=g) / math.sqrt(k)).cuda()
+    b = torch.randn(n, generator=g).cuda()
+    ad = a.to(act_dtype(precision)).contiguous()
+    dact = torch.empty(m, n, dtype=act_dtype(precision), device="cuda")
+    got = dense_nt(precision, 1, ad, w, b, dact=dact, drop_p=p, seed=77, site=5).float().double()
+    fac = torch.from_numpy(factors(p, 77, 5, m * n)).reshape(m, n).cuda().double()
+    x = (rnd(a, precision).double() @ rnd(w, precision).double().t() + b.double()).requires_grad_(True)
+    y = F.gelu(x)
+    (dy,) = torch.autograd.grad(y.sum(), x)
+    e1, e2 = (got - y.detach() * fac).abs().max().item(), (dact.float().double() - dy * fac).abs().max().item()
+    print(f"[gelu 64-row strips p={p}] out {e1:.2e} dact {e2:.2e}")
+    assert e1 < tol(precision, 4.0) and e2 < tol(precision, 2.0)
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_dense_nt_epilogues(precision):
     from oracle.enc_dropout import factors
