@@ -78,6 +78,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnArgs a) {
     }
 }
 
+// rows in flight per wave x workgroups: measured at 187 K rows (us): 4 x 1024 156, 8 x 1024 157, 8 x 512 150, 4 x 2048 142,
+// 2 x 2048 131.5 (4.4 TB/s), 3 x 2048 131.4, 1 x 2048 135, 2 x 4096 145 -- all eight waves per SIMD resident, two rows each
+#ifndef PF_LN_BWD_U
+#define PF_LN_BWD_U 2
+#endif
+#ifndef PF_LN_BWD_GRID
+#define PF_LN_BWD_GRID 2048
+#endif
 template <bool BF16>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnArgs a) {
     __shared__ float s_red[2][4][kEncD];
@@ -88,9 +96,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnArgs a) {
     f32x4 dg = {0.f, 0.f, 0.f, 0.f}, db = {0.f, 0.f, 0.f, 0.f};
     const uint32_t thr = enc_drop_threshold(a.drop_p);
     const float dscale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
-    // U rows per iteration, every load requested before the first row's arithmetic: with one row in flight a wave's
-    // ~46 rows were 46 global round trips in a row (228 us per 187 K rows = 2.9 TB/s)
-    constexpr int U = 4;
+    // U rows per iteration, every load requested before the first row's arithmetic: with one row in flight and 1024 workgroups a
+    // wave's ~46 rows were 46 global round trips in a row (228 us per 187 K rows = 2.9 TB/s)
+    constexpr int U = PF_LN_BWD_U;
     const int64_t stride = (int64_t)gridDim.x * 4;
     for (int64_t m0 = (int64_t)blockIdx.x * 4 + wave; m0 < a.M; m0 += stride * U) {
         f32x4 x[U], dy[U], dr[U];
@@ -698,7 +706,7 @@ int ln_forward(bool bf16, const LnArgs& a, hipStream_t s) {
 }
 int ln_backward(bool bf16, const LnArgs& a, hipStream_t s) {
     if (a.M <= 0) return PF_OK;
-    const unsigned grid = grid_for(a.M, 4 * 16, 1024);
+    const unsigned grid = grid_for(a.M, 4 * 16, PF_LN_BWD_GRID);
     if (bf16) hipLaunchKernelGGL(ln_bwd_kernel<true>, dim3(grid), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(ln_bwd_kernel<false>, dim3(grid), dim3(256), 0, s, a);
     return launch_status();
