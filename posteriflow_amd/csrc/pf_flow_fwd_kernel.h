@@ -126,16 +126,11 @@ __device__ __forceinline__ float pf_max2(float a, float b) {
 // found by a 4-level binary search over the 17 knots (select trees on knots, heights and derivatives: 57 selects
 // instead of 6 per bin) -- knots increase strictly (min bin width), so it finds searchsorted's bin, including x = B
 // (last knot + 1e-6: never compared, the search ends in bin 15).
-__device__ __forceinline__ void rqs_pair_fast16(const float* par, float x, const FwdParams& p, float& y, float& ld) {
-    float uw[16], uh[16], kd[17];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(par + 4 * q);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(par + 16 + 4 * q);
-        const f32x4 c = *reinterpret_cast<const f32x4*>(par + 32 + 4 * q);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { uw[4 * q + e] = a[e]; uh[4 * q + e] = b[e]; kd[1 + 4 * q + e] = c[e]; }
-    }
+// (the parameters in registers: uw / uh = the 16 raw widths / heights (overwritten), kd[1 .. 15] = the raw interior derivatives,
+// kd[0] and kd[16] are set here; rqs_pair_fast16 below loads them from a transpose, the mid-batch kernel hands them over from
+// its accumulators)
+__device__ __forceinline__ void rqs_fast16_regs(float (&uw)[16], float (&uh)[16], float (&kd)[17], float x, const FwdParams& p,
+                                                float& y, float& ld) {
     const float tb = p.tail_bound, span = 2.f * tb;
     kd[0] = p.deriv_const; kd[16] = p.deriv_const;
     constexpr float kL2E = 1.44269504f;
@@ -195,6 +190,18 @@ __device__ __forceinline__ void rqs_pair_fast16(const float* par, float x, const
     const bool inside = (x >= -tb) && (x <= tb);
     y = inside ? yl + numer * __builtin_amdgcn_rcpf(den) : x;
     ld = inside ? (__builtin_amdgcn_logf(dnum) - 2.f * __builtin_amdgcn_logf(den)) * 0.693147181f : 0.f;
+}
+__device__ __forceinline__ void rqs_pair_fast16(const float* par, float x, const FwdParams& p, float& y, float& ld) {
+    float uw[16], uh[16], kd[17];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(par + 4 * q);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(par + 16 + 4 * q);
+        const f32x4 c = *reinterpret_cast<const f32x4*>(par + 32 + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { uw[4 * q + e] = a[e]; uh[4 * q + e] = b[e]; kd[1 + 4 * q + e] = c[e]; }
+    }
+    rqs_fast16_regs(uw, uh, kd, x, p, y, ld);
 }
 
 // Forward RQS of one (row, feature) pair by one lane.  par: 16 raw widths | 16 raw heights |

@@ -19,9 +19,11 @@
 //   C = 288).  B operands are read per k-step, PF_MID_BD k-steps AHEAD of their MFMAs in an order pinned by sched_barrier:
 //   left to the compiler every ds_read sat right in front of its MFMA and a k-step cost an LDS round trip (216 -> 192 us).
 //   Back part (final masked layer + spline): wave w owns ONE feature batch (widths | heights of two features + their
-//   derivatives = three 32-unit tiles, consecutive in the stream: one chain) for both row blocks, B = h from buffer 0;
-//   after a barrier the transposes (wave-private, overlaying the activation buffers) take the parameters and one
-//   (row, feature) pair per lane goes through rqs_pair_fast16, row block after row block.
+//   derivatives = three 32-unit tiles, consecutive in the stream: one chain) for both row blocks, B = h from buffer 0.
+//   The spline parameters go from the accumulator layout to one (row, feature) pair per lane IN REGISTERS: lane (n, hf)
+//   needs what its partner (n, 1 - hf) holds of the same tile -- 24 v_permlane32_swap per row block -- and
+//   rqs_fast16_regs evaluates from there (first version: wave-private LDS transposes overlaying the activation buffers,
+//   a second barrier in the back part, 104 KiB of LDS for them; 183 -> 176 us).
 //   What bounds it (ablations, LABLOG R4.9): LDS reads of the B operands (2 KiB per fragment and wave = 1.9 MB per layer:
 //   ~50 us at the LDS peak), the MFMAs (50 us) and the weight stream (7.7 MB per workgroup = 85 us at the CU's ingest rate)
 //   overlap only partly; balancing the waves' k-step counts does not change the time (built and measured).
@@ -61,11 +63,9 @@ namespace pf {
 namespace mid {
 constexpr int kRowsPerWG = 64, kWaves = 8, kThreads = 64 * kWaves;
 constexpr int kXS = 16;                                            // floats per row of the x / z exchange
-constexpr int kPS = wide::kParStride;                              // floats per (row, feature) pair of the spline transpose
 constexpr int kP = PF_MID_P;                                             // weight fragments in flight per ring (two rings)
 constexpr int kActBytes = 2 * 2 * wide::kKSteps * wide::kFrag;     // [buffer][row block][k-step][1 KiB]
-constexpr int kParBytes = kWaves * 64 * kPS * 4;                   // wave-private spline transposes (overlay the above)
-constexpr int kRegionA = kParBytes > kActBytes ? kParBytes : kActBytes;
+constexpr int kRegionA = kActBytes;
 constexpr int ctx_bytes(int CKS) { return 2 * CKS * wide::kFrag; }
 constexpr int kXBytes = 2 * 2 * 32 * kXS * 4;                      // [row block][current | next][32 rows][kXS]
 constexpr int lds_bytes(int CKS) { return kRegionA + ctx_bytes(CKS) + kXBytes + wide::kBiasFloats * 4; }
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(mid::kThreads) void flow_mid_kernel(const FwdParams
     typedef __attribute__((address_space(3))) float lds_mf32_t;
     constexpr int NFP = W::n_frags_padded(D, CKS);
     constexpr int NB = W::n_batches(D);
-    constexpr int P = M::kP, PS = M::kPS, XS = M::kXS;
+    constexpr int P = M::kP, XS = M::kXS;
     static_assert(D >= 2 && D <= 16 && CKS > 0, "2 <= D <= 16, conditional flow");
     static_assert(M::lds_bytes(CKS) <= 160 * 1024, "LDS budget");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -91,7 +91,6 @@ __global__ __launch_bounds__(mid::kThreads) void flow_mid_kernel(const FwdParams
     const int n = lane & 31, hf = lane >> 5;
     const int ub = wave & 3, rb = wave >> 2;
     char* const s_act = smem;
-    float* const s_par = reinterpret_cast<float*>(smem) + wave * (64 * PS);
     char* const s_ctx = smem + M::kRegionA;
     float* const s_x = reinterpret_cast<float*>(s_ctx + M::ctx_bytes(CKS));
     float* const s_bias = s_x + 2 * 2 * 32 * XS;
@@ -105,7 +104,6 @@ __global__ __launch_bounds__(mid::kThreads) void flow_mid_kernel(const FwdParams
     auto ld_u4 = [](uint32_t a) { return *reinterpret_cast<const lds_mu32x4_t*>(a); };
     auto st_u4 = [](uint32_t a, mu32x4 v) { *reinterpret_cast<lds_mu32x4_t*>(a) = v; };
     auto ld_f4 = [](uint32_t a) { return *reinterpret_cast<const lds_mf32x4_t*>(a); };
-    auto st_f4 = [](uint32_t a, f32x4 v) { *reinterpret_cast<lds_mf32x4_t*>(a) = v; };
     auto ld_f = [](uint32_t a) { return *reinterpret_cast<const lds_mf32_t*>(a); };
     auto st_f = [](uint32_t a, float v) { *reinterpret_cast<lds_mf32_t*>(a) = v; };
 
@@ -154,7 +152,6 @@ __global__ __launch_bounds__(mid::kThreads) void flow_mid_kernel(const FwdParams
 
     // ---- per-lane LDS addresses ---------------------------------------------------------------------------------------
     uint32_t sb = lds_a(s_bias + 4 * hf);
-    uint32_t spw = lds_a(s_par + n * PS + 4 * hf);
 
     // ---- weight fragments: buffer loads, entry E of the layer at byte offset `base` -----------------------------------------
     // (num_records = the packed buffer's size: a fragment request past its end would return zeros instead of touching memory)
@@ -405,29 +402,50 @@ __global__ __launch_bounds__(mid::kThreads) void flow_mid_kernel(const FwdParams
                   });
         }
         span(3);
-        barrier();                                            // everyone is done with h: the buffers become the spline transposes
-        // accumulator quad q (units 8 q + 4 hf .. + 3 of the tile) + bias -> the transpose of lane pair (n, feature)
-        auto put = [&](const f32x16& accA, const f32x16& accB, const f32x16& accD) {
-            constexpr bool HASB = 2 * MB + 1 < D;
-            constexpr int OB = W::kBiasOut + 96 * MB;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 ba = ld_f4(sb + 4 * (OB + 8 * q));
-                st_f4(spw + 4 * (8 * q), f32x4{accA[4 * q] + ba[0], accA[4 * q + 1] + ba[1], accA[4 * q + 2] + ba[2], accA[4 * q + 3] + ba[3]});
-                if constexpr (HASB) {
-                    const f32x4 bbv = ld_f4(sb + 4 * (OB + 8 * (4 + q)));
-                    st_f4(spw + 4 * (32 * PS + 8 * q),
-                          f32x4{accB[4 * q] + bbv[0], accB[4 * q + 1] + bbv[1], accB[4 * q + 2] + bbv[2], accB[4 * q + 3] + bbv[3]});
-                }
-                const f32x4 bd = ld_f4(sb + 4 * (OB + 8 * (8 + q)));
-                st_f4(spw + 4 * ((q >> 1) * 32 * PS + 32 + 8 * (q & 1)),
-                      f32x4{accD[4 * q] + bd[0], accD[4 * q + 1] + bd[1], accD[4 * q + 2] + bd[2], accD[4 * q + 3] + bd[3]});
-            }
-        };
-        // one (row, feature) pair per lane: row n of row block r, feature 2 MB + hf
+        // ---- spline: one (row, feature) pair per lane -- row n of row block r, feature 2 MB + hf -- with the parameters handed over
+        // IN REGISTERS.  In the accumulator layout lane (n, hf) holds units 8 q + 4 hf .. + 3 of each tile for row n; the lane that
+        // evaluates feature 2 MB (hf = 0) needs all 32 units of tile A (widths | heights) and units 0 .. 15 of tile D, its partner
+        // (n, hf = 1) all of tile B and units 16 .. 31 of D: v_permlane32_swap exchanges exactly those halves (lanes 32-63 of one
+        // register with lanes 0-31 of another), 24 swaps per row block.  (First version: through wave-private LDS transposes that
+        // overlaid the activation buffers -- 24 b128 stores + 24 b128 loads per lane and row block, two drains, and a second
+        // barrier in the back part because nobody may overwrite h before everyone has multiplied it.)
         auto spline = [&](auto rc) {
             constexpr int r = decltype(rc)::value;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // wave-private transpose: the wave's own writes, no barrier
+            constexpr bool HASB = 2 * MB + 1 < D;
+            constexpr int OB = W::kBiasOut + 96 * MB;
+            f32x16& tA = acc[0][r];
+            f32x16& tB = acc[1][r];
+            f32x16& tD = acc[2][r];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                       // biases, still in the accumulator layout
+                const f32x4 ba = ld_f4(sb + 4 * (OB + 8 * q));
+                const f32x4 bd = ld_f4(sb + 4 * (OB + 8 * (8 + q)));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { tA[4 * q + e] += ba[e]; tD[4 * q + e] += bd[e]; }
+                if constexpr (HASB) {
+                    const f32x4 bbv = ld_f4(sb + 4 * (OB + 8 * (4 + q)));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) tB[4 * q + e] += bbv[e];
+                }
+            }
+            float uw[16], uh[16], kd[17];
+            static_for<0, 16>([&](auto jj) {
+                constexpr int j = decltype(jj)::value, u0 = 8 * (j >> 2) + (j & 3);      // unit of register j in the lanes hf = 0; + 4: hf = 1
+                // (copies first: __builtin_bit_cast applied to a vector ELEMENT reads element 0 whatever the index -- clang 19)
+                const float ea = tA[j], eb = tB[j];
+                const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, ea), __builtin_bit_cast(unsigned, eb), false, false);
+                const unsigned s0 = sw[0], s1 = sw[1];      // (copies again: see above)
+                if constexpr (u0 < 16) { uw[u0] = __builtin_bit_cast(float, s0); uw[u0 + 4] = __builtin_bit_cast(float, s1); }
+                else { uh[u0 - 16] = __builtin_bit_cast(float, s0); uh[u0 - 12] = __builtin_bit_cast(float, s1); }
+            });
+            static_for<0, 8>([&](auto jj) {
+                constexpr int j = decltype(jj)::value, u0 = 8 * (j >> 2) + (j & 3);
+                const float ea = tD[j], eb = tD[j + 8];
+                const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, ea), __builtin_bit_cast(unsigned, eb), false, false);
+                const unsigned s0 = sw[0], s1 = sw[1];
+                kd[1 + u0] = __builtin_bit_cast(float, s0);
+                kd[1 + u0 + 4] = __builtin_bit_cast(float, s1);
+            });
             const int f = 2 * MB + hf;
             if (f < D) {
                 const uint32_t sxr = sx_base + ((r * 2) * 32 * XS + n * XS) * 4;
@@ -435,17 +453,15 @@ __global__ __launch_bounds__(mid::kThreads) void flow_mid_kernel(const FwdParams
                 const int64_t rr = row0 + 32 * r + n;
                 if (p.u_save && rr < p.batch) p.u_save[((int64_t)l * p.batch + rr) * D + f] = xv;
                 float y, ld;
-                if (PF_MID_ABLATE & 1) { y = xv + s_par[lane * PS]; ld = 0.f; }
-                else rqs_pair_fast16(s_par + lane * PS, xv, p, y, ld);
+                if (PF_MID_ABLATE & 1) { y = xv + uw[0]; ld = 0.f; }
+                else rqs_fast16_regs(uw, uh, kd, xv, p, y, ld);
                 ld_acc[r] += ld;
                 st_f(sxr + (sxc_off ^ 1) * (32 * XS * 4) + 4 * (D - 1 - f), y);   // the next layer starts with ReversePermutation
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the transpose is read: it may be rewritten)
         };
         if constexpr (HASM) {
-            put(acc[0][0], acc[1][0], acc[2][0]);
+            if constexpr (!(2 * MB + 1 < D)) { acc[1][0] = zero16; acc[1][1] = zero16; }
             spline(ic<0>{});
-            put(acc[0][1], acc[1][1], acc[2][1]);
             spline(ic<1>{});
         }
         span(4);
@@ -492,7 +508,7 @@ __global__ __launch_bounds__(mid::kThreads) void flow_mid_kernel(const FwdParams
         // per-lane LDS bases re-"defined" at the top of every layer: left alone, the compiler hoists every base + constant out
         // of the layer loop into its own register and spills them (37 spilled VGPRs, reloaded behind the weight loads in
         // flight); this way base + constant stays an instruction offset (all of them fit the 16-bit field)
-        asm volatile("" : "+v"(act_0), "+v"(ctx_0), "+v"(sb), "+v"(spw), "+v"(sx_base));
+        asm volatile("" : "+v"(act_0), "+v"(ctx_0), "+v"(sb), "+v"(sx_base));
         if (wave == 0) front(ic<PF_MID_T0>{}, ic<mb_of(0)>{}, l);
         else if (wave == 1) front(ic<PF_MID_T1>{}, ic<mb_of(1)>{}, l);
         else if (wave == 2) front(ic<PF_MID_T2>{}, ic<mb_of(2)>{}, l);
