@@ -27,12 +27,11 @@ int launch_flow_mid_d11(const FwdParams&, hipStream_t);
 // A PF_FLAG_WIDE plan is served by two kernels over the same packed stream: the mid-batch kernel (64 rows per workgroup, 8
 // waves = two per SIMD: pf_flow_mid_kernel.h) and the large-batch kernel (128 rows per workgroup, one wave per SIMD).  A launch
 // costs first round + (rounds - 1) x following round (measured on one box, us: 256 64-row workgroups 178 / 150 -- consecutive
-// rounds overlap at their ends --, 256 128-row workgroups 324 / 290): the mid kernel wins where the large-batch kernel's last
+// rounds overlap at their ends --, 256 128-row workgroups 316 / 286): the mid kernel wins where the large-batch kernel's last
 // round would be mostly empty (8 193 - 16 384 rows, 32 769 - 49 152, 65 537 - 81 920, ...), the large-batch kernel elsewhere,
-// by a few per cent (measured at 32 768 / 49 152 / 65 536 / 98 304 / 131 072 rows: 324 / 583 / 615 / 902 / 1194 us against
-// 331 / 478 / 628 / 929 / 1227).
+// by a few per cent (measured at 32 768 / 49 152 / 65 536 rows: 316 / ~575 / 601 us against 331 / 478 / 628).
 // $PF_FLOW_MID (test knob, read per call): 0 never the mid kernel, 1 always.
-constexpr double kMidFirstUs = 178.0, kMidNextUs = 150.0, kWideFirstUs = 324.0, kWideNextUs = 290.0;
+constexpr double kMidFirstUs = 178.0, kMidNextUs = 150.0, kWideFirstUs = 316.0, kWideNextUs = 286.0;
 static bool use_mid(const FlowPlan& L, int64_t batch) {
     if (!L.wide) return false;
     if (const char* e = getenv("PF_FLOW_MID")) return atoi(e) != 0;

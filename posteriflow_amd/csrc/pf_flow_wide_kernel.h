@@ -33,6 +33,9 @@
 #ifndef PF_WIDE_ABLATE
 #define PF_WIDE_ABLATE 0   // timing experiments only: 1 no spline, 2 no weight DMA, 4 no MFMA, 8 no sigmoid, 16 no fragment reads, 32 no bias reads
 #endif
+#ifndef PF_WIDE_REGSPLINE
+#define PF_WIDE_REGSPLINE 1   // 1: spline parameters from the accumulator layout to one (row, feature) pair per lane by v_permlane32_swap
+#endif                        // (registers) instead of through the wave-private LDS transpose (round 4, LABLOG R4.11)
 #ifndef PF_WIDE_P
 #define PF_WIDE_P 3        // A fragments requested ahead of their MFMA
 #endif
@@ -438,12 +441,16 @@ __global__ __launch_bounds__(256) void flow_wide_kernel(const FwdParams p) {
                     auto piece = [&](auto which, auto jj) {
                         constexpr int WH = decltype(which)::value, i = decltype(jj)::value, Q = WH * 4 + i / 4;
                         if constexpr (i % 4 == 0 && Q + 1 < 12) bq0[(Q + 1) & 1] = lds_ld_f4(sb + 4 * (OB + 8 * (Q + 1)));
-                        const f32x16& acc = WH == 0 ? accA : (WH == 1 ? accB : accD);
+                        f32x16& acc = WH == 0 ? accA : (WH == 1 ? accB : accD);
+                        if constexpr (PF_WIDE_REGSPLINE) {
+                            acc[i] = acc[i] + bq0[Q & 1][i & 3];           // in place: the tile is handed over in registers below
+                        } else {
                         t4[i & 3] = acc[i] + bq0[Q & 1][i & 3];
                         if constexpr ((i & 3) == 3) {
                             constexpr int q = i / 4;
                             constexpr int off = WH == 0 ? 8 * q : (WH == 1 ? 32 * PS + 8 * q : (q >> 1) * 32 * PS + 32 + 8 * (q & 1));
                             lds_st_f4(spw + 4 * off, f32x4{t4[0], t4[1], t4[2], t4[3]});
+                        }
                         }
                     };
                     interleave(ic<NA>{}, ic<0>{}, [&](auto kk) { step(ic<E0 + decltype(kk)::value>{}, ic<(decltype(kk)::value == 0)>{}, bin[decltype(kk)::value], accA); },
@@ -467,16 +474,60 @@ __global__ __launch_bounds__(256) void flow_wide_kernel(const FwdParams p) {
                         if constexpr (HASB) piece(ic<2>{}, jj);
                         else {                                   // DD with its own queue start (bq0[0] reloaded above)
                             if constexpr (i % 4 == 0 && i / 4 + 1 < 4) bq0[(i / 4 + 1) & 1] = lds_ld_f4(sb + 4 * (OB + 64 + 8 * (i / 4 + 1)));
+                            if constexpr (PF_WIDE_REGSPLINE) {
+                                accD[i] = accD[i] + bq0[(i / 4) & 1][i & 3];
+                            } else {
                             t4[i & 3] = accD[i] + bq0[(i / 4) & 1][i & 3];
                             if constexpr ((i & 3) == 3) {
                                 constexpr int q = i / 4;
                                 lds_st_f4(spw + 4 * ((q >> 1) * 32 * PS + 32 + 8 * (q & 1)), f32x4{t4[0], t4[1], t4[2], t4[3]});
                             }
+                            }
                         }
                     });
-                    fence();
+                    if constexpr (PF_WIDE_REGSPLINE) {
+                        float uw[16], uh[16], kd[17];            // this lane's pair: raw widths | heights | derivatives
+                        // lane (n, hf) holds units 8 q + 4 hf .. + 3 of each tile for row n; the lane that evaluates feature 2 M
+                        // (hf = 0) needs all of tile A and units 0 .. 15 of the derivative tile, its partner all of tile B and units
+                        // 16 .. 31: v_permlane32_swap exchanges exactly those halves (pf_flow_mid_kernel.h has the same hand-over).
+                        // (element copies first: __builtin_bit_cast applied to a vector ELEMENT reads element 0 -- clang 19)
+                        static_for<0, 16>([&](auto jj) {
+                            constexpr int j = decltype(jj)::value, u0 = 8 * (j >> 2) + (j & 3);
+                            const float ea = accA[j], eb = HASB ? accB[j] : 0.f;
+                            const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, ea), __builtin_bit_cast(unsigned, eb), false, false);
+                            const unsigned s0 = sw[0], s1 = sw[1];
+                            if constexpr (u0 < 16) { uw[u0] = __builtin_bit_cast(float, s0); uw[u0 + 4] = __builtin_bit_cast(float, s1); }
+                            else { uh[u0 - 16] = __builtin_bit_cast(float, s0); uh[u0 - 12] = __builtin_bit_cast(float, s1); }
+                        });
+                        static_for<0, 8>([&](auto jj) {
+                            constexpr int j = decltype(jj)::value, u0 = 8 * (j >> 2) + (j & 3);
+                            const float ea = accD[j], eb = accD[j + 8];
+                            const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, ea), __builtin_bit_cast(unsigned, eb), false, false);
+                            const unsigned s0 = sw[0], s1 = sw[1];
+                            kd[1 + u0] = __builtin_bit_cast(float, s0);
+                            kd[1 + u0 + 4] = __builtin_bit_cast(float, s1);
+                        });
+                        fence();
+                        span(3);
+                        // one lane per pair: lane (n, hf) <-> (row n, feature 2 M + hf); evaluated here, inside the batch's own code
+                        // path (the parameters' 49 registers do not have to survive the merge of the eight paths)
+                        const int f = 2 * M + hf;
+                        if (f < D) {
+                            const float xv = lds_ld_f(sxc + 4 * f);
+                            if (p.u_save && live) p.u_save[((int64_t)l * p.batch + row) * D + f] = xv;
+                            float y, ld;
+                            if (PF_WIDE_ABLATE & 1) { y = xv + uw[0]; ld = 0.f; }
+                            else rqs_fast16_regs(uw, uh, kd, xv, p, y, ld);
+                            ld_acc += ld;
+                            lds_st_f(sxn + 4 * (D - 1 - f), y);    // the next layer starts with ReversePermutation
+                        }
+                        span(4);
+                    } else {
+                        fence();
+                    }
                 }
             });
+            if constexpr (!PF_WIDE_REGSPLINE) {
             span(3);
             // one lane per pair: lane (n, hf) <-> (row n, feature 2 m + hf)
             const int f = 2 * m + hf;
@@ -490,6 +541,7 @@ __global__ __launch_bounds__(256) void flow_wide_kernel(const FwdParams p) {
                 lds_st_f(sxn + 4 * (D - 1 - f), y);            // the next layer starts with ReversePermutation
             }
             span(4);
+            }
         }
         // ---- the pad fragments of this layer: keep the ring turning, prime the queue for the next layer ------------
         static_for<NF, NFP - NF>([&](auto e) {
