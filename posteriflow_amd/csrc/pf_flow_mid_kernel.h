@@ -68,7 +68,7 @@ constexpr int kActBytes = 2 * 2 * wide::kKSteps * wide::kFrag;     // [buffer][r
 constexpr int kRegionA = kActBytes;
 constexpr int ctx_bytes(int CKS) { return 2 * CKS * wide::kFrag; }
 constexpr int kXBytes = 2 * 2 * 32 * kXS * 4;                      // [row block][current | next][32 rows][kXS]
-constexpr int lds_bytes(int CKS) { return kRegionA + ctx_bytes(CKS) + kXBytes + wide::kBiasFloats * 4; }
+constexpr int lds_bytes(int CKS) { return kRegionA + ctx_bytes(CKS) + kXBytes + 2 * wide::kBiasFloats * 4; }   // (two bias blocks: layers alternate)
 }  // namespace mid
 
 template <int D, int CKS>
@@ -151,7 +151,8 @@ __global__ __launch_bounds__(mid::kThreads) void flow_mid_kernel(const FwdParams
     __syncthreads();
 
     // ---- per-lane LDS addresses ---------------------------------------------------------------------------------------
-    uint32_t sb = lds_a(s_bias + 4 * hf);
+    uint32_t sb = lds_a(s_bias + 4 * hf);                                         // this layer's bias block (layer l: block l & 1)
+    const uint32_t sb_flip = lds_a(s_bias + 4 * hf) ^ lds_a(s_bias + W::kBiasFloats + 4 * hf);
 
     // ---- weight fragments: buffer loads, entry E of the layer at byte offset `base` -----------------------------------------
     // (num_records = the packed buffer's size: a fragment request past its end would return zeros instead of touching memory)
@@ -542,13 +543,15 @@ __global__ __launch_bounds__(mid::kThreads) void flow_mid_kernel(const FwdParams
         if (!PF_MID_S1_EARLY) stage1_begin(next_base);
         sxc_off ^= 1;
         lbase += NFP * W::kFrag;
-        // the layer's end: every spline has written its z; the next layer's biases replace this layer's
-        barrier();
-        if (l + 1 < NL) {
-            reinterpret_cast<f32x4*>(s_bias)[tid] = nb0;
-            if (tid + M::kThreads < NBQ4) reinterpret_cast<f32x4*>(s_bias)[tid + M::kThreads] = nb1;
-            barrier();
+        // the next layer's biases go to the OTHER bias block (nobody reads it during this layer), so the barrier that ends the layer
+        // -- every spline has written its z -- publishes them too (first version: one block, a second barrier behind the stores)
+        {
+            f32x4* nb = reinterpret_cast<f32x4*>(s_bias + ((l + 1) & 1) * W::kBiasFloats);
+            nb[tid] = nb0;
+            if (tid + M::kThreads < NBQ4) nb[tid + M::kThreads] = nb1;
         }
+        sb ^= sb_flip;
+        barrier();
         span(5);
     }
     if (PF_MID_TRACE && p.fail_flags && blockIdx.x == 0 && wave == PF_MID_TRACE_WAVE && lane == 0) {
