@@ -39,8 +39,12 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 constexpr int kStemLayers = 4;
+#ifndef PF_STEM_ABLATE
+#define PF_STEM_ABLATE 0      // experiments on conv3 / conv4 (side builds only): 1 no staging loads, 2 no k-loop, 4 no stores
+#endif
 struct StemLayer { int cin, cout, kw, stride, lin, lout; };
 // 16384 -> 2041 -> 507 -> 125 -> 61   (lean_npe.py:158-163)
 __host__ __device__ constexpr StemLayer stem_layer(int i) {
@@ -66,6 +70,12 @@ struct ConvParams {
 
 __device__ __forceinline__ float gelu_exact(float x) {         // nn.GELU() default: erf form
     return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
+}
+
+// lean_npe.py:207: nan -> 0, +-inf -> +-100, clamp to [-100, 100] (v_med3 + one compare / select)
+__device__ __forceinline__ float sanitize(float x) {
+    const float c = __builtin_amdgcn_fmed3f(x, -100.f, 100.f);
+    return (x != x) ? 0.f : c;
 }
 
 // slot swizzle of a 64-byte LDS row (4 slots of 16 B): (4 - (row >> 2)) & 3, see the staging code
@@ -110,14 +120,15 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_gemm_kernel(const ConvParams
             else
 #pragma unroll
                 for (int e = 0; e < 4; ++e) if (in0 + i + e < LIN) v[e] = src[in0 + i + e];
+            float s4 = 0.f;                                                // a chunk never straddles a window (i % 4 == 0)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float x = v[e];
-                x = (x != x) ? 0.f : x;                                    // nan -> 0
-                x = fminf(fmaxf(x, -100.f), 100.f);                        // +-inf -> +-100, clamp
-                if (i + e < P * S) sq[(i + e) >> 10] += x * x;             // own range: 2 windows of 1024
+                const float x = sanitize(v[e]);
+                s4 += x * x;
                 v[e] = BF16 ? asinh_fast(x) : asinhf(x);
             }
+#pragma unroll
+            for (int w = 0; w < 2; ++w) sq[w] += ((i >> 10) == w && i < P * S) ? s4 : 0.f;   // own range: 2 windows of 1024
             const bool keep = p.sig && i < P * S && in0 + i + 3 < LIN;     // this workgroup's own 2048 samples
             if (BF16) {
                 bf16x4 o;
@@ -174,15 +185,15 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_gemm_kernel(const ConvParams
             else
 #pragma unroll
                 for (int e = 0; e < 4; ++e) if (s0 + i + e < LIN0) v[e] = src[s0 + i + e];
+            float s4 = 0.f;                                                // a chunk never straddles a window (i % 4 == 0)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float x = v[e];
-                x = (x != x) ? 0.f : x;
-                x = fminf(fmaxf(x, -100.f), 100.f);
-#pragma unroll
-                for (int w = 0; w < NWIN; ++w) if (((i + e) >> 10) == w && i + e < OWN) sq[w] += x * x;
+                const float x = sanitize(v[e]);
+                s4 += x * x;
                 v[e] = BF16 ? asinh_fast(x) : asinhf(x);
             }
+#pragma unroll
+            for (int w = 0; w < NWIN; ++w) sq[w] += ((i >> 10) == w && i < OWN) ? s4 : 0.f;
             if (BF16) {
                 bf16x4 o;
 #pragma unroll
@@ -211,7 +222,11 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_gemm_kernel(const ConvParams
 #pragma unroll
         for (int t = 0; t < 2; ++t) b1[t] = *reinterpret_cast<const f32x4*>(p.bias0 + 16 * t + 4 * g);
         for (int pt = wave; pt < NPT; pt += NWAVES) {
-            f32x4 acc1[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            // bf16: the accumulators start from the bias (one packed add per pair less in the epilogue); the fp32 parity
+            // mode keeps the reference's order (bias last)
+            f32x4 acc1[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc1[t] = BF16 ? b1[t] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < NKS0; ++ks) {
                 const int idx = S0 * (16 * pt + c) + KSTEP * ks + (KSTEP / 4) * g;
@@ -236,12 +251,12 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_gemm_kernel(const ConvParams
                 for (int t = 0; t < 2; ++t) {
                     f32x4 v;
                     if constexpr (BF16) {
-                        v = gelu_erf_fast4(acc1[t] + b1[t]);
+                        v = gelu_erf_fast4(acc1[t]);
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = gelu_exact(acc1[t][e] + b1[t][e]);
                     }
-                    if (in0 + pos >= LOUT0) v = f32x4{0.f, 0.f, 0.f, 0.f};      // beyond conv1's output: zero padding
+                    const bool pad = in0 + pos >= LOUT0;                            // beyond conv1's output: zero padding
                     const int ch = 16 * t + 4 * g;                                  // first of this lane's 4 channels
                     const int cb = ch / CHB, byte = (ch % CHB) * ESZ;
                     char* dst = smem + ((size_t)((r * CB + cb) * Q + q) * 64) + ((((byte >> 4) ^ row_swz(q)) << 4) | (byte & 15));
@@ -249,8 +264,11 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_gemm_kernel(const ConvParams
                         bf16x4 o;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
-                        *reinterpret_cast<bf16x4*>(dst) = o;
+                        u32x2 ow = __builtin_bit_cast(u32x2, o);                    // (the select on the packed pair: 2 instead of 4)
+                        ow[0] = pad ? 0u : ow[0]; ow[1] = pad ? 0u : ow[1];
+                        *reinterpret_cast<u32x2*>(dst) = ow;
                     } else {
+                        if (pad) v = f32x4{0.f, 0.f, 0.f, 0.f};
                         *reinterpret_cast<f32x4*>(dst) = v;
                     }
                 }
@@ -277,7 +295,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_gemm_kernel(const ConvParams
             const int i = tid + it * NTHR;
             const int pos = i / CHUNKS, ch16 = i - pos * CHUNKS;
             v[it] = u32x4{0u, 0u, 0u, 0u};
-            if (i < SPAN * CHUNKS && in0 + pos < LIN)
+            if (i < SPAN * CHUNKS && in0 + pos < LIN && !((PF_STEM_ABLATE & 1) && LAYER >= 2 && p.n_seq > 0))
                 v[it] = *reinterpret_cast<const u32x4*>(src + ((size_t)(in0 + pos) * CIN * ESZ) + ch16 * 16);
         }
 #pragma unroll
@@ -312,66 +330,86 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_gemm_kernel(const ConvParams
         }
     };
 
+    // A wave's TPW channel tiles run TOGETHER: every B fragment read from LDS feeds TPW MFMAs (conv3: 2, conv4: 3 -- with one
+    // tile per wave those layers were bound by the LDS reads, 1 KiB per 16-cycle MFMA on each of four SIMDs), and every weight
+    // fragment is still read from L2 exactly once per workgroup.
     const float* bias = p.bias;
-#pragma unroll 1
+    const u32x4* wf[TPW];
+    f32x4 b4[TPW];
+    f32x4 acc[TPW][CG];
+#pragma unroll
     for (int t = 0; t < TPW; ++t) {
         const int tile = wave * TPW + t;
-        const u32x4* wf = p.wfrags + (size_t)tile * NKS * 64 + lane;
-        f32x4 acc[CG];
+        wf[t] = p.wfrags + (size_t)tile * NKS * 64 + lane;
+        // bf16: the accumulators start from the bias; the fp32 parity mode adds it last, as the reference does
+        b4[t] = *reinterpret_cast<const f32x4*>(bias + tile * 16 + 4 * g);
 #pragma unroll
-        for (int cg = 0; cg < CG; ++cg) acc[cg] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // weight fragments of this tile: register double buffer in chunks of 8 k-steps
-        constexpr int CH = NKS < 8 ? NKS : 8;
-        u32x4 a0[CH], a1[CH];
+        for (int cg = 0; cg < CG; ++cg) acc[t][cg] = BF16 ? b4[t] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // weight fragments: register double buffer in chunks of CH k-steps per tile
+    constexpr int CH0 = TPW > 1 ? 4 : 8;
+    constexpr int CH = NKS < CH0 ? NKS : CH0;
+    u32x4 a0[TPW][CH], a1[TPW][CH];
 #pragma unroll
-        for (int k = 0; k < CH; ++k) a0[k] = wf[(size_t)k * 64];
-        // fully unrolled: with the k-step a compile-time constant the LDS address of every B fragment is an
-        // immediate offset from one per-lane base (tap / channel-block arithmetic folds away)
+    for (int t = 0; t < TPW; ++t)
 #pragma unroll
-        for (int k0 = 0; k0 < NKS; k0 += 2 * CH) {
-            if (k0 + CH < NKS) {
+        for (int k = 0; k < CH; ++k) a0[t][k] = wf[t][(size_t)k * 64];
+    // fully unrolled: with the k-step a compile-time constant the LDS address of every B fragment is an
+    // immediate offset from one per-lane base (tap / channel-block arithmetic folds away)
 #pragma unroll
-                for (int k = 0; k < CH; ++k) a1[k] = wf[(size_t)(k0 + CH + k) * 64];
-            }
-            auto run = [&](const u32x4 (&a)[CH], int kb) {
+    for (int k0 = 0; k0 < (((PF_STEM_ABLATE & 2) && LAYER >= 2) ? 0 : NKS); k0 += 2 * CH) {
+        if (k0 + CH < NKS) {
 #pragma unroll
-                for (int k = 0; k < CH; ++k) {
+            for (int t = 0; t < TPW; ++t)
 #pragma unroll
-                    for (int cg = 0; cg < CG; ++cg) {
-                        const u32x4 b = bfrag(kb + k, cg);
+                for (int k = 0; k < CH; ++k) a1[t][k] = wf[t][(size_t)(k0 + CH + k) * 64];
+        }
+        auto run = [&](const u32x4 (&a)[TPW][CH], int kb) {
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+#pragma unroll
+                for (int cg = 0; cg < CG; ++cg) {
+                    const u32x4 b = bfrag(kb + k, cg);
+#pragma unroll
+                    for (int t = 0; t < TPW; ++t) {
                         if (BF16) {
-                            acc[cg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                                __builtin_bit_cast(bf16x8, a[k]), __builtin_bit_cast(bf16x8, b), acc[cg], 0, 0, 0);
+                            acc[t][cg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                __builtin_bit_cast(bf16x8, a[t][k]), __builtin_bit_cast(bf16x8, b), acc[t][cg], 0, 0, 0);
                         } else {
-                            const f32x4 af = __builtin_bit_cast(f32x4, a[k]), bf = __builtin_bit_cast(f32x4, b);
+                            const f32x4 af = __builtin_bit_cast(f32x4, a[t][k]), bf = __builtin_bit_cast(f32x4, b);
 #pragma unroll
                             for (int q = 0; q < 4; ++q)
-                                acc[cg] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q], bf[q], acc[cg], 0, 0, 0);
+                                acc[t][cg] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q], bf[q], acc[t][cg], 0, 0, 0);
                         }
                     }
                 }
-            };
-            run(a0, k0);
-            if (k0 + CH < NKS) {
-                if (k0 + 2 * CH < NKS) {
-#pragma unroll
-                    for (int k = 0; k < CH; ++k) a0[k] = wf[(size_t)(k0 + 2 * CH + k) * 64];
-                }
-                run(a1, k0 + CH);
             }
+        };
+        run(a0, k0);
+        if (k0 + CH < NKS) {
+            if (k0 + 2 * CH < NKS) {
+#pragma unroll
+                for (int t = 0; t < TPW; ++t)
+#pragma unroll
+                    for (int k = 0; k < CH; ++k) a0[t][k] = wf[t][(size_t)(k0 + 2 * CH + k) * 64];
+            }
+            run(a1, k0 + CH);
         }
-        // epilogue: bias + GELU, 4 consecutive channels of one position per lane
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + tile * 16 + 4 * g);
+    }
+    // epilogue: bias + GELU, 4 consecutive channels of one position per lane
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int tile = wave * TPW + t;
 #pragma unroll
         for (int cg = 0; cg < CG; ++cg) {
             const int pos = p0 + 16 * cg + c;
-            if (pos < LOUT) {
+            if (pos < LOUT && !((PF_STEM_ABLATE & 4) && LAYER >= 2 && p.n_seq > 0)) {
                 f32x4 v;
                 if constexpr (BF16) {
-                    v = gelu_erf_fast4(acc[cg] + b4);
+                    v = gelu_erf_fast4(acc[t][cg]);
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_exact(acc[cg][e] + b4[e]);
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_exact(acc[t][cg][e] + b4[t][e]);
                 }
                 const size_t off = ((size_t)n * LOUT + pos) * COUT + tile * 16 + 4 * g;
                 if (p.dact) {                                       // training: gelu'(pre-activation) for the backward
@@ -379,8 +417,8 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_gemm_kernel(const ConvParams
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float ye, de;
-                        if constexpr (BF16) gelu_fast_pair(acc[cg][e] + b4[e], ye, de);
-                        else de = gelu_grad_f32(acc[cg][e] + b4[e]);
+                        if constexpr (BF16) gelu_fast_pair(acc[t][cg][e], ye, de);
+                        else de = gelu_grad_f32(acc[t][cg][e] + b4[t][e]);
                         dv[e] = de;
                     }
                     if constexpr (BF16) {
@@ -405,12 +443,131 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_gemm_kernel(const ConvParams
     }
 }
 
+// ---- conv3 / conv4, bf16: persistent workgroups --------------------------------------------------
+// The per-sequence workgroups above run load -> LDS -> k-loop -> GELU -> store as one latency chain, and with two of them per
+// CU the three phases measured additive (no loads -0.21 ms, no k-loop -0.20, no stores -0.27 of conv3 + conv4's 0.76 ms per
+// 12 288 sequences, LABLOG R4.12).  Here ONE workgroup per CU walks its share of the sequences:
+//   * the wave's weight tile (16 k-steps = 64 VGPRs) is read from L2 once per workgroup and stays in registers;
+//   * the input span of the NEXT sequence is in flight (registers) under the k-loop and the epilogue of the current one;
+//   * order per sequence: k-loop -> barrier -> staged registers to LDS -> request the sequence after -> GELU + stores ->
+//     barrier.  The only VMEM wait of the loop (in front of the LDS stores) meets loads requested a whole epilogue + k-loop
+//     earlier and output stores issued before that k-loop, so nothing on it is fresh.
+// One workgroup = one whole sequence (conv3: 125 of 128 positions, conv4: 61 of 64), wave w owns channel tile w.
+template <int LAYER, int CG, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void conv_persist_kernel(const ConvParams p) {
+    constexpr StemLayer SL = stem_layer(LAYER);
+    constexpr bool LAST = LAYER == kStemLayers - 1;
+    constexpr int CIN = SL.cin, COUT = SL.cout, KW = SL.kw, S = SL.stride, LIN = SL.lin, LOUT = SL.lout;
+    constexpr int KK = KW * CIN, NKS = KK / 32, CHB = 32, CB = CIN / CHB;
+    constexpr int P = CG * 16, SPAN = (P - 1) * S + KW, Q = (SPAN + S - 1) / S + 1;
+    constexpr int CHUNKS = CIN * 2 / 16, NTHR = NWAVES * 64, ITERS = (SPAN * CHUNKS + NTHR - 1) / NTHR;
+    static_assert(COUT / 16 == NWAVES && P >= LOUT && LAYER >= 2, "one tile per wave, one sequence per workgroup");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, c = lane & 15;
+    const int64_t n0 = blockIdx.y, stride = gridDim.y, N = p.n_seq;
+
+    u32x4 aw[NKS];
+#pragma unroll
+    for (int k = 0; k < NKS; ++k) aw[k] = p.wfrags[((size_t)wave * NKS + k) * 64 + lane];
+    const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + wave * 16 + 4 * g);
+
+    u32x4 v[ITERS];
+    auto request = [&](int64_t n) {                                  // the sequence's [LIN][CIN] activations, 16 B per lane
+        const char* src = reinterpret_cast<const char*>(p.in) + (size_t)n * LIN * CIN * 2;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int i = tid + it * NTHR, pos = i / CHUNKS, ch16 = i - pos * CHUNKS;
+            v[it] = u32x4{0u, 0u, 0u, 0u};
+            if (i < SPAN * CHUNKS && pos < LIN) v[it] = *reinterpret_cast<const u32x4*>(src + (size_t)pos * CIN * 2 + ch16 * 16);
+        }
+    };
+    auto stash = [&]() {                                             // -> rows (pos % S, channel block, pos / S), see above
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int i = tid + it * NTHR;
+            if (i < SPAN * CHUNKS) {
+                const int pos = i / CHUNKS, ch16 = i - pos * CHUNKS;
+                const int r = pos % S, q = pos / S, cb = ch16 / 4, sub = ch16 & 3;
+                *reinterpret_cast<u32x4*>(smem + ((size_t)((r * CB + cb) * Q + q) * 64) + ((sub ^ row_swz(q)) << 4)) = v[it];
+            }
+        }
+    };
+    auto bfrag = [&](int ks, int cg) -> u32x4 {
+        const int kk0 = 32 * ks, tap = kk0 / CIN, cb = (kk0 % CIN) / CHB;
+        const int r = tap % S, q = 16 * cg + c + tap / S;
+        return *reinterpret_cast<const u32x4*>(smem + ((size_t)((r * CB + cb) * Q + q) * 64) + ((g ^ row_swz(q)) << 4));
+    };
+
+    request(n0);
+    stash();
+    __syncthreads();
+    if (n0 + stride < N) request(n0 + stride);
+    for (int64_t n = n0; n < N; n += stride) {
+        f32x4 acc[CG];
+#pragma unroll
+        for (int cg = 0; cg < CG; ++cg) acc[cg] = b4;
+#pragma unroll
+        for (int k = 0; k < NKS; ++k)
+#pragma unroll
+            for (int cg = 0; cg < CG; ++cg)
+                acc[cg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, aw[k]),
+                                                                  __builtin_bit_cast(bf16x8, bfrag(k, cg)), acc[cg], 0, 0, 0);
+        const bool has_next = n + stride < N;
+        if (has_next) {
+            __syncthreads();                                         // every wave is done with this sequence's image
+            stash();
+            if (n + 2 * stride < N) request(n + 2 * stride);
+        }
+#pragma unroll
+        for (int cg = 0; cg < CG; ++cg) {
+            const int pos = 16 * cg + c;
+            if (pos < LOUT) {
+                const f32x4 y = gelu_erf_fast4(acc[cg]);
+                const size_t off = ((size_t)n * LOUT + pos) * COUT + wave * 16 + 4 * g;
+                if (p.dact) {                                        // training: gelu'(pre-activation) for the backward
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float ye, de;
+                        gelu_fast_pair(acc[cg][e], ye, de);
+                        o[e] = (__bf16)de;
+                    }
+                    *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p.dact) + off) = o;
+                }
+                if (!LAST) {
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (__bf16)y[e];
+                    *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p.out) + off) = o;
+                } else {
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + off) = y;
+                }
+            }
+        }
+        if (has_next) __syncthreads();                               // the next image is complete
+    }
+}
+
 // ---- host side ---------------------------------------------------------------------------------
 struct StemGeom { int cg, nwaves; };
+#ifndef PF_CONV3_WAVES
+#define PF_CONV3_WAVES 8
+#endif
+#ifndef PF_CONV4_WAVES
+#define PF_CONV4_WAVES 12
+#endif
+// conv3 / conv4: one channel tile per wave.  Two / three tiles per wave sharing their B fragments (4 waves), or 64 positions per
+// conv3 workgroup, measure the same (LABLOG R4.12: those layers are bound by their load -> k-loop -> store latency chain)
+#ifndef PF_CONV3_CG
+#define PF_CONV3_CG 8
+#endif
+constexpr int kConv3Waves = PF_CONV3_WAVES, kConv4Waves = PF_CONV4_WAVES, kConv3CG = PF_CONV3_CG;
 // positions per workgroup / waves per workgroup for each layer
 constexpr StemGeom stem_geom(int layer) {
-    return layer == 0 ? StemGeom{16, 2} : layer == 1 ? StemGeom{16, 4} : layer == 2 ? StemGeom{8, 8}
-                                                                                       : StemGeom{4, 12};
+    return layer == 0 ? StemGeom{16, 2} : layer == 1 ? StemGeom{16, 4} : layer == 2 ? StemGeom{kConv3CG, kConv3Waves}
+                                                                                       : StemGeom{4, kConv4Waves};
 }
 
 constexpr int kFuseCG = 4;       // conv1 -> conv2 fused: 64 conv2 positions per workgroup (32: 2.23 ms, 64: 2.07, 128: 2.13)
@@ -491,10 +648,32 @@ int64_t stem_workspace_bytes(bool bf16, int64_t n_seq) {
     return n_seq * (a + b) * esz + 256;
 }
 
+static int stem_cu_count() {
+    static const int n = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            cus = 0;
+        return cus > 0 ? cus : 256;
+    }();
+    return n;
+}
+
 template <bool BF16, int LAYER>
 static int launch_layer(const ConvParams& p, hipStream_t s) {
     constexpr StemGeom G = stem_geom(LAYER);
     constexpr StemLayer L = stem_layer(LAYER);
+    if constexpr (BF16 && LAYER >= 2 && G.nwaves * 16 == L.cout && G.cg * 16 >= L.lout) {
+        // persistent workgroups, one per CU: the LDS request is raised above half a CU's so that two never share one
+        static const bool per_seq = std::getenv("PF_STEM_PER_SEQUENCE") != nullptr;      // (the per-sequence kernel, for A/B runs)
+        if (!per_seq) {
+            const size_t lds1 = std::max(stem_lds(LAYER, true), (size_t)82 * 1024);
+            auto k = conv_persist_kernel<LAYER, G.cg, G.nwaves>;
+            if (!opt_in_lds(reinterpret_cast<const void*>(k), (int)lds1)) return PF_ERR_HIP;
+            const unsigned gy = (unsigned)std::min<int64_t>(p.n_seq, stem_cu_count());
+            hipLaunchKernelGGL(k, dim3(1, gy), dim3(G.nwaves * 64), lds1, s, p);
+            return launch_status();
+        }
+    }
     const size_t lds = stem_lds(LAYER, BF16);
     auto k = conv_gemm_kernel<BF16, LAYER, G.cg, G.nwaves>;
     if (lds > 64 * 1024 && !opt_in_lds(reinterpret_cast<const void*>(k), (int)lds)) return PF_ERR_HIP;

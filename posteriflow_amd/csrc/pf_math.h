@@ -12,24 +12,26 @@ typedef __attribute__((ext_vector_type(4))) float pf_f32x4;
 // -- a degree-6 Horner, four squarings and ONE hardware reciprocal per value, all on packed fp32
 // instructions (7.1.26, used first, needs a reciprocal AND an exponential: the two quarter-rate
 // transcendental ops were 2/3 of its cost).  p^16 overflows to +inf for |v| > ~13, where 1/inf = 0 gives erf = 1.
+// Evaluated as  gelu(v) = max(v, 0) - (|v| / 2) r,  r = p(|v|)^-16  with the 2^(-k/2) of x = |v| / sqrt 2 folded into
+// the coefficients: no copysign, no 1 - r, no 1 + erf (12.5 issue slots per value instead of 17 with the bias add
+// and the accumulator reads counted, LABLOG R4.12), and the negative tail keeps its relative precision (v r / 2 instead
+// of v (1 - (1 - r)) / 2).  max(v, 0) is 0.5 v + 0.5 |v|: exact, and a packed fma.
 __device__ __forceinline__ pf_f32x4 gelu_erf_fast4(pf_f32x4 v) {
-    pf_f32x4 x, r, e;
+    pf_f32x4 x, r;
 #pragma unroll
     for (int k = 0; k < 4; ++k) x[k] = fabsf(v[k]);
-    x = x * 0.70710678118654752f;
-    pf_f32x4 p = x * 0.0000430638f + 0.0002765672f;
-    p = p * x + 0.0001520143f;
-    p = p * x + 0.0092705272f;
-    p = p * x + 0.0422820123f;
-    p = p * x + 0.0705230784f;
+    pf_f32x4 p = x * (0.0000430638f * 0.125f) + (0.0002765672f * 0.17677669529663688f);
+    p = p * x + (0.0001520143f * 0.25f);
+    p = p * x + (0.0092705272f * 0.35355339059327376f);
+    p = p * x + (0.0422820123f * 0.5f);
+    p = p * x + (0.0705230784f * 0.70710678118654752f);
     p = p * x + 1.f;
     p = p * p; p = p * p; p = p * p; p = p * p;
 #pragma unroll
     for (int k = 0; k < 4; ++k) r[k] = __builtin_amdgcn_rcpf(p[k]);
-    const pf_f32x4 erf_abs = 1.f - r;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) e[k] = copysignf(erf_abs[k], v[k]);
-    return v * 0.5f * (e + 1.f);
+    const pf_f32x4 h = x * 0.5f;
+    const pf_f32x4 m = v * 0.5f + h;
+    return m - h * r;
 }
 
 // GELU (erf form) and its derivative, exact fp32 (parity mode) ...
@@ -56,7 +58,9 @@ __device__ __forceinline__ void gelu_fast_pair(float x, float& y, float& dy) {
 // cancellation in log(1 + small).  Relative error < 1e-4 over |x| <= 100.
 __device__ __forceinline__ float asinh_fast(float x) {
     const float a = fabsf(x);
-    const float big = __logf(a + __builtin_amdgcn_sqrtf(a * a + 1.f));
+    // the argument of the logarithm is >= 1: the bare v_log_f32 (no denormal scaling, no compensated ln 2 product: 12 of
+    // the library form's 14 instructions)
+    const float big = 0.69314718055994531f * __builtin_amdgcn_logf(a + __builtin_amdgcn_sqrtf(a * a + 1.f));
     return copysignf(a < 1e-3f ? a : big, x);
 }
 }  // namespace pf
