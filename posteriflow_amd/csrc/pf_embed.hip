@@ -72,6 +72,12 @@ __device__ __forceinline__ float gelu_exact(float x) {         // nn.GELU() defa
     return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
 }
 
+// rows per (position mod stride, channel block) of a layer's LDS input image, made ODD: consecutive (r, block) row groups then
+// start 16 banks apart, so the image STORES of a pass (positions r .. r + 3 of one q, or two positions x two channel blocks)
+// land on distinct banks -- with the even counts (68 / 130 / 66) they were 4- / 2-way conflicts, half of the fused kernel's
+// LDS-active cycles (profiles/r03_stem_pmc_sq.txt).  The B-fragment reads only see q and are unaffected.
+__host__ __device__ constexpr int image_rows(int span, int stride) { return ((span + stride - 1) / stride + 1) | 1; }
+
 // lean_npe.py:207: nan -> 0, +-inf -> +-100, clamp to [-100, 100] (v_med3 + one compare / select)
 __device__ __forceinline__ float sanitize(float x) {
     const float c = __builtin_amdgcn_fmed3f(x, -100.f, 100.f);
@@ -165,7 +171,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_gemm_kernel(const ConvParams
         constexpr StemLayer L0 = stem_layer(0);
         constexpr int S0 = L0.stride, KW0 = L0.kw, LIN0 = L0.lin, LOUT0 = L0.lout;
         constexpr int CB = CIN / CHB;
-        constexpr int Q = (SPAN + S - 1) / S + 1;
+        constexpr int Q = image_rows(SPAN, S);
         constexpr int NPT = (SPAN + 15) / 16;                       // conv1 position tiles
         constexpr int NSIG = (16 * NPT - 1) * S0 + KW0;             // strain samples those tiles read
         constexpr int NKS0 = KW0 / KSTEP;
@@ -282,7 +288,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_gemm_kernel(const ConvParams
     } else {
         // activations [pos][CIN] -> LDS rows (r = pos % S, channel block, q = pos / S), 64 B each
         constexpr int CB = CIN / CHB;                  // channel blocks per position
-        constexpr int Q = (SPAN + S - 1) / S + 1;      // rows per (r, block)
+        constexpr int Q = image_rows(SPAN, S);      // rows per (r, block)
         const char* src = reinterpret_cast<const char*>(p.in) + ((size_t)n * LIN) * CIN * ESZ;
         constexpr int CHUNKS = CIN * ESZ / 16;         // 16-byte chunks per position
         // all of a thread's 16-byte chunks are requested before the first one is stored: a loop that loads
@@ -322,7 +328,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_gemm_kernel(const ConvParams
             return *reinterpret_cast<const u32x4*>(smem + (size_t)idx * ESZ);
         } else {
             constexpr int CB = CIN / CHB;
-            constexpr int Q = (SPAN + S - 1) / S + 1;
+            constexpr int Q = image_rows(SPAN, S);
             const int kk0 = KSTEP * ks;                // kk = tap * CIN + ch
             const int tap = kk0 / CIN, cb = (kk0 % CIN) / CHB;
             const int r = tap % S, q = 16 * cg + c + tap / S;
@@ -445,22 +451,36 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_gemm_kernel(const ConvParams
 
 // ---- conv3 / conv4, bf16: persistent workgroups --------------------------------------------------
 // The per-sequence workgroups above run load -> LDS -> k-loop -> GELU -> store as one latency chain, and with two of them per
-// CU the three phases measured additive (no loads -0.21 ms, no k-loop -0.20, no stores -0.27 of conv3 + conv4's 0.76 ms per
-// 12 288 sequences, LABLOG R4.12).  Here ONE workgroup per CU walks its share of the sequences:
+// CU the three phases measured additive (no loads -0.21 ms, no k-loop -0.20, no GELU + stores -0.27 of conv3 + conv4's 0.76 ms
+// per 12 288 sequences, LABLOG R4.12).  Here ONE workgroup per CU walks its share of the sequences:
 //   * the wave's weight tile (16 k-steps = 64 VGPRs) is read from L2 once per workgroup and stays in registers;
-//   * the input span of the NEXT sequence is in flight (registers) under the k-loop and the epilogue of the current one;
-//   * order per sequence: k-loop -> barrier -> staged registers to LDS -> request the sequence after -> GELU + stores ->
-//     barrier.  The only VMEM wait of the loop (in front of the LDS stores) meets loads requested a whole epilogue + k-loop
-//     earlier and output stores issued before that k-loop, so nothing on it is fresh.
+//   * the input span of the sequence after the next is in flight (registers, buffer loads whose range check supplies the zero
+//     padding) while the next one's image sits in LDS;
+//   * the k-loop of sequence i + 1 (MFMA + LDS reads) and the epilogue of sequence i (GELU on VALU, stores) are ONE
+//     branch-free block over two accumulator sets -- the stores of positions >= LOUT are dropped by the buffer range check
+//     instead of an exec-mask branch -- so the scheduler can put the epilogue's VALU work into the MFMA / LDS shadows;
+//   * per sequence: barrier -> staged registers to LDS -> request -> barrier -> that block.  The only VMEM wait of the loop
+//     (in front of the LDS stores) meets loads requested a whole block earlier.
 // One workgroup = one whole sequence (conv3: 125 of 128 positions, conv4: 61 of 64), wave w owns channel tile w.
-template <int LAYER, int CG, int NWAVES>
+#ifndef PF_STEM_SCHED
+#define PF_STEM_SCHED 1       // 1: sched_group_barrier pattern (MFMA, LDS read, a few VALU) over the fused block; 0: scheduler's choice
+#endif
+#ifndef PF_STEM_AHEAD
+#define PF_STEM_AHEAD 3
+#endif
+#ifndef PF_STEM_VALU
+#define PF_STEM_VALU 4
+#endif
+template <int LAYER, int CG, int NWAVES, bool DACT>
 __global__ __launch_bounds__(NWAVES * 64) void conv_persist_kernel(const ConvParams p) {
     constexpr StemLayer SL = stem_layer(LAYER);
     constexpr bool LAST = LAYER == kStemLayers - 1;
     constexpr int CIN = SL.cin, COUT = SL.cout, KW = SL.kw, S = SL.stride, LIN = SL.lin, LOUT = SL.lout;
     constexpr int KK = KW * CIN, NKS = KK / 32, CHB = 32, CB = CIN / CHB;
-    constexpr int P = CG * 16, SPAN = (P - 1) * S + KW, Q = (SPAN + S - 1) / S + 1;
+    constexpr int P = CG * 16, SPAN = (P - 1) * S + KW, Q = image_rows(SPAN, S);
     constexpr int CHUNKS = CIN * 2 / 16, NTHR = NWAVES * 64, ITERS = (SPAN * CHUNKS + NTHR - 1) / NTHR;
+    constexpr int OESZ = LAST ? 4 : 2;
+    constexpr unsigned kOob = 0x7fffff00u;                            // beyond every range below: loads return 0, stores are dropped
     static_assert(COUT / 16 == NWAVES && P >= LOUT && LAYER >= 2, "one tile per wave, one sequence per workgroup");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -475,12 +495,12 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_persist_kernel(const ConvPar
 
     u32x4 v[ITERS];
     auto request = [&](int64_t n) {                                  // the sequence's [LIN][CIN] activations, 16 B per lane
-        const char* src = reinterpret_cast<const char*>(p.in) + (size_t)n * LIN * CIN * 2;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(reinterpret_cast<const char*>(p.in)) + (size_t)n * LIN * CIN * 2, 0, LIN * CIN * 2, 0x00020000);
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
-            const int i = tid + it * NTHR, pos = i / CHUNKS, ch16 = i - pos * CHUNKS;
-            v[it] = u32x4{0u, 0u, 0u, 0u};
-            if (i < SPAN * CHUNKS && pos < LIN) v[it] = *reinterpret_cast<const u32x4*>(src + (size_t)pos * CIN * 2 + ch16 * 16);
+            const int i = tid + it * NTHR;                           // chunk i = position i / CHUNKS, 16-byte piece i % CHUNKS:
+            v[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, i * 16, 0, 0);   // byte i * 16; positions >= LIN read as zeros
         }
     };
     auto stash = [&]() {                                             // -> rows (pos % S, channel block, pos / S), see above
@@ -499,13 +519,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_persist_kernel(const ConvPar
         const int r = tap % S, q = 16 * cg + c + tap / S;
         return *reinterpret_cast<const u32x4*>(smem + ((size_t)((r * CB + cb) * Q + q) * 64) + ((g ^ row_swz(q)) << 4));
     };
-
-    request(n0);
-    stash();
-    __syncthreads();
-    if (n0 + stride < N) request(n0 + stride);
-    for (int64_t n = n0; n < N; n += stride) {
-        f32x4 acc[CG];
+    auto kloop = [&](f32x4 (&acc)[CG]) {
 #pragma unroll
         for (int cg = 0; cg < CG; ++cg) acc[cg] = b4;
 #pragma unroll
@@ -514,40 +528,72 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_persist_kernel(const ConvPar
             for (int cg = 0; cg < CG; ++cg)
                 acc[cg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, aw[k]),
                                                                   __builtin_bit_cast(bf16x8, bfrag(k, cg)), acc[cg], 0, 0, 0);
-        const bool has_next = n + stride < N;
-        if (has_next) {
-            __syncthreads();                                         // every wave is done with this sequence's image
-            stash();
-            if (n + 2 * stride < N) request(n + 2 * stride);
-        }
+    };
+    // GELU + stores of sequence n; lane (g, c): channels 16 wave + 4 g .. + 3 of position 16 cg + c
+    unsigned ooff[CG];
+#pragma unroll
+    for (int cg = 0; cg < CG; ++cg) {
+        const int pos = 16 * cg + c;
+        ooff[cg] = pos < LOUT ? (unsigned)((pos * COUT + wave * 16 + 4 * g)) : kOob;      // in elements (kOob stays out of range)
+    }
+    auto epilogue = [&](int64_t n, const f32x4 (&acc)[CG]) {
+        const size_t seq = (size_t)n * LOUT * COUT;
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+            reinterpret_cast<char*>(p.out) + seq * OESZ, 0, LOUT * COUT * OESZ, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+            DACT ? reinterpret_cast<char*>(p.dact) + seq * 2 : reinterpret_cast<char*>(p.out), 0, DACT ? LOUT * COUT * 2 : 0, 0x00020000);
 #pragma unroll
         for (int cg = 0; cg < CG; ++cg) {
-            const int pos = 16 * cg + c;
-            if (pos < LOUT) {
-                const f32x4 y = gelu_erf_fast4(acc[cg]);
-                const size_t off = ((size_t)n * LOUT + pos) * COUT + wave * 16 + 4 * g;
-                if (p.dact) {                                        // training: gelu'(pre-activation) for the backward
-                    bf16x4 o;
+            const f32x4 y = gelu_erf_fast4(acc[cg]);
+            if constexpr (DACT) {                                    // training: gelu'(pre-activation) for the backward
+                bf16x4 o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float ye, de;
-                        gelu_fast_pair(acc[cg][e], ye, de);
-                        o[e] = (__bf16)de;
-                    }
-                    *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p.dact) + off) = o;
+                for (int e = 0; e < 4; ++e) {
+                    float ye, de;
+                    gelu_fast_pair(acc[cg][e], ye, de);
+                    o[e] = (__bf16)de;
                 }
-                if (!LAST) {
-                    bf16x4 o;
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rd, ooff[cg] == kOob ? kOob : ooff[cg] * 2, 0, 0);
+            }
+            if constexpr (!LAST) {
+                bf16x4 o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (__bf16)y[e];
-                    *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p.out) + off) = o;
-                } else {
-                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + off) = y;
-                }
+                for (int e = 0; e < 4; ++e) o[e] = (__bf16)y[e];
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), ro, ooff[cg] == kOob ? kOob : ooff[cg] * 2, 0, 0);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), ro, ooff[cg] == kOob ? kOob : ooff[cg] * 4, 0, 0);
             }
         }
-        if (has_next) __syncthreads();                               // the next image is complete
+    };
+
+    request(n0);
+    stash();
+    __syncthreads();
+    if (n0 + stride < N) request(n0 + stride);
+    f32x4 acc[CG];
+    kloop(acc);
+    int64_t n = n0;
+    for (; n + stride < N; n += stride) {
+        __syncthreads();                                             // every wave is done with sequence n's image
+        stash();                                                     // sequence n + stride
+        if (n + 2 * stride < N) request(n + 2 * stride);
+        __syncthreads();
+        f32x4 acc2[CG];
+        kloop(acc2);                                                 // sequence n + stride: MFMA pipe, LDS
+        epilogue(n, acc);                                            // sequence n: VALU, stores
+#if PF_STEM_SCHED
+        __builtin_amdgcn_sched_group_barrier(0x100, PF_STEM_AHEAD, 0);          // B fragments requested a few MFMAs ahead
+#pragma unroll
+        for (int i = 0; i < NKS * CG; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // one LDS read
+            __builtin_amdgcn_sched_group_barrier(0x002, DACT ? 2 * PF_STEM_VALU : PF_STEM_VALU, 0);   // VALU work in its shadow
+        }
+#endif
+#pragma unroll
+        for (int cg = 0; cg < CG; ++cg) acc[cg] = acc2[cg];
     }
+    epilogue(n, acc);
 }
 
 // ---- host side ---------------------------------------------------------------------------------
@@ -574,7 +620,7 @@ constexpr int kFuseCG = 4;       // conv1 -> conv2 fused: 64 conv2 positions per
 static size_t stem_lds_fused(bool bf16) {
     const StemLayer L = stem_layer(1), L0 = stem_layer(0);
     const int esz = bf16 ? 2 : 4, P = kFuseCG * 16, span = (P - 1) * L.stride + L.kw;
-    const int chb = 64 / esz, cb = L.cin / chb, q = (span + L.stride - 1) / L.stride + 1;
+    const int chb = 64 / esz, cb = L.cin / chb, q = image_rows(span, L.stride);
     const int npt = (span + 15) / 16, nsig = (16 * npt - 1) * L0.stride + L0.kw;
     return (size_t)L.stride * cb * q * 64 + (((size_t)nsig * esz + 15) & ~(size_t)15) + 64;
 }
@@ -583,7 +629,7 @@ static size_t stem_lds(int layer, bool bf16) {
     const StemGeom G = stem_geom(layer);
     const int esz = bf16 ? 2 : 4, P = G.cg * 16, span = (P - 1) * L.stride + L.kw;
     if (layer == 0) return (((size_t)span * esz + 15) & ~(size_t)15) + 64;
-    const int chb = 64 / esz, cb = L.cin / chb, q = (span + L.stride - 1) / L.stride + 1;
+    const int chb = 64 / esz, cb = L.cin / chb, q = image_rows(span, L.stride);
     return (size_t)L.stride * cb * q * 64;
 }
 
@@ -667,7 +713,7 @@ static int launch_layer(const ConvParams& p, hipStream_t s) {
         static const bool per_seq = std::getenv("PF_STEM_PER_SEQUENCE") != nullptr;      // (the per-sequence kernel, for A/B runs)
         if (!per_seq) {
             const size_t lds1 = std::max(stem_lds(LAYER, true), (size_t)82 * 1024);
-            auto k = conv_persist_kernel<LAYER, G.cg, G.nwaves>;
+            auto k = p.dact ? conv_persist_kernel<LAYER, G.cg, G.nwaves, true> : conv_persist_kernel<LAYER, G.cg, G.nwaves, false>;
             if (!opt_in_lds(reinterpret_cast<const void*>(k), (int)lds1)) return PF_ERR_HIP;
             const unsigned gy = (unsigned)std::min<int64_t>(p.n_seq, stem_cu_count());
             hipLaunchKernelGGL(k, dim3(1, gy), dim3(G.nwaves * 64), lds1, s, p);
