@@ -1,7 +1,7 @@
 #!/bin/bash
 # SQ counter passes for the stem's pf::conv_gemm_kernel launches (4096 events x 3 detectors, bf16); one rocprofv3 run per pass.
 set -u
-OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_stem_sq
+OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_stem_sq${1:+_$1}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 PASSES=(
@@ -16,4 +16,4 @@ for P in "${PASSES[@]}"; do
       python3 $GRAFT_REPO_ROOT/scripts/prof_stem.py > $OUT/p$i.log 2>&1
   echo "pass $i rc=$? : $P"
 done
-python3 $GRAFT_REPO_ROOT/scripts/pmc_summary.py $OUT conv_gemm_kernel | tee $OUT/summary.txt
+python3 $GRAFT_REPO_ROOT/scripts/pmc_summary.py $OUT conv_ | tee $OUT/summary.txt
