@@ -72,11 +72,10 @@ __device__ __forceinline__ float gelu_exact(float x) {         // nn.GELU() defa
     return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
 }
 
-// rows per (position mod stride, channel block) of a layer's LDS input image, made ODD: consecutive (r, block) row groups then
-// start 16 banks apart, so the image STORES of a pass (positions r .. r + 3 of one q, or two positions x two channel blocks)
-// land on distinct banks -- with the even counts (68 / 130 / 66) they were 4- / 2-way conflicts, half of the fused kernel's
-// LDS-active cycles (profiles/r03_stem_pmc_sq.txt).  The B-fragment reads only see q and are unaffected.
-__host__ __device__ constexpr int image_rows(int span, int stride) { return ((span + stride - 1) / stride + 1) | 1; }
+// rows per (position mod stride, channel block) of a layer's LDS input image.  (Odd counts -- consecutive row groups 16 banks
+// apart for the image STORES -- were tried in round 4: SQ_LDS_BANK_CONFLICT of the fused kernel stayed at 169.08 M cycles per
+// 12 288 sequences and the time did not move; the counted cycles belong to the 16-byte fragment reads, LABLOG R4.12.)
+__host__ __device__ constexpr int image_rows(int span, int stride) { return (span + stride - 1) / stride + 1; }
 
 // lean_npe.py:207: nan -> 0, +-inf -> +-100, clamp to [-100, 100] (v_med3 + one compare / select)
 __device__ __forceinline__ float sanitize(float x) {

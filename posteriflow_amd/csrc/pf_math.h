@@ -11,11 +11,14 @@ typedef __attribute__((ext_vector_type(4))) float pf_f32x4;
 //   erf(x) = 1 - (1 + a1 x + ... + a6 x^6)^-16,  x >= 0,  |error| <= 3e-7
 // -- a degree-6 Horner, four squarings and ONE hardware reciprocal per value, all on packed fp32
 // instructions (7.1.26, used first, needs a reciprocal AND an exponential: the two quarter-rate
-// transcendental ops were 2/3 of its cost).  p^16 overflows to +inf for |v| > ~13, where 1/inf = 0 gives erf = 1.
+// transcendental ops were 2/3 of its cost).  p^16 overflows to +inf for |v| > ~13, where 1 / inf = 0 gives erf = 1.
 // Evaluated as  gelu(v) = max(v, 0) - (|v| / 2) r,  r = p(|v|)^-16  with the 2^(-k/2) of x = |v| / sqrt 2 folded into
 // the coefficients: no copysign, no 1 - r, no 1 + erf (12.5 issue slots per value instead of 17 with the bias add
 // and the accumulator reads counted, LABLOG R4.12), and the negative tail keeps its relative precision (v r / 2 instead
 // of v (1 - (1 - r)) / 2).  max(v, 0) is 0.5 v + 0.5 |v|: exact, and a packed fma.
+// (One reciprocal shared by the four values -- r_i = rcp(p0 p1 p2 p3) x the other three, |v| clamped at 6 -- is 10.75 slots
+// on paper and measured SLOWER in both users, stem 1.82 vs 1.74 ms, mixer 4.36 vs 4.20: one long dependency chain per four
+// values instead of four short ones.  Not kept.)
 __device__ __forceinline__ pf_f32x4 gelu_erf_fast4(pf_f32x4 v) {
     pf_f32x4 x, r;
 #pragma unroll
