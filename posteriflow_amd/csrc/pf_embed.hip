@@ -42,6 +42,9 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 constexpr int kStemLayers = 4;
+#ifndef PF_STEM_HOIST
+#define PF_STEM_HOIST 0
+#endif
 #ifndef PF_STEM_ABLATE
 #define PF_STEM_ABLATE 0      // experiments on conv3 / conv4 (side builds only): 1 no staging loads, 2 no k-loop, 4 no stores
 #endif
@@ -110,6 +113,31 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_gemm_kernel(const ConvParams
     const int64_t n = blockIdx.y;
     const int p0 = blockIdx.x * P;                     // first output position
     const int in0 = p0 * S;                            // first input position of the span
+
+    // weight fragments: register double buffer in chunks of CH k-steps per tile; bias (bf16: the accumulators start from it,
+    // the fp32 parity mode adds it last, as the reference does)
+    constexpr int CH0 = TPW > 1 ? 4 : 8;
+    constexpr int CH = NKS < CH0 ? NKS : CH0;
+    const float* bias = p.bias;
+    const u32x4* wf[TPW];
+    f32x4 b4[TPW];
+    f32x4 acc[TPW][CG];
+    u32x4 a0[TPW][CH], a1[TPW][CH];
+    auto prime = [&]() {
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            const int tile = wave * TPW + t;
+            wf[t] = p.wfrags + (size_t)tile * NKS * 64 + lane;
+            b4[t] = *reinterpret_cast<const f32x4*>(bias + tile * 16 + 4 * g);
+#pragma unroll
+            for (int k = 0; k < CH; ++k) a0[t][k] = wf[t][(size_t)k * 64];
+        }
+    };
+#if PF_STEM_HOIST
+    // fused kernel: conv2's first weight chunk is requested before the strain is staged (its L2 round trip otherwise sits
+    // between the conv1 phase and the first conv2 MFMA of every workgroup)
+    if constexpr (FUSE) { prime(); __builtin_amdgcn_sched_barrier(0); }
+#endif
 
     // ---- stage the input span ------------------------------------------------------------------
     if constexpr (FIRST) {
@@ -335,30 +363,17 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_gemm_kernel(const ConvParams
         }
     };
 
-    // A wave's TPW channel tiles run TOGETHER: every B fragment read from LDS feeds TPW MFMAs (conv3: 2, conv4: 3 -- with one
-    // tile per wave those layers were bound by the LDS reads, 1 KiB per 16-cycle MFMA on each of four SIMDs), and every weight
-    // fragment is still read from L2 exactly once per workgroup.
-    const float* bias = p.bias;
-    const u32x4* wf[TPW];
-    f32x4 b4[TPW];
-    f32x4 acc[TPW][CG];
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-        const int tile = wave * TPW + t;
-        wf[t] = p.wfrags + (size_t)tile * NKS * 64 + lane;
-        // bf16: the accumulators start from the bias; the fp32 parity mode adds it last, as the reference does
-        b4[t] = *reinterpret_cast<const f32x4*>(bias + tile * 16 + 4 * g);
-#pragma unroll
-        for (int cg = 0; cg < CG; ++cg) acc[t][cg] = BF16 ? b4[t] : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    // weight fragments: register double buffer in chunks of CH k-steps per tile
-    constexpr int CH0 = TPW > 1 ? 4 : 8;
-    constexpr int CH = NKS < CH0 ? NKS : CH0;
-    u32x4 a0[TPW][CH], a1[TPW][CH];
+    // A wave's TPW channel tiles run TOGETHER (every B fragment read from LDS feeds TPW MFMAs, every weight fragment is read
+    // from L2 once per workgroup); the dispatched geometries have one tile per wave.
+#if PF_STEM_HOIST
+    if constexpr (!FUSE) prime();
+#else
+    prime();
+#endif
 #pragma unroll
     for (int t = 0; t < TPW; ++t)
 #pragma unroll
-        for (int k = 0; k < CH; ++k) a0[t][k] = wf[t][(size_t)k * 64];
+        for (int cg = 0; cg < CG; ++cg) acc[t][cg] = BF16 ? b4[t] : f32x4{0.f, 0.f, 0.f, 0.f};
     // fully unrolled: with the k-step a compile-time constant the LDS address of every B fragment is an
     // immediate offset from one per-lane base (tap / channel-block arithmetic folds away)
 #pragma unroll
