@@ -45,6 +45,19 @@
 
 #include "pf_flow_fwd_kernel.h"
 
+// side-build switches (scripts/side_obj.sh NAME pf_flow_inc -DPF_INC_ROT=1, A/B with scripts/ab_inc.sh; LABLOG R4.13):
+// PF_INC_SKIP (default on, +5 %): a whole group of four masked-zero k-steps is jumped over;
+// PF_INC_ROT (tile ownership rotated with the workgroup) and PF_INC_PRIO (s_setprio around the chains): measured, no gain
+#ifndef PF_INC_ROT
+#define PF_INC_ROT 0
+#endif
+#ifndef PF_INC_SKIP
+#define PF_INC_SKIP 1
+#endif
+#ifndef PF_INC_PRIO
+#define PF_INC_PRIO 0
+#endif
+
 namespace pf {
 namespace {
 constexpr int kParS = kParStride;          // floats per row in the spline-parameter transpose (52)
@@ -208,7 +221,11 @@ void flow_inverse_inc_kernel(const IncParams p) {
     uint32_t* const badf = reinterpret_cast<uint32_t*>(ldacc + kRows);
 
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // tile ownership rotates with the workgroup (PF_INC_ROT, experiment): the waves of the workgroups that share a CU own
+    // their tiles on different SIMDs (the fourth wave has no tile in stages a-e, the third often none)
+    const int wave_hw = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = PF_INC_ROT == 0 ? wave_hw
+                   : (wave_hw + (PF_INC_ROT == 1 ? (int)(blockIdx.x >> 8) : PF_INC_ROT == 2 ? (int)blockIdx.x : (int)(blockIdx.x >> 3))) & (kThreads / 64 - 1);
     const int64_t row0 = (int64_t)blockIdx.x * kRows;
     auto act_of = [&](int s) { return act + (size_t)s * kRows * AS; };
     const int lane16 = lane * 16;
@@ -272,6 +289,9 @@ void flow_inverse_inc_kernel(const IncParams p) {
                 buf[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16 + 4096 * (ks >> 2) + (ks & 3) * 1024, 0, 0);
         };
         auto gemm = [&](const u32x4 (&a)[NF], const char* src, int kmax, f32x4 (&v)[kCols]) {
+#if PF_INC_PRIO
+            __builtin_amdgcn_s_setprio(PF_INC_PRIO);          // (experiment) the chain's wave ahead of its SIMD's other workgroups
+#endif
 #pragma unroll
             for (int cc = 0; cc < kCols; ++cc) {
                 // (k-steps >= kmax multiply zero weights -- see fetch -- with whatever finite activations the row holds:
@@ -300,6 +320,12 @@ void flow_inverse_inc_kernel(const IncParams p) {
                 } else {
 #pragma unroll
                     for (int k0 = 0; k0 < NF; k0 += 4) {      // four operand reads in flight (register budget of the 4-wave variant)
+#if PF_INC_SKIP
+                        // a whole group of masked-zero fragments (units of degree > i): no reads, no MFMAs.  One uniform
+                        // branch per chain, not one per k-step (that puts an LDS round trip between consecutive MFMAs);
+                        // the fragment LOADS stay unconditional: their count must not depend on a branch
+                        if (k0 > 0 && k0 >= kmax) continue;
+#endif
                         u32x4 b[4];
 #pragma unroll
                         for (int ks = 0; ks < 4; ++ks) b[ks] = *reinterpret_cast<const u32x4*>(brow + swz[ks] + (k0 >> 2) * 256);
@@ -312,6 +338,9 @@ void flow_inverse_inc_kernel(const IncParams p) {
                 }
                 v[cc] = v0 + v1;
             }
+#if PF_INC_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
         };
         // activation tile of this lane (4 consecutive units of row 16 cc + c) into stage s
         auto put = [&](int s, int cc, int u, f32x4 val) {
